@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (container only).
+
+Usage (build container, where /root/reference exists):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference's PyTorch tree (/root/reference/pytorch/core) is imported, fed
+procedurally generated weights and inputs (oracle/weights.py, seeds below) and
+its OUTPUTS are stored.  No reference source is copied; the fixtures are data.
+Each fixture records the seeds/shapes needed to regenerate the inputs.
+"""
+import argparse
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/pytorch")
+warnings.filterwarnings("ignore")
+
+from core.corr import CorrBlock                      # noqa: E402  (reference)
+from core.raft import RAFT                           # noqa: E402
+from core.update import BasicUpdateBlock, SmallUpdateBlock  # noqa: E402
+from core.utils.utils import InputPadder, coords_grid, upflow8  # noqa: E402
+
+from oracle.weights import procedural_state_dict, rand_tensor, rand_uniform, synthetic_pair  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def args_ns(small):
+    return argparse.Namespace(small=small, mixed_precision=False, alternate_corr=False, dropout=0,
+                              corr_levels=4, corr_radius=3 if small else 4)
+
+
+def shapes_of(module):
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()}
+
+
+# ---------------------------------------------------------------- G1 / G2
+CORR_CASES = [
+    # name, B, C, H, W, radius, seed
+    ("corr_tiny", 1, 8, 16, 16, 3, 101),
+    ("corr_odd", 1, 32, 17, 19, 4, 102),
+    ("corr_mid", 2, 256, 16, 24, 4, 103),
+]
+
+
+def gen_corr():
+    for name, B, C, H, W, r, seed in CORR_CASES:
+        f1 = rand_tensor((B, C, H, W), seed, 1.0).requires_grad_(True)
+        f2 = rand_tensor((B, C, H, W), seed + 1, 1.0).requires_grad_(True)
+        blk = CorrBlock(f1, f2, num_levels=4, radius=r)
+        coords = coords_grid(B, H, W) + rand_uniform((B, 2, H, W), seed + 2, -6.0, 6.0)
+        # make a few queries land far outside / exactly on integers
+        coords[:, :, 0, 0] = -20.0
+        coords[:, :, 1, 1] = torch.tensor([float(W + 7), float(H + 9)]).view(1, 2)
+        coords[:, :, 2, 2] = torch.tensor([3.0, 2.0]).view(1, 2)
+        out = blk(coords)
+        g = rand_tensor(tuple(out.shape), seed + 3, 1.0)
+        (out * g).sum().backward()
+        d = {f"pyr{l}": p for l, p in enumerate(blk.corr_pyramid)}
+        save(name, B=B, C=C, H=H, W=W, radius=r, seed=seed, coords=coords, out=out,
+             dfmap1=f1.grad, dfmap2=f2.grad, **d)
+
+
+# ---------------------------------------------------------------- G3
+def gen_update():
+    for small in (False, True):
+        a = args_ns(small)
+        blk = SmallUpdateBlock(a, hidden_dim=96) if small else BasicUpdateBlock(a, hidden_dim=128)
+        shapes = shapes_of(blk)
+        tag = "small" if small else "basic"
+        with open(os.path.join(HERE, f"update_{tag}_shapes.json"), "w") as f:
+            json.dump({k: list(v) for k, v in shapes.items()}, f, indent=0)
+        seed = 300 + int(small)
+        blk.load_state_dict(procedural_state_dict(shapes, seed))
+        B, H, W = 1, 12, 16
+        hd, cd = (96, 64) if small else (128, 128)
+        cp = 4 * (2 * a.corr_radius + 1) ** 2
+        net = torch.tanh(rand_tensor((B, hd, H, W), seed + 10)).requires_grad_(True)
+        inp = torch.relu(rand_tensor((B, cd, H, W), seed + 11)).requires_grad_(True)
+        corr = rand_tensor((B, cp, H, W), seed + 12, 2.0).requires_grad_(True)
+        flow = rand_tensor((B, 2, H, W), seed + 13, 3.0).requires_grad_(True)
+        net2, mask, delta = blk(net, inp, corr, flow)
+        loss = (net2 * rand_tensor(tuple(net2.shape), seed + 20)).sum() + (delta * rand_tensor(tuple(delta.shape), seed + 21)).sum()
+        if mask is not None:
+            loss = loss + (mask * rand_tensor(tuple(mask.shape), seed + 22)).sum()
+        loss.backward()
+        d = dict(B=B, H=H, W=W, seed=seed, net_out=net2, delta=delta,
+                 dnet=net.grad, dinp=inp.grad, dcorr=corr.grad, dflow=flow.grad)
+        if mask is not None:
+            d["mask"] = mask
+        for k, p in blk.named_parameters():
+            # big tensors: L2 norm + a 4096-element strided sample (stride = numel // 4096)
+            g = p.grad.reshape(-1)
+            d["dparam_norm." + k] = g.norm()
+            d["dparam." + k] = g if g.numel() <= 4096 else g[:: g.numel() // 4096][:4096].clone()
+        save(f"update_{tag}", **d)
+
+
+# ---------------------------------------------------------------- G4 / G6
+def gen_upsample():
+    model = RAFT(args_ns(False))
+    N, H, W = 2, 6, 8
+    flow = rand_tensor((N, 2, H, W), 401, 2.0).requires_grad_(True)
+    mask = rand_tensor((N, 576, H, W), 402, 1.5).requires_grad_(True)
+    up = model.upsample_flow(flow, mask)
+    g = rand_tensor(tuple(up.shape), 403)
+    (up * g).sum().backward()
+    save("upsample", N=N, H=H, W=W, up=up, dflow=flow.grad, dmask=mask.grad)
+
+    f = rand_tensor((2, 2, 5, 7), 411, 2.0)
+    pads = {}
+    for mode in ("sintel", "kitti"):
+        for (h, w) in ((436, 1024), (375, 1242), (368, 496), (128, 256), (370, 1226)):
+            pads[f"pad_{mode}_{h}_{w}"] = np.array(InputPadder((1, 3, h, w), mode=mode)._pad)
+    save("helpers", upflow8=upflow8(f), coords_grid=coords_grid(2, 3, 5), **pads)
+
+
+# ---------------------------------------------------------------- G5
+E2E_CASES = [
+    # name, small, B, H, W, iters, seed, stride for flow_up
+    ("e2e_small_128x256", True, 1, 128, 256, 4, 501, 1),
+    ("e2e_basic_368x496", False, 1, 368, 496, 12, 502, 4),
+    ("e2e_basic_440x1024", False, 1, 440, 1024, 12, 503, 4),
+]
+
+
+def gen_e2e():
+    for name, small, B, H, W, iters, seed, stride in E2E_CASES:
+        model = RAFT(args_ns(small))
+        shapes = shapes_of(model)
+        tag = "small" if small else "basic"
+        with open(os.path.join(HERE, f"raft_{tag}_shapes.json"), "w") as f:
+            json.dump({k: list(v) for k, v in shapes.items()}, f, indent=0)
+        model.load_state_dict(procedural_state_dict(shapes, seed))
+        model.eval()
+        im1, im2 = synthetic_pair(B, H, W, seed + 1)
+        with torch.no_grad():
+            flow_low, flow_up = model(im1, im2, iters=iters, test_mode=True)
+        save(name, small=small, B=B, H=H, W=W, iters=iters, seed=seed, stride=stride,
+             flow_low=flow_low, flow_up_strided=flow_up[:, :, ::stride, ::stride].contiguous(),
+             flow_up_absmean=flow_up.abs().mean())
+
+
+def gen_train_step():
+    """fwd+bwd of the whole model (frozen BN), small shapes: loss + parameter-grad digests."""
+    for small, H, W, iters, seed in ((False, 128, 192, 3, 601), (True, 128, 192, 3, 602)):
+        model = RAFT(args_ns(small))
+        shapes = shapes_of(model)
+        model.load_state_dict(procedural_state_dict(shapes, seed))
+        model.train()
+        model.freeze_bn()
+        im1, im2 = synthetic_pair(2, H, W, seed + 1)
+        preds = model(im1, im2, iters=iters)
+        n = len(preds)
+        loss = 0.0
+        for i, p in enumerate(preds):
+            loss = loss + (0.8 ** (n - i - 1)) * torch.sqrt(p * p + 1e-6).mean()
+        loss.backward()
+        d = dict(small=small, H=H, W=W, iters=iters, seed=seed, loss=loss.detach(), last=preds[-1].detach())
+        for k, p in model.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            d["gnorm." + k] = g.norm()
+            d["ghead." + k] = g.reshape(-1)[:32].clone()
+        save("train_step_" + ("small" if small else "basic"), **d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "train"]
+    if "corr" in which:
+        gen_corr()
+    if "update" in which:
+        gen_update()
+    if "upsample" in which:
+        gen_upsample()
+    if "e2e" in which:
+        gen_e2e()
+    if "train" in which:
+        gen_train_step()

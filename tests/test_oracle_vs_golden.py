@@ -1,0 +1,160 @@
+"""Pin the CPU oracle (oracle/raft_torch.py) against fixtures produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raft_torch as O
+from oracle.weights import procedural_state_dict, rand_tensor, synthetic_pair
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, atol, rtol=1e-4):
+    a = a if isinstance(a, torch.Tensor) else T(a)
+    b = b if isinstance(b, torch.Tensor) else T(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    lim = atol + rtol * b.abs().max().item()
+    assert err <= lim, f"max abs err {err:.3e} > {lim:.3e}"
+
+
+@pytest.mark.parametrize("name", ["corr_tiny", "corr_odd", "corr_mid"])
+def test_corr_volume_pyramid_lookup_and_grads(name):
+    g = load(name)
+    B, C, H, W, r, seed = (int(g[k]) for k in ("B", "C", "H", "W", "radius", "seed"))
+    f1 = rand_tensor((B, C, H, W), seed).requires_grad_(True)
+    f2 = rand_tensor((B, C, H, W), seed + 1).requires_grad_(True)
+    pyr = O.corr_pyramid(f1, f2, 4)
+    for l in range(4):
+        close(pyr[l].detach(), g[f"pyr{l}"], 2e-5)
+    coords = T(g["coords"])
+    out = O.corr_lookup(pyr, coords, r)
+    close(out.detach(), g["out"], 5e-5)
+    up = rand_tensor(tuple(out.shape), seed + 3)
+    (out * up).sum().backward()
+    close(f1.grad, g["dfmap1"], 1e-4)
+    close(f2.grad, g["dfmap2"], 1e-4)
+
+
+@pytest.mark.parametrize("name", ["corr_tiny", "corr_odd", "corr_mid"])
+def test_alt_corr_equals_corrblock(name):
+    """a4/a5: the on-the-fly path must reproduce CorrBlock."""
+    g = load(name)
+    B, C, H, W, r, seed = (int(g[k]) for k in ("B", "C", "H", "W", "radius", "seed"))
+    f1 = rand_tensor((B, C, H, W), seed).requires_grad_(True)
+    f2 = rand_tensor((B, C, H, W), seed + 1).requires_grad_(True)
+    out = O.alt_corr_lookup(f1, f2, T(g["coords"]), 4, r)
+    close(out.detach(), g["out"], 1e-4)
+    up = rand_tensor(tuple(out.shape), seed + 3)
+    (out * up).sum().backward()
+    close(f1.grad, g["dfmap1"], 2e-4)
+    close(f2.grad, g["dfmap2"], 2e-4)
+
+
+@pytest.mark.parametrize("tag", ["basic", "small"])
+def test_update_block(tag):
+    g = load("update_" + tag)
+    small = tag == "small"
+    shapes = json.load(open(os.path.join(G, f"update_{tag}_shapes.json")))
+    seed = int(g["seed"])
+    sd = {k: v.requires_grad_(True) for k, v in procedural_state_dict(shapes, seed).items()}
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    hd, cd, r = (96, 64, 3) if small else (128, 128, 4)
+    cp = 4 * (2 * r + 1) ** 2
+    net = torch.tanh(rand_tensor((B, hd, H, W), seed + 10)).requires_grad_(True)
+    inp = torch.relu(rand_tensor((B, cd, H, W), seed + 11)).requires_grad_(True)
+    corr = rand_tensor((B, cp, H, W), seed + 12, 2.0).requires_grad_(True)
+    flow = rand_tensor((B, 2, H, W), seed + 13, 3.0).requires_grad_(True)
+    fn = O.small_update_block if small else O.basic_update_block
+    net2, mask, delta = fn(sd, "", net, inp, corr, flow)
+    close(net2.detach(), g["net_out"], 1e-5)
+    close(delta.detach(), g["delta"], 1e-5)
+    loss = (net2 * rand_tensor(tuple(net2.shape), seed + 20)).sum() + (delta * rand_tensor(tuple(delta.shape), seed + 21)).sum()
+    if mask is not None:
+        close(mask.detach(), g["mask"], 1e-5)
+        loss = loss + (mask * rand_tensor(tuple(mask.shape), seed + 22)).sum()
+    loss.backward()
+    close(net.grad, g["dnet"], 1e-4)
+    close(inp.grad, g["dinp"], 1e-4)
+    close(corr.grad, g["dcorr"], 1e-4)
+    close(flow.grad, g["dflow"], 1e-4)
+    for k, p in sd.items():
+        gr = p.grad.reshape(-1)
+        np.testing.assert_allclose(gr.norm().item(), float(g["dparam_norm." + k]), rtol=1e-4)
+        samp = gr if gr.numel() <= 4096 else gr[:: gr.numel() // 4096][:4096]
+        close(samp, g["dparam." + k], 1e-4, 1e-3)
+
+
+def test_upsample_and_helpers():
+    g = load("upsample")
+    N, H, W = int(g["N"]), int(g["H"]), int(g["W"])
+    flow = rand_tensor((N, 2, H, W), 401, 2.0).requires_grad_(True)
+    mask = rand_tensor((N, 576, H, W), 402, 1.5).requires_grad_(True)
+    up = O.upsample_flow(flow, mask)
+    close(up.detach(), g["up"], 1e-5)
+    (up * rand_tensor(tuple(up.shape), 403)).sum().backward()
+    close(flow.grad, g["dflow"], 1e-5)
+    close(mask.grad, g["dmask"], 1e-5)
+    h = load("helpers")
+    close(O.upflow8(rand_tensor((2, 2, 5, 7), 411, 2.0)), h["upflow8"], 1e-5)
+    close(O.coords_grid(2, 3, 5), h["coords_grid"], 0)
+    for k, v in h.items():
+        if k.startswith("pad_"):
+            _, mode, ht, wd = k.split("_")
+            assert O.input_pad_amounts(int(ht), int(wd), mode) == list(v)
+
+
+@pytest.mark.parametrize("name", ["e2e_small_128x256", "e2e_basic_368x496"])
+def test_end_to_end_flow(name):
+    g = load(name)
+    small = bool(g["small"])
+    shapes = json.load(open(os.path.join(G, f"raft_{'small' if small else 'basic'}_shapes.json")))
+    seed = int(g["seed"])
+    sd = procedural_state_dict(shapes, seed)
+    im1, im2 = synthetic_pair(int(g["B"]), int(g["H"]), int(g["W"]), seed + 1)
+    with torch.no_grad():
+        low, up = O.raft_forward(sd, im1, im2, iters=int(g["iters"]), small=small, test_mode=True)
+    s = int(g["stride"])
+    e_low = O.epe(low, T(g["flow_low"])).item()
+    e_up = O.epe(up[:, :, ::s, ::s], T(g["flow_up_strided"])).item()
+    assert e_low < 1e-4 and e_up < 1e-4, (e_low, e_up)
+
+
+@pytest.mark.parametrize("tag", ["basic", "small"])
+def test_train_step_grads(tag):
+    g = load("train_step_" + tag)
+    small = tag == "small"
+    shapes = json.load(open(os.path.join(G, f"raft_{tag}_shapes.json")))
+    seed = int(g["seed"])
+    sd = procedural_state_dict(shapes, seed)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    im1, im2 = synthetic_pair(2, int(g["H"]), int(g["W"]), seed + 1)
+    preds = O.raft_forward(sd, im1, im2, iters=int(g["iters"]), small=small)
+    loss = O.sequence_loss_zero_gt(preds)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    loss.backward()
+    bad = []
+    for k in g:
+        if not k.startswith("gnorm."):
+            continue
+        name = k[len("gnorm."):]
+        gr = sd[name].grad
+        gn = 0.0 if gr is None else gr.norm().item()
+        ref = float(g[k])
+        if abs(gn - ref) > 1e-3 * max(ref, 1e-6) + 1e-7:
+            bad.append((name, gn, ref))
+    assert not bad, bad[:5]
