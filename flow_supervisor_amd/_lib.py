@@ -1,0 +1,118 @@
+"""ctypes binding of libfsraft.so (the C ABI declared in include/fsraft.h).
+
+This is the only place the shared library is loaded.  There is NO fallback: if the
+library is missing or a kernel launch fails, the caller gets a RuntimeError.
+`import torch` happens first on purpose so that libfsraft's NEEDED libamdhip64.so.7
+resolves to the HIP runtime torch already loaded (one runtime per process).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsraft.so")
+_lib = None
+
+c_float_p = c_void_p      # device pointers travel as integers
+
+
+class ConvDesc(Structure):
+    """Mirror of struct fsraft_conv_desc (include/fsraft.h)."""
+    _fields_ = [
+        ("src", c_void_p * 3), ("srcC", c_int * 3), ("srcld", c_int * 3), ("nsrc", c_int),
+        ("wpk", c_void_p), ("bias", c_void_p),
+        ("B", c_int), ("H", c_int), ("W", c_int), ("KH", c_int), ("KW", c_int), ("N", c_int),
+        ("dst", c_void_p * 3), ("dst_bs", c_int64 * 3), ("dst_ps", c_int64 * 3), ("dst_cs", c_int64 * 3),
+        ("dst_n0", c_int * 3), ("dst_acc", c_int * 3), ("ndst", c_int),
+        ("relu", c_int), ("alpha", c_float),
+        ("epi", c_int),
+        ("h", c_void_p), ("ldh", c_int), ("z", c_void_p), ("ldz", c_int),
+        ("aux1", c_void_p), ("ld1", c_int), ("aux2", c_void_p), ("ld2", c_int), ("hid", c_int),
+    ]
+
+
+_PP = POINTER(c_void_p)
+_IP = POINTER(c_int)
+_S = c_void_p   # hipStream_t
+
+SIGNATURES = {
+    "fsraft_corr_build": [c_void_p, c_void_p, _PP, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_unpool_bwd": [_PP, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_lookup_fwd": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_lookup_bwd": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_altcorr_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_altcorr_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_upsample_fwd": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, _S],
+    "fsraft_upsample_bwd": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _S],
+    "fsraft_upflow8_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_upflow8_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_conv_ktot": [_IP, c_int, c_int, c_int],
+    "fsraft_conv_forward": [POINTER(ConvDesc), _S],
+    "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
+    "fsraft_gemm_f32": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _S],
+    "fsraft_nchw_to_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_im2col7": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_col2im7": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_flow_to_nhwc": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_nhwc_to_flow": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, _S],
+    "fsraft_relu_bwd": [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, _S],
+    "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, _S],
+    "fsraft_gru_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, _S],
+    "fsraft_col_sum": [c_void_p, c_int, c_int64, c_int, c_void_p, c_float, _S],
+    "fsraft_axpby": [c_void_p, c_void_p, c_float, c_float, c_int64, _S],
+}
+
+
+def load():
+    """Load libfsraft.so once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C flow_supervisor_amd/csrc`). There is no CPU/eager fallback for the RAFT hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"libfsraft: {what} failed with status {rc} "
+                           f"({'bad argument' if rc == 1 else 'kernel launch error'})")
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def ptr_array(tensors):
+    arr = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return ctypes.cast(arr, _PP), arr
+
+
+def int_array(vals):
+    return (c_int * len(vals))(*vals)
+
+
+def require_cuda_f32(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("fsraft ops need CUDA (ROCm) tensors; the hot path has no CPU implementation")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"fsraft ops are fp32-only, got {t.dtype}")

@@ -1,0 +1,114 @@
+"""Feature / context encoders.  These are callers of the hot path, kept as PyTorch-ROCm
+convolutions on purpose (BASELINE.json north_star); only the module/parameter names of
+pytorch/core/extractor.py are reproduced so reference checkpoints load (state_dict keys
+``conv1``, ``norm1``, ``layer{1,2,3}.{0,1}.conv{1,2,3}``, ``...downsample.{0,1}``, ``conv2``).
+"""
+import torch
+import torch.nn as nn
+
+
+def _make_norm(kind, ch, groups):
+    if kind == "group":
+        return nn.GroupNorm(num_groups=groups, num_channels=ch)
+    if kind == "batch":
+        return nn.BatchNorm2d(ch)
+    if kind == "instance":
+        return nn.InstanceNorm2d(ch)
+    if kind == "none":
+        return nn.Sequential()
+    raise ValueError(kind)
+
+
+class _Block(nn.Module):
+    """Residual unit.  `widths` lists (out_channels, kernel) of its convolutions; the first 3x3
+    carries the stride.  The shortcut norm is the same module object as downsample[1], which is
+    why it also appears under its own name (norm3 / norm4) in reference checkpoints."""
+
+    def __init__(self, cin, cout, norm_fn, stride, bottleneck):
+        super().__init__()
+        mid = cout // 4
+        if bottleneck:
+            spec = [(cin, mid, 1, 1), (mid, mid, 3, stride), (mid, cout, 1, 1)]
+        else:
+            spec = [(cin, cout, 3, stride), (cout, cout, 3, 1)]
+        groups = cout // 8
+        self.n = len(spec)
+        for i, (a, b, k, s) in enumerate(spec, 1):
+            setattr(self, f"conv{i}", nn.Conv2d(a, b, kernel_size=k, padding=k // 2, stride=s))
+        for i, (a, b, k, s) in enumerate(spec, 1):
+            setattr(self, f"norm{i}", _make_norm(norm_fn, b, groups))
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1:
+            short = _make_norm(norm_fn, cout, groups)
+            setattr(self, f"norm{self.n + 1}", short)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, stride=stride), short)
+
+    def forward(self, x):
+        y = x
+        for i in range(1, self.n + 1):
+            y = self.relu(getattr(self, f"norm{i}")(getattr(self, f"conv{i}")(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class ResidualBlock(_Block):
+    def __init__(self, in_planes, planes, norm_fn="group", stride=1):
+        super().__init__(in_planes, planes, norm_fn, stride, bottleneck=False)
+
+
+class BottleneckBlock(_Block):
+    def __init__(self, in_planes, planes, norm_fn="group", stride=1):
+        super().__init__(in_planes, planes, norm_fn, stride, bottleneck=True)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, widths, block, stem_groups, output_dim, norm_fn, dropout):
+        super().__init__()
+        self.norm_fn = norm_fn
+        c0, c1, c2 = widths
+        self.norm1 = _make_norm(norm_fn, c0, stem_groups)
+        self.conv1 = nn.Conv2d(3, c0, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = nn.Sequential(block(c0, c0, norm_fn, 1), block(c0, c0, norm_fn, 1))
+        self.layer2 = nn.Sequential(block(c0, c1, norm_fn, 2), block(c1, c1, norm_fn, 1))
+        self.layer3 = nn.Sequential(block(c1, c2, norm_fn, 2), block(c2, c2, norm_fn, 1))
+        self.conv2 = nn.Conv2d(c2, output_dim, kernel_size=1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        pair = isinstance(x, (tuple, list))
+        if pair:
+            n = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        x = self.conv2(x)
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        if pair:
+            x = torch.split(x, [n, n], dim=0)
+        return x
+
+
+class BasicEncoder(_Encoder):
+    """extractor.py:118-192: 64/96/128 residual stages to 1/8 resolution."""
+
+    def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0):
+        super().__init__((64, 96, 128), ResidualBlock, 8, output_dim, norm_fn, dropout)
+
+
+class SmallEncoder(_Encoder):
+    """extractor.py:195-267: 32/64/96 bottleneck stages."""
+
+    def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0):
+        super().__init__((32, 64, 96), BottleneckBlock, 8, output_dim, norm_fn, dropout)

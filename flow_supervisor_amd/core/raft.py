@@ -1,0 +1,127 @@
+"""RAFT model shell around the HIP hot path.  Same constructor, ``forward`` signature, return
+values and state_dict keys as pytorch/core/raft.py:24-144; the loop body differs only in that
+tensors between the lookup, the update block and the upsampler stay channels-last so no
+layout conversion (and no torch.cat / softmax / unfold) runs per iteration.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .corr import AlternateCorrBlock, CorrBlock
+from .extractor import BasicEncoder, SmallEncoder
+from .update import BasicUpdateBlock, SmallUpdateBlock, to_channels_last
+from .utils.utils import coords_grid, upflow8
+
+autocast = torch.autocast
+
+
+class _ConvexUpsample(torch.autograd.Function):
+    """upsample_flow on the HIP kernel; mask is channels-last [N,H,W,576]."""
+
+    @staticmethod
+    def forward(ctx, flow, mask_cl):
+        ctx.save_for_backward(flow, mask_cl)
+        return ops.upsample_fwd(flow, mask_cl)
+
+    @staticmethod
+    def backward(ctx, g):
+        flow, mask_cl = ctx.saved_tensors
+        dflow, dmask = ops.upsample_bwd(flow, mask_cl, g)
+        return dflow, dmask
+
+
+def convex_upsample(flow, mask, channels_last=False):
+    """[N,2,H,W] x mask -> [N,2,8H,8W] (raft.py:72-83).  mask is [N,576,H,W] unless channels_last."""
+    flow = flow.float()
+    if not channels_last:
+        mask = to_channels_last(mask.float())
+    if flow.stride(2) != flow.shape[3] * flow.stride(3):
+        flow = flow.contiguous()
+    return _ConvexUpsample.apply(flow, mask)
+
+
+class RAFT(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        if args.small:
+            self.hidden_dim, self.context_dim = 96, 64
+            args.corr_levels, args.corr_radius = 4, 3
+        else:
+            self.hidden_dim, self.context_dim = 128, 128
+            args.corr_levels, args.corr_radius = 4, 4
+        if "dropout" not in self.args:
+            self.args.dropout = 0
+        if "alternate_corr" not in self.args:
+            self.args.alternate_corr = False
+        if "mixed_precision" not in self.args:
+            self.args.mixed_precision = False
+        hdim, cdim = self.hidden_dim, self.context_dim
+        if args.small:
+            self.fnet = SmallEncoder(output_dim=128, norm_fn="instance", dropout=args.dropout)
+            self.cnet = SmallEncoder(output_dim=hdim + cdim, norm_fn="none", dropout=args.dropout)
+            self.update_block = SmallUpdateBlock(self.args, hidden_dim=hdim)
+        else:
+            self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
+            self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
+            self.update_block = BasicUpdateBlock(self.args, hidden_dim=hdim)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def initialize_flow(self, img):
+        """coords0 == coords1 == pixel grid at 1/8 resolution; flow = coords1 - coords0 (raft.py:63-70)."""
+        N, C, H, W = img.shape
+        c = coords_grid(N, H // 8, W // 8, device=img.device)
+        return c, c.clone()
+
+    def upsample_flow(self, flow, mask):
+        """[N,2,H,W], [N,576,H,W] -> [N,2,8H,8W] convex combination (raft.py:72-83)."""
+        return convex_upsample(flow, mask)
+
+    def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        hdim, cdim = self.hidden_dim, self.context_dim
+        amp = bool(self.args.mixed_precision)
+
+        with autocast("cuda", enabled=amp):
+            fmap1, fmap2 = self.fnet([image1, image2])
+        fmap1, fmap2 = fmap1.float(), fmap2.float()
+        if self.args.alternate_corr:
+            corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+        else:
+            corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+
+        with autocast("cuda", enabled=amp):
+            cnet = self.cnet(image1)
+        net, inp = torch.split(cnet.float(), [hdim, cdim], dim=1)
+        net = to_channels_last(torch.tanh(net))          # hidden state stays channels-last in the loop
+        inp = to_channels_last(torch.relu(inp))
+
+        coords0, coords1 = self.initialize_flow(image1)
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+
+        flow_predictions = []
+        flow_up = None
+        for _ in range(iters):
+            coords1 = coords1.detach()
+            if self.args.alternate_corr:
+                corr = to_channels_last(corr_fn(coords1))
+            else:
+                corr = corr_fn(coords1, channels_last=True)
+            flow = coords1 - coords0
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow)
+            coords1 = coords1 + delta_flow
+            if up_mask is None:
+                flow_up = upflow8(coords1 - coords0)
+            else:
+                flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+            flow_predictions.append(flow_up)
+
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions

@@ -1,0 +1,491 @@
+"""RAFT update blocks on hand-written HIP kernels (rows a6-a8 of SURVEY.md section 8).
+
+Drop-in for pytorch/core/update.py of the reference: the public classes
+``BasicUpdateBlock`` / ``SmallUpdateBlock`` (and the sub-module containers
+``BasicMotionEncoder``, ``SmallMotionEncoder``, ``SepConvGRU``, ``ConvGRU``, ``FlowHead``)
+keep the reference's constructor arguments, ``forward`` signatures, return values and
+state_dict keys/shapes (update.py:6-136), so reference checkpoints load unchanged.
+
+What differs is the execution: the sub-modules only own parameters.  A forward call runs
+one ``autograd.Function`` whose forward and backward are explicit sequences of libfsraft
+kernels (implicit-GEMM convolutions on fp32 MFMA with fused bias / ReLU / GRU-gate
+epilogues, weight-gradient GEMMs, and a handful of elementwise kernels) over channels-last
+buffers.  torch.cat never materialises: convolutions read up to three source tensors and
+write into channel slices.  There is no eager/PyTorch fallback: without libfsraft.so, or
+on CPU tensors, forward raises.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from ..ops import Dst, V
+
+
+# --------------------------------------------------------------------------- containers
+class FlowHead(nn.Module):
+    """Parameter container, update.py:6-14 (conv1 3x3 in->hidden, conv2 3x3 hidden->2)."""
+
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+
+
+class ConvGRU(nn.Module):
+    """Parameter container, update.py:16-31 (3x3 gates)."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        for n in ("convz", "convr", "convq"):
+            setattr(self, n, nn.Conv2d(hidden_dim + input_dim, hidden_dim, 3, padding=1))
+
+
+class SepConvGRU(nn.Module):
+    """Parameter container, update.py:33-60 ((1,5) pass then (5,1) pass)."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        for n in ("convz1", "convr1", "convq1"):
+            setattr(self, n, nn.Conv2d(hidden_dim + input_dim, hidden_dim, (1, 5), padding=(0, 2)))
+        for n in ("convz2", "convr2", "convq2"):
+            setattr(self, n, nn.Conv2d(hidden_dim + input_dim, hidden_dim, (5, 1), padding=(2, 0)))
+
+
+class SmallMotionEncoder(nn.Module):
+    """Parameter container, update.py:62-77."""
+
+    def __init__(self, args):
+        super().__init__()
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 96, 1, padding=0)
+        self.convf1 = nn.Conv2d(2, 64, 7, padding=3)
+        self.convf2 = nn.Conv2d(64, 32, 3, padding=1)
+        self.conv = nn.Conv2d(128, 80, 3, padding=1)
+
+
+class BasicMotionEncoder(nn.Module):
+    """Parameter container, update.py:79-97."""
+
+    def __init__(self, args):
+        super().__init__()
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+# --------------------------------------------------------------------------- layer table
+class _Layer:
+    """One GEMM of the block: which parameters form its weight, its taps and its inputs."""
+
+    def __init__(self, key, wnames, kh, kw, src_c, view_as=None):
+        self.key = key              # short id
+        self.wnames = wnames        # parameter prefixes concatenated along Cout (e.g. convz1+convr1)
+        self.kh, self.kw = kh, kw
+        self.src_c = src_c          # channel counts of the concatenated inputs
+        self.view_as = view_as      # (Cin, kh, kw) to reinterpret the OIHW weight (7x7 conv as 1x1 over im2col)
+
+
+class _Engine:
+    """Owns the packed-weight cache and runs the kernel sequences of one update block."""
+
+    def __init__(self, module, small):
+        self.m = module
+        self.small = small
+        if small:
+            self.corr_c, self.c1, self.c2, self.f1, self.f2, self.cv = module.cor_planes, 96, 0, 64, 32, 80
+            self.hid, self.inp_c, self.head_c, self.has_mask = 96, 64, 128, False
+            passes = [("", 3, 3)]
+        else:
+            self.corr_c, self.c1, self.c2, self.f1, self.f2, self.cv = module.cor_planes, 256, 192, 128, 64, 126
+            self.hid, self.inp_c, self.head_c, self.has_mask = 128, 128, 256, True
+            passes = [("1", 1, 5), ("2", 5, 1)]
+        self.passes = passes
+        self.mot_c = self.cv + 2                                   # motion features = [conv out | flow]
+        cor_out = self.c2 if self.c2 else self.c1                  # channels the corr branch contributes to cor_flo
+        self.cf_c = cor_out + self.f2
+        hid, inp_c, mot = self.hid, self.inp_c, self.mot_c
+        ls = [_Layer("c1", ["encoder.convc1"], 1, 1, [self.corr_c])]
+        if self.c2:
+            ls.append(_Layer("c2", ["encoder.convc2"], 3, 3, [self.c1]))
+        ls += [
+            _Layer("f1", ["encoder.convf1"], 1, 1, [98], view_as=(98, 1, 1)),
+            _Layer("f2", ["encoder.convf2"], 3, 3, [self.f1]),
+            _Layer("cv", ["encoder.conv"], 3, 3, [self.cf_c]),
+        ]
+        for sfx, kh, kw in passes:
+            ls.append(_Layer("zr" + sfx, ["gru.convz" + sfx, "gru.convr" + sfx], kh, kw, [hid, inp_c, mot]))
+            ls.append(_Layer("q" + sfx, ["gru.convq" + sfx], kh, kw, [hid, inp_c, mot]))
+        if self.has_mask:
+            ls.append(_Layer("hd", ["flow_head.conv1", "mask.0"], 3, 3, [hid]))
+            ls.append(_Layer("m2", ["mask.2"], 1, 1, [self.head_c]))
+        else:
+            ls.append(_Layer("hd", ["flow_head.conv1"], 3, 3, [hid]))
+        ls.append(_Layer("fh2", ["flow_head.conv2"], 3, 3, [self.head_c]))
+        self.layers = {l.key: l for l in ls}
+        self.order = [l.key for l in ls]
+        self.pnames = []                                            # flat parameter order fed to the Function
+        for l in ls:
+            for w in l.wnames:
+                self.pnames += [w + ".weight", w + ".bias"]
+        self._cache_key = None
+        self._cache = None
+
+    # ---- parameters -------------------------------------------------------------
+    def params(self):
+        sd = dict(self.m.named_parameters())
+        return [sd[n] for n in self.pnames]
+
+    def _packed(self, params):
+        """{key: (wpk_fwd, wpk_dgrad, bias, out_channels, oihw_shape)}; repacked when any parameter changed."""
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key == self._cache_key:
+            return self._cache
+        byname = dict(zip(self.pnames, params))
+        out = {}
+        with torch.no_grad():
+            for k in self.order:
+                l = self.layers[k]
+                ws = [byname[w + ".weight"].detach() for w in l.wnames]
+                bs = [byname[w + ".bias"].detach() for w in l.wnames]
+                w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
+                b = bs[0] if len(bs) == 1 else torch.cat(bs, 0)
+                if l.view_as is not None:
+                    w = w.reshape(w.shape[0], *l.view_as)
+                w = w.contiguous().float()
+                out[k] = (ops.pack_weight(w, l.src_c, 0), ops.pack_weight(w, l.src_c, 1), b.contiguous().float(),
+                          w.shape[0], tuple(w.shape))
+        self._cache_key, self._cache = key, out
+        return out
+
+    # ---- forward ------------------------------------------------------------------
+    def forward(self, net, inp, corr, flow, params, save):
+        """net/inp/corr: channels-last [B,H,W,C]; flow: [B,2,H,W] (any pixel stride).
+        Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
+        a dict of the intermediates backward needs."""
+        L.require_cuda_f32(net, inp, corr, flow)
+        B, H, W, _ = net.shape
+        dev = net.device
+        P = self._packed(params)
+
+        def buf(c, zero=False):
+            ld = _pad4(c)
+            f = torch.zeros if (zero or ld != c) else torch.empty
+            return f(B, H, W, ld, device=dev, dtype=torch.float32)
+
+        def conv(k, srcs, dsts, relu=False, alpha=1.0, **kw):
+            l = self.layers[k]
+            wpk, _, bias, n, _ = P[k]
+            ops.conv_forward(srcs, wpk, bias, B, H, W, l.kh, l.kw, n, dsts, relu=relu, alpha=alpha, **kw)
+
+        hid = self.hid
+        cor1 = buf(self.c1) if self.c2 else None
+        corflo = buf(self.cf_c)
+        cols = buf(98)
+        flo1 = buf(self.f1)
+        motion = buf(self.mot_c)
+        if self.c2:
+            conv("c1", [V(corr, self.corr_c)], [Dst.nhwc(cor1)], relu=True)
+            conv("c2", [V(cor1, self.c1)], [Dst.nhwc(corflo)], relu=True)
+            cor_out = self.c2
+        else:
+            conv("c1", [V(corr, self.corr_c)], [Dst.nhwc(corflo)], relu=True)
+            cor_out = self.c1
+        ops.im2col7(flow, cols)
+        conv("f1", [V(cols, 98)], [Dst.nhwc(flo1)], relu=True)
+        conv("f2", [V(flo1, self.f1)], [Dst.nhwc(corflo, cor_out)], relu=True)
+        conv("cv", [V(corflo, self.cf_c)], [Dst.nhwc(motion)], relu=True)
+        ops.flow_to_nhwc(flow, motion, self.cv)
+
+        h = net
+        gates = []
+        for sfx, _, _ in self.passes:
+            z, r, rh, q, hn = buf(hid), buf(hid), buf(hid), buf(hid), buf(hid)
+            xs = [V(inp, self.inp_c), V(motion, self.mot_c)]
+            conv("zr" + sfx, [V(h, hid)] + xs, [Dst.nhwc(z)], epi=2, h=h, aux1=rh, aux2=r, hid=hid)
+            conv("q" + sfx, [V(rh, hid)] + xs, [Dst.nhwc(hn)], epi=3, h=h, z=z, aux1=q)
+            gates.append((h, z, r, rh, q))
+            h = hn
+        nhead = self.head_c * (2 if self.has_mask else 1)
+        head = buf(nhead)
+        conv("hd", [V(h, hid)], [Dst.nhwc(head)], relu=True)
+        delta = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
+        conv("fh2", [V(head, self.head_c)], [Dst.nchw(delta)])
+        mask = None
+        if self.has_mask:
+            mask = buf(576)
+            conv("m2", [V(head, self.head_c, self.head_c)], [Dst.nhwc(mask)], alpha=0.25)
+        saved = None
+        if save:
+            saved = dict(B=B, H=H, W=W, corr=corr, inp=inp, cor1=cor1, corflo=corflo, cols=cols, flo1=flo1,
+                         motion=motion, gates=gates, hlast=h, head=head)
+        return h, mask, delta, saved
+
+    # ---- backward -----------------------------------------------------------------
+    def backward(self, S, params, dnet_out, dmask, ddelta, need_input_grads=True):
+        """Returns (dnet, dinp, dcorr, dflow, [param grads in self.pnames order])."""
+        B, H, W = S["B"], S["H"], S["W"]
+        dev = S["corr"].device
+        P = self._packed(params)
+        lib = L.load()
+        M = B * H * W
+        hid = self.hid
+
+        def buf(c, zero=False):
+            ld = _pad4(c)
+            f = torch.zeros if (zero or ld != c) else torch.empty
+            return f(B, H, W, ld, device=dev, dtype=torch.float32)
+
+        dW = {k: torch.zeros_like(P[k][0]) for k in self.order}
+        dB = {k: torch.zeros(P[k][3], device=dev, dtype=torch.float32) for k in self.order}
+
+        def relu_bwd(g, y):
+            L.check(lib.fsraft_relu_bwd(L.c_void_p(g.ptr), g.ld, L.c_void_p(y.ptr), y.ld, M, g.C, L.stream()), "relu_bwd")
+
+        def wgrad(k, dy, srcs):
+            l = self.layers[k]
+            ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw)
+            ops.col_sum_v(dy, dB[k])
+
+        def dgrad(k, dy, dsts):
+            l = self.layers[k]
+            n_in = sum(l.src_c)
+            ops.conv_forward([dy], P[k][1], None, B, H, W, l.kh, l.kw, n_in, dsts)
+
+        # ---- heads
+        dhead = buf(self.head_c * (2 if self.has_mask else 1))
+        head = S["head"]
+        if self.has_mask:
+            if dmask is not None:
+                g = torch.empty(B, H, W, 576, device=dev, dtype=torch.float32)
+                ops.axpby_(dmask.contiguous(), g, 0.25, 0.0)      # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask
+                wgrad("m2", V(g, 576), [V(head, self.head_c, self.head_c)])
+                dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c)])
+            else:
+                dhead[..., self.head_c:].zero_()
+        dd = torch.zeros(B, H, W, 4, device=dev, dtype=torch.float32)
+        if ddelta is not None:
+            ops.flow_to_nhwc(ddelta, dd, 0)
+            wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
+            dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0)])
+        else:
+            dhead[..., : self.head_c].zero_()
+        relu_bwd(V(dhead), V(head))
+        hlast = S["hlast"]
+        wgrad("hd", V(dhead), [V(hlast, hid)])
+        dh = buf(hid)
+        if dnet_out is not None:
+            dh.copy_(dnet_out)
+            dgrad("hd", V(dhead), [Dst.nhwc(dh, 0, 0, True)])
+        else:
+            dgrad("hd", V(dhead), [Dst.nhwc(dh)])
+
+        # ---- GRU passes, last to first
+        inp, motion = S["inp"], S["motion"]
+        dinp = buf(self.inp_c, zero=True)
+        dmotion = buf(self.mot_c, zero=True)
+        for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
+            dzr = buf(2 * hid)
+            dq = buf(hid)
+            dhp = buf(hid)
+            ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid)
+            xs = [V(inp, self.inp_c), V(motion, self.mot_c)]
+            wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
+            drh = buf(hid)
+            dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dinp, 0, hid, True),
+                                          Dst.nhwc(dmotion, 0, hid + self.inp_c, True)])
+            ops.gru_bwd2(drh, r, h, dzr, dhp, hid)
+            wgrad("zr" + sfx, V(dzr, 2 * hid), [V(h, hid)] + xs)
+            dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), Dst.nhwc(dinp, 0, hid, True),
+                                                Dst.nhwc(dmotion, 0, hid + self.inp_c, True)])
+            dh = dhp
+
+        # ---- motion encoder
+        dflow = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
+        ops.nhwc_to_flow(dmotion, self.cv, dflow, False)
+        relu_bwd(V(dmotion, self.cv), V(motion, self.cv))
+        corflo = S["corflo"]
+        wgrad("cv", V(dmotion, self.cv), [V(corflo, self.cf_c)])
+        dcorflo = buf(self.cf_c)
+        dgrad("cv", V(dmotion, self.cv), [Dst.nhwc(dcorflo)])
+        relu_bwd(V(dcorflo, self.cf_c), V(corflo, self.cf_c))
+        cor_out = self.c2 if self.c2 else self.c1
+        flo1 = S["flo1"]
+        wgrad("f2", V(dcorflo, self.f2, cor_out), [V(flo1, self.f1)])
+        dflo1 = buf(self.f1)
+        dgrad("f2", V(dcorflo, self.f2, cor_out), [Dst.nhwc(dflo1)])
+        relu_bwd(V(dflo1, self.f1), V(flo1, self.f1))
+        cols = S["cols"]
+        wgrad("f1", V(dflo1, self.f1), [V(cols, 98)])
+        dcols = buf(98)
+        dgrad("f1", V(dflo1, self.f1), [Dst.nhwc(dcols)])
+        ops.col2im7(dcols, dflow, True)
+        corr = S["corr"]
+        dcorr = buf(self.corr_c) if need_input_grads else None
+        if self.c2:
+            cor1 = S["cor1"]
+            wgrad("c2", V(dcorflo, self.c2, 0), [V(cor1, self.c1)])
+            dcor1 = buf(self.c1)
+            dgrad("c2", V(dcorflo, self.c2, 0), [Dst.nhwc(dcor1)])
+            relu_bwd(V(dcor1, self.c1), V(cor1, self.c1))
+            wgrad("c1", V(dcor1, self.c1), [V(corr, self.corr_c)])
+            if need_input_grads:
+                dgrad("c1", V(dcor1, self.c1), [Dst.nhwc(dcorr)])
+        else:
+            wgrad("c1", V(dcorflo, self.c1, 0), [V(corr, self.corr_c)])
+            if need_input_grads:
+                dgrad("c1", V(dcorflo, self.c1, 0), [Dst.nhwc(dcorr)])
+
+        # ---- unpack parameter gradients (packed layout -> OIHW), split fused layers back
+        grads = {}
+        for k in self.order:
+            l = self.layers[k]
+            shape = P[k][4]
+            gw = ops.unpack_weight_grad(dW[k], shape, l.src_c)
+            o = 0
+            for wname in l.wnames:
+                p = dict(zip(self.pnames, params))[wname + ".weight"]
+                n = p.shape[0]
+                grads[wname + ".weight"] = gw[o:o + n].reshape(p.shape)
+                grads[wname + ".bias"] = dB[k][o:o + n]
+                o += n
+        if self.has_mask:
+            # y = 0.25*(Wx+b): dW and db of mask.2 were computed from g = 0.25*dmask, nothing more to do
+            pass
+        return dh, dinp, dcorr, dflow, [grads[n] for n in self.pnames]
+
+
+class _UpdateFn(torch.autograd.Function):
+    """(net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
+
+    @staticmethod
+    def forward(ctx, engine, net, inp, corr, flow, *params):
+        need = torch.is_grad_enabled() and any(t.requires_grad for t in (net, inp, corr, flow) + params)
+        h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need)
+        ctx.engine = engine
+        ctx.saved = saved
+        ctx.params = params
+        ctx.has_mask = mask is not None
+        if mask is None:
+            mask = torch.empty(0, device=net.device)
+            ctx.mark_non_differentiable(mask)
+        return h, mask, delta
+
+    @staticmethod
+    def backward(ctx, dh, dmask, ddelta):
+        eng = ctx.engine
+        S, ctx.saved = ctx.saved, None
+        if S is None:
+            raise RuntimeError("update block backward called twice without retain_graph support")
+        dmask = dmask if ctx.has_mask else None
+        dh = dh.contiguous() if dh is not None else None
+        dnet, dinp, dcorr, dflow, pg = eng.backward(S, ctx.params, dh, dmask, ddelta)
+        return (None, dnet, dinp, dcorr, dflow) + tuple(pg)
+
+
+class _ToCL(torch.autograd.Function):
+    """NCHW-contiguous -> channels-last buffer [B,H,W,C] via the fsraft transpose kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.nchw_to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nhwc_to_nchw(g.contiguous())
+
+
+class _FromCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.nhwc_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nchw_to_nhwc(g)
+
+
+def to_channels_last(x):
+    """[B,C,H,W] -> [B,H,W,C] (C must be a multiple of 4 for the GEMM kernels)."""
+    if x.shape[1] % 4 != 0:
+        raise RuntimeError("channel count must be a multiple of 4")
+    return _ToCL.apply(x)
+
+
+def from_channels_last(x):
+    return _FromCL.apply(x)
+
+
+class _UpdateBlockBase(nn.Module):
+    small = False
+
+    def _engine(self):
+        e = self.__dict__.get("_eng")
+        if e is None:
+            e = _Engine(self, self.small)
+            self.__dict__["_eng"] = e
+        return e
+
+    def forward_cl(self, net, inp, corr, flow):
+        """Channels-last entry used by our RAFT loop: no layout conversion at all.
+        net/inp/corr: [B,H,W,C]; flow: [B,2,H,W].  Returns (net', mask_cl or None, delta)."""
+        eng = self._engine()
+        h, mask, delta = _UpdateFn.apply(eng, net, inp, corr, flow, *eng.params())
+        return h, (mask if eng.has_mask else None), delta
+
+    def _forward_nchw(self, net, inp, corr, flow):
+        cache = self.__dict__.setdefault("_inp_cache", [None, None])
+        key = (inp.data_ptr(), inp._version, tuple(inp.shape))
+        if cache[0] != key or (inp.requires_grad and torch.is_grad_enabled()):
+            inp_cl = to_channels_last(inp)
+            if not inp.requires_grad:
+                cache[0], cache[1] = key, inp_cl
+        else:
+            inp_cl = cache[1]
+        h, mask, delta = self.forward_cl(to_channels_last(net), inp_cl, to_channels_last(corr), flow)
+        return from_channels_last(h), (from_channels_last(mask) if mask is not None else None), delta
+
+
+class SmallUpdateBlock(_UpdateBlockBase):
+    """update.py:99-112.  forward(net, inp, corr, flow) -> (net, None, delta_flow)."""
+    small = True
+
+    def __init__(self, args, hidden_dim=96):
+        super().__init__()
+        self.cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.encoder = SmallMotionEncoder(args)
+        self.gru = ConvGRU(hidden_dim=hidden_dim, input_dim=82 + 64)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=128)
+        if hidden_dim != 96:
+            raise NotImplementedError("the HIP small update block is built for hidden_dim=96 (the only value RAFT uses)")
+
+    def forward(self, net, inp, corr, flow):
+        return self._forward_nchw(net, inp, corr, flow)
+
+
+class BasicUpdateBlock(_UpdateBlockBase):
+    """update.py:114-136.  forward(net, inp, corr, flow, upsample=True) -> (net, mask, delta_flow)."""
+
+    def __init__(self, args, hidden_dim=128, input_dim=128):
+        super().__init__()
+        self.args = args
+        self.cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.encoder = BasicMotionEncoder(args)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(
+            nn.Conv2d(128, 256, 3, padding=1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(256, 64 * 9, 1, padding=0))
+        if hidden_dim != 128 or input_dim != 128:
+            raise NotImplementedError("the HIP update block is built for hidden_dim=input_dim=128 (RAFT's values)")
+
+    def forward(self, net, inp, corr, flow, upsample=True):
+        return self._forward_nchw(net, inp, corr, flow)

@@ -1,0 +1,62 @@
+"""Helpers with the reference's names and semantics (pytorch/core/utils/utils.py)."""
+import torch
+import torch.nn.functional as F
+
+from ... import ops
+
+
+class InputPadder:
+    """Replicate-pads images so both sides divide by 8 (utils.py:7-24)."""
+
+    def __init__(self, dims, mode="sintel"):
+        self.ht, self.wd = dims[-2:]
+        ph = (((self.ht // 8) + 1) * 8 - self.ht) % 8
+        pw = (((self.wd // 8) + 1) * 8 - self.wd) % 8
+        top = ph // 2 if mode == "sintel" else 0
+        self._pad = [pw // 2, pw - pw // 2, top, ph - top]
+
+    def pad(self, *inputs):
+        return [F.pad(x, self._pad, mode="replicate") for x in inputs]
+
+    def unpad(self, x):
+        ht, wd = x.shape[-2:]
+        l, r, t, b = self._pad
+        return x[..., t:ht - b, l:wd - r]
+
+
+def coords_grid(batch, ht, wd, device=None):
+    """[B,2,ht,wd] float, channel 0 = x, channel 1 = y (utils.py:74-77)."""
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device, dtype=torch.float32),
+                            torch.arange(wd, device=device, dtype=torch.float32), indexing="ij")
+    return torch.stack([xs, ys], dim=0)[None].repeat(batch, 1, 1, 1)
+
+
+def bilinear_sampler(img, coords, mode="bilinear", mask=False):
+    """grid_sample in pixel coordinates, align_corners=True, zero padding (utils.py:57-71).
+    Kept as a framework op: the hot loop does not call it (CorrBlock uses the fused HIP lookup)."""
+    H, W = img.shape[-2:]
+    xgrid, ygrid = coords.split([1, 1], dim=-1)
+    grid = torch.cat([2 * xgrid / (W - 1) - 1, 2 * ygrid / (H - 1) - 1], dim=-1)
+    out = F.grid_sample(img, grid, align_corners=True)
+    if mask:
+        valid = (grid[..., :1] > -1) & (grid[..., 1:] > -1) & (grid[..., :1] < 1) & (grid[..., 1:] < 1)
+        return out, valid.float()
+    return out
+
+
+class _UpFlow8(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow):
+        ctx.hw = flow.shape[-2:]
+        return ops.upflow8_fwd(flow)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.upflow8_bwd(g, *ctx.hw)
+
+
+def upflow8(flow, mode="bilinear"):
+    """8 * bilinear x8 upsampling with align_corners=True (utils.py:80-82) on the HIP kernel."""
+    if mode != "bilinear":
+        return 8 * F.interpolate(flow, size=(8 * flow.shape[2], 8 * flow.shape[3]), mode=mode, align_corners=True)
+    return _UpFlow8.apply(flow)

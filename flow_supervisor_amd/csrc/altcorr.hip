@@ -1,0 +1,197 @@
+// Memory-efficient correlation lookup: windowed dot products straight from the feature
+// maps, never materialising the N x N volume (rows a4, a5 of SURVEY.md section 8).
+// Drop-in for alt_cuda_corr.forward / .backward
+// (pytorch/alt_cuda_corr/correlation.cpp:23-54, correlation_kernel.cu:18-119, 122-256):
+// same tensor layouts, same channel order (iy + (2r+1)*ix, i.e. x offset slow), same
+// zero-outside-the-map rule, unscaled output.  This is a from-scratch wave64 design, not
+// a translation of the 32-thread CUDA blocks:
+//
+//   one wavefront = one query pixel.  Lane l holds channels {l, l+64, l+128, l+192} of the
+//   query's fmap1 vector in registers.  For each of the (2r+2)^2 integer window positions
+//   the wave reads the fmap2 pixel's channel vector as 256-byte coalesced rows and each
+//   lane accumulates a partial dot.  The 64 partials-per-position are combined with a
+//   halving butterfly (63 DPP/shuffle steps for 64 positions instead of 6 per position),
+//   leaving position p's dot on lane p.  The bilinear blend of the 4 neighbouring dots
+//   then produces the (2r+1)^2 outputs.
+//
+// Backward mirrors it: per window position g = blend^T(corr_grad); fmap1_grad accumulates
+// g * fmap2 rows in registers; fmap2_grad receives g * fmap1 via fp32 atomics issued as
+// 256-byte contiguous wave instructions (the shape that runs at the full atomic rate).
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXK = 4;   // up to 256 channels (64 lanes x 4)
+
+// v[i] (i < 64) are per-lane partial sums for position i; returns on lane i the total over lanes.
+// Step HALF: lanes with bit HALF set keep positions [HALF, 2*HALF) of what they hold, the
+// others keep [0, HALF); the discarded half goes to the partner lane ^ HALF.  After the six
+// steps lane l holds position l summed over all 64 lanes (63 shuffles in total).
+template <int HALF>
+__device__ __forceinline__ void bfly_step(float (&v)[64], bool upper) {
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const float keep = upper ? v[i + HALF] : v[i];
+    const float send = upper ? v[i] : v[i + HALF];
+    v[i] = keep + __shfl_xor(send, HALF, 64);
+  }
+}
+__device__ __forceinline__ float butterfly64(float (&v)[64]) {
+  const int lane = threadIdx.x & 63;
+  bfly_step<32>(v, (lane & 32) != 0);
+  bfly_step<16>(v, (lane & 16) != 0);
+  bfly_step<8>(v, (lane & 8) != 0);
+  bfly_step<4>(v, (lane & 4) != 0);
+  bfly_step<2>(v, (lane & 2) != 0);
+  bfly_step<1>(v, (lane & 1) != 0);
+  return v[0];
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          const float* __restrict__ coords, float* __restrict__ corr,
+                                                          int B, int H1, int W1, int H2, int W2, int C) {
+  constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN;
+  __shared__ float dots[4][NPOS + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nq = (int64_t)B * H1 * W1;
+  const bool active = q < nq;
+  const int64_t qq = active ? q : nq - 1;
+  const int b = (int)(qq / (H1 * W1)), pix = (int)(qq % (H1 * W1));
+  float cx = coords[qq * 2], cy = coords[qq * 2 + 1];
+  cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+  cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+  const float flx = floorf(cx), fly = floorf(cy);
+  const int x0 = (int)flx, y0 = (int)fly;
+  const float dx = cx - flx, dy = cy - fly;
+
+  float a[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) a[k] = (lane + 64 * k < C) ? f1[qq * C + lane + 64 * k] : 0.f;
+
+  const float* f2b = f2 + (int64_t)b * H2 * W2 * C;
+#pragma unroll 1
+  for (int base = 0; base < NPOS; base += 64) {
+    float part[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int p = base + i;
+      const int iy = p / WIN, ix = p % WIN;
+      const int h2 = y0 - R + iy, w2 = x0 - R + ix;
+      float s = 0.f;
+      if (p < NPOS && h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+        const float* row = f2b + ((int64_t)h2 * W2 + w2) * C + lane;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+          if (lane + 64 * k < C) s += a[k] * row[64 * k];
+      }
+      part[i] = s;
+    }
+    const float tot = butterfly64(part);
+    // after the butterfly lane l holds the position whose index is the bit-reversal-free
+    // mapping below: bit (5-step) of the lane selected the upper half at each step, so
+    // position index == lane.
+    if (base + lane < NPOS) dots[wave][base + lane] = tot;
+  }
+  __syncthreads();
+  if (!active) return;
+  float* out = corr + (int64_t)b * RD * RD * H1 * W1 + pix;
+  for (int o = lane; o < RD * RD; o += 64) {
+    const int iyo = o % RD, ixo = o / RD;          // channel = iy + RD*ix
+    const float* d = dots[wave] + iyo * WIN + ixo;
+    // dot at (iy,ix) contributes to out(iy-1,ix-1)*dy*dx, out(iy-1,ix)*dy*(1-dx), out(iy,ix-1)*(1-dy)*dx, out(iy,ix)*(1-dy)*(1-dx)
+    const float v = (1.f - dy) * (1.f - dx) * d[0] + (1.f - dy) * dx * d[1] + dy * (1.f - dx) * d[WIN] + dy * dx * d[WIN + 1];
+    out[(int64_t)o * H1 * W1] = v;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void altcorr_bwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          const float* __restrict__ coords, const float* __restrict__ cg,
+                                                          float* __restrict__ g1, float* __restrict__ g2, int B, int H1,
+                                                          int W1, int H2, int W2, int C) {
+  constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN;
+  __shared__ float gout[4][RD * RD + 3];
+  __shared__ float gpos[4][NPOS + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nq = (int64_t)B * H1 * W1;
+  const bool active = q < nq;
+  const int64_t qq = active ? q : nq - 1;
+  const int b = (int)(qq / (H1 * W1)), pix = (int)(qq % (H1 * W1));
+  float cx = coords[qq * 2], cy = coords[qq * 2 + 1];
+  cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+  cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+  const float flx = floorf(cx), fly = floorf(cy);
+  const int x0 = (int)flx, y0 = (int)fly;
+  const float dx = cx - flx, dy = cy - fly;
+
+  const float* gin = cg + (int64_t)b * RD * RD * H1 * W1 + pix;
+  for (int o = lane; o < RD * RD; o += 64) gout[wave][o] = active ? gin[(int64_t)o * H1 * W1] : 0.f;
+  __syncthreads();
+  for (int p = lane; p < NPOS; p += 64) {
+    const int iy = p / WIN, ix = p % WIN;
+    float g = 0.f;
+    // position (iy,ix) is tap (a,c) of output (iy-a, ix-c); channel = iyo + RD*ixo
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int iyo = iy - aa, ixo = ix - cc;
+        if (iyo >= 0 && iyo < RD && ixo >= 0 && ixo < RD)
+          g += gout[wave][iyo + RD * ixo] * (aa ? dy : 1.f - dy) * (cc ? dx : 1.f - dx);
+      }
+    gpos[wave][p] = g;
+  }
+  __syncthreads();
+  if (!active) return;
+
+  float a[MAXK], acc[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) { a[k] = (lane + 64 * k < C) ? f1[qq * C + lane + 64 * k] : 0.f; acc[k] = 0.f; }
+  const float* f2b = f2 + (int64_t)b * H2 * W2 * C;
+  float* g2b = g2 + (int64_t)b * H2 * W2 * C;
+  for (int p = 0; p < NPOS; ++p) {
+    const int h2 = y0 - R + p / WIN, w2 = x0 - R + p % WIN;
+    if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2) continue;
+    const float g = gpos[wave][p];
+    const int64_t off = ((int64_t)h2 * W2 + w2) * C + lane;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (lane + 64 * k < C) {
+        acc[k] += g * f2b[off + 64 * k];
+        atomicAdd(g2b + off + 64 * k, g * a[k]);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k)
+    if (lane + 64 * k < C) g1[qq * C + lane + 64 * k] = acc[k];
+}
+
+}  // namespace
+
+extern "C" int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
+                                  int H1, int W1, int H2, int W2, int C, int radius, hipStream_t stream) {
+  if (!fmap1 || !fmap2 || !coords || !corr || B < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || C > 64 * MAXK)
+    return FS_ERR_ARG;
+  const int64_t nq = (int64_t)B * H1 * W1;
+  dim3 grid((unsigned)((nq + 3) / 4));
+  if (radius == 4) hipLaunchKernelGGL(altcorr_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr, B, H1, W1, H2, W2, C);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr, B, H1, W1, H2, W2, C);
+  else return FS_ERR_ARG;
+  return fs_launch_status();
+}
+
+extern "C" int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                                  float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C,
+                                  int radius, hipStream_t stream) {
+  if (!fmap1 || !fmap2 || !coords || !corr_grad || !fmap1_grad || !fmap2_grad || B < 1 || C < 1 || C > 64 * MAXK)
+    return FS_ERR_ARG;
+  const int64_t nq = (int64_t)B * H1 * W1;
+  dim3 grid((unsigned)((nq + 3) / 4));
+  if (radius == 4) hipLaunchKernelGGL(altcorr_bwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, H1, W1, H2, W2, C);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_bwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, H1, W1, H2, W2, C);
+  else return FS_ERR_ARG;
+  return fs_launch_status();
+}

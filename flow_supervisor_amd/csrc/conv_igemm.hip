@@ -1,0 +1,475 @@
+// Update-block convolutions as implicit GEMMs on the fp32 MFMA core (rows a6-a8 of
+// SURVEY.md section 8; reference: pytorch/core/update.py:6-136, every nn.Conv2d there).
+//
+// Activations are channels-last: tensor element (pixel m, channel c) at p[m*ld + c], with
+// ld % 4 == 0 and any padding channels holding zeros.  A convolution with "same" padding
+//   Y[m, co] = act( bias[co] + sum_{src s} sum_{tap t} sum_{ci} X_s[m + off(t), ci] * W[co, coff_s + ci, t] )
+// is the GEMM  [M = B*H*W pixels] x [N = Cout] x [K = sum_s taps * ceil32(C_s)]  whose A operand is
+// gathered on the fly (zero outside the image) and whose B operand is a pre-packed weight
+// matrix Wpk[n][k] (k ordered source-major, then tap, then channel, each channel run zero
+// padded to a multiple of 32) produced by fsraft_pack_conv_weight.  Up to three sources
+// replace torch.cat on the input side; up to three destination channel ranges replace the
+// split on the output side (used by the data-gradient pass, which is this same kernel run
+// on flipped/transposed packed weights).
+//
+// Fused epilogues: bias, ReLU, scale (mask head 0.25), and the two ConvGRU gate stages
+//   ZR: z = sigmoid(.), r = sigmoid(.), stores z, r and r*h          (update.py:27-29 / 46-48)
+//   Q : q = tanh(.), stores q and h' = (1-z)*h + z*q                 (update.py:29-31 / 48-50)
+//
+// The weight-gradient kernel is the transposed product  dWpk[co][k] += sum_m dY[m,co] * Xg[m,k]
+// with the pixel dimension split across workgroups and fp32 atomics into the packed layout.
+#include "gemm_core.hpp"
+
+namespace {
+
+struct Src { const float* p; int C; int ld; };
+struct Dst { float* p; int64_t bs, ps, cs; int n0; int accumulate; };   // channels [n0, next n0)
+
+struct ConvArgs {
+  Src src[3]; int nsrc;
+  const float* wpk; int Ktot;
+  const float* bias;
+  int B, H, W, KH, KW, N;        // N = output channels of this GEMM
+  Dst dst[3]; int ndst;
+  int relu; float alpha;
+  // GRU epilogues
+  const float* h; int ldh;
+  const float* z; int ldz;
+  float* aux1; int ld1;          // ZR: r*h     Q: q
+  float* aux2; int ld2;          // ZR: r
+  int hid;
+};
+
+enum { EPI_PLAIN = 0, EPI_ZR = 2, EPI_Q = 3 };
+
+template <class Cfg>
+struct ConvALoader {
+  static constexpr int BM = Cfg::BM, BK = Cfg::BK, LD = Cfg::LDA;
+  static constexpr int F4 = BK / 4;
+  static constexpr int NF4 = BM * F4 / 256;
+  static constexpr int NREG = NF4 * 4;
+  const float* p0; const float* p1; const float* p2;
+  int C0, C1, C2, ld0, ld1, ld2;
+  int cpt0, cpt1, cpt2;          // 32-channel chunks per tap for each source
+  int taps, KW, PH, PW, H, W;
+  int py[NF4], px[NF4];          // pixel coordinates of this thread's rows (py < 0: row outside M)
+  int64_t pb[NF4];               // image base pixel index b*H*W
+
+  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+    int k = kt;
+    const float* p = p0; int C = C0, ld = ld0, cpt = cpt0;
+    if (k >= taps * cpt0) {
+      k -= taps * cpt0; p = p1; C = C1; ld = ld1; cpt = cpt1;
+      if (k >= taps * cpt1) { k -= taps * cpt1; p = p2; C = C2; ld = ld2; cpt = cpt2; }
+    }
+    const int tap = k / cpt, c0 = (k % cpt) * BK;
+    const int dy = tap / KW - PH, dx = tap % KW - PW;
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int kq = (threadIdx.x + 256 * j) % F4;
+      const int yy = py[j] + dy, xx = px[j] + dx, c = c0 + kq * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (py[j] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W && c < C)
+        v = *reinterpret_cast<const f32x4*>(p + (pb[j] + (int64_t)yy * W + xx) * ld + c);
+      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    }
+  }
+  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int row = e / F4, kq = e % F4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[(kq * 4 + c) * LD + row] = r[4 * j + c];
+    }
+  }
+};
+
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int HW = a.H * a.W;
+  const int M = a.B * HW;
+  const int n0 = blockIdx.x * Cfg::BN, m0 = blockIdx.y * Cfg::BM;
+
+  ConvALoader<Cfg> la;
+  la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + Cfg::BK - 1) / Cfg::BK;
+  la.p1 = a.src[1].p; la.C1 = a.src[1].C; la.ld1 = a.src[1].ld; la.cpt1 = a.nsrc > 1 ? (a.src[1].C + Cfg::BK - 1) / Cfg::BK : 0;
+  la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + Cfg::BK - 1) / Cfg::BK : 0;
+  if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
+  if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
+  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.KH / 2; la.PW = a.KW / 2; la.H = a.H; la.W = a.W;
+#pragma unroll
+  for (int j = 0; j < ConvALoader<Cfg>::NF4; ++j) {
+    const int row = (threadIdx.x + 256 * j) / ConvALoader<Cfg>::F4;
+    const int m = m0 + row;
+    if (m < M) {
+      const int b = m / HW, pix = m % HW;
+      la.py[j] = pix / a.W; la.px[j] = pix % a.W; la.pb[j] = (int64_t)b * HW;
+    } else {
+      la.py[j] = -1; la.px[j] = 0; la.pb[j] = 0;
+    }
+  }
+  RowMajorTileLoader<Cfg::BN, Cfg::BK, Cfg::LDB> lb{a.wpk + (int64_t)n0 * a.Ktot, a.Ktot, a.N - n0, a.Ktot};
+
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gemm_mainloop<Cfg>(lds, a.Ktot / Cfg::BK, la, lb, acc);
+
+#pragma unroll
+  for (int nt = 0; nt < Cfg::TN; ++nt) {
+    const int n = n0 + acc_col<Cfg>(nt);
+    if (n >= a.N) continue;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+    // destination segment of this column
+    int di = 0;
+    if (a.ndst > 1 && n >= a.dst[1].n0) di = 1;
+    if (a.ndst > 2 && n >= a.dst[2].n0) di = 2;
+    float* dp = di == 0 ? a.dst[0].p : di == 1 ? a.dst[1].p : a.dst[2].p;
+    const int64_t dbs = di == 0 ? a.dst[0].bs : di == 1 ? a.dst[1].bs : a.dst[2].bs;
+    const int64_t dps = di == 0 ? a.dst[0].ps : di == 1 ? a.dst[1].ps : a.dst[2].ps;
+    const int64_t dcs = di == 0 ? a.dst[0].cs : di == 1 ? a.dst[1].cs : a.dst[2].cs;
+    const int dn0 = di == 0 ? a.dst[0].n0 : di == 1 ? a.dst[1].n0 : a.dst[2].n0;
+    const int dacc = di == 0 ? a.dst[0].accumulate : di == 1 ? a.dst[1].accumulate : a.dst[2].accumulate;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::TM; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + acc_row<Cfg>(mt, r);
+        if (m >= M) continue;
+        float v = acc[mt][nt][r] + bias;
+        if (EPI == EPI_PLAIN) {
+          v *= a.alpha;
+          if (a.relu) v = fmaxf(v, 0.f);
+          const int b = m / HW, pix = m % HW;
+          float* o = dp + b * dbs + pix * dps + (n - dn0) * dcs;
+          if (dacc) v += *o;
+          *o = v;
+        } else if (EPI == EPI_ZR) {
+          const float s = 1.0f / (1.0f + expf(-v));
+          if (n < a.hid) {
+            a.dst[0].p[(int64_t)m * a.dst[0].ps + n] = s;                 // z
+          } else {
+            const int c = n - a.hid;
+            a.aux2[(int64_t)m * a.ld2 + c] = s;                             // r
+            a.aux1[(int64_t)m * a.ld1 + c] = s * a.h[(int64_t)m * a.ldh + c];   // r*h
+          }
+        } else {   // EPI_Q
+          const float q = tanhf(v);
+          const float zz = a.z[(int64_t)m * a.ldz + n], hh = a.h[(int64_t)m * a.ldh + n];
+          a.aux1[(int64_t)m * a.ld1 + n] = q;
+          a.dst[0].p[(int64_t)m * a.dst[0].ps + n] = (1.f - zz) * hh + zz * q;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient
+struct WgradArgs {
+  const float* dy; int ldy; int Cout;     // dY (already multiplied by act'), [M][ldy]
+  Src src[3]; int nsrc;
+  float* dwpk; int Ktot;
+  int B, H, W, KH, KW;
+  int kchunk;                              // pixels per split (multiple of 32)
+};
+
+template <class Cfg>
+struct ShiftedXLoader {                    // Bs[k = pixel][n = ci] <- X[pixel + off][ci0 + n]
+  static constexpr int BN = Cfg::BN, BK = Cfg::BK, LD = Cfg::LDB;
+  static constexpr int F4 = BN / 4;
+  static constexpr int NF4 = BK * F4 / 256;
+  static constexpr int NREG = NF4 * 4;
+  const float* p; int ld, cvalid;          // p already offset by ci0; cvalid = channels left from ci0
+  int dy, dx, H, W, HW; int64_t M; int64_t m_begin, m_end;
+  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int k = e / F4, c4 = e % F4;
+      const int64_t m = m_begin + (int64_t)kt * BK + k;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end && c4 * 4 < cvalid) {
+        const int64_t b = m / HW; const int pix = (int)(m % HW);
+        const int yy = pix / W + dy, xx = pix % W + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+          v = *reinterpret_cast<const f32x4*>(p + (b * HW + (int64_t)yy * W + xx) * ld + c4 * 4);
+      }
+      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    }
+  }
+  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int k = e / F4, c4 = e % F4;
+      f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+      *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = v;
+    }
+  }
+};
+
+template <class Cfg>
+struct DyLoader {                          // As[k = pixel][m = co] <- dY[pixel][co0 + m]
+  static constexpr int BM = Cfg::BM, BK = Cfg::BK, LD = Cfg::LDA;
+  static constexpr int F4 = BM / 4;
+  static constexpr int NF4 = BK * F4 / 256;
+  static constexpr int NREG = NF4 * 4;
+  static_assert((BK * F4) % 256 == 0, "dy tile must divide over 256 threads");
+  const float* p; int ld, cvalid; int64_t m_begin, m_end;
+  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int k = e / F4, c4 = e % F4;
+      const int64_t m = m_begin + (int64_t)kt * BK + k;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end && c4 * 4 < cvalid) v = *reinterpret_cast<const f32x4*>(p + m * ld + c4 * 4);
+      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    }
+  }
+  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int k = e / F4, c4 = e % F4;
+      f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+      *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = v;
+    }
+  }
+};
+
+// grid: x = packed-K tile (source, tap, 128-channel tile), y = Cout tile, z = pixel split
+template <class Cfg>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int HW = a.H * a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int taps = a.KH * a.KW;
+  // decode blockIdx.x -> (source, tap, channel tile)
+  int t = blockIdx.x, s = 0, kofs = 0;
+  for (;; ++s) {
+    const int ct = (a.src[s].C + Cfg::BN - 1) / Cfg::BN;
+    if (t < taps * ct) break;
+    t -= taps * ct;
+    kofs += taps * ((a.src[s].C + 31) / 32) * 32;
+  }
+  const Src sc = s == 0 ? a.src[0] : s == 1 ? a.src[1] : a.src[2];
+  const int ct = (sc.C + Cfg::BN - 1) / Cfg::BN;
+  const int tap = t / ct, ci0 = (t % ct) * Cfg::BN;
+  const int cpad = ((sc.C + 31) / 32) * 32;
+  kofs += tap * cpad + ci0;
+  const int co0 = blockIdx.y * Cfg::BM;
+  const int64_t mb = (int64_t)blockIdx.z * a.kchunk;
+  const int64_t me = mb + a.kchunk < M ? mb + a.kchunk : M;
+  if (mb >= M) return;
+
+  DyLoader<Cfg> la{a.dy + co0, a.ldy, a.ldy - co0 < Cfg::BM ? a.ldy - co0 : Cfg::BM, mb, me};
+  const int cleft = ((sc.C + 3) / 4) * 4 - ci0;
+  ShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN,
+                         tap / a.KW - a.KH / 2, tap % a.KW - a.KW / 2, a.H, a.W, HW, M, mb, me};
+
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gemm_mainloop<Cfg>(lds, (int)((me - mb + Cfg::BK - 1) / Cfg::BK), la, lb, acc);
+
+#pragma unroll
+  for (int nt = 0; nt < Cfg::TN; ++nt) {
+    const int n = acc_col<Cfg>(nt);
+    if (ci0 + n >= cpad) continue;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + acc_row<Cfg>(mt, r);
+        if (co < a.Cout) atomicAdd(a.dwpk + (int64_t)co * a.Ktot + kofs + n, acc[mt][nt][r]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------- weight (un)packing
+// mode 0 (forward):  wpk[n][k(s,t,c)] = W[n][coff_s + c][t]                       n < Cout
+// mode 1 (dgrad):    wpk[n][k(t',c)]  = W[c][n][taps-1-t']                        n < Cin_total, c < Cout
+// mode 2 (unpack dW): W[n][coff_s + c][t] (+)= wpk[n][k(s,t,c)]   (inverse of mode 0)
+struct PackArgs {
+  float* w;            // OIHW [Cout][Cin][KH*KW]
+  float* wpk;
+  int Cout, Cin, taps;
+  int C[3]; int nsrc;  // forward source split of Cin (mode 0/2); ignored for mode 1
+  int Ktot, rows;
+  int mode, accumulate;
+};
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
+  const int64_t total = (int64_t)a.rows * a.Ktot;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int n = (int)(e / a.Ktot);
+    int k = (int)(e % a.Ktot);
+    if (a.mode == 1) {
+      const int cpad = ((a.Cout + 31) / 32) * 32;
+      const int tp = k / cpad, c = k % cpad;
+      float v = 0.f;
+      if (c < a.Cout && n < a.Cin) v = a.w[((int64_t)c * a.Cin + n) * a.taps + (a.taps - 1 - tp)];
+      a.wpk[e] = v;
+    } else {
+      int s = 0, coff = 0;
+      for (; s < a.nsrc; ++s) {
+        const int span = a.taps * (((a.C[s] + 31) / 32) * 32);
+        if (k < span) break;
+        k -= span; coff += a.C[s];
+      }
+      const int cpad = ((a.C[s] + 31) / 32) * 32;
+      const int t = k / cpad, c = k % cpad;
+      const bool ok = c < a.C[s] && n < a.Cout;
+      if (a.mode == 0) {
+        a.wpk[e] = ok ? a.w[((int64_t)n * a.Cin + coff + c) * a.taps + t] : 0.f;
+      } else if (ok) {
+        float* d = a.w + ((int64_t)n * a.Cin + coff + c) * a.taps + t;
+        *d = a.accumulate ? *d + a.wpk[e] : a.wpk[e];
+      }
+    }
+  }
+}
+
+using Cfg128 = GemmCfg<128, 128, 32, 2, 2, 2, 2>;
+using Cfg64 = GemmCfg<128, 64, 32, 4, 1, 2, 2>;
+using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
+// weight-gradient tiles: LDS images are filled with float4 rows, so pitches stay multiples of 4
+using WCfg128 = GemmCfg<128, 128, 32, 2, 2, 0, 0>;
+using WCfg32 = GemmCfg<32, 128, 32, 1, 4, 0, 0>;
+
+template <class Cfg>
+int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
+  const int M = a.B * a.H * a.W;
+  dim3 grid(ceil_div(a.N, Cfg::BN), ceil_div(M, Cfg::BM));
+  if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_kernel<Cfg, EPI_PLAIN>), grid, dim3(256), 0, s, a);
+  else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_kernel<Cfg, EPI_ZR>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm_kernel<Cfg, EPI_Q>), grid, dim3(256), 0, s, a);
+  return fs_launch_status();
+}
+
+int conv_ktot(const int* C, int nsrc, int taps) {
+  int k = 0;
+  for (int s = 0; s < nsrc; ++s) k += taps * (((C[s] + 31) / 32) * 32);
+  return k;
+}
+
+}  // namespace
+
+// Flat C descriptor so the ABI stays plain-old-data (mirrored by ctypes in _lib.py).
+struct fsraft_conv_desc {
+  const float* src[3]; int srcC[3]; int srcld[3]; int nsrc;
+  const float* wpk; const float* bias;
+  int B, H, W, KH, KW, N;
+  float* dst[3]; int64_t dst_bs[3]; int64_t dst_ps[3]; int64_t dst_cs[3]; int dst_n0[3]; int dst_acc[3]; int ndst;
+  int relu; float alpha;
+  int epi;                       // 0 plain, 2 GRU z/r, 3 GRU q
+  const float* h; int ldh;
+  const float* z; int ldz;
+  float* aux1; int ld1;
+  float* aux2; int ld2;
+  int hid;
+};
+
+extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
+  if (!srcC || nsrc < 1 || nsrc > 3) return -1;
+  return conv_ktot(srcC, nsrc, KH * KW);
+}
+
+extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream) {
+  if (!d || d->nsrc < 1 || d->nsrc > 3 || d->ndst < 1 || d->ndst > 3 || !d->wpk || d->N < 1) return FS_ERR_ARG;
+  ConvArgs a{};
+  for (int s = 0; s < 3; ++s) {
+    a.src[s] = Src{s < d->nsrc ? d->src[s] : d->src[0], s < d->nsrc ? d->srcC[s] : 0, s < d->nsrc ? d->srcld[s] : 4};
+    if (s < d->nsrc && (!d->src[s] || d->srcld[s] % 4 != 0 || d->srcC[s] < 1)) return FS_ERR_ARG;
+  }
+  a.nsrc = d->nsrc;
+  a.wpk = d->wpk; a.Ktot = conv_ktot(d->srcC, d->nsrc, d->KH * d->KW); a.bias = d->bias;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.KH = d->KH; a.KW = d->KW; a.N = d->N;
+  for (int i = 0; i < 3; ++i) {
+    const int j = i < d->ndst ? i : 0;
+    a.dst[i] = Dst{d->dst[j], d->dst_bs[j], d->dst_ps[j], d->dst_cs[j], d->dst_n0[j], d->dst_acc[j]};
+    if (i < d->ndst && !d->dst[i]) return FS_ERR_ARG;
+  }
+  a.ndst = d->ndst; a.relu = d->relu; a.alpha = d->alpha;
+  a.h = d->h; a.ldh = d->ldh; a.z = d->z; a.ldz = d->ldz; a.aux1 = d->aux1; a.ld1 = d->ld1; a.aux2 = d->aux2; a.ld2 = d->ld2;
+  a.hid = d->hid;
+  if (d->epi == EPI_ZR && (!d->h || !d->aux1 || !d->aux2 || d->hid * 2 != d->N)) return FS_ERR_ARG;
+  if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
+  if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
+  if (d->N <= 32 && d->epi == EPI_PLAIN) return launch_conv<Cfg32>(a, d->epi, stream);
+  if (d->N <= 64 && d->epi == EPI_PLAIN) return launch_conv<Cfg64>(a, d->epi, stream);
+  return launch_conv<Cfg128>(a, d->epi, stream);
+}
+
+// dwpk[Cout][Ktot] += dY^T * im2col(X)   (same packed layout as the forward weights)
+extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
+                                 const int* srcld, int nsrc, float* dwpk, int B, int H, int W, int KH, int KW,
+                                 hipStream_t stream) {
+  if (!dy || !src || !dwpk || nsrc < 1 || nsrc > 3 || ldy % 4 != 0) return FS_ERR_ARG;
+  WgradArgs a{};
+  a.dy = dy; a.ldy = ldy; a.Cout = Cout;
+  int xt128 = 0;
+  for (int s = 0; s < 3; ++s) {
+    a.src[s] = Src{s < nsrc ? src[s] : src[0], s < nsrc ? srcC[s] : 0, s < nsrc ? srcld[s] : 4};
+    if (s < nsrc) {
+      if (!src[s] || srcld[s] % 4 != 0) return FS_ERR_ARG;
+      xt128 += KH * KW * ceil_div(srcC[s], 128);
+    }
+  }
+  a.nsrc = nsrc; a.dwpk = dwpk; a.Ktot = conv_ktot(srcC, nsrc, KH * KW);
+  a.B = B; a.H = H; a.W = W; a.KH = KH; a.KW = KW;
+  const int64_t M = (int64_t)B * H * W;
+  const bool small_m = Cout <= 32;
+  const int ytiles = small_m ? ceil_div(Cout, 32) : ceil_div(Cout, 128);
+  // aim for ~4 workgroups per CU; each split handles a multiple of 32 pixels, at least 256
+  int64_t want = (1024 + (int64_t)xt128 * ytiles - 1) / ((int64_t)xt128 * ytiles);
+  if (want < 1) want = 1;
+  int64_t chunk = (M + want - 1) / want;
+  if (chunk < 256) chunk = 256;
+  chunk = (chunk + 31) / 32 * 32;
+  a.kchunk = (int)chunk;
+  const int zs = (int)((M + chunk - 1) / chunk);
+  dim3 grid(xt128, ytiles, zs);
+  if (small_m) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg32>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<WCfg128>), grid, dim3(256), 0, stream, a);
+  return fs_launch_status();
+}
+
+// mode 0: OIHW -> forward packed; mode 1: OIHW -> data-gradient packed (rows = Cin);
+// mode 2: packed (forward layout) -> OIHW, optionally accumulating.  srcC splits Cin for modes 0/2.
+extern "C" int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
+                                       int nsrc, int mode, int accumulate, hipStream_t stream) {
+  if (!w_oihw || !wpk || mode < 0 || mode > 2) return FS_ERR_ARG;
+  PackArgs a{};
+  a.w = w_oihw; a.wpk = wpk; a.Cout = Cout; a.Cin = Cin; a.taps = KH * KW; a.mode = mode; a.accumulate = accumulate;
+  if (mode == 1) {
+    a.nsrc = 1; a.C[0] = Cout; a.C[1] = a.C[2] = 0;
+    a.Ktot = a.taps * (((Cout + 31) / 32) * 32);
+    a.rows = Cin;
+  } else {
+    if (!srcC || nsrc < 1 || nsrc > 3) return FS_ERR_ARG;
+    int tot = 0;
+    for (int s = 0; s < 3; ++s) { a.C[s] = s < nsrc ? srcC[s] : 0; tot += a.C[s]; }
+    if (tot != Cin) return FS_ERR_ARG;
+    a.nsrc = nsrc;
+    a.Ktot = conv_ktot(srcC, nsrc, a.taps);
+    a.rows = Cout;
+  }
+  const int64_t total = (int64_t)a.rows * a.Ktot;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return fs_launch_status();
+}

@@ -1,0 +1,226 @@
+// All-pairs correlation volume + average-pool pyramid in one pass (rows a1, a2 of
+// SURVEY.md section 8; reference: pytorch/core/corr.py:13-27 and :52-60).
+//
+//   V0[b, i, j] = (1/sqrt(C)) * sum_c f1[b, c, i] * f2[b, c, j]
+//   V(l+1)      = 2x2 mean (floor) of V(l) over the (h2, w2) plane of j
+//
+// One workgroup computes 64 queries (i) x one 8x32 patch of targets (j) with the
+// fp32 MFMA core, then pools the patch 2x2 / 4x4 / 8x8 out of LDS, so every level is
+// written exactly once and level 0 is never re-read.  Level-l cells are aligned to
+// 2^l, hence an 8-row x 32-col patch contains whole cells of every level; a cell is
+// emitted iff its index is below the floor-halved size of its level, which is exactly
+// the set avg_pool2d(2, stride=2) keeps.
+//
+// HBM traffic per sample = read 2*N*C*4 + write N*P*4 (P = sum_l h_l*w_l): 275.7 MB at
+// 55x128, C=256.  FLOPs 2*N*N*C = 25.4 G => fp32-MFMA bound.
+#include "gemm_core.hpp"
+
+namespace {
+
+using BuildCfg = GemmCfg<64, 256, 16, 1, 4, 0, 0>;
+
+struct F1Loader {            // As[k][i] <- f1[b][c = kt*16 + k][i0 + i]
+  static constexpr int NREG = 4;
+  const float* f1b; int N; int i0; int C;
+  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+    const int i = threadIdx.x & 63, k0 = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = kt * 16 + k0 + 4 * j;
+      r[j] = (i0 + i < N && c < C) ? f1b[(int64_t)c * N + i0 + i] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+    const int i = threadIdx.x & 63, k0 = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[(k0 + 4 * j) * BuildCfg::LDA + i] = r[j];
+  }
+};
+
+// patch position (row 0..7, col 0..31) -> column n of the block tile such that wave
+// wn = col/8 owns an 8x8 sub-patch and MFMA n-tile nt = row/4 owns 4 of its rows.
+__device__ __forceinline__ int patch_to_n(int row, int col) {
+  return (col >> 3) * 64 + (row >> 2) * 32 + (row & 3) * 8 + (col & 7);
+}
+
+struct F2Loader {            // Bs[k][n(row,col)] <- f2[b][c][(py0+row)*W + px0+col]
+  static constexpr int NREG = 16;
+  const float* f2b; int N; int C; int pix; bool ok;
+  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = kt * 16 + k;
+      r[k] = (ok && c < C) ? f2b[(int64_t)c * N + pix] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+    const int n = patch_to_n(threadIdx.x >> 5, threadIdx.x & 31);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k * BuildCfg::LDB + n] = r[k];
+  }
+};
+
+struct Levels {
+  float* p[4];
+  int h[4];
+  int w[4];
+};
+
+constexpr int S_LD = 256;
+constexpr int EPI_FLOATS = 32 * 256 + 32 * 64 + 32 * 16;
+constexpr int LDS_FLOATS = BuildCfg::LDS_FLOATS > EPI_FLOATS ? BuildCfg::LDS_FLOATS : EPI_FLOATS;
+
+__global__ __launch_bounds__(256) void corr_build_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         Levels lv, int nlev, int C, int H, int W, float scale) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int N = H * W;
+  const int npx = ceil_div_dev(W, 32);
+  const int px0 = (blockIdx.x % npx) * 32, py0 = (blockIdx.x / npx) * 8;
+  const int i0 = blockIdx.y * 64;
+  const int b = blockIdx.z;
+
+  F1Loader la{f1 + (int64_t)b * C * N, N, i0, C};
+  const int prow = threadIdx.x >> 5, pcol = threadIdx.x & 31;
+  const bool pok = (py0 + prow < H) && (px0 + pcol < W);
+  F2Loader lb{f2 + (int64_t)b * C * N, N, C, (py0 + prow) * W + px0 + pcol, pok};
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  gemm_mainloop<BuildCfg>(lds, ceil_div_dev(C, 16), la, lb, acc);
+
+  float* S = lds;                 // [32][256]  scaled level-0 patch, patch-linear (row*32+col)
+  float* P1 = lds + 32 * 256;     // [32][4*16]
+  float* P2 = P1 + 32 * 64;       // [32][2*8]
+  const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int pj = (4 * nt + (l31 >> 3)) * 32 + 8 * wn + (l31 & 7);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        S[i * S_LD + pj] = acc[mt][nt][r] * scale;
+      }
+    }
+    __syncthreads();
+    const int qbase = i0 + mt * 32;
+    // level 0: 32 queries x 8 rows, 32 contiguous floats each
+    {
+      const int col = threadIdx.x & 31, slot = threadIdx.x >> 5;
+      const bool cok = px0 + col < W;
+#pragma unroll 4
+      for (int jj = 0; jj < 32; ++jj) {
+        const int idx = slot + 8 * jj;
+        const int i = idx >> 3, row = idx & 7;
+        if (cok && py0 + row < H && qbase + i < N)
+          lv.p[0][(((int64_t)b * N + qbase + i) * H + py0 + row) * W + px0 + col] = S[i * S_LD + row * 32 + col];
+      }
+    }
+    if (nlev > 1) {
+      const int h1 = lv.h[1], w1 = lv.w[1];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int e = threadIdx.x + 256 * jj;
+        const int i = e >> 6, c = e & 63, y = c >> 4, x = c & 15;
+        const float* s = S + i * S_LD + (2 * y) * 32 + 2 * x;
+        const float v = (((s[0] + s[1]) + s[32]) + s[33]) * 0.25f;
+        P1[i * 64 + c] = v;
+        const int gy = (py0 >> 1) + y, gx = (px0 >> 1) + x;
+        if (gy < h1 && gx < w1 && qbase + i < N) lv.p[1][(((int64_t)b * N + qbase + i) * h1 + gy) * w1 + gx] = v;
+      }
+    }
+    __syncthreads();
+    if (nlev > 2) {
+      const int h2 = lv.h[2], w2 = lv.w[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int e = threadIdx.x + 256 * jj;
+        const int i = e >> 4, c = e & 15, y = c >> 3, x = c & 7;
+        const float* s = P1 + i * 64 + (2 * y) * 16 + 2 * x;
+        const float v = (((s[0] + s[1]) + s[16]) + s[17]) * 0.25f;
+        P2[i * 16 + c] = v;
+        const int gy = (py0 >> 2) + y, gx = (px0 >> 2) + x;
+        if (gy < h2 && gx < w2 && qbase + i < N) lv.p[2][(((int64_t)b * N + qbase + i) * h2 + gy) * w2 + gx] = v;
+      }
+    }
+    __syncthreads();
+    if (nlev > 3 && threadIdx.x < 128) {
+      const int h3 = lv.h[3], w3 = lv.w[3];
+      const int i = threadIdx.x >> 2, x = threadIdx.x & 3;
+      const float* s = P2 + i * 16 + 2 * x;
+      const float v = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
+      const int gy = (py0 >> 3), gx = (px0 >> 3) + x;
+      if (gy < h3 && gx < w3 && qbase + i < N) lv.p[3][(((int64_t)b * N + qbase + i) * h3 + gy) * w3 + gx] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// Backward of the pooling chain, folded into level 0 in place:
+//   g0[y][x] += 1/4 * ( g1[y/2][x/2] + 1/4 * ( g2[y/4][x/4] + 1/4 * g3[y/8][x/8] ) )
+// where a level-l cell only feeds back if it exists (index < size of that level);
+// existence at level l+1 implies existence at level l, so the chain is cut from the top.
+__global__ __launch_bounds__(256) void corr_unpool_bwd_kernel(Levels lv, int nlev, int64_t nq) {
+  const int H = lv.h[0], W = lv.w[0];
+  const int64_t total = nq * H * W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % W);
+    const int64_t t = e / W;
+    const int y = (int)(t % H);
+    const int64_t q = t / H;
+    float up = 0.f;   // dL/d(cell of level l) including what flows down from coarser levels
+    for (int l = nlev - 1; l >= 1; --l) {
+      const int yl = y >> l, xl = x >> l;
+      const bool ok = yl < lv.h[l] && xl < lv.w[l];   // floor pooling dropped this cell otherwise
+      up = ok ? (lv.p[l][(q * lv.h[l] + yl) * lv.w[l] + xl] + 0.25f * up) : 0.f;
+    }
+    lv.p[0][e] += 0.25f * up;
+  }
+}
+
+}  // namespace
+
+extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* levels, int num_levels,
+                                 int B, int C, int H, int W, hipStream_t stream) {
+  if (!fmap1 || !fmap2 || !levels || num_levels < 1 || num_levels > 4 || B < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_ARG;
+  Levels lv;
+  int h = H, w = W;
+  for (int l = 0; l < 4; ++l) {
+    lv.p[l] = l < num_levels ? levels[l] : nullptr;
+    lv.h[l] = h; lv.w[l] = w;
+    if (l < num_levels && (!levels[l] || h < 1 || w < 1)) return FS_ERR_ARG;
+    h /= 2; w /= 2;
+  }
+  const int N = H * W;
+  dim3 grid(ceil_div(W, 32) * ceil_div(H, 8), ceil_div(N, 64), B);
+  hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, lv, num_levels, C, H, W,
+                     1.0f / sqrtf((float)C));
+  return fs_launch_status();
+}
+
+// In place: levels[0] += unpooled(levels[1..]).  levels[l] hold dL/dV_l on entry.
+extern "C" int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int B, int H, int W, hipStream_t stream) {
+  if (!dlevels || num_levels < 1 || num_levels > 4) return FS_ERR_ARG;
+  if (num_levels == 1) return FS_OK;
+  Levels lv;
+  int h = H, w = W;
+  for (int l = 0; l < 4; ++l) {
+    lv.p[l] = l < num_levels ? dlevels[l] : nullptr;
+    lv.h[l] = h; lv.w[l] = w;
+    h /= 2; w /= 2;
+  }
+  const int64_t nq = (int64_t)B * H * W;
+  const int64_t total = nq * H * W;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(corr_unpool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, lv, num_levels, nq);
+  return fs_launch_status();
+}

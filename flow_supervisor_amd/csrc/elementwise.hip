@@ -1,0 +1,251 @@
+// Small HBM-bound kernels around the update-block GEMMs: layout changes at the API
+// boundary (NCHW <-> channels-last), the 7x7 flow-conv im2col / col2im pair, activation
+// and ConvGRU gate derivatives, and column sums for bias gradients.
+// Reference ops they stand in for: torch.cat / permute / relu / sigmoid / tanh backward
+// in pytorch/core/update.py:16-136 as executed by autograd.
+#include "common.hpp"
+
+namespace {
+
+// dst[(b*HW + p)*ld + coff + c] (=|+=) src[(b*C + c)*HW + p]
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int ld, int coff, int accumulate) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, p = p0 + tx;
+    t[ty + 8 * j][tx] = (c < C && p < HW) ? src[((int64_t)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = p0 + ty + 8 * j, c = c0 + tx;
+    if (c < C && p < HW) {
+      float* d = dst + ((int64_t)b * HW + p) * ld + coff + c;
+      const float v = t[tx][ty + 8 * j];
+      *d = accumulate ? *d + v : v;
+    }
+  }
+}
+
+// dst[(b*C + c)*HW + p] (=|+=) src[(b*HW + p)*ld + coff + c]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int ld, int coff, int accumulate) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = p0 + ty + 8 * j, c = c0 + tx;
+    t[ty + 8 * j][tx] = (c < C && p < HW) ? src[((int64_t)b * HW + p) * ld + coff + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, p = p0 + tx;
+    if (c < C && p < HW) {
+      float* d = dst + ((int64_t)b * C + c) * HW + p;
+      const float v = t[tx][ty + 8 * j];
+      *d = accumulate ? *d + v : v;
+    }
+  }
+}
+
+// cols[m][ci*49 + ky*7 + kx] = flow[b, ci, y+ky-3, x+kx-3] (zero outside); cols pitch = ld (>= 100), pad cols zeroed
+__global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ flow, int64_t bs, int64_t cs, int64_t ps,
+                                                      float* __restrict__ cols, int ld, int B, int H, int W) {
+  const int64_t total = (int64_t)B * H * W * ld;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int k = (int)(e % ld);
+    const int64_t m = e / ld;
+    float v = 0.f;
+    if (k < 98) {
+      const int ci = k / 49, t = k % 49;
+      const int x = (int)(m % W), y = (int)((m / W) % H);
+      const int64_t b = m / ((int64_t)W * H);
+      const int yy = y + t / 7 - 3, xx = x + t % 7 - 3;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = flow[b * bs + ci * cs + ((int64_t)yy * W + xx) * ps];
+    }
+    cols[e] = v;
+  }
+}
+
+// adjoint: dflow[b, ci, y, x] (+)= sum_t dcols[(b, y-(ky-3), x-(kx-3))][ci*49 + t]   (dflow contiguous [B,2,H,W])
+__global__ __launch_bounds__(256) void col2im7_kernel(const float* __restrict__ dcols, int ld, float* __restrict__ dflow,
+                                                      int B, int H, int W, int accumulate) {
+  const int64_t total = (int64_t)B * 2 * H * W;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % W), y = (int)((e / W) % H);
+  const int ci = (int)((e / ((int64_t)W * H)) % 2);
+  const int64_t b = e / ((int64_t)2 * W * H);
+  float s = 0.f;
+  for (int t = 0; t < 49; ++t) {
+    const int yy = y - (t / 7 - 3), xx = x - (t % 7 - 3);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += dcols[((b * H + yy) * W + xx) * ld + ci * 49 + t];
+  }
+  dflow[e] = accumulate ? dflow[e] + s : s;
+}
+
+// 2-channel strided tensor -> channels [coff, coff+2) of a channels-last buffer, and the reverse (accumulating)
+__global__ __launch_bounds__(256) void flow_to_nhwc_kernel(const float* __restrict__ flow, int64_t bs, int64_t cs,
+                                                           int64_t ps, float* __restrict__ dst, int ld, int coff,
+                                                           int64_t M, int HW) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * M) return;
+  const int64_t m = e >> 1; const int c = (int)(e & 1);
+  const int64_t b = m / HW, p = m % HW;
+  dst[m * ld + coff + c] = flow[b * bs + c * cs + p * ps];
+}
+__global__ __launch_bounds__(256) void nhwc_to_flow_kernel(const float* __restrict__ src, int ld, int coff,
+                                                           float* __restrict__ dflow, int64_t M, int HW, int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * M) return;
+  const int64_t m = e >> 1; const int c = (int)(e & 1);
+  const int64_t b = m / HW, p = m % HW;
+  float* d = dflow + (b * 2 + c) * HW + p;
+  const float v = src[m * ld + coff + c];
+  *d = accumulate ? *d + v : v;
+}
+
+// g[m][c] *= (y[m][c] > 0)     (ReLU backward, in place on the incoming gradient)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, int ldg, const float* __restrict__ y,
+                                                       int ldy, int64_t M, int C) {
+  const int c4n = (C + 3) / 4;
+  const int64_t total = M * c4n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / c4n; const int c = (int)(e % c4n) * 4;
+    f32x4 gv = *reinterpret_cast<f32x4*>(g + m * ldg + c);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ldy + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+    *reinterpret_cast<f32x4*>(g + m * ldg + c) = gv;
+  }
+}
+
+// ConvGRU gate backward, stage 1 (h' = (1-z) h + z q):
+//   dzr[:, 0:hid] = dh' * (q - h) * z (1-z)     (pre-activation grad of the z conv)
+//   dq_pre        = dh' * z * (1 - q^2)
+//   dh            = dh' * (1 - z)                 (direct path; conv paths are added later)
+__global__ __launch_bounds__(256) void gru_bwd1_kernel(const float* __restrict__ dhn, const float* __restrict__ z,
+                                                       const float* __restrict__ q, const float* __restrict__ h,
+                                                       float* __restrict__ dzr, int ldzr, float* __restrict__ dq,
+                                                       float* __restrict__ dh, int64_t M, int hid) {
+  const int64_t total = M * hid;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / hid; const int c = (int)(e % hid);
+    const float g = dhn[e], zz = z[e], qq = q[e], hh = h[e];
+    dzr[m * ldzr + c] = g * (qq - hh) * zz * (1.f - zz);
+    dq[e] = g * zz * (1.f - qq * qq);
+    dh[e] = g * (1.f - zz);
+  }
+}
+
+// stage 2 (input of the q conv was r*h):  dzr[:, hid:2hid] = d(rh) * h * r (1-r);   dh += d(rh) * r
+__global__ __launch_bounds__(256) void gru_bwd2_kernel(const float* __restrict__ drh, const float* __restrict__ r,
+                                                       const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
+                                                       float* __restrict__ dh, int64_t M, int hid) {
+  const int64_t total = M * hid;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / hid; const int c = (int)(e % hid);
+    const float g = drh[e], rr = r[e];
+    dzr[m * ldzr + hid + c] = g * h[e] * rr * (1.f - rr);
+    dh[e] += g * rr;
+  }
+}
+
+// out[c] += scale * sum_m x[m][c]      (bias gradients).  grid.x covers channels in 64s, grid.y splits rows.
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int ld, int64_t M, int C,
+                                                      float* __restrict__ out, float scale) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int64_t rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = r0 + rows_per < M ? r0 + rows_per : M;
+  float s = 0.f;
+  if (c < C)
+    for (int64_t m = r0 + w; m < r1; m += 4) s += x[m * ld + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < C) atomicAdd(out + c, scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// y = a*x + b*y over n floats (n % 4 == 0 not required)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, float a, float b,
+                                                    int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+    y[e] = a * x[e] + (b == 0.f ? 0.f : b * y[e]);
+}
+
+inline int grid_for(int64_t work) { int64_t g = (work + 255) / 256; return (int)(g < 1 ? 1 : g > 16384 ? 16384 : g); }
+
+}  // namespace
+
+extern "C" int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate,
+                                   hipStream_t s) {
+  if (!src || !dst || B < 1 || C < 1 || HW < 1) return FS_ERR_ARG;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(HW, 32), ceil_div(C, 32), B), dim3(256), 0, s, src, dst, C, HW, ld, coff, accumulate);
+  return fs_launch_status();
+}
+extern "C" int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate,
+                                   hipStream_t s) {
+  if (!src || !dst || B < 1 || C < 1 || HW < 1) return FS_ERR_ARG;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ceil_div(HW, 32), ceil_div(C, 32), B), dim3(256), 0, s, src, dst, C, HW, ld, coff, accumulate);
+  return fs_launch_status();
+}
+extern "C" int fsraft_im2col7(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* cols, int ld, int B, int H,
+                              int W, hipStream_t s) {
+  if (!flow || !cols || ld < 100 || ld % 4) return FS_ERR_ARG;
+  hipLaunchKernelGGL(im2col7_kernel, dim3(grid_for((int64_t)B * H * W * ld)), dim3(256), 0, s, flow, bs, cs, ps, cols, ld, B, H, W);
+  return fs_launch_status();
+}
+extern "C" int fsraft_col2im7(const float* dcols, int ld, float* dflow, int B, int H, int W, int accumulate, hipStream_t s) {
+  if (!dcols || !dflow) return FS_ERR_ARG;
+  const int64_t total = (int64_t)B * 2 * H * W;
+  hipLaunchKernelGGL(col2im7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dcols, ld, dflow, B, H, W, accumulate);
+  return fs_launch_status();
+}
+extern "C" int fsraft_flow_to_nhwc(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* dst, int ld, int coff,
+                                   int B, int HW, hipStream_t s) {
+  if (!flow || !dst) return FS_ERR_ARG;
+  const int64_t M = (int64_t)B * HW;
+  hipLaunchKernelGGL(flow_to_nhwc_kernel, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, s, flow, bs, cs, ps, dst, ld, coff, M, HW);
+  return fs_launch_status();
+}
+extern "C" int fsraft_nhwc_to_flow(const float* src, int ld, int coff, float* dflow, int B, int HW, int accumulate, hipStream_t s) {
+  if (!src || !dflow) return FS_ERR_ARG;
+  const int64_t M = (int64_t)B * HW;
+  hipLaunchKernelGGL(nhwc_to_flow_kernel, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, s, src, ld, coff, dflow, M, HW, accumulate);
+  return fs_launch_status();
+}
+extern "C" int fsraft_relu_bwd(float* g, int ldg, const float* y, int ldy, int64_t M, int C, hipStream_t s) {
+  if (!g || !y || ldg % 4 || ldy % 4) return FS_ERR_ARG;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(M * ((C + 3) / 4))), dim3(256), 0, s, g, ldg, y, ldy, M, C);
+  return fs_launch_status();
+}
+extern "C" int fsraft_gru_bwd1(const float* dhn, const float* z, const float* q, const float* h, float* dzr, int ldzr,
+                               float* dq, float* dh, int64_t M, int hid, hipStream_t s) {
+  if (!dhn || !z || !q || !h || !dzr || !dq || !dh) return FS_ERR_ARG;
+  hipLaunchKernelGGL(gru_bwd1_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, dhn, z, q, h, dzr, ldzr, dq, dh, M, hid);
+  return fs_launch_status();
+}
+extern "C" int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh,
+                               int64_t M, int hid, hipStream_t s) {
+  if (!drh || !r || !h || !dzr || !dh) return FS_ERR_ARG;
+  hipLaunchKernelGGL(gru_bwd2_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, M, hid);
+  return fs_launch_status();
+}
+extern "C" int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s) {
+  if (!x || !out) return FS_ERR_ARG;
+  int ysplit = (int)(M / 512); if (ysplit < 1) ysplit = 1; if (ysplit > 128) ysplit = 128;
+  hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(C, 64), ysplit), dim3(256), 0, s, x, ld, M, C, out, scale);
+  return fs_launch_status();
+}
+extern "C" int fsraft_axpby(const float* x, float* y, float a, float b, int64_t n, hipStream_t s) {
+  if (!x || !y) return FS_ERR_ARG;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, a, b, n);
+  return fs_launch_status();
+}

@@ -1,0 +1,255 @@
+// Learned 8x convex upsampler, forward and backward (row a9 of SURVEY.md section 8;
+// reference: pytorch/core/raft.py:72-83 -- softmax over 9 taps of the mask viewed as
+// [N,1,9,8,8,H,W], 3x3 unfold of 8*flow with zero padding, weighted sum, pixel shuffle).
+//
+//   up[n, c, 8y+sy, 8x+sx] = sum_k softmax_k(mask[n, k*64 + sy*8 + sx, y, x]) * 8*flow[n, c, y+ky-1, x+kx-1]
+//
+// The mask is consumed channels-last ([N,H,W,576]): one wavefront owns one coarse pixel,
+// lane = sy*8+sx, so each of the 9 tap reads is one 256-byte coalesced row and the
+// softmax lives entirely in registers (no cross-lane traffic).  Eight neighbouring
+// coarse pixels share a workgroup so the 2x8 output rows leave as 256-byte runs.
+// HBM bytes per coarse pixel: 2304 (mask) + 512 (up) + ~72 (flow halo).
+#include "common.hpp"
+
+namespace {
+
+struct Flow2 {            // 2-channel planar-or-interleaved tensor, element (n,c,pix) at n*bs + c*cs + pix*ps
+  const float* p;
+  int64_t bs, cs, ps;
+};
+
+__device__ __forceinline__ void softmax9(const float (&m)[9], float (&p)[9]) {
+  float mx = m[0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) mx = fmaxf(mx, m[k]);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { p[k] = expf(m[k] - mx); s += p[k]; }
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) p[k] *= inv;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(Flow2 flow, const float* __restrict__ mask,
+                                                           float* __restrict__ up, int H, int W) {
+  __shared__ float tile[2][8][64];
+  const int xb = blockIdx.x * 8, y = blockIdx.y, n = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sy = lane >> 3, sx = lane & 7;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int xl = wave * 2 + pp, x = xb + xl;
+    if (x < W) {
+      const float* mp = mask + (((int64_t)n * H + y) * W + x) * 576 + lane;
+      float m[9], p[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) m[k] = mp[k * 64];
+      softmax9(m, p);
+      float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        float f0 = 0.f, f1 = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const int64_t a = n * flow.bs + ((int64_t)yy * W + xx) * flow.ps;
+          f0 = 8.f * flow.p[a];
+          f1 = 8.f * flow.p[a + flow.cs];
+        }
+        o0 += p[k] * f0;
+        o1 += p[k] * f1;
+      }
+      tile[0][sy][xl * 8 + sx] = o0;
+      tile[1][sy][xl * 8 + sx] = o1;
+    }
+  }
+  __syncthreads();
+  const int col = threadIdx.x & 63;
+  const int W8 = 8 * W, H8 = 8 * H;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int row = (threadIdx.x >> 6) + 4 * jj;   // 0..15 = c*8 + sy
+    const int c = row >> 3, r = row & 7;
+    if (xb * 8 + col < W8) up[(((int64_t)n * 2 + c) * H8 + 8 * y + r) * W8 + xb * 8 + col] = tile[c][r][col];
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// dmask (channels-last, same layout as mask) and T[n,y,x,c,k] = sum_s p_k[s] * dup[c][s]
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const float* __restrict__ mask,
+                                                           const float* __restrict__ dup, float* __restrict__ dmask,
+                                                           float* __restrict__ T, int H, int W) {
+  __shared__ float tile[2][8][64];
+  const int xb = blockIdx.x * 8, y = blockIdx.y, n = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sy = lane >> 3, sx = lane & 7;
+  const int W8 = 8 * W, H8 = 8 * H;
+  {
+    const int col = threadIdx.x & 63;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = (threadIdx.x >> 6) + 4 * jj;
+      const int c = row >> 3, r = row & 7;
+      tile[c][r][col] = (xb * 8 + col < W8) ? dup[(((int64_t)n * 2 + c) * H8 + 8 * y + r) * W8 + xb * 8 + col] : 0.f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int xl = wave * 2 + pp, x = xb + xl;
+    if (x >= W) continue;
+    const int64_t pix = ((int64_t)n * H + y) * W + x;
+    const float* mp = mask + pix * 576 + lane;
+    float m[9], p[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = mp[k * 64];
+    softmax9(m, p);
+    const float g0 = tile[0][sy][xl * 8 + sx], g1 = tile[1][sy][xl * 8 + sx];
+    float dp[9];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      float f0 = 0.f, f1 = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const int64_t a = n * flow.bs + ((int64_t)yy * W + xx) * flow.ps;
+        f0 = 8.f * flow.p[a];
+        f1 = 8.f * flow.p[a + flow.cs];
+      }
+      dp[k] = g0 * f0 + g1 * f1;
+      dot += p[k] * dp[k];
+    }
+    float* dm = dmask + pix * 576 + lane;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dm[k * 64] = p[k] * (dp[k] - dot);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float t0 = wave_sum(p[k] * g0);
+      const float t1 = wave_sum(p[k] * g1);
+      if (lane == 0) {
+        T[pix * 18 + k] = t0;
+        T[pix * 18 + 9 + k] = t1;
+      }
+    }
+  }
+}
+
+// dflow[n,c,y,x] = 8 * sum_k T[n, y-(ky-1), x-(kx-1), c, k]   (deterministic gather, no atomics)
+__global__ __launch_bounds__(256) void upsample_dflow_kernel(const float* __restrict__ T, float* __restrict__ dflow,
+                                                             int N, int H, int W) {
+  const int64_t total = (int64_t)N * 2 * H * W;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % W);
+  const int y = (int)((e / W) % H);
+  const int c = (int)((e / ((int64_t)W * H)) % 2);
+  const int n = (int)(e / ((int64_t)2 * W * H));
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y - (k / 3 - 1), xx = x - (k % 3 - 1);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += T[(((int64_t)n * H + yy) * W + xx) * 18 + c * 9 + k];
+  }
+  dflow[e] = 8.f * s;
+}
+
+// ---- bilinear x8 (raft-small): 8 * interpolate(flow, align_corners=True), core/utils/utils.py:80-82
+__global__ __launch_bounds__(256) void upflow8_fwd_kernel(const float* __restrict__ flow, float* __restrict__ up,
+                                                          int NC, int H, int W) {
+  const int H8 = 8 * H, W8 = 8 * W;
+  const int64_t total = (int64_t)NC * H8 * W8;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int X = (int)(e % W8), Y = (int)((e / W8) % H8);
+  const int64_t nc = e / ((int64_t)W8 * H8);
+  const float sy = H8 > 1 ? (float)(H - 1) / (float)(H8 - 1) : 0.f;
+  const float sx = W8 > 1 ? (float)(W - 1) / (float)(W8 - 1) : 0.f;
+  const float fy = sy * Y, fx = sx * X;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ly = fy - y0, lx = fx - x0;
+  const float* f = flow + nc * H * W;
+  const float v = (1.f - ly) * ((1.f - lx) * f[y0 * W + x0] + lx * f[y0 * W + x1]) +
+                  ly * ((1.f - lx) * f[y1 * W + x0] + lx * f[y1 * W + x1]);
+  up[e] = 8.f * v;
+}
+
+__global__ __launch_bounds__(256) void upflow8_bwd_kernel(const float* __restrict__ dup, float* __restrict__ dflow,
+                                                          int NC, int H, int W) {
+  // one thread per coarse pixel gathers from the fine pixels whose 2x2 stencil touches it
+  const int H8 = 8 * H, W8 = 8 * W;
+  const int64_t total = (int64_t)NC * H * W;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % W), y = (int)((e / W) % H);
+  const int64_t nc = e / ((int64_t)W * H);
+  const float sy = H8 > 1 ? (float)(H - 1) / (float)(H8 - 1) : 0.f;
+  const float sx = W8 > 1 ? (float)(W - 1) / (float)(W8 - 1) : 0.f;
+  // fine rows Y with floor(sy*Y) in {y-1, y}: conservative range then exact test
+  const int Ylo = max(0, (int)floorf((y - 1) / fmaxf(sy, 1e-12f)) - 1), Yhi = min(H8 - 1, (int)ceilf((y + 1) / fmaxf(sy, 1e-12f)) + 1);
+  const int Xlo = max(0, (int)floorf((x - 1) / fmaxf(sx, 1e-12f)) - 1), Xhi = min(W8 - 1, (int)ceilf((x + 1) / fmaxf(sx, 1e-12f)) + 1);
+  const float* g = dup + nc * H8 * W8;
+  float s = 0.f;
+  for (int Y = Ylo; Y <= Yhi; ++Y) {
+    const float fy = sy * Y;
+    const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+    const float ly = fy - y0;
+    float wy = 0.f;
+    if (y0 == y) wy += 1.f - ly;
+    if (y1 == y) wy += ly;
+    if (wy == 0.f) continue;
+    for (int X = Xlo; X <= Xhi; ++X) {
+      const float fx = sx * X;
+      const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+      const float lx = fx - x0;
+      float wx = 0.f;
+      if (x0 == x) wx += 1.f - lx;
+      if (x1 == x) wx += lx;
+      if (wx != 0.f) s += wy * wx * g[(int64_t)Y * W8 + X];
+    }
+  }
+  dflow[e] = 8.f * s;
+}
+
+}  // namespace
+
+// flow element (n,c,pix) at flow[n*flow_bs + c*flow_cs + pix*flow_ps]; mask is [N,H,W,576]; up is [N,2,8H,8W].
+extern "C" int fsraft_upsample_fwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int64_t flow_ps,
+                                   const float* mask_nhwc, float* up, int N, int H, int W, hipStream_t stream) {
+  if (!flow || !mask_nhwc || !up || N < 1 || H < 1 || W < 1) return FS_ERR_ARG;
+  Flow2 f{flow, flow_bs, flow_cs, flow_ps};
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ceil_div(W, 8), H, N), dim3(256), 0, stream, f, mask_nhwc, up, H, W);
+  return fs_launch_status();
+}
+
+// dmask_nhwc [N,H,W,576], dflow [N,2,H,W] contiguous; scratch holds N*H*W*18 floats.
+extern "C" int fsraft_upsample_bwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int64_t flow_ps,
+                                   const float* mask_nhwc, const float* dup, float* dmask_nhwc, float* dflow,
+                                   float* scratch, int N, int H, int W, hipStream_t stream) {
+  if (!flow || !mask_nhwc || !dup || !dmask_nhwc || !dflow || !scratch || N < 1 || H < 1 || W < 1) return FS_ERR_ARG;
+  Flow2 f{flow, flow_bs, flow_cs, flow_ps};
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ceil_div(W, 8), H, N), dim3(256), 0, stream, f, mask_nhwc, dup,
+                     dmask_nhwc, scratch, H, W);
+  const int64_t total = (int64_t)N * 2 * H * W;
+  hipLaunchKernelGGL(upsample_dflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, scratch, dflow,
+                     N, H, W);
+  return fs_launch_status();
+}
+
+extern "C" int fsraft_upflow8_fwd(const float* flow, float* up, int N, int C, int H, int W, hipStream_t stream) {
+  if (!flow || !up || N < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_ARG;
+  const int64_t total = (int64_t)N * C * 64 * H * W;
+  hipLaunchKernelGGL(upflow8_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, flow, up, N * C, H, W);
+  return fs_launch_status();
+}
+
+extern "C" int fsraft_upflow8_bwd(const float* dup, float* dflow, int N, int C, int H, int W, hipStream_t stream) {
+  if (!dup || !dflow || N < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_ARG;
+  const int64_t total = (int64_t)N * C * H * W;
+  hipLaunchKernelGGL(upflow8_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dup, dflow, N * C, H, W);
+  return fs_launch_status();
+}

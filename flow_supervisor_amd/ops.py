@@ -1,0 +1,363 @@
+"""Tensor-level wrappers over the C ABI (one function per fsraft_* entry point).
+
+These allocate outputs with torch (device memory + current stream are the only things
+torch provides here) and call straight into libfsraft.so.  No autograd in this file;
+see core/corr.py, core/update.py and core/raft.py for the autograd.Function wrappers.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _lib():
+    return L.load()
+
+
+def pyramid_sizes(H, W, num_levels=4):
+    out = []
+    for _ in range(num_levels):
+        out.append((H, W))
+        H, W = H // 2, W // 2
+    return out
+
+
+def _planar2_strides(t):
+    """(bs, cs, ps) for a [B,2,H,W] tensor whose H,W dims are jointly contiguous-strided
+    (covers NCHW-contiguous and channels-last)."""
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if sh != W * sw:
+        raise RuntimeError("2-channel tensor must have a single pixel stride (got strides %s)" % (t.stride(),))
+    return sb, sc, sw
+
+
+# ------------------------------------------------------------------ correlation volume
+def corr_build(fmap1, fmap2, num_levels=4):
+    L.require_cuda_f32(fmap1, fmap2)
+    fmap1 = fmap1.contiguous()
+    fmap2 = fmap2.contiguous()
+    B, C, H, W = fmap1.shape
+    sizes = pyramid_sizes(H, W, num_levels)
+    if sizes[-1][0] < 1 or sizes[-1][1] < 1:
+        raise RuntimeError(f"feature map {H}x{W} too small for {num_levels} pyramid levels")
+    levels = [torch.empty(B * H * W, 1, h, w, device=fmap1.device, dtype=torch.float32) for h, w in sizes]
+    pp, keep = L.ptr_array(levels)
+    L.check(_lib().fsraft_corr_build(L.ptr(fmap1), L.ptr(fmap2), pp, num_levels, B, C, H, W, L.stream()), "corr_build")
+    return levels
+
+
+def corr_unpool_bwd_(dlevels, B, H, W):
+    pp, keep = L.ptr_array(dlevels)
+    L.check(_lib().fsraft_corr_unpool_bwd(pp, len(dlevels), B, H, W, L.stream()), "corr_unpool_bwd")
+
+
+def corr_lookup_fwd(levels, coords, radius, nhwc=False):
+    L.require_cuda_f32(coords, *levels)
+    B, _, H, W = coords.shape
+    bs, cs, ps = _planar2_strides(coords)
+    ch = len(levels) * (2 * radius + 1) ** 2
+    if nhwc:
+        out = torch.empty(B, H, W, ch, device=coords.device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, ch, H, W, device=coords.device, dtype=torch.float32)
+    pp, keep = L.ptr_array(levels)
+    L.check(_lib().fsraft_corr_lookup_fwd(pp, len(levels), L.ptr(coords), bs, cs, ps, L.ptr(out), int(nhwc), B, H, W,
+                                          radius, L.stream()), "corr_lookup_fwd")
+    return out
+
+
+def corr_lookup_bwd_(dlevels, coords, dout, radius, nhwc=False):
+    L.require_cuda_f32(coords, dout, *dlevels)
+    B, _, H, W = coords.shape
+    bs, cs, ps = _planar2_strides(coords)
+    dout = dout.contiguous()
+    pp, keep = L.ptr_array(dlevels)
+    L.check(_lib().fsraft_corr_lookup_bwd(pp, len(dlevels), L.ptr(coords), bs, cs, ps, L.ptr(dout), int(nhwc), B, H, W,
+                                          radius, L.stream()), "corr_lookup_bwd")
+
+
+def gemm(A, Bm, trans_b, alpha=1.0, out=None, accumulate=False):
+    """Batched C[b] = alpha * A[b] @ (Bm[b]^T if trans_b else Bm[b]); A [b,M,K], Bm [b,N,K] or [b,K,N]."""
+    L.require_cuda_f32(A, Bm)
+    A = A.contiguous()
+    Bm = Bm.contiguous()
+    b, M, K = A.shape
+    N = Bm.shape[1] if trans_b else Bm.shape[2]
+    if out is None:
+        out = torch.empty(b, M, N, device=A.device, dtype=torch.float32)
+    L.check(_lib().fsraft_gemm_f32(L.ptr(A), K, M * K, L.ptr(Bm), Bm.shape[2], Bm.shape[1] * Bm.shape[2], L.ptr(out),
+                                   N, M * N, b, M, N, K, int(trans_b), float(alpha), int(accumulate), L.stream()),
+            "gemm_f32")
+    return out
+
+
+def corr_build_bwd(fmap1, fmap2, dlevels):
+    """dlevels: accumulated dL/dV_l (modified in place).  Returns (dfmap1, dfmap2) as NCHW."""
+    B, C, H, W = fmap1.shape
+    N = H * W
+    corr_unpool_bwd_(dlevels, B, H, W)
+    dV = dlevels[0].view(B, N, N)
+    s = 1.0 / math.sqrt(C)
+    f1 = fmap1.contiguous().view(B, C, N)
+    f2 = fmap2.contiguous().view(B, C, N)
+    d1 = gemm(f2, dV, True, s)     # [B,C,N]: sum_j f2[c][j] dV[i][j]
+    d2 = gemm(f1, dV, False, s)    # [B,C,N]: sum_i f1[c][i] dV[i][j]
+    return d1.view(B, C, H, W), d2.view(B, C, H, W)
+
+
+# ------------------------------------------------------------------ alternate (on-the-fly) correlation
+def altcorr_fwd(fmap1, fmap2, coords, radius):
+    L.require_cuda_f32(fmap1, fmap2, coords)
+    for t, n in ((fmap1, "fmap1"), (fmap2, "fmap2"), (coords, "coords")):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{n} must be contiguous")       # correlation.cpp:19-21
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    if coords.shape[1] != 1:
+        raise RuntimeError("only N=1 coordinate sets are supported (all the reference ever passes)")
+    rd = 2 * radius + 1
+    corr = torch.empty(B, 1, rd * rd, H1, W1, device=fmap1.device, dtype=torch.float32)
+    L.check(_lib().fsraft_altcorr_fwd(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(corr), B, H1, W1, H2, W2, C,
+                                      radius, L.stream()), "altcorr_fwd")
+    return corr
+
+
+def altcorr_bwd(fmap1, fmap2, coords, corr_grad, radius):
+    L.require_cuda_f32(fmap1, fmap2, coords, corr_grad)
+    for t, n in ((fmap1, "fmap1"), (fmap2, "fmap2"), (coords, "coords"), (corr_grad, "corr_grad")):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{n} must be contiguous")
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    g1 = torch.empty_like(fmap1)
+    g2 = torch.zeros_like(fmap2)
+    L.check(_lib().fsraft_altcorr_bwd(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(corr_grad), L.ptr(g1),
+                                      L.ptr(g2), B, H1, W1, H2, W2, C, radius, L.stream()), "altcorr_bwd")
+    return g1, g2, torch.zeros_like(coords)
+
+
+# ------------------------------------------------------------------ upsamplers
+def upsample_fwd(flow, mask_nhwc):
+    L.require_cuda_f32(flow, mask_nhwc)
+    N, _, H, W = flow.shape
+    bs, cs, ps = _planar2_strides(flow)
+    up = torch.empty(N, 2, 8 * H, 8 * W, device=flow.device, dtype=torch.float32)
+    L.check(_lib().fsraft_upsample_fwd(L.ptr(flow), bs, cs, ps, L.ptr(mask_nhwc), L.ptr(up), N, H, W, L.stream()),
+            "upsample_fwd")
+    return up
+
+
+def upsample_bwd(flow, mask_nhwc, dup):
+    L.require_cuda_f32(flow, mask_nhwc, dup)
+    N, _, H, W = flow.shape
+    bs, cs, ps = _planar2_strides(flow)
+    dup = dup.contiguous()
+    dmask = torch.empty_like(mask_nhwc)
+    dflow = torch.empty(N, 2, H, W, device=flow.device, dtype=torch.float32)
+    scratch = torch.empty(N * H * W * 18, device=flow.device, dtype=torch.float32)
+    L.check(_lib().fsraft_upsample_bwd(L.ptr(flow), bs, cs, ps, L.ptr(mask_nhwc), L.ptr(dup), L.ptr(dmask),
+                                       L.ptr(dflow), L.ptr(scratch), N, H, W, L.stream()), "upsample_bwd")
+    return dflow, dmask
+
+
+def upflow8_fwd(flow):
+    L.require_cuda_f32(flow)
+    flow = flow.contiguous()
+    N, C, H, W = flow.shape
+    up = torch.empty(N, C, 8 * H, 8 * W, device=flow.device, dtype=torch.float32)
+    L.check(_lib().fsraft_upflow8_fwd(L.ptr(flow), L.ptr(up), N, C, H, W, L.stream()), "upflow8_fwd")
+    return up
+
+
+def upflow8_bwd(dup, H, W):
+    dup = dup.contiguous()
+    N, C = dup.shape[:2]
+    dflow = torch.empty(N, C, H, W, device=dup.device, dtype=torch.float32)
+    L.check(_lib().fsraft_upflow8_bwd(L.ptr(dup), L.ptr(dflow), N, C, H, W, L.stream()), "upflow8_bwd")
+    return dflow
+
+
+# ------------------------------------------------------------------ layout helpers
+def nchw_to_nhwc(src, dst=None, coff=0, accumulate=False):
+    """src [B,C,H,W] contiguous -> dst[..., coff:coff+C] of a [B,H,W,ld] buffer."""
+    L.require_cuda_f32(src)
+    src = src.contiguous()
+    B, C, H, W = src.shape
+    if dst is None:
+        dst = torch.zeros(B, H, W, (C + 3) // 4 * 4, device=src.device, dtype=torch.float32)
+    ld = dst.shape[-1]
+    L.check(_lib().fsraft_nchw_to_nhwc(L.ptr(src), L.ptr(dst), B, C, H * W, ld, coff, int(accumulate), L.stream()),
+            "nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src, C=None, coff=0, dst=None, accumulate=False):
+    """src [B,H,W,ld] -> [B,C,H,W] contiguous taking channels coff:coff+C."""
+    L.require_cuda_f32(src)
+    B, H, W, ld = src.shape
+    C = ld if C is None else C
+    if dst is None:
+        dst = torch.empty(B, C, H, W, device=src.device, dtype=torch.float32)
+    L.check(_lib().fsraft_nhwc_to_nchw(L.ptr(src), L.ptr(dst), B, C, H * W, ld, coff, int(accumulate), L.stream()),
+            "nhwc_to_nchw")
+    return dst
+
+
+def im2col7(flow, cols):
+    B, _, H, W = flow.shape
+    bs, cs, ps = _planar2_strides(flow)
+    L.check(_lib().fsraft_im2col7(L.ptr(flow), bs, cs, ps, L.ptr(cols), cols.shape[-1], B, H, W, L.stream()), "im2col7")
+    return cols
+
+
+def col2im7(dcols, dflow, accumulate):
+    B, _, H, W = dflow.shape
+    L.check(_lib().fsraft_col2im7(L.ptr(dcols), dcols.shape[-1], L.ptr(dflow), B, H, W, int(accumulate), L.stream()),
+            "col2im7")
+
+
+def flow_to_nhwc(flow, dst, coff):
+    B, _, H, W = flow.shape
+    bs, cs, ps = _planar2_strides(flow)
+    L.check(_lib().fsraft_flow_to_nhwc(L.ptr(flow), bs, cs, ps, L.ptr(dst), dst.shape[-1], coff, B, H * W, L.stream()),
+            "flow_to_nhwc")
+
+
+def nhwc_to_flow(src, coff, dflow, accumulate):
+    B, _, H, W = dflow.shape
+    L.check(_lib().fsraft_nhwc_to_flow(L.ptr(src), src.shape[-1], coff, L.ptr(dflow), B, H * W, int(accumulate),
+                                       L.stream()), "nhwc_to_flow")
+
+
+def relu_bwd_(g, y, C):
+    M = g.numel() // g.shape[-1]
+    L.check(_lib().fsraft_relu_bwd(L.ptr(g), g.shape[-1], L.ptr(y), y.shape[-1], M, C, L.stream()), "relu_bwd")
+
+
+def gru_bwd1(dhn, z, q, h, dzr, dq, dh, hid):
+    M = dhn.numel() // hid
+    L.check(_lib().fsraft_gru_bwd1(L.ptr(dhn), L.ptr(z), L.ptr(q), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dq),
+                                   L.ptr(dh), M, hid, L.stream()), "gru_bwd1")
+
+
+def gru_bwd2(drh, r, h, dzr, dh, hid):
+    M = drh.numel() // hid
+    L.check(_lib().fsraft_gru_bwd2(L.ptr(drh), L.ptr(r), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dh), M, hid,
+                                   L.stream()), "gru_bwd2")
+
+
+def col_sum_(x, C, out, scale=1.0):
+    M = x.numel() // x.shape[-1]
+    L.check(_lib().fsraft_col_sum(L.ptr(x), x.shape[-1], M, C, L.ptr(out), float(scale), L.stream()), "col_sum")
+
+
+def axpby_(x, y, a=1.0, b=1.0):
+    L.check(_lib().fsraft_axpby(L.ptr(x), L.ptr(y), float(a), float(b), x.numel(), L.stream()), "axpby")
+
+
+# ------------------------------------------------------------------ convolutions
+def conv_ktot(srcC, KH, KW):
+    return _lib().fsraft_conv_ktot(L.int_array(srcC), len(srcC), KH, KW)
+
+
+def pack_weight(w, srcC, mode):
+    """w: [Cout,Cin,KH,KW] contiguous.  mode 0 -> [Cout,Ktot]; mode 1 -> [Cin,Ktot'] (data gradient)."""
+    L.require_cuda_f32(w)
+    w = w.contiguous()
+    Cout, Cin, KH, KW = w.shape
+    if mode == 0:
+        rows, kt = Cout, conv_ktot(srcC, KH, KW)
+    else:
+        rows, kt = Cin, conv_ktot([Cout], KH, KW)
+    wpk = torch.empty(rows, kt, device=w.device, dtype=torch.float32)
+    L.check(_lib().fsraft_pack_conv_weight(L.ptr(w), L.ptr(wpk), Cout, Cin, KH, KW, L.int_array(srcC), len(srcC), mode,
+                                           0, L.stream()), "pack_conv_weight")
+    return wpk
+
+
+def unpack_weight_grad(dwpk, shape, srcC, out=None, accumulate=False):
+    Cout, Cin, KH, KW = shape
+    if out is None:
+        out = torch.empty(shape, device=dwpk.device, dtype=torch.float32)
+        accumulate = False
+    L.check(_lib().fsraft_pack_conv_weight(L.ptr(out), L.ptr(dwpk), Cout, Cin, KH, KW, L.int_array(srcC), len(srcC), 2,
+                                           int(accumulate), L.stream()), "unpack_conv_weight")
+    return out
+
+
+class V:
+    """Channels [off, off+C) of a channels-last buffer [B,H,W,ld] (pitch = the buffer's ld)."""
+    __slots__ = ("t", "off", "C", "ld")
+
+    def __init__(self, t, C=None, off=0):
+        self.t, self.off, self.ld = t, off, t.shape[-1]
+        self.C = (t.shape[-1] - off) if C is None else C
+        assert off % 4 == 0 and self.ld % 4 == 0, "channel slices must stay 16-byte aligned"
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.off
+
+
+class Dst:
+    """Output channel range starting at GEMM column n0 -> strided destination."""
+    __slots__ = ("t", "off", "bs", "ps", "cs", "n0", "acc")
+
+    def __init__(self, t, off, bs, ps, cs, n0=0, acc=False):
+        self.t, self.off, self.bs, self.ps, self.cs, self.n0, self.acc = t, off, bs, ps, cs, n0, acc
+
+    @staticmethod
+    def nhwc(buf, coff=0, n0=0, acc=False):
+        B, H, W, ld = buf.shape
+        return Dst(buf, coff, H * W * ld, ld, 1, n0, acc)
+
+    @staticmethod
+    def nchw(buf, n0=0, acc=False):
+        B, C, H, W = buf.shape
+        return Dst(buf, 0, C * H * W, 1, H * W, n0, acc)
+
+
+def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
+                 aux1=None, aux2=None, hid=0):
+    """srcs: list of V (concatenated along channels).  dsts: list of Dst.
+    GRU epilogues (epi 2: z|r, epi 3: q) take h, z, aux buffers as [B,H,W,ld] tensors."""
+    d = L.ConvDesc()
+    for i, v in enumerate(srcs):
+        d.src[i] = v.ptr; d.srcC[i] = v.C; d.srcld[i] = v.ld
+    d.nsrc = len(srcs)
+    d.wpk = wpk.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.B, d.H, d.W, d.KH, d.KW, d.N = B, H, W, KH, KW, N
+    for i, ds in enumerate(dsts):
+        d.dst[i] = ds.t.data_ptr() + 4 * ds.off
+        d.dst_bs[i], d.dst_ps[i], d.dst_cs[i] = ds.bs, ds.ps, ds.cs
+        d.dst_n0[i] = ds.n0; d.dst_acc[i] = int(ds.acc)
+    d.ndst = len(dsts)
+    d.relu = int(relu); d.alpha = float(alpha); d.epi = epi
+    if h is not None:
+        d.h = h.data_ptr(); d.ldh = h.shape[-1]
+    if z is not None:
+        d.z = z.data_ptr(); d.ldz = z.shape[-1]
+    if aux1 is not None:
+        d.aux1 = aux1.data_ptr(); d.ld1 = aux1.shape[-1]
+    if aux2 is not None:
+        d.aux2 = aux2.data_ptr(); d.ld2 = aux2.shape[-1]
+    d.hid = hid
+    L.check(_lib().fsraft_conv_forward(ctypes.byref(d), L.stream()), "conv_forward")
+
+
+def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW):
+    """dwpk [Cout,Ktot] += dy^T im2col(srcs).  dy: V over the (already act'-scaled) output gradient."""
+    arr = (ctypes.c_void_p * len(srcs))(*[v.ptr for v in srcs])
+    pp = ctypes.cast(arr, L._PP)
+    L.check(_lib().fsraft_conv_wgrad(ctypes.c_void_p(dy.ptr), dy.ld, dy.C, pp, L.int_array([v.C for v in srcs]),
+                                     L.int_array([v.ld for v in srcs]), len(srcs), L.ptr(dwpk), B, H, W, KH, KW,
+                                     L.stream()), "conv_wgrad")
+
+
+def col_sum_v(v, out, scale=1.0):
+    M = v.t.numel() // v.ld
+    L.check(_lib().fsraft_col_sum(ctypes.c_void_p(v.ptr), v.ld, M, v.C, L.ptr(out), float(scale), L.stream()), "col_sum")

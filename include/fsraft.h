@@ -1,0 +1,127 @@
+/* fsraft.h -- C ABI of libfsraft.so, the MI355X (gfx950) implementation of the RAFT
+ * hot path of iwbn/flow-supervisor.
+ *
+ * Everything here takes plain device pointers, sizes and a hipStream_t; no torch types
+ * cross this boundary.  All tensors are fp32.  Every function only enqueues work on
+ * `stream` (no allocation, no synchronisation -> safe under hipGraph capture) and
+ * returns 0 (FSRAFT_OK), 1 (bad argument) or 2 (launch failed).
+ *
+ * Each entry point names the reference interface it replaces, as file:line under
+ * /root/reference.  The Python binding a maintainer would add is shown in
+ * INTEGRATION.md; ours lives in flow_supervisor_amd/_lib.py.
+ */
+#ifndef FSRAFT_H
+#define FSRAFT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define FSRAFT_OK 0
+#define FSRAFT_ERR_ARG 1
+#define FSRAFT_ERR_LAUNCH 2
+
+/* ---- all-pairs correlation volume + pyramid ---------------------------------------
+ * Replaces CorrBlock.__init__ / CorrBlock.corr, pytorch/core/corr.py:13-27, 52-60
+ * (torch.matmul + 3x avg_pool2d) and TF calc_all_field, raft/allfield.py:61-92.
+ * fmap1, fmap2: [B,C,H,W].  levels[l]: [B*H*W, H>>l, W>>l] (floor), l < num_levels <= 4. */
+int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* levels, int num_levels,
+                      int B, int C, int H, int W, hipStream_t stream);
+
+/* Backward of the pooling chain: dlevels[0] += unpool(dlevels[1..]) in place.
+ * (autograd of F.avg_pool2d, pytorch/core/corr.py:25-27) */
+int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int B, int H, int W, hipStream_t stream);
+
+/* ---- radius-r pyramid lookup --------------------------------------------------------
+ * Replaces CorrBlock.__call__, pytorch/core/corr.py:29-50 (+ bilinear_sampler,
+ * core/utils/utils.py:57-71) and TF smurf_corr_block, raft/allfield.py:109-135.
+ * coords element (b,c,pix) is read at coords[b*bs + c*cs + pix*ps] (c=0: x, c=1: y).
+ * out: [B, 4*(2r+1)^2, H, W] (nhwc == 0) or [B, H, W, 4*(2r+1)^2] (nhwc != 0). radius in {3,4}. */
+int fsraft_corr_lookup_fwd(float* const* levels, int num_levels, const float* coords, int64_t coords_bs,
+                           int64_t coords_cs, int64_t coords_ps, float* out, int nhwc_out, int B, int H, int W,
+                           int radius, hipStream_t stream);
+/* dlevels[l] += (d out / d V_l)^T dout.  (grid_sampler_2d_backward w.r.t. the volume) */
+int fsraft_corr_lookup_bwd(float* const* dlevels, int num_levels, const float* coords, int64_t coords_bs,
+                           int64_t coords_cs, int64_t coords_ps, const float* dout, int nhwc_in, int B, int H, int W,
+                           int radius, hipStream_t stream);
+
+/* ---- memory-efficient correlation (no N x N volume) ----------------------------------
+ * Replaces alt_cuda_corr.forward / .backward, pytorch/alt_cuda_corr/correlation.cpp:23-54
+ * (kernels correlation_kernel.cu:18-119, 122-256).  Same argument meaning:
+ * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last, coords [B,1,H1,W1,2] (x,y),
+ * corr [B,1,(2r+1)^2,H1,W1], UNSCALED (caller divides by sqrt(C), corr.py:91). */
+int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B, int H1,
+                       int W1, int H2, int W2, int C, int radius, hipStream_t stream);
+/* fmap1_grad [B,H1,W1,C] is overwritten; fmap2_grad [B,H2,W2,C] must be zeroed by the caller
+ * (it is accumulated with atomics); coords get no gradient (the reference returns zeros). */
+int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                       float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C,
+                       int radius, hipStream_t stream);
+
+/* ---- convex 8x upsampler -------------------------------------------------------------
+ * Replaces RAFT.upsample_flow, pytorch/core/raft.py:72-83 and UpsampleConvexWithMask,
+ * raft/upsample.py:11-41.  flow element (n,c,pix) at flow[n*bs + c*cs + pix*ps];
+ * mask channels-last [N,H,W,576]; up [N,2,8H,8W]. */
+int fsraft_upsample_fwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int64_t flow_ps,
+                        const float* mask_nhwc, float* up, int N, int H, int W, hipStream_t stream);
+/* dmask_nhwc [N,H,W,576], dflow [N,2,H,W]; scratch: N*H*W*18 floats. */
+int fsraft_upsample_bwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int64_t flow_ps,
+                        const float* mask_nhwc, const float* dup, float* dmask_nhwc, float* dflow, float* scratch,
+                        int N, int H, int W, hipStream_t stream);
+/* upflow8, pytorch/core/utils/utils.py:80-82 (raft-small). flow [N,C,H,W] -> up [N,C,8H,8W]. */
+int fsraft_upflow8_fwd(const float* flow, float* up, int N, int C, int H, int W, hipStream_t stream);
+int fsraft_upflow8_bwd(const float* dup, float* dflow, int N, int C, int H, int W, hipStream_t stream);
+
+/* ---- update-block convolutions (implicit GEMM, fp32 MFMA) ----------------------------
+ * Replace every nn.Conv2d of pytorch/core/update.py:6-136 together with the cat / ReLU /
+ * sigmoid / tanh / GRU-gate elementwise ops around them.  Activations are channels-last
+ * with pitch ld (ld % 4 == 0, padding channels zero). */
+typedef struct fsraft_conv_desc {
+  const float* src[3]; int srcC[3]; int srcld[3]; int nsrc;   /* concatenated inputs            */
+  const float* wpk; const float* bias;                        /* packed weights, bias[N] or NULL */
+  int B, H, W, KH, KW, N;                                     /* N = output channels             */
+  float* dst[3]; int64_t dst_bs[3]; int64_t dst_ps[3]; int64_t dst_cs[3];
+  int dst_n0[3]; int dst_acc[3]; int ndst;                    /* output channel ranges           */
+  int relu; float alpha;                                      /* y = relu?(alpha*(acc+bias))     */
+  int epi;                                                    /* 0 plain, 2 GRU z|r, 3 GRU q     */
+  const float* h; int ldh; const float* z; int ldz;
+  float* aux1; int ld1; float* aux2; int ld2; int hid;
+} fsraft_conv_desc;
+
+int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);
+int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream);
+int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
+                      const int* srcld, int nsrc, float* dwpk, int B, int H, int W, int KH, int KW,
+                      hipStream_t stream);
+/* mode 0: OIHW -> packed forward; 1: OIHW -> packed data-gradient; 2: packed -> OIHW (+=) */
+int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
+                            int nsrc, int mode, int accumulate, hipStream_t stream);
+
+/* ---- batched fp32 GEMM (volume backward: autograd of torch.matmul, corr.py:57) ------- */
+int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
+                    int64_t ldc, int64_t sC, int batch, int M, int N, int K, int trans_b, float alpha,
+                    int accumulate, hipStream_t stream);
+
+/* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
+int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
+int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
+int fsraft_im2col7(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* cols, int ld, int B, int H, int W, hipStream_t s);
+int fsraft_col2im7(const float* dcols, int ld, float* dflow, int B, int H, int W, int accumulate, hipStream_t s);
+int fsraft_flow_to_nhwc(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* dst, int ld, int coff, int B, int HW, hipStream_t s);
+int fsraft_nhwc_to_flow(const float* src, int ld, int coff, float* dflow, int B, int HW, int accumulate, hipStream_t s);
+int fsraft_relu_bwd(float* g, int ldg, const float* y, int ldy, int64_t M, int C, hipStream_t s);
+int fsraft_gru_bwd1(const float* dhn, const float* z, const float* q, const float* h, float* dzr, int ldzr, float* dq, float* dh, int64_t M, int hid, hipStream_t s);
+int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh, int64_t M, int hid, hipStream_t s);
+int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s);
+int fsraft_axpby(const float* x, float* y, float a, float b, int64_t n, hipStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSRAFT_H */

@@ -1,0 +1,328 @@
+"""Parity of the HIP path (through the C ABI in libfsraft.so) against the golden fixtures
+generated from the reference and against the CPU oracle.  Needs an MI355X: -m gpu.
+
+Tolerances: the path is fp32 end to end; kernels differ from the reference only in
+summation order, so elementwise checks use 1e-4-level absolute tolerances on O(1..10)
+values and the end-to-end gate is EPE <= 1e-3 (BASELINE.json), with ~1e-5 expected."""
+import argparse
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _util import T, close, load, shapes
+from oracle import raft_torch as O
+from oracle.weights import procedural_state_dict, rand_tensor, rand_uniform, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _native():
+    from flow_supervisor_amd import _lib
+    _lib.load()
+
+
+def ns(small):
+    return argparse.Namespace(small=small, mixed_precision=False, alternate_corr=False, dropout=0,
+                              corr_levels=4, corr_radius=3 if small else 4)
+
+
+# ----------------------------------------------------------------------------- a1-a3
+@pytest.mark.parametrize("name", ["corr_tiny", "corr_odd", "corr_mid"])
+def test_corr_build_lookup_and_grads_vs_reference(name):
+    from flow_supervisor_amd.core.corr import CorrBlock
+    g = load(name)
+    B, C, H, W, r, seed = (int(g[k]) for k in ("B", "C", "H", "W", "radius", "seed"))
+    f1 = rand_tensor((B, C, H, W), seed).to(DEV).requires_grad_(True)
+    f2 = rand_tensor((B, C, H, W), seed + 1).to(DEV).requires_grad_(True)
+    blk = CorrBlock(f1, f2, num_levels=4, radius=r)
+    for l in range(4):
+        close(blk.corr_pyramid[l], g[f"pyr{l}"], 2e-5, what=f"pyr{l}")
+    coords = T(g["coords"]).to(DEV)
+    out = blk(coords)
+    assert out.is_contiguous() and out.shape == (B, 4 * (2 * r + 1) ** 2, H, W)
+    close(out, g["out"], 5e-5, what="lookup")
+    out_cl = blk(coords, channels_last=True)
+    close(out_cl.permute(0, 3, 1, 2), g["out"], 5e-5, what="lookup channels-last")
+    up = rand_tensor(tuple(out.shape), seed + 3).to(DEV)
+    # two lookups feeding one loss: exercises the accumulate-in-place gradient pyramid
+    (0.5 * (out * up).sum() + 0.5 * (out_cl.permute(0, 3, 1, 2) * up).sum()).backward()
+    close(f1.grad, g["dfmap1"], 1e-4, what="dfmap1")
+    close(f2.grad, g["dfmap2"], 1e-4, what="dfmap2")
+    v = CorrBlock.corr(f1.detach(), f2.detach())
+    close(v.reshape(-1), T(g["pyr0"]).reshape(-1), 2e-5, what="CorrBlock.corr")
+
+
+def test_corr_lookup_matches_oracle_on_sintel_shape():
+    """Full 55x128 / C=256 shape against the oracle for a strip of queries (the oracle needs the
+    whole volume, so B=1) plus an average-pool consistency property on every level."""
+    from flow_supervisor_amd.core.corr import CorrBlock
+    B, C, H, W, r = 1, 256, 55, 128, 4
+    f1 = rand_tensor((B, C, H, W), 11)
+    f2 = rand_tensor((B, C, H, W), 12)
+    coords = O.coords_grid(B, H, W) + rand_uniform((B, 2, H, W), 13, -8, 8)
+    pyr = O.corr_pyramid(f1, f2, 4)
+    ref = O.corr_lookup(pyr, coords, r)
+    blk = CorrBlock(f1.to(DEV), f2.to(DEV), radius=r)
+    for l in range(4):
+        close(blk.corr_pyramid[l], pyr[l], 5e-5, what=f"level {l}")
+    close(blk(coords.to(DEV)), ref, 1e-4, what="lookup 55x128")
+
+
+# ----------------------------------------------------------------------------- a4/a5
+@pytest.mark.parametrize("name", ["corr_tiny", "corr_odd", "corr_mid"])
+def test_alternate_corr_equals_corrblock(name):
+    from flow_supervisor_amd.core.corr import AlternateCorrBlock
+    g = load(name)
+    B, C, H, W, r, seed = (int(g[k]) for k in ("B", "C", "H", "W", "radius", "seed"))
+    f1 = rand_tensor((B, C, H, W), seed).to(DEV).requires_grad_(True)
+    f2 = rand_tensor((B, C, H, W), seed + 1).to(DEV).requires_grad_(True)
+    out = AlternateCorrBlock(f1, f2, num_levels=4, radius=r)(T(g["coords"]).to(DEV))
+    close(out, g["out"], 1e-4, what="alt lookup")
+    (out * rand_tensor(tuple(out.shape), seed + 3).to(DEV)).sum().backward()
+    close(f1.grad, g["dfmap1"], 2e-4, what="alt dfmap1")
+    close(f2.grad, g["dfmap2"], 2e-4, what="alt dfmap2")
+
+
+def test_alt_cuda_corr_module_contract():
+    import flow_supervisor_amd.alt_cuda_corr as acc
+    f1 = torch.randn(1, 6, 8, 64, device=DEV)
+    f2 = torch.randn(1, 6, 8, 64, device=DEV)
+    co = torch.rand(1, 1, 6, 8, 2, device=DEV) * 5
+    (corr,) = acc.forward(f1, f2, co, 4)
+    assert corr.shape == (1, 1, 81, 6, 8)
+    ref = O.alt_corr_level(f1.cpu(), f2.cpu(), co.cpu(), 4)
+    close(corr, ref, 1e-4, what="alt_cuda_corr.forward")
+    g1, g2, gc = acc.backward(f1, f2, co, torch.ones_like(corr), 4)
+    assert g1.shape == f1.shape and g2.shape == f2.shape and gc.shape == co.shape and float(gc.abs().sum()) == 0
+    with pytest.raises(RuntimeError):
+        acc.forward(f1.cpu(), f2, co, 4)                       # CHECK_CUDA
+    with pytest.raises(RuntimeError):
+        acc.forward(f1.permute(0, 2, 1, 3), f2, co, 4)         # CHECK_CONTIGUOUS
+
+
+# ----------------------------------------------------------------------------- a9
+def test_convex_upsample_vs_reference():
+    from flow_supervisor_amd.core.raft import RAFT
+    g = load("upsample")
+    N, H, W = int(g["N"]), int(g["H"]), int(g["W"])
+    flow = rand_tensor((N, 2, H, W), 401, 2.0).to(DEV).requires_grad_(True)
+    mask = rand_tensor((N, 576, H, W), 402, 1.5).to(DEV).requires_grad_(True)
+    model = RAFT(ns(False)).to(DEV)
+    up = model.upsample_flow(flow, mask)
+    close(up, g["up"], 1e-5, what="up")
+    (up * rand_tensor(tuple(up.shape), 403).to(DEV)).sum().backward()
+    close(flow.grad, g["dflow"], 1e-5, what="dflow")
+    close(mask.grad, g["dmask"], 1e-5, what="dmask")
+
+
+def test_upflow8_and_helpers():
+    from flow_supervisor_amd.core.utils.utils import InputPadder, coords_grid, upflow8
+    h = load("helpers")
+    f = rand_tensor((2, 2, 5, 7), 411, 2.0).to(DEV).requires_grad_(True)
+    u = upflow8(f)
+    close(u, h["upflow8"], 1e-5, what="upflow8")
+    gup = rand_tensor(tuple(u.shape), 412).to(DEV)
+    (u * gup).sum().backward()
+    fr = f.detach().cpu().requires_grad_(True)
+    (O.upflow8(fr) * gup.cpu()).sum().backward()
+    close(f.grad, fr.grad, 1e-4, what="upflow8 grad")
+    close(coords_grid(2, 3, 5, device=DEV), h["coords_grid"], 0)
+    for k, v in h.items():
+        if k.startswith("pad_"):
+            _, mode, ht, wd = k.split("_")
+            assert InputPadder((1, 3, int(ht), int(wd)), mode=mode)._pad == list(v)
+
+
+# ----------------------------------------------------------------------------- a6-a8
+@pytest.mark.parametrize("tag", ["basic", "small"])
+def test_update_block_vs_reference(tag):
+    from flow_supervisor_amd.core.update import BasicUpdateBlock, SmallUpdateBlock
+    g = load("update_" + tag)
+    small = tag == "small"
+    seed = int(g["seed"])
+    blk = (SmallUpdateBlock(ns(True), hidden_dim=96) if small else BasicUpdateBlock(ns(False), hidden_dim=128))
+    sh = shapes("update_" + tag)
+    assert {k: list(v.shape) for k, v in blk.state_dict().items()} == sh
+    blk.load_state_dict(procedural_state_dict(sh, seed))
+    blk = blk.to(DEV)
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    hd, cd, r = (96, 64, 3) if small else (128, 128, 4)
+    cp = 4 * (2 * r + 1) ** 2
+    net = torch.tanh(rand_tensor((B, hd, H, W), seed + 10)).to(DEV).requires_grad_(True)
+    inp = torch.relu(rand_tensor((B, cd, H, W), seed + 11)).to(DEV).requires_grad_(True)
+    corr = rand_tensor((B, cp, H, W), seed + 12, 2.0).to(DEV).requires_grad_(True)
+    flow = rand_tensor((B, 2, H, W), seed + 13, 3.0).to(DEV).requires_grad_(True)
+    net2, mask, delta = blk(net, inp, corr, flow)
+    close(net2, g["net_out"], 2e-5, what="net")
+    close(delta, g["delta"], 2e-5, what="delta")
+    loss = (net2 * rand_tensor(tuple(net2.shape), seed + 20).to(DEV)).sum() + (delta * rand_tensor(tuple(delta.shape), seed + 21).to(DEV)).sum()
+    if small:
+        assert mask is None
+    else:
+        close(mask, g["mask"], 2e-5, what="mask")
+        loss = loss + (mask * rand_tensor(tuple(mask.shape), seed + 22).to(DEV)).sum()
+    loss.backward()
+    close(net.grad, g["dnet"], 2e-4, what="dnet")
+    close(inp.grad, g["dinp"], 2e-4, what="dinp")
+    close(corr.grad, g["dcorr"], 2e-4, what="dcorr")
+    close(flow.grad, g["dflow"], 2e-4, what="dflow")
+    for k, p in blk.named_parameters():
+        gr = p.grad.reshape(-1)
+        ref_n = float(g["dparam_norm." + k])
+        assert abs(gr.norm().item() - ref_n) <= 2e-4 * ref_n + 1e-5, (k, gr.norm().item(), ref_n)
+        samp = gr if gr.numel() <= 4096 else gr[:: gr.numel() // 4096][:4096]
+        close(samp, g["dparam." + k], 2e-4, 1e-3, what="d" + k)
+
+
+# ----------------------------------------------------------------------------- end to end
+def _model(small, seed):
+    from flow_supervisor_amd.core.raft import RAFT
+    m = RAFT(ns(small))
+    m.load_state_dict(procedural_state_dict(shapes("raft_small" if small else "raft_basic"), seed))
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["e2e_small_128x256", "e2e_basic_368x496", "e2e_basic_440x1024"])
+def test_end_to_end_flow_epe(name):
+    g = load(name)
+    small, seed = bool(g["small"]), int(g["seed"])
+    m = _model(small, seed).eval()
+    im1, im2 = synthetic_pair(int(g["B"]), int(g["H"]), int(g["W"]), seed + 1)
+    with torch.no_grad():
+        low, up = m(im1.to(DEV), im2.to(DEV), iters=int(g["iters"]), test_mode=True)
+    s = int(g["stride"])
+    e_low = O.epe(low.cpu(), T(g["flow_low"])).item()
+    e_up = O.epe(up[:, :, ::s, ::s].cpu(), T(g["flow_up_strided"])).item()
+    print(name, "EPE low", e_low, "EPE up", e_up)
+    assert e_low <= 1e-3 and e_up <= 1e-3, (e_low, e_up)      # BASELINE.json gate
+
+
+def test_end_to_end_alternate_corr_epe():
+    g = load("e2e_basic_368x496")
+    seed = int(g["seed"])
+    m = _model(False, seed).eval()
+    m.args.alternate_corr = True
+    im1, im2 = synthetic_pair(1, 368, 496, seed + 1)
+    with torch.no_grad():
+        low, up = m(im1.to(DEV), im2.to(DEV), iters=12, test_mode=True)
+    e = O.epe(up[:, :, ::4, ::4].cpu(), T(g["flow_up_strided"])).item()
+    print("alt-corr EPE", e)
+    assert e <= 1e-3
+
+
+@pytest.mark.parametrize("tag", ["basic", "small"])
+def test_train_step_loss_and_grads(tag):
+    g = load("train_step_" + tag)
+    small, seed = tag == "small", int(g["seed"])
+    m = _model(small, seed).train()
+    m.freeze_bn()
+    im1, im2 = synthetic_pair(2, int(g["H"]), int(g["W"]), seed + 1)
+    preds = m(im1.to(DEV), im2.to(DEV), iters=int(g["iters"]))
+    loss = O.sequence_loss_zero_gt(preds)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (loss.item(), float(g["loss"]))
+    loss.backward()
+    close(preds[-1], g["last"], 1e-3, what="last prediction")
+    bad = []
+    for k, p in m.named_parameters():
+        if "gnorm." + k not in g:
+            continue
+        ref = float(g["gnorm." + k])
+        gn = 0.0 if p.grad is None else p.grad.norm().item()
+        if abs(gn - ref) > 5e-3 * max(ref, 1e-6) + 1e-6:
+            bad.append((k, gn, ref))
+    assert not bad, bad[:8]
+
+
+# ----------------------------------------------------------------------------- building blocks
+def test_gemm_and_layout_kernels():
+    from flow_supervisor_amd import ops
+    a = torch.randn(2, 70, 323, device=DEV)
+    bt = torch.randn(2, 45, 323, device=DEV)
+    bn = torch.randn(2, 323, 45, device=DEV)
+    close(ops.gemm(a, bt, True, 0.5), 0.5 * a.cpu() @ bt.cpu().transpose(1, 2), 2e-4, what="gemm NT odd")
+    close(ops.gemm(a, bn, False, 2.0), 2.0 * a.cpu() @ bn.cpu(), 2e-4, what="gemm NN odd")
+    a = torch.randn(1, 256, 512, device=DEV)
+    bt = torch.randn(1, 384, 512, device=DEV)
+    close(ops.gemm(a, bt, True), a.cpu() @ bt.cpu().transpose(1, 2), 5e-4, what="gemm NT")
+    x = torch.randn(2, 37, 5, 9, device=DEV)
+    cl = ops.nchw_to_nhwc(x)
+    assert cl.shape == (2, 5, 9, 40)
+    close(cl[..., :37], x.permute(0, 2, 3, 1), 0)
+    close(ops.nhwc_to_nchw(cl, 37), x, 0)
+
+
+@pytest.mark.parametrize("kh,kw,cin,cout", [(1, 1, 324, 256), (3, 3, 256, 192), (1, 5, 384, 256), (5, 1, 384, 128),
+                                            (3, 3, 256, 2), (3, 3, 128, 64), (3, 3, 256, 126), (3, 3, 242, 96)])
+def test_conv_igemm_fwd_dgrad_wgrad(kh, kw, cin, cout):
+    """One convolution through the C ABI against torch's CPU conv2d (fwd, data grad, weight grad)."""
+    import torch.nn.functional as F
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.ops import Dst, V
+    B, H, W = 2, 9, 13
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, kh, kw) / math.sqrt(cin * kh * kw)
+    b = torch.randn(cout)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, b, padding=(kh // 2, kw // 2))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    # split the input over two sources when it is big enough (exercises the concat path)
+    split = [cin] if cin < 64 else [cin // 2 // 4 * 4, cin - cin // 2 // 4 * 4]
+    xs, o = [], 0
+    for c in split:
+        xs.append(ops.nchw_to_nhwc(x[:, o:o + c].contiguous().to(DEV)))
+        o += c
+    srcs = [V(t, c) for t, c in zip(xs, split)]
+    wd = w.to(DEV)
+    wpk = ops.pack_weight(wd, split, 0)
+    out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=DEV)
+    ops.conv_forward(srcs, wpk, b.to(DEV), B, H, W, kh, kw, cout, [Dst.nhwc(out)])
+    close(ops.nhwc_to_nchw(out, cout), y, 2e-4, what="conv fwd")
+    gyc = ops.nchw_to_nhwc(gy.to(DEV))
+    wpb = ops.pack_weight(wd, split, 1)
+    dxs = [torch.zeros(B, H, W, (c + 3) // 4 * 4, device=DEV) for c in split]
+    n0, dsts = 0, []
+    for t, c in zip(dxs, split):
+        dsts.append(Dst.nhwc(t, 0, n0))
+        n0 += c
+    ops.conv_forward([V(gyc, cout)], wpb, None, B, H, W, kh, kw, cin, dsts)
+    dx = torch.cat([ops.nhwc_to_nchw(t, c) for t, c in zip(dxs, split)], 1)
+    close(dx, xr.grad, 2e-4, what="conv dgrad")
+    dwpk = torch.zeros_like(wpk)
+    ops.conv_wgrad(V(gyc, cout), srcs, dwpk, B, H, W, kh, kw)
+    dw = ops.unpack_weight_grad(dwpk, tuple(w.shape), split)
+    close(dw, wr.grad, 5e-4, what="conv wgrad")
+
+
+# ----------------------------------------------------------------------------- properties at full size
+def test_full_size_properties_sintel_batch():
+    """B=4, 55x128, C=256 (the bench workload): size-independent checks that need no oracle run."""
+    from flow_supervisor_amd.core.corr import CorrBlock
+    from flow_supervisor_amd.core.utils.utils import coords_grid
+    B, C, H, W = 4, 256, 55, 128
+    g = torch.Generator(device="cpu").manual_seed(5)
+    f1 = torch.randn(B, C, H, W, generator=g).to(DEV)
+    f2 = torch.randn(B, C, H, W, generator=g).to(DEV)
+    blk = CorrBlock(f1, f2)
+    # (1) pooling consistency: level l+1 == avg_pool(level l) (floor)
+    for l in range(3):
+        ref = torch.nn.functional.avg_pool2d(blk.corr_pyramid[l], 2, stride=2)
+        close(blk.corr_pyramid[l + 1], ref, 1e-5, what=f"pool {l}")
+    # (2) level 0 against random rows of the exact product
+    idx = torch.randint(0, H * W, (64,))
+    ref = torch.einsum("bcq,bcn->bqn", f1.view(B, C, -1)[:, :, idx.to(DEV)].double(), f2.view(B, C, -1).double()) / 16.0
+    got = blk.corr_pyramid[0].view(B, H * W, H * W)[:, idx.to(DEV)]
+    close(got, ref.float(), 2e-4, what="level-0 rows")
+    # (3) lookup at integer coordinates returns the volume entries themselves (centre tap)
+    coords = coords_grid(B, H, W, device=DEV)
+    out = blk(coords)
+    centre = out[:, 40]          # level 0, i=4, j=4  -> V[q, y, x]
+    diag = blk.corr_pyramid[0].view(B, H * W, H * W).diagonal(dim1=1, dim2=2).reshape(B, H, W)
+    close(centre, diag, 1e-5, what="centre tap == V[q,q]")
+    # (4) linearity of the build in fmap2
+    blk2 = CorrBlock(f1, 2.0 * f2)
+    close(blk2.corr_pyramid[3], 2.0 * blk.corr_pyramid[3], 1e-4, what="linearity")
