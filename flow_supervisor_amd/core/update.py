@@ -367,7 +367,7 @@ class _UpdateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, net, inp, corr, flow, *params):
-        need = torch.is_grad_enabled() and any(t.requires_grad for t in (net, inp, corr, flow) + params)
+        need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
         h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need)
         ctx.engine = engine
         ctx.saved = saved
