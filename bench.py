@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Benchmark of the RAFT hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one full training step of RAFT (full model, 12 GRU iterations) on a batch of
+synthetic 440x1024 (= padded 436x1024 Sintel) image pairs, 4 pairs per GPU: forward, sequence
+loss, backward, gradient all-reduce over RCCL, gradient clipping and AdamW.  Inputs are resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+value    = image pairs processed by all ranks / wall time (max over ranks) of K steps
+roofline = the dominant hand-written kernel family of the step, timed per launch with events on
+           the launching stream inside the timed region (achieved = algorithmic FLOPs or bytes of
+           all its launches / their summed duration); `kernels` lists the other families the same
+           way, including the HBM-bound correlation build + lookup the north star asks about.
+cpu_baseline = the CPU oracle (oracle/raft_torch.py, a port of the reference's PyTorch path) timed
+           on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_MFMA_TF = 157.3    # v_mfma_f32_32x32x2_f32 (exact fp32) dense peak, same guide
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--height", type=int, default=440)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(height, width, iters):
+    """Oracle fwd+bwd on the host cores, one pair, one step (bounded: ~10-30 s of CPU work)."""
+    from oracle import raft_torch as O
+    from oracle.weights import synthetic_pair
+    from flow_supervisor_amd.core.raft import RAFT
+    # torch's CPU kernels oversubscribe badly on big hosts (256 threads ran this sample 30x slower
+    # than 8 did); 16 threads is the sweet spot measured, and `cores` reports what was actually used.
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    im1, im2 = synthetic_pair(1, height, width, 1234)
+    # page-in at a small size so the sample measures compute, not first-touch
+    O.sequence_loss_zero_gt(O.raft_forward(sd, im1[:, :, :64, :128], im2[:, :, :64, :128], iters=1)).backward()
+    t0 = time.perf_counter()
+    loss = O.sequence_loss_zero_gt(O.raft_forward(sd, im1, im2, iters=iters))
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 pair {height}x{width}, {iters} iters, fwd+bwd, 1 step, oracle/raft_torch.py (torch CPU fp32), {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.parallel import barrier, broadcast_parameters, init_distributed, max_over_ranks
+    from flow_supervisor_amd.train import TrainStep
+
+    rank, world, local = init_distributed("cuda")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True            # MIOpen find for the (framework) encoder convs
+
+    torch.manual_seed(0)
+    model = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(dev).train()
+    model.freeze_bn()                                 # pytorch/train.py:203-204
+    broadcast_parameters(model)
+    step = TrainStep(model, iters=a.iters)
+
+    B = a.batch_per_gpu
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    im1 = torch.rand(B, 3, a.height, a.width, device=dev, generator=g) * 255.0
+    im2 = (torch.roll(im1, shifts=(3, -5), dims=(2, 3)) + 2.0 * torch.randn(B, 3, a.height, a.width, device=dev, generator=g)).clamp(0, 255)
+
+    for _ in range(a.warmup):
+        step(im1, im2)
+    timer = None if a.no_kernel_timing else ops.KernelTimer()
+    barrier()
+    torch.cuda.synchronize()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(im1, im2)
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    dt = max_over_ranks(dt, dev)
+    loss_v = float(loss)
+
+    if rank != 0:
+        return
+    pairs = B * world * a.steps
+    out = {
+        "metric": "image-pairs/s fwd+bwd, 12 GRU iters, 436x1024", "value": pairs / dt, "unit": "image-pairs/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"RAFT full, {a.height}x{a.width} (Sintel 436x1024 padded), {a.iters} GRU iters, "
+                               f"{B} pairs/GPU, train step = fwd + sequence loss + bwd + RCCL all-reduce + clip + AdamW",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v},
+    }
+    if timer is not None:
+        kern = {}
+        for fam, s in timer.summary().items():
+            mfma = fam in ("conv_igemm", "conv_wgrad", "gemm_f32")
+            sec = s["ms_total"] * 1e-3
+            if mfma:
+                ach, peak, unit = s["flops"] / sec / 1e12, PEAK_F32_MFMA_TF, "TFLOP/s"
+            else:
+                ach, peak, unit = s["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+            kern[fam] = {"bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": unit,
+                         "frac": ach / peak, "traffic": None, "launches_per_step": s["launches"] / a.steps,
+                         "ms_per_step": s["ms_total"] / a.steps, "avg_launch_us": 1e3 * s["ms_avg"]}
+            if fam == "corr_build":     # report both views: HBM (the north-star bound) and fp32 MFMA (the real one)
+                kern[fam]["mfma_tflops"] = s["flops"] / sec / 1e12
+                kern[fam]["mfma_frac"] = s["flops"] / sec / 1e12 / PEAK_F32_MFMA_TF
+        dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+        out["roofline"] = dict(kern[dom], kernel=dom)
+        out["kernels"] = kern
+        tr = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
+        if os.path.exists(tr):
+            t = json.load(open(tr))
+            for fam, v in t.items():
+                if fam in kern:
+                    kern[fam]["traffic"] = v
+            out["roofline"]["traffic"] = kern[dom]["traffic"]
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,37 @@ def _lib():
     return L.load()
 
 
+class KernelTimer:
+    """Optional per-launch timing with events recorded on the launching stream (torch's current
+    stream is the stream every fsraft kernel is enqueued on).  bench.py installs one for the
+    timed region; when `ops.TIMER is None` (the default) nothing is recorded."""
+
+    def __init__(self):
+        self.rec = {}          # family -> list of (start_event, end_event, flops, bytes)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, family, e0, flops=0.0, nbytes=0.0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.setdefault(family, []).append((e0, e1, flops, nbytes))
+
+    def summary(self):
+        """{family: dict(launches, ms_total, ms_avg, flops, bytes)} -- call after a device sync."""
+        out = {}
+        for fam, rows in self.rec.items():
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in rows)
+            out[fam] = dict(launches=len(rows), ms_total=ms, ms_avg=ms / len(rows),
+                            flops=sum(r[2] for r in rows), bytes=sum(r[3] for r in rows))
+        return out
+
+
+TIMER = None
+
+
 def pyramid_sizes(H, W, num_levels=4):
     out = []
     for _ in range(num_levels):
@@ -45,7 +76,12 @@ def corr_build(fmap1, fmap2, num_levels=4):
         raise RuntimeError(f"feature map {H}x{W} too small for {num_levels} pyramid levels")
     levels = [torch.empty(B * H * W, 1, h, w, device=fmap1.device, dtype=torch.float32) for h, w in sizes]
     pp, keep = L.ptr_array(levels)
+    t = TIMER
+    e0 = t.begin() if t else None
     L.check(_lib().fsraft_corr_build(L.ptr(fmap1), L.ptr(fmap2), pp, num_levels, B, C, H, W, L.stream()), "corr_build")
+    if t:
+        N = H * W
+        t.end("corr_build", e0, 2.0 * B * N * N * C, 4.0 * B * (2 * N * C + N * sum(h * w for h, w in sizes)))
     return levels
 
 
@@ -64,8 +100,12 @@ def corr_lookup_fwd(levels, coords, radius, nhwc=False):
     else:
         out = torch.empty(B, ch, H, W, device=coords.device, dtype=torch.float32)
     pp, keep = L.ptr_array(levels)
+    t = TIMER
+    e0 = t.begin() if t else None
     L.check(_lib().fsraft_corr_lookup_fwd(pp, len(levels), L.ptr(coords), bs, cs, ps, L.ptr(out), int(nhwc), B, H, W,
                                           radius, L.stream()), "corr_lookup_fwd")
+    if t:   # per query: L*(2r+2)^2 window floats + 2 coords in, L*(2r+1)^2 out  
+        t.end("corr_lookup_fwd", e0, 0.0, 4.0 * B * H * W * (len(levels) * (2 * radius + 2) ** 2 + 2 + ch))
     return out
 
 
@@ -75,8 +115,14 @@ def corr_lookup_bwd_(dlevels, coords, dout, radius, nhwc=False):
     bs, cs, ps = _planar2_strides(coords)
     dout = dout.contiguous()
     pp, keep = L.ptr_array(dlevels)
+    t = TIMER
+    e0 = t.begin() if t else None
     L.check(_lib().fsraft_corr_lookup_bwd(pp, len(dlevels), L.ptr(coords), bs, cs, ps, L.ptr(dout), int(nhwc), B, H, W,
                                           radius, L.stream()), "corr_lookup_bwd")
+    if t:   # read dout, read-modify-write the window taps
+        nl = len(dlevels)
+        t.end("corr_lookup_bwd", e0, 0.0,
+              4.0 * B * H * W * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2))
 
 
 def gemm(A, Bm, trans_b, alpha=1.0, out=None, accumulate=False):
@@ -88,9 +134,13 @@ def gemm(A, Bm, trans_b, alpha=1.0, out=None, accumulate=False):
     N = Bm.shape[1] if trans_b else Bm.shape[2]
     if out is None:
         out = torch.empty(b, M, N, device=A.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_f32(L.ptr(A), K, M * K, L.ptr(Bm), Bm.shape[2], Bm.shape[1] * Bm.shape[2], L.ptr(out),
                                    N, M * N, b, M, N, K, int(trans_b), float(alpha), int(accumulate), L.stream()),
             "gemm_f32")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
     return out
 
 
@@ -145,8 +195,12 @@ def upsample_fwd(flow, mask_nhwc):
     N, _, H, W = flow.shape
     bs, cs, ps = _planar2_strides(flow)
     up = torch.empty(N, 2, 8 * H, 8 * W, device=flow.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
     L.check(_lib().fsraft_upsample_fwd(L.ptr(flow), bs, cs, ps, L.ptr(mask_nhwc), L.ptr(up), N, H, W, L.stream()),
             "upsample_fwd")
+    if t:
+        t.end("upsample_fwd", e0, 0.0, 4.0 * N * H * W * (576 + 128 + 2))
     return up
 
 
@@ -346,16 +400,25 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     if aux2 is not None:
         d.aux2 = aux2.data_ptr(); d.ld2 = aux2.shape[-1]
     d.hid = hid
+    t = TIMER
+    e0 = t.begin() if t else None
     L.check(_lib().fsraft_conv_forward(ctypes.byref(d), L.stream()), "conv_forward")
+    if t:
+        cin = sum(v.C for v in srcs)
+        t.end("conv_igemm", e0, 2.0 * B * H * W * N * cin * KH * KW, 4.0 * B * H * W * (cin + N))
 
 
 def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW):
     """dwpk [Cout,Ktot] += dy^T im2col(srcs).  dy: V over the (already act'-scaled) output gradient."""
     arr = (ctypes.c_void_p * len(srcs))(*[v.ptr for v in srcs])
     pp = ctypes.cast(arr, L._PP)
+    e0w = TIMER.begin() if TIMER else None
     L.check(_lib().fsraft_conv_wgrad(ctypes.c_void_p(dy.ptr), dy.ld, dy.C, pp, L.int_array([v.C for v in srcs]),
                                      L.int_array([v.ld for v in srcs]), len(srcs), L.ptr(dwpk), B, H, W, KH, KW,
                                      L.stream()), "conv_wgrad")
+    if TIMER:
+        cin = sum(v.C for v in srcs)
+        TIMER.end("conv_wgrad", e0w, 2.0 * B * H * W * dy.C * cin * KH * KW, 4.0 * B * H * W * (cin + dy.C))
 
 
 def col_sum_v(v, out, scale=1.0):
