@@ -85,7 +85,9 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True            # MIOpen find for the (framework) encoder convs
+    # MIOpen exhaustive find (cudnn.benchmark) costs ~7 minutes of start-up for the encoder shapes and
+    # is off: the encoders are framework callers of the path, not what this benchmark is about.
+    torch.backends.cudnn.benchmark = False
 
     torch.manual_seed(0)
     model = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(dev).train()

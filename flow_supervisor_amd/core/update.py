@@ -137,6 +137,51 @@ class _Engine:
                 self.pnames += [w + ".weight", w + ".bias"]
         self._cache_key = None
         self._cache = None
+        self._pstate = None
+
+    # ---- parameter-gradient accumulation across the calls of one step -----------------
+    def param_state(self, params):
+        """(state, anchor) shared by every forward call made with the same parameter values.
+        Weight/bias gradients of all those calls accumulate in ONE packed arena and are unpacked
+        once, when autograd reaches the anchor's producer (_ParamFn) -- i.e. after the last of
+        the 12 update-block backwards of a RAFT step -- instead of 26 tensors x 12 iterations."""
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+            return None, None
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        st = self._pstate
+        if st is None or st.key != key or st.consumed:
+            st = _ParamState(key)
+            st.anchor = _ParamFn.apply(self, st, *params)
+            self._pstate = st
+        return st, st.anchor
+
+    def _grad_arena(self, st, P, dev):
+        if st.arena is None:
+            sizes = [(k, P[k][0].numel(), P[k][3]) for k in self.order]
+            total = sum((a + 3) // 4 * 4 + (b + 3) // 4 * 4 for _, a, b in sizes)
+            st.arena = torch.zeros(total, device=dev, dtype=torch.float32)
+            st.dW, st.dB, o = {}, {}, 0
+            for k, a, b in sizes:
+                st.dW[k] = st.arena[o:o + a].view_as(P[k][0]); o += (a + 3) // 4 * 4
+                st.dB[k] = st.arena[o:o + b]; o += (b + 3) // 4 * 4
+        return st.dW, st.dB
+
+    def unpack_param_grads(self, st, P, params):
+        """packed arena -> list of gradients in self.pnames order (fused layers split back)."""
+        byname = dict(zip(self.pnames, params))
+        grads = {}
+        for k in self.order:
+            l = self.layers[k]
+            gw = ops.unpack_weight_grad(st.dW[k], P[k][4], l.src_c)
+            o = 0
+            for wname in l.wnames:
+                p = byname[wname + ".weight"]
+                n = p.shape[0]
+                grads[wname + ".weight"] = gw[o:o + n].reshape(p.shape)
+                grads[wname + ".bias"] = st.dB[k][o:o + n].clone()
+                o += n
+        st.arena = st.dW = st.dB = None
+        return [grads[n] for n in self.pnames]
 
     # ---- parameters -------------------------------------------------------------
     def params(self):
@@ -229,11 +274,11 @@ class _Engine:
         return h, mask, delta, saved
 
     # ---- backward -----------------------------------------------------------------
-    def backward(self, S, params, dnet_out, dmask, ddelta, need_input_grads=True):
-        """Returns (dnet, dinp, dcorr, dflow, [param grads in self.pnames order])."""
+    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True):
+        """Accumulates parameter gradients into the packed arena of `st`;
+        returns (dnet, dinp, dcorr, dflow)."""
         B, H, W = S["B"], S["H"], S["W"]
         dev = S["corr"].device
-        P = self._packed(params)
         lib = L.load()
         M = B * H * W
         hid = self.hid
@@ -243,8 +288,7 @@ class _Engine:
             f = torch.zeros if (zero or ld != c) else torch.empty
             return f(B, H, W, ld, device=dev, dtype=torch.float32)
 
-        dW = {k: torch.zeros_like(P[k][0]) for k in self.order}
-        dB = {k: torch.zeros(P[k][3], device=dev, dtype=torch.float32) for k in self.order}
+        dW, dB = self._grad_arena(st, P, dev)
 
         def relu_bwd(g, y):
             L.check(lib.fsraft_relu_bwd(L.c_void_p(g.ptr), g.ld, L.c_void_p(y.ptr), y.ld, M, g.C, L.stream()), "relu_bwd")
@@ -343,35 +387,44 @@ class _Engine:
             if need_input_grads:
                 dgrad("c1", V(dcorflo, self.c1, 0), [Dst.nhwc(dcorr)])
 
-        # ---- unpack parameter gradients (packed layout -> OIHW), split fused layers back
-        grads = {}
-        for k in self.order:
-            l = self.layers[k]
-            shape = P[k][4]
-            gw = ops.unpack_weight_grad(dW[k], shape, l.src_c)
-            o = 0
-            for wname in l.wnames:
-                p = dict(zip(self.pnames, params))[wname + ".weight"]
-                n = p.shape[0]
-                grads[wname + ".weight"] = gw[o:o + n].reshape(p.shape)
-                grads[wname + ".bias"] = dB[k][o:o + n]
-                o += n
-        if self.has_mask:
-            # y = 0.25*(Wx+b): dW and db of mask.2 were computed from g = 0.25*dmask, nothing more to do
-            pass
-        return dh, dinp, dcorr, dflow, [grads[n] for n in self.pnames]
+        return dh, dinp, dcorr, dflow
+
+
+class _ParamState:
+    __slots__ = ("key", "anchor", "arena", "dW", "dB", "consumed", "zero")
+
+    def __init__(self, key):
+        self.key, self.anchor, self.arena, self.dW, self.dB, self.consumed, self.zero = key, None, None, None, None, False, None
+
+
+class _ParamFn(torch.autograd.Function):
+    """params -> 1-element anchor.  Its backward delivers the accumulated parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, engine, st, *params):
+        ctx.engine, ctx.st, ctx.params = engine, st, params
+        ctx.P = engine._packed(params)
+        st.zero = torch.zeros(1, device=params[0].device)
+        return torch.zeros(1, device=params[0].device)
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        st.consumed = True
+        if st.arena is None:
+            return (None, None) + tuple(torch.zeros_like(p) for p in ctx.params)
+        return (None, None) + tuple(ctx.engine.unpack_param_grads(st, ctx.P, ctx.params))
 
 
 class _UpdateFn(torch.autograd.Function):
-    """(net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
+    """(anchor; net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
 
     @staticmethod
-    def forward(ctx, engine, net, inp, corr, flow, *params):
+    def forward(ctx, engine, st, params, anchor, net, inp, corr, flow):
         need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
         h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need)
-        ctx.engine = engine
-        ctx.saved = saved
-        ctx.params = params
+        ctx.engine, ctx.st, ctx.saved = engine, st, saved
+        ctx.P = engine._packed(params) if need else None
         ctx.has_mask = mask is not None
         if mask is None:
             mask = torch.empty(0, device=net.device)
@@ -383,11 +436,11 @@ class _UpdateFn(torch.autograd.Function):
         eng = ctx.engine
         S, ctx.saved = ctx.saved, None
         if S is None:
-            raise RuntimeError("update block backward called twice without retain_graph support")
+            raise RuntimeError("update block backward ran twice on the same graph (retain_graph is not supported)")
         dmask = dmask if ctx.has_mask else None
         dh = dh.contiguous() if dh is not None else None
-        dnet, dinp, dcorr, dflow, pg = eng.backward(S, ctx.params, dh, dmask, ddelta)
-        return (None, dnet, dinp, dcorr, dflow) + tuple(pg)
+        dnet, dinp, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta)
+        return None, None, None, ctx.st.zero, dnet, dinp, dcorr, dflow
 
 
 class _ToCL(torch.autograd.Function):
@@ -437,7 +490,16 @@ class _UpdateBlockBase(nn.Module):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W].  Returns (net', mask_cl or None, delta)."""
         eng = self._engine()
-        h, mask, delta = _UpdateFn.apply(eng, net, inp, corr, flow, *eng.params())
+        params = tuple(eng.params())
+        st, anchor = eng.param_state(params)
+        if anchor is None:
+            if torch.is_grad_enabled() and any(t.requires_grad for t in (net, inp, corr, flow)):
+                st, anchor = _ParamState(None), torch.zeros(1, device=net.device)   # inputs need grads, params frozen
+                st.zero = anchor
+            else:
+                h, mask, delta, _ = eng.forward(net, inp, corr, flow, params, save=False)
+                return h, mask, delta
+        h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, inp, corr, flow)
         return h, (mask if eng.has_mask else None), delta
 
     def _forward_nchw(self, net, inp, corr, flow):

@@ -122,12 +122,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   gemm_mainloop<Cfg>(lds, a.Ktot / Cfg::BK, la, lb, acc);
 
+  // Epilogue.  Everything is batched per 32x32 MFMA tile: 16 addresses, then (optionally) 16
+  // loads in flight, then 16 stores, with no wait between consecutive stores.  Rows of one
+  // accumulator tile are m = mbase + (r&3) + 8*(r>>2); a 128-row tile crosses at most one
+  // image boundary, so (batch, pixel) is derived from one division per tile.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int nt = 0; nt < Cfg::TN; ++nt) {
     const int n = n0 + acc_col<Cfg>(nt);
-    if (n >= a.N) continue;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-    // destination segment of this column
+    const bool nok = n < a.N;
+    const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
     int di = 0;
     if (a.ndst > 1 && n >= a.dst[1].n0) di = 1;
     if (a.ndst > 2 && n >= a.dst[2].n0) di = 2;
@@ -136,35 +140,73 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int64_t dps = di == 0 ? a.dst[0].ps : di == 1 ? a.dst[1].ps : a.dst[2].ps;
     const int64_t dcs = di == 0 ? a.dst[0].cs : di == 1 ? a.dst[1].cs : a.dst[2].cs;
     const int dn0 = di == 0 ? a.dst[0].n0 : di == 1 ? a.dst[1].n0 : a.dst[2].n0;
-    const int dacc = di == 0 ? a.dst[0].accumulate : di == 1 ? a.dst[1].accumulate : a.dst[2].accumulate;
+    const bool dacc = (di == 0 ? a.dst[0].accumulate : di == 1 ? a.dst[1].accumulate : a.dst[2].accumulate) != 0;
 #pragma unroll
     for (int mt = 0; mt < Cfg::TM; ++mt) {
+      const int mbase = m0 + (wave / Cfg::WN) * (Cfg::TM * 32) + mt * 32 + 4 * (lane >> 5);
+      const int b0 = mbase / HW, pix0 = mbase - b0 * HW;
+      if (EPI == EPI_PLAIN) {
+        float* o[16];
+        bool ok[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + acc_row<Cfg>(mt, r);
-        if (m >= M) continue;
-        float v = acc[mt][nt][r] + bias;
-        if (EPI == EPI_PLAIN) {
-          v *= a.alpha;
+        for (int r = 0; r < 16; ++r) {
+          const int d = (r & 3) + 8 * (r >> 2);
+          int pix = pix0 + d, b = b0;
+          if (pix >= HW) { pix -= HW; ++b; }
+          ok[r] = nok && (mbase + d < M);
+          o[r] = dp + b * dbs + pix * dps + (n - dn0) * dcs;
+        }
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = (dacc && ok[r]) ? *o[r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = (acc[mt][nt][r] + bias) * a.alpha;
           if (a.relu) v = fmaxf(v, 0.f);
-          const int b = m / HW, pix = m % HW;
-          float* o = dp + b * dbs + pix * dps + (n - dn0) * dcs;
-          if (dacc) v += *o;
-          *o = v;
-        } else if (EPI == EPI_ZR) {
-          const float s = 1.0f / (1.0f + expf(-v));
-          if (n < a.hid) {
-            a.dst[0].p[(int64_t)m * a.dst[0].ps + n] = s;                 // z
-          } else {
-            const int c = n - a.hid;
-            a.aux2[(int64_t)m * a.ld2 + c] = s;                             // r
-            a.aux1[(int64_t)m * a.ld1 + c] = s * a.h[(int64_t)m * a.ldh + c];   // r*h
+          if (ok[r]) *o[r] = v + old[r];
+        }
+      } else if (EPI == EPI_ZR) {
+        const bool isz = n < a.hid;
+        const int c = isz ? n : n - a.hid;
+        float hh[16];
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          ok[r] = nok && m < M;
+          hh[r] = (ok[r] && !isz) ? a.h[(int64_t)m * a.ldh + c] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+          const float sg = 1.0f / (1.0f + expf(-(acc[mt][nt][r] + bias)));
+          if (ok[r]) {
+            if (isz) {
+              a.dst[0].p[m * a.dst[0].ps + c] = sg;                 // z
+            } else {
+              a.aux2[m * a.ld2 + c] = sg;                           // r
+              a.aux1[m * a.ld1 + c] = sg * hh[r];                   // r*h
+            }
           }
-        } else {   // EPI_Q
-          const float q = tanhf(v);
-          const float zz = a.z[(int64_t)m * a.ldz + n], hh = a.h[(int64_t)m * a.ldh + n];
-          a.aux1[(int64_t)m * a.ld1 + n] = q;
-          a.dst[0].p[(int64_t)m * a.dst[0].ps + n] = (1.f - zz) * hh + zz * q;
+        }
+      } else {   // EPI_Q
+        float hh[16], zz[16];
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+          ok[r] = nok && m < M;
+          hh[r] = ok[r] ? a.h[m * a.ldh + n] : 0.f;
+          zz[r] = ok[r] ? a.z[m * a.ldz + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+          const float q = tanhf(acc[mt][nt][r] + bias);
+          if (ok[r]) {
+            a.aux1[m * a.ld1 + n] = q;
+            a.dst[0].p[m * a.dst[0].ps + n] = (1.f - zz[r]) * hh[r] + zz[r] * q;
+          }
         }
       }
     }
@@ -345,6 +387,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
 
 using Cfg128 = GemmCfg<128, 128, 32, 2, 2, 2, 2>;
 using Cfg64 = GemmCfg<128, 64, 32, 4, 1, 2, 2>;
+using CfgM64 = GemmCfg<64, 128, 32, 1, 4, 2, 2>;     // half-height tile: doubles the workgroup count for narrow N
 using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
 // weight-gradient tiles: LDS images are filled with float4 rows, so pitches stay multiples of 4
 using WCfg128 = GemmCfg<128, 128, 32, 2, 2, 0, 0>;
@@ -411,6 +454,10 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
   if (d->N <= 32 && d->epi == EPI_PLAIN) return launch_conv<Cfg32>(a, d->epi, stream);
   if (d->N <= 64 && d->epi == EPI_PLAIN) return launch_conv<Cfg64>(a, d->epi, stream);
+  // one workgroup per CU is not enough to keep the matrix pipe busy: when the 128x128 grid has
+  // fewer than ~2 workgroups per CU, halve the tile height
+  const int M = d->B * d->H * d->W;
+  if ((int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 512) return launch_conv<CfgM64>(a, d->epi, stream);
   return launch_conv<Cfg128>(a, d->epi, stream);
 }
 

@@ -75,16 +75,34 @@ __global__ __launch_bounds__(256) void corr_lookup_fwd_kernel(Pyr pyr, Coords co
   query_setup<R, NLEV, QB>(qi, co, q0, nq, HW);
   __syncthreads();
 
-  for (int e = threadIdx.x; e < QB * NLEV * S::WIN2; e += 256) {
-    const int q = e / (NLEV * S::WIN2), rem = e % (NLEV * S::WIN2);
-    const int l = rem / S::WIN2, w = rem % S::WIN2;
-    const int wy = w / S::WIN, wx = w % S::WIN;
-    const QInfo v = qi[q * NLEV + l];
-    const int gy = v.y0 - R + wy, gx = v.x0 - R + wx;
-    float val = 0.f;
-    if (q0 + q < nq && gy >= 0 && gy < pyr.h[l] && gx >= 0 && gx < pyr.w[l])
-      val = pyr.p[l][((q0 + q) * pyr.h[l] + gy) * pyr.w[l] + gx];
-    win[q * S::QLD + rem] = val;
+  // Stage the windows.  Loads are issued in batches of UNR with nothing (no LDS store, no
+  // LDS load that could alias) between them, so every lane keeps UNR global loads in flight.
+  constexpr int TOTAL = QB * NLEV * S::WIN2;
+  constexpr int UNR = 10;
+  for (int e0 = threadIdx.x; e0 < TOTAL; e0 += 256 * UNR) {
+    const float* src[UNR];
+    int dst[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + 256 * u;
+      src[u] = nullptr; dst[u] = -1;
+      if (e < TOTAL) {
+        const int q = e / (NLEV * S::WIN2), rem = e % (NLEV * S::WIN2);
+        const int l = rem / S::WIN2, w = rem % S::WIN2;
+        const int wy = w / S::WIN, wx = w % S::WIN;
+        const QInfo v = qi[q * NLEV + l];
+        const int gy = v.y0 - R + wy, gx = v.x0 - R + wx;
+        dst[u] = q * S::QLD + rem;
+        if (q0 + q < nq && gy >= 0 && gy < pyr.h[l] && gx >= 0 && gx < pyr.w[l])
+          src[u] = pyr.p[l] + ((q0 + q) * pyr.h[l] + gy) * pyr.w[l] + gx;
+      }
+    }
+    float val[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) val[u] = src[u] ? *src[u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (dst[u] >= 0) win[dst[u]] = val[u];
   }
   __syncthreads();
 
@@ -131,29 +149,45 @@ __global__ __launch_bounds__(256) void corr_lookup_bwd_kernel(Pyr dpyr, Coords c
   }
   __syncthreads();
 
-  for (int e = threadIdx.x; e < QB * NLEV * S::WIN2; e += 256) {
-    const int q = e / (NLEV * S::WIN2), rem = e % (NLEV * S::WIN2);
-    const int l = rem / S::WIN2, w = rem % S::WIN2;
-    const int wy = w / S::WIN, wx = w % S::WIN;
-    if (q0 + q >= nq) continue;
-    const QInfo v = qi[q * NLEV + l];
-    const int gy = v.y0 - R + wy, gx = v.x0 - R + wx;
-    if (gy < 0 || gy >= dpyr.h[l] || gx < 0 || gx >= dpyr.w[l]) continue;
-    const float* gp = g + q * S::GLD + l * S::N1 * S::N1;
-    float d = 0.f;
-    // window cell (wy,wx) is tap (a,c) of output (j = wy-a, i = wx-c)
+  constexpr int TOTAL = QB * NLEV * S::WIN2;
+  constexpr int UNR = 10;
+  for (int e0 = threadIdx.x; e0 < TOTAL; e0 += 256 * UNR) {
+    float* dst[UNR];
+    float d[UNR];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + 256 * u;
+      dst[u] = nullptr; d[u] = 0.f;
+      if (e >= TOTAL) continue;
+      const int q = e / (NLEV * S::WIN2), rem = e % (NLEV * S::WIN2);
+      const int l = rem / S::WIN2, w = rem % S::WIN2;
+      const int wy = w / S::WIN, wx = w % S::WIN;
+      if (q0 + q >= nq) continue;
+      const QInfo v = qi[q * NLEV + l];
+      const int gy = v.y0 - R + wy, gx = v.x0 - R + wx;
+      if (gy < 0 || gy >= dpyr.h[l] || gx < 0 || gx >= dpyr.w[l]) continue;
+      const float* gp = g + q * S::GLD + l * S::N1 * S::N1;
+      float acc = 0.f;
+      // window cell (wy,wx) is tap (a,c) of output (j = wy-a, i = wx-c)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int j = wy - a, i = wx - c;
-        if (j >= 0 && j < S::N1 && i >= 0 && i < S::N1) {
-          const float wgt = (a ? v.fy : 1.f - v.fy) * (c ? v.fx : 1.f - v.fx);
-          d += gp[i * S::N1 + j] * wgt;
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int j = wy - a, i = wx - c;
+          if (j >= 0 && j < S::N1 && i >= 0 && i < S::N1) {
+            const float wgt = (a ? v.fy : 1.f - v.fy) * (c ? v.fx : 1.f - v.fx);
+            acc += gp[i * S::N1 + j] * wgt;
+          }
         }
-      }
-    float* dst = dpyr.p[l] + ((q0 + q) * dpyr.h[l] + gy) * dpyr.w[l] + gx;
-    *dst += d;
+      d[u] = acc;
+      dst[u] = dpyr.p[l] + ((q0 + q) * dpyr.h[l] + gy) * dpyr.w[l] + gx;
+    }
+    float old[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) old[u] = dst[u] ? *dst[u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (dst[u]) *dst[u] = old[u] + d[u];
   }
 }
 

@@ -240,7 +240,7 @@ extern "C" int fsraft_gru_bwd2(const float* drh, const float* r, const float* h,
 }
 extern "C" int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s) {
   if (!x || !out) return FS_ERR_ARG;
-  int ysplit = (int)(M / 512); if (ysplit < 1) ysplit = 1; if (ysplit > 128) ysplit = 128;
+  int ysplit = (int)(M / 128); if (ysplit < 1) ysplit = 1; if (ysplit > 2048) ysplit = 2048;
   hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(C, 64), ysplit), dim3(256), 0, s, x, ld, M, C, out, scale);
   return fs_launch_status();
 }

@@ -60,18 +60,31 @@ __device__ __forceinline__ void gemm_mainloop(float* __restrict__ lds, int KT, c
     }
     const float* As = cur + lh * Cfg::LDA + wm * (Cfg::TM * 32) + l31;
     const float* Bs = cur + Cfg::A_TILE + lh * Cfg::LDB + wn * (Cfg::TN * 32) + l31;
+    // fragment reads run one k-pair ahead of the MFMAs that consume them, so the LDS latency
+    // of step ks+1 hides under the 4 x 64-cycle MFMAs of step ks
+    float a[2][Cfg::TM], b[2][Cfg::TN];
+#pragma unroll
+    for (int mt = 0; mt < Cfg::TM; ++mt) a[0][mt] = As[mt * 32];
+#pragma unroll
+    for (int nt = 0; nt < Cfg::TN; ++nt) b[0][nt] = Bs[nt * 32];
 #pragma unroll
     for (int ks = 0; ks < Cfg::BK / 2; ++ks) {
-      float a[Cfg::TM], b[Cfg::TN];
+      const int c = ks & 1, n = c ^ 1;
+      if (ks + 1 < Cfg::BK / 2) {
 #pragma unroll
-      for (int mt = 0; mt < Cfg::TM; ++mt) a[mt] = As[(2 * ks) * Cfg::LDA + mt * 32];
+        for (int mt = 0; mt < Cfg::TM; ++mt) a[n][mt] = As[(2 * ks + 2) * Cfg::LDA + mt * 32];
 #pragma unroll
-      for (int nt = 0; nt < Cfg::TN; ++nt) b[nt] = Bs[(2 * ks) * Cfg::LDB + nt * 32];
+        for (int nt = 0; nt < Cfg::TN; ++nt) b[n][nt] = Bs[(2 * ks + 2) * Cfg::LDB + nt * 32];
+      }
+      // pin the order: hipcc otherwise sinks the prefetch reads back next to their use and
+      // waits lgkmcnt(0) in front of every MFMA group
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < Cfg::TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < Cfg::TN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][mt], b[c][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
       la.store(nxt, ra);

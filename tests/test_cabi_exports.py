@@ -1,0 +1,93 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/fsraft.h declares, the ctypes table covers them all, and the product path fails loudly
+(no CPU / eager fallback) when it cannot run on the HIP library."""
+import argparse
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "fsraft.h")).read()
+    return sorted(set(re.findall(r"^int (fsraft_\w+)\(", txt, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    from flow_supervisor_amd import _lib
+    names = header_symbols()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
+    _lib.load()
+
+
+def test_conv_desc_layout_matches_header():
+    """Field order of the ctypes mirror == field order of struct fsraft_conv_desc."""
+    from flow_supervisor_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "fsraft.h")).read()
+    body = txt[txt.index("typedef struct fsraft_conv_desc {"):txt.index("} fsraft_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.sub(r"\[\d+\]", "", part.split()[-1].lstrip("*")))
+    assert fields == [f[0] for f in _lib.ConvDesc._fields_]
+
+
+def test_ktot_host_logic():
+    """Packed-K size rule used on both sides of the ABI (no GPU work: pure host arithmetic)."""
+    from flow_supervisor_amd import ops
+    assert ops.conv_ktot([324], 1, 1) == 352
+    assert ops.conv_ktot([128, 128, 128], 1, 5) == 1920
+    assert ops.conv_ktot([96, 64, 82], 3, 3) == 9 * (96 + 64 + 96)
+    assert ops.pyramid_sizes(55, 128) == [(55, 128), (27, 64), (13, 32), (6, 16)]
+
+
+def test_hot_path_refuses_cpu_tensors():
+    from flow_supervisor_amd.core.corr import CorrBlock
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.core.update import BasicUpdateBlock
+    a = argparse.Namespace(small=False, corr_levels=4, corr_radius=4)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        CorrBlock(torch.zeros(1, 8, 16, 16), torch.zeros(1, 8, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        BasicUpdateBlock(a)(torch.zeros(1, 128, 8, 8), torch.zeros(1, 128, 8, 8), torch.zeros(1, 324, 8, 8), torch.zeros(1, 2, 8, 8))
+    with pytest.raises(RuntimeError):
+        RAFT(argparse.Namespace(small=False))(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+
+
+def test_missing_library_is_loud(monkeypatch):
+    from flow_supervisor_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfsraft.so")
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _lib.load()
+
+
+def test_state_dict_keys_match_reference():
+    import json
+    from flow_supervisor_amd.core.raft import RAFT
+    for small in (False, True):
+        m = RAFT(argparse.Namespace(small=small))
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", f"raft_{'small' if small else 'basic'}_shapes.json")))
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure; nothing shipped may import it."""
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "flow_supervisor_amd")):
+        for f in files:
+            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(d, f)).read(), flags=re.M):
+                bad.append(f)
+    assert not bad, bad

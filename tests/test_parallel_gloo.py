@@ -1,0 +1,70 @@
+"""world_size-2 checks of the data-parallel layer on CPU (gloo): flat-gradient all-reduce,
+batch sharding, parameter broadcast and the max-over-ranks timing reduction bench.py uses."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from flow_supervisor_amd.parallel import (FlatGradients, barrier, broadcast_parameters, init_distributed,
+                                              max_over_ranks, shard_batch)
+    from flow_supervisor_amd.train import sequence_loss
+    r, w, _ = init_distributed("cpu")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                      # deliberately different init per rank
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    broadcast_parameters(model)
+    grads = FlatGradients(model.parameters())
+    torch.manual_seed(7)
+    x = torch.randn(6, 3, 10, 12)                      # the GLOBAL batch, identical on every rank
+    s, n = shard_batch(6, rank, world)
+    grads.zero_()
+    # per-rank mean loss over its shard; mean over ranks of per-rank means == global mean (equal shards)
+    loss = sequence_loss([model(x[s:s + n]), 0.5 * model(x[s:s + n])])
+    loss.backward()
+    grads.all_reduce_mean_()
+    total = grads.clip_norm_(1.0)
+    barrier()
+    t = max_over_ranks(1.0 + rank, torch.device("cpu"))
+    if rank == 0:
+        torch.save({"flat": grads.flat.clone(), "w0": model[0].weight.detach().clone(), "t": t, "norm": total}, out)
+
+
+def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single-process reference on the whole batch with rank 0's initial weights
+    sys.path.insert(0, ROOT)
+    from flow_supervisor_amd.parallel import FlatGradients, shard_batch
+    from flow_supervisor_amd.train import sequence_loss
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    assert torch.equal(model[0].weight, got["w0"])     # broadcast from rank 0 took effect
+    grads = FlatGradients(model.parameters())
+    torch.manual_seed(7)
+    x = torch.randn(6, 3, 10, 12)
+    sequence_loss([model(x), 0.5 * model(x)]).backward()
+    ref_norm = grads.flat.norm()
+    grads.clip_norm_(1.0)
+    assert torch.allclose(got["flat"], grads.flat, atol=1e-6, rtol=1e-5)
+    assert abs(float(got["norm"]) - float(ref_norm)) < 1e-5
+    assert got["t"] == 2.0                               # max over ranks of (1, 2)
+    assert [shard_batch(7, r, 3) for r in range(3)] == [(0, 3), (3, 2), (5, 2)]
