@@ -48,40 +48,40 @@ struct ConvALoader {
   static constexpr int F4 = BK / 4;
   static constexpr int NF4 = BM * F4 / 256;
   static constexpr int NREG = NF4 * 4;
+  static constexpr int NCH = NF4;
   const float* p0; const float* p1; const float* p2;
   int C0, C1, C2, ld0, ld1, ld2;
   int cpt0, cpt1, cpt2;          // 32-channel chunks per tap for each source
   int taps, KW, PH, PW, H, W;
   int py[NF4], px[NF4];          // pixel coordinates of this thread's rows (py < 0: row outside M)
   int64_t pb[NF4];               // image base pixel index b*H*W
-
-  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
-    int k = kt;
-    const float* p = p0; int C = C0, ld = ld0, cpt = cpt0;
-    if (k >= taps * cpt0) {
-      k -= taps * cpt0; p = p1; C = C1; ld = ld1; cpt = cpt1;
-      if (k >= taps * cpt1) { k -= taps * cpt1; p = p2; C = C2; ld = ld2; cpt = cpt2; }
-    }
+  __device__ __forceinline__ bool fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    // source select written as sums of two-way selects: a three-way select chain over kernel
+    // arguments is turned by hipcc into a private (scratch) lookup table that is then re-read,
+    // with s_waitcnt vmcnt(0), in front of every load of the k-loop
+    const int n0 = taps * cpt0, n1 = taps * cpt1;
+    const bool is1 = kt >= n0, is2 = kt >= n0 + n1;
+    const int k = kt - (is1 ? n0 : 0) - (is2 ? n1 : 0);
+    const int C = C0 + (is1 ? C1 - C0 : 0) + (is2 ? C2 - C1 : 0);
+    const int ld = ld0 + (is1 ? ld1 - ld0 : 0) + (is2 ? ld2 - ld1 : 0);
+    const int cpt = cpt0 + (is1 ? cpt1 - cpt0 : 0) + (is2 ? cpt2 - cpt1 : 0);
+    const float* p = p0 + (is1 ? p1 - p0 : 0) + (is2 ? p2 - p1 : 0);
     const int tap = k / cpt, c0 = (k % cpt) * BK;
     const int dy = tap / KW - PH, dx = tap % KW - PW;
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int kq = (threadIdx.x + 256 * j) % F4;
-      const int yy = py[j] + dy, xx = px[j] + dx, c = c0 + kq * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (py[j] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W && c < C)
-        v = *reinterpret_cast<const f32x4*>(p + (pb[j] + (int64_t)yy * W + xx) * ld + c);
-      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
-    }
+    const int kq = (threadIdx.x + 256 * j) % F4;
+    const int yy = py[j] + dy, xx = px[j] + dx, c = c0 + kq * 4;
+    // unconditional load from a clamped address; the zero-select happens in store_chunk so that
+    // nothing consumes the load result here (a use would force s_waitcnt right behind the load)
+    const bool ok = py[j] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W && c < C;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + (ok ? (pb[j] + (int64_t)yy * W + xx) * ld + c : 0));
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    return ok;
   }
-  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+  __device__ __forceinline__ void store_chunk(float* t, const float (&r)[NREG], int j, bool ok) const {
+    const int e = threadIdx.x + 256 * j;
+    const int row = e / F4, kq = e % F4;
 #pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int row = e / F4, kq = e % F4;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) t[(kq * 4 + c) * LD + row] = r[4 * j + c];
-    }
+    for (int c = 0; c < 4; ++c) t[(kq * 4 + c) * LD + row] = ok ? r[4 * j + c] : 0.f;
   }
 };
 
@@ -146,24 +146,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int mbase = m0 + (wave / Cfg::WN) * (Cfg::TM * 32) + mt * 32 + 4 * (lane >> 5);
       const int b0 = mbase / HW, pix0 = mbase - b0 * HW;
       if (EPI == EPI_PLAIN) {
-        float* o[16];
-        bool ok[16];
+        // two batches of 8 rows: 8 element offsets (32-bit), 8 optional loads in flight, 8 stores
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = (r & 3) + 8 * (r >> 2);
-          int pix = pix0 + d, b = b0;
-          if (pix >= HW) { pix -= HW; ++b; }
-          ok[r] = nok && (mbase + d < M);
-          o[r] = dp + b * dbs + pix * dps + (n - dn0) * dcs;
-        }
-        float old[16];
+        for (int hb = 0; hb < 2; ++hb) {
+          int off[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = (dacc && ok[r]) ? *o[r] : 0.f;
+          for (int q = 0; q < 8; ++q) {
+            const int r = hb * 8 + q;
+            const int d = (r & 3) + 8 * (r >> 2);
+            int pix = pix0 + d, b = b0;
+            if (pix >= HW) { pix -= HW; ++b; }
+            const bool ok = nok && (mbase + d < M);
+            off[q] = ok ? (int)(b * dbs + pix * dps + (n - dn0) * dcs) : -1;
+          }
+          float old[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = (acc[mt][nt][r] + bias) * a.alpha;
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (ok[r]) *o[r] = v + old[r];
+          for (int q = 0; q < 8; ++q) old[q] = (dacc && off[q] >= 0) ? dp[off[q]] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float v = (acc[mt][nt][hb * 8 + q] + bias) * a.alpha;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (off[q] >= 0) dp[off[q]] = v + old[q];
+          }
         }
       } else if (EPI == EPI_ZR) {
         const bool isz = n < a.hid;
@@ -228,32 +232,27 @@ struct ShiftedXLoader {                    // Bs[k = pixel][n = ci] <- X[pixel +
   static constexpr int F4 = BN / 4;
   static constexpr int NF4 = BK * F4 / 256;
   static constexpr int NREG = NF4 * 4;
+  static constexpr int NCH = NF4;
   const float* p; int ld, cvalid;          // p already offset by ci0; cvalid = channels left from ci0
   int dy, dx, H, W, HW; int64_t M; int64_t m_begin, m_end;
-  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / F4, c4 = e % F4;
-      const int64_t m = m_begin + (int64_t)kt * BK + k;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end && c4 * 4 < cvalid) {
-        const int64_t b = m / HW; const int pix = (int)(m % HW);
-        const int yy = pix / W + dy, xx = pix % W + dx;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-          v = *reinterpret_cast<const f32x4*>(p + (b * HW + (int64_t)yy * W + xx) * ld + c4 * 4);
-      }
-      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
-    }
+  __device__ __forceinline__ bool fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / F4, c4 = e % F4;
+    const int64_t m = m_begin + (int64_t)kt * BK + k;
+    const int64_t mm = m < m_end ? m : m_begin;
+    const int64_t b = mm / HW; const int pix = (int)(mm % HW);
+    const int yy = pix / W + dy, xx = pix % W + dx;
+    const bool ok = m < m_end && c4 * 4 < cvalid && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + (ok ? (b * HW + (int64_t)yy * W + xx) * ld + c4 * 4 : 0));
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    return ok;
   }
-  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / F4, c4 = e % F4;
-      f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
-      *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = v;
-    }
+  __device__ __forceinline__ void store_chunk(float* t, const float (&r)[NREG], int j, bool ok) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / F4, c4 = e % F4;
+    f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = ok ? v : z;
   }
 };
 
@@ -264,26 +263,23 @@ struct DyLoader {                          // As[k = pixel][m = co] <- dY[pixel]
   static constexpr int NF4 = BK * F4 / 256;
   static constexpr int NREG = NF4 * 4;
   static_assert((BK * F4) % 256 == 0, "dy tile must divide over 256 threads");
+  static constexpr int NCH = NF4;
   const float* p; int ld, cvalid; int64_t m_begin, m_end;
-  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / F4, c4 = e % F4;
-      const int64_t m = m_begin + (int64_t)kt * BK + k;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end && c4 * 4 < cvalid) v = *reinterpret_cast<const f32x4*>(p + m * ld + c4 * 4);
-      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
-    }
+  __device__ __forceinline__ bool fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / F4, c4 = e % F4;
+    const int64_t m = m_begin + (int64_t)kt * BK + k;
+    const bool ok = m < m_end && c4 * 4 < cvalid;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + (ok ? m * ld + c4 * 4 : 0));
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    return ok;
   }
-  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / F4, c4 = e % F4;
-      f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
-      *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = v;
-    }
+  __device__ __forceinline__ void store_chunk(float* t, const float (&r)[NREG], int j, bool ok) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / F4, c4 = e % F4;
+    f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = ok ? v : z;
   }
 };
 
@@ -388,6 +384,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
 using Cfg128 = GemmCfg<128, 128, 32, 2, 2, 2, 2>;
 using Cfg64 = GemmCfg<128, 64, 32, 4, 1, 2, 2>;
 using CfgM64 = GemmCfg<64, 128, 32, 1, 4, 2, 2>;     // half-height tile: doubles the workgroup count for narrow N
+using Cfg6464 = GemmCfg<64, 64, 32, 2, 2, 2, 2>;     // small tile: 4 workgroups/CU, fine-grained balance over 256 CUs
+using WCfg6464 = GemmCfg<64, 64, 32, 2, 2, 0, 0>;
+
+int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
+int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
+int g_wgrad_blocks = 1024;  // target workgroup count of the pixel split              (key 2)
 using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
 // weight-gradient tiles: LDS images are filled with float4 rows, so pitches stay multiples of 4
 using WCfg128 = GemmCfg<128, 128, 32, 2, 2, 0, 0>;
@@ -457,8 +459,19 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   // one workgroup per CU is not enough to keep the matrix pipe busy: when the 128x128 grid has
   // fewer than ~2 workgroups per CU, halve the tile height
   const int M = d->B * d->H * d->W;
+  if (g_conv_tile == 3) return launch_conv<Cfg6464>(a, d->epi, stream);
+  if (g_conv_tile == 2) return launch_conv<CfgM64>(a, d->epi, stream);
+  if (g_conv_tile == 1) return launch_conv<Cfg128>(a, d->epi, stream);
   if ((int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 512) return launch_conv<CfgM64>(a, d->epi, stream);
   return launch_conv<Cfg128>(a, d->epi, stream);
+}
+
+extern "C" int fsraft_set_tuning(int key, int value) {
+  if (key == 0) g_conv_tile = value;
+  else if (key == 1) g_wgrad_tile = value;
+  else if (key == 2) g_wgrad_blocks = value;
+  else return FS_ERR_ARG;
+  return FS_OK;
 }
 
 // dwpk[Cout][Ktot] += dY^T * im2col(X)   (same packed layout as the forward weights)
@@ -468,21 +481,23 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   if (!dy || !src || !dwpk || nsrc < 1 || nsrc > 3 || ldy % 4 != 0) return FS_ERR_ARG;
   WgradArgs a{};
   a.dy = dy; a.ldy = ldy; a.Cout = Cout;
+  const bool small_m = Cout <= 32;
+  const bool t64 = !small_m && g_wgrad_tile == 3;
+  const int bn = t64 ? 64 : 128, bm = small_m ? 32 : (t64 ? 64 : 128);
   int xt128 = 0;
   for (int s = 0; s < 3; ++s) {
     a.src[s] = Src{s < nsrc ? src[s] : src[0], s < nsrc ? srcC[s] : 0, s < nsrc ? srcld[s] : 4};
     if (s < nsrc) {
       if (!src[s] || srcld[s] % 4 != 0) return FS_ERR_ARG;
-      xt128 += KH * KW * ceil_div(srcC[s], 128);
+      xt128 += KH * KW * ceil_div(srcC[s], bn);
     }
   }
   a.nsrc = nsrc; a.dwpk = dwpk; a.Ktot = conv_ktot(srcC, nsrc, KH * KW);
   a.B = B; a.H = H; a.W = W; a.KH = KH; a.KW = KW;
   const int64_t M = (int64_t)B * H * W;
-  const bool small_m = Cout <= 32;
-  const int ytiles = small_m ? ceil_div(Cout, 32) : ceil_div(Cout, 128);
+  const int ytiles = ceil_div(Cout, bm);
   // aim for ~4 workgroups per CU; each split handles a multiple of 32 pixels, at least 256
-  int64_t want = (1024 + (int64_t)xt128 * ytiles - 1) / ((int64_t)xt128 * ytiles);
+  int64_t want = (g_wgrad_blocks + (int64_t)xt128 * ytiles - 1) / ((int64_t)xt128 * ytiles);
   if (want < 1) want = 1;
   int64_t chunk = (M + want - 1) / want;
   if (chunk < 256) chunk = 256;
@@ -491,6 +506,7 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   const int zs = (int)((M + chunk - 1) / chunk);
   dim3 grid(xt128, ytiles, zs);
   if (small_m) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg32>), grid, dim3(256), 0, stream, a);
+  else if (t64) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg6464>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<WCfg128>), grid, dim3(256), 0, stream, a);
   return fs_launch_status();
 }

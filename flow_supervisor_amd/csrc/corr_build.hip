@@ -20,20 +20,18 @@ namespace {
 using BuildCfg = GemmCfg<64, 256, 16, 1, 4, 0, 0>;
 
 struct F1Loader {            // As[k][i] <- f1[b][c = kt*16 + k][i0 + i]
-  static constexpr int NREG = 4;
+  static constexpr int NREG = 4, NCH = 4;
   const float* f1b; int N; int i0; int C;
-  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+  __device__ __forceinline__ bool fetch_chunk(int kt, float (&r)[NREG], int j) const {
     const int i = threadIdx.x & 63, k0 = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = kt * 16 + k0 + 4 * j;
-      r[j] = (i0 + i < N && c < C) ? f1b[(int64_t)c * N + i0 + i] : 0.f;
-    }
+    const int c = kt * 16 + k0 + 4 * j;
+    const bool ok = i0 + i < N && c < C;
+    r[j] = f1b[ok ? (int64_t)c * N + i0 + i : 0];
+    return ok;
   }
-  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+  __device__ __forceinline__ void store_chunk(float* t, const float (&r)[NREG], int j, bool ok) const {
     const int i = threadIdx.x & 63, k0 = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[(k0 + 4 * j) * BuildCfg::LDA + i] = r[j];
+    t[(k0 + 4 * j) * BuildCfg::LDA + i] = ok ? r[j] : 0.f;
   }
 };
 
@@ -44,19 +42,19 @@ __device__ __forceinline__ int patch_to_n(int row, int col) {
 }
 
 struct F2Loader {            // Bs[k][n(row,col)] <- f2[b][c][(py0+row)*W + px0+col]
-  static constexpr int NREG = 16;
+  static constexpr int NREG = 16, NCH = 8;
   const float* f2b; int N; int C; int pix; bool ok;
-  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+  __device__ __forceinline__ bool fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    // both channels of a chunk share one flag: C is required to be even (checked on the host)
+    const bool okc = ok && kt * 16 + 2 * j < C;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int c = kt * 16 + k;
-      r[k] = (ok && c < C) ? f2b[(int64_t)c * N + pix] : 0.f;
-    }
+    for (int k = 2 * j; k < 2 * j + 2; ++k) r[k] = f2b[okc ? (int64_t)(kt * 16 + k) * N + pix : 0];
+    return okc;
   }
-  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+  __device__ __forceinline__ void store_chunk(float* t, const float (&r)[NREG], int j, bool ok) const {
     const int n = patch_to_n(threadIdx.x >> 5, threadIdx.x & 31);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t[k * BuildCfg::LDB + n] = r[k];
+    for (int k = 2 * j; k < 2 * j + 2; ++k) t[k * BuildCfg::LDB + n] = ok ? r[k] : 0.f;
   }
 };
 
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(256) void corr_unpool_bwd_kernel(Levels lv, int nle
 
 extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* levels, int num_levels,
                                  int B, int C, int H, int W, hipStream_t stream) {
-  if (!fmap1 || !fmap2 || !levels || num_levels < 1 || num_levels > 4 || B < 1 || C < 1 || H < 1 || W < 1) return FS_ERR_ARG;
+  if (!fmap1 || !fmap2 || !levels || num_levels < 1 || num_levels > 4 || B < 1 || C < 2 || (C & 1) || H < 1 || W < 1) return FS_ERR_ARG;
   Levels lv;
   int h = H, w = W;
   for (int l = 0; l < 4; ++l) {

@@ -13,9 +13,11 @@
 // the register-staged double buffer below does (fetch tile t+1 -> VGPRs, MFMA on
 // tile t from LDS, then write the VGPRs to the other LDS buffer, one barrier).
 //
-// Loader concept (duck-typed):
-//   struct L { static constexpr int NREG; __device__ void fetch(int kt, float (&r)[NREG]) const;
-//              __device__ void store(float* lds_tile, const float (&r)[NREG]) const; };
+// Loader concept (duck-typed): the staging of one k-tile is cut into NCH chunks (typically one
+// 16-byte load each) so the mainloop can interleave them with MFMAs:
+//   struct L { static constexpr int NREG, NCH;
+//              __device__ void fetch_chunk(int kt, float (&r)[NREG], int c) const;   // global -> VGPR
+//              __device__ void store_chunk(float* lds_tile, const float (&r)[NREG], int c) const; };
 // `lds_tile` is the [BK][LD] image for that operand.
 #pragma once
 #include "common.hpp"
@@ -33,6 +35,13 @@ struct GemmCfg {
 };
 
 // acc[mt][nt] += A_tile * B_tile over KT k-tiles.
+//
+// Schedule of one k-tile (measured with scripts/probe/mfma_probe.hip, 512 workgroups, 2 per CU):
+// global loads of the next tile first (branch-free, nothing consumes them yet), then G = BK/2 MFMA
+// groups whose LDS fragment reads run one group ahead (+6 % over reading right before use), then
+// the LDS stores of the staged tile and one barrier.  Spreading the loads/stores between the MFMA
+// groups, or prefetching two tiles deep, measured no better (the load latency is already hidden;
+// the remaining gap to the bare-MFMA rate is issue overhead at 2 waves per SIMD).
 template <class Cfg, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(float* __restrict__ lds, int KT, const LA& la, const LB& lb,
                                               f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
@@ -40,37 +49,43 @@ __device__ __forceinline__ void gemm_mainloop(float* __restrict__ lds, int KT, c
   const int wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int l31 = lane & 31, lh = lane >> 5;
+  constexpr int G = Cfg::BK / 2;
 
   float ra[LA::NREG];
   float rb[LB::NREG];
+  // validity of each staged chunk (zero-select is applied when the chunk is written to LDS, so
+  // nothing consumes a load result right behind the load)
+  bool oka[LA::NCH], okb[LB::NCH];
   if (KT > 0) {
-    la.fetch(0, ra);
-    lb.fetch(0, rb);
-    la.store(lds, ra);
-    lb.store(lds + Cfg::A_TILE, rb);
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c) oka[c] = la.fetch_chunk(0, ra, c);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c) okb[c] = lb.fetch_chunk(0, rb, c);
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c) la.store_chunk(lds, ra, c, oka[c]);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c) lb.store_chunk(lds + Cfg::A_TILE, rb, c, okb[c]);
   }
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     float* cur = lds + (kt & 1) * Cfg::STAGE;
     float* nxt = lds + ((kt + 1) & 1) * Cfg::STAGE;
-    const bool more = (kt + 1) < KT;
-    if (more) {
-      la.fetch(kt + 1, ra);
-      lb.fetch(kt + 1, rb);
-    }
+    const int ktn = (kt + 1 < KT) ? kt + 1 : kt;   // last iteration re-stages its own tile: keeps the body branch-free
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c) oka[c] = la.fetch_chunk(ktn, ra, c);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c) okb[c] = lb.fetch_chunk(ktn, rb, c);
     const float* As = cur + lh * Cfg::LDA + wm * (Cfg::TM * 32) + l31;
     const float* Bs = cur + Cfg::A_TILE + lh * Cfg::LDB + wn * (Cfg::TN * 32) + l31;
-    // fragment reads run one k-pair ahead of the MFMAs that consume them, so the LDS latency
-    // of step ks+1 hides under the 4 x 64-cycle MFMAs of step ks
     float a[2][Cfg::TM], b[2][Cfg::TN];
 #pragma unroll
     for (int mt = 0; mt < Cfg::TM; ++mt) a[0][mt] = As[mt * 32];
 #pragma unroll
     for (int nt = 0; nt < Cfg::TN; ++nt) b[0][nt] = Bs[nt * 32];
 #pragma unroll
-    for (int ks = 0; ks < Cfg::BK / 2; ++ks) {
+    for (int ks = 0; ks < G; ++ks) {
       const int c = ks & 1, n = c ^ 1;
-      if (ks + 1 < Cfg::BK / 2) {
+      if (ks + 1 < G) {
 #pragma unroll
         for (int mt = 0; mt < Cfg::TM; ++mt) a[n][mt] = As[(2 * ks + 2) * Cfg::LDA + mt * 32];
 #pragma unroll
@@ -86,10 +101,10 @@ __device__ __forceinline__ void gemm_mainloop(float* __restrict__ lds, int KT, c
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][mt], b[c][nt], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
-      la.store(nxt, ra);
-      lb.store(nxt + Cfg::A_TILE, rb);
-    }
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c) la.store_chunk(nxt, ra, c, oka[c]);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c) lb.store_chunk(nxt + Cfg::A_TILE, rb, c, okb[c]);
     __syncthreads();
   }
 }
@@ -116,37 +131,37 @@ struct RowMajorTileLoader {
   static constexpr int F4_PER_ROW = BK / 4;
   static constexpr int NF4 = ROWS * F4_PER_ROW / 256;
   static constexpr int NREG = NF4 * 4;
+  static constexpr int NCH = NF4;
   static_assert((ROWS * F4_PER_ROW) % 256 == 0, "tile must divide over 256 threads");
   const float* base;   // already offset to the tile's first row / first k
   int64_t ld;
   int rows_valid;      // rows >= rows_valid read as zero
   int k_valid_total;   // k >= k_valid_total reads as zero
   bool vec = true;     // false: ld or k_valid_total not a multiple of 4 -> guarded scalar loads
-  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+  // Loads are unconditional (address clamped into the tile, result zeroed by a select): a
+  // branch around a load makes hipcc wait vmcnt(0) at the join and serialises the prefetch.
+  __device__ __forceinline__ bool fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int row = e / F4_PER_ROW, kq = e % F4_PER_ROW;
+    const int k = kt * BK + kq * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (vec) {
+      ok = row < rows_valid && k < k_valid_total;
+      v = *reinterpret_cast<const f32x4*>(base + (ok ? (int64_t)row * ld + k : 0));
+    } else if (row < rows_valid) {
 #pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int row = e / F4_PER_ROW, kq = e % F4_PER_ROW;
-      const int k = kt * BK + kq * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {
-        if (row < rows_valid && k < k_valid_total) v = *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + k);
-      } else if (row < rows_valid) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (k + c < k_valid_total) v[c] = base[(int64_t)row * ld + k + c];
-      }
-      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+      for (int c = 0; c < 4; ++c)
+        if (k + c < k_valid_total) v[c] = base[(int64_t)row * ld + k + c];
     }
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    return ok;
   }
-  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
+  __device__ __forceinline__ void store_chunk(float* t, const float (&r)[NREG], int j, bool ok) const {
+    const int e = threadIdx.x + 256 * j;
+    const int row = e / F4_PER_ROW, kq = e % F4_PER_ROW;
 #pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int row = e / F4_PER_ROW, kq = e % F4_PER_ROW;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) t[(kq * 4 + c) * LD + row] = r[4 * j + c];
-    }
+    for (int c = 0; c < 4; ++c) t[(kq * 4 + c) * LD + row] = ok ? r[4 * j + c] : 0.f;
   }
 };
 
@@ -157,6 +172,7 @@ struct KMajorTileLoader {
   static constexpr int F4_PER_K = COLS / 4;
   static constexpr int NF4 = BK * F4_PER_K / 256;
   static constexpr int NREG = NF4 * 4;
+  static constexpr int NCH = NF4;
   static_assert((BK * F4_PER_K) % 256 == 0, "tile must divide over 256 threads");
   static_assert(LD % 4 == 0, "LDS row pitch must keep float4 alignment");
   const float* base;
@@ -164,30 +180,28 @@ struct KMajorTileLoader {
   int cols_valid;
   int k_valid_total;
   bool vec = true;     // false: ld or cols_valid not a multiple of 4 -> guarded scalar loads
-  __device__ __forceinline__ void fetch(int kt, float (&r)[NREG]) const {
+  __device__ __forceinline__ bool fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / F4_PER_K, c4 = e % F4_PER_K;
+    const int kk = kt * BK + k;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (vec) {
+      ok = kk < k_valid_total && c4 * 4 < cols_valid;
+      v = *reinterpret_cast<const f32x4*>(base + (ok ? (int64_t)kk * ld + c4 * 4 : 0));
+    } else if (kk < k_valid_total) {
 #pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / F4_PER_K, c4 = e % F4_PER_K;
-      const int kk = kt * BK + k;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {
-        if (kk < k_valid_total && c4 * 4 < cols_valid) v = *reinterpret_cast<const f32x4*>(base + (int64_t)kk * ld + c4 * 4);
-      } else if (kk < k_valid_total) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c4 * 4 + c < cols_valid) v[c] = base[(int64_t)kk * ld + c4 * 4 + c];
-      }
-      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+      for (int c = 0; c < 4; ++c)
+        if (c4 * 4 + c < cols_valid) v[c] = base[(int64_t)kk * ld + c4 * 4 + c];
     }
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    return ok;
   }
-  __device__ __forceinline__ void store(float* t, const float (&r)[NREG]) const {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / F4_PER_K, c4 = e % F4_PER_K;
-      f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
-      *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = v;
-    }
+  __device__ __forceinline__ void store_chunk(float* t, const float (&r)[NREG], int j, bool ok) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / F4_PER_K, c4 = e % F4_PER_K;
+    f32x4 v = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(t + k * LD + c4 * 4) = ok ? v : z;
   }
 };

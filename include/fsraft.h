@@ -103,6 +103,11 @@ int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* sr
 int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
                             int nsrc, int mode, int accumulate, hipStream_t stream);
 
+/* Tuning knobs for experiments (tile selection); not part of the reference interface.
+ * key 0: conv tile (0 auto, 1 128x128, 2 64x128, 3 64x64); key 1: wgrad tile (0 128x128, 3 64x64);
+ * key 2: target workgroup count of the wgrad pixel split. */
+int fsraft_set_tuning(int key, int value);
+
 /* ---- batched fp32 GEMM (volume backward: autograd of torch.matmul, corr.py:57) ------- */
 int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
                     int64_t ldc, int64_t sC, int batch, int M, int N, int K, int trans_b, float alpha,

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the update-block GEMM shapes at the bench size (M = 4*55*128 pixels).
+Prints per-layer time and fp32-MFMA efficiency; meant to run under rocprofv3 as well."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from flow_supervisor_amd import ops  # noqa: E402
+from flow_supervisor_amd.ops import Dst, V  # noqa: E402
+
+B, H, W = 4, 55, 128
+M = B * H * W
+dev = "cuda"
+LAYERS = [  # name, kh, kw, src channels, Cout
+    ("c1 1x1 324->256", 1, 1, [324], 256),
+    ("c2 3x3 256->192", 3, 3, [256], 192),
+    ("cv 3x3 256->126", 3, 3, [256], 126),
+    ("zr 1x5 384->256", 1, 5, [128, 128, 128], 256),
+    ("q  1x5 384->128", 1, 5, [128, 128, 128], 128),
+    ("hd 3x3 128->512", 3, 3, [128], 512),
+    ("m2 1x1 256->576", 1, 1, [256], 576),
+    ("fh2 3x3 256->2", 3, 3, [256], 2),
+]
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+from flow_supervisor_amd import _lib  # noqa: E402
+for i, v in enumerate(sys.argv[3:6]):
+    _lib.load().fsraft_set_tuning(i, int(v))
+print("tuning:", sys.argv[3:6])
+for name, kh, kw, cs, cout in LAYERS:
+    if only and not name.startswith(only):
+        continue
+    cin = sum(cs)
+    srcs = [V(torch.randn(B, H, W, (c + 3) // 4 * 4, device=dev), c) for c in cs]
+    w = torch.randn(cout, cin, kh, kw, device=dev) * 0.05
+    bias = torch.randn(cout, device=dev)
+    wpk = ops.pack_weight(w, cs, 0)
+    out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=dev)
+    dy = torch.randn(B, H, W, (cout + 3) // 4 * 4, device=dev)
+    dwpk = torch.zeros_like(wpk)
+    for kind in ("fwd", "wgrad"):
+        def run():
+            if kind == "fwd":
+                ops.conv_forward(srcs, wpk, bias, B, H, W, kh, kw, cout, [Dst.nhwc(out)], relu=True)
+            else:
+                ops.conv_wgrad(V(dy, cout), srcs, dwpk, B, H, W, kh, kw)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        fl = 2.0 * M * cout * cin * kh * kw
+        print(f"{name:18s} {kind:5s} {dt * 1e6:8.1f} us  {fl / dt / 1e12:6.1f} TF  ({fl / dt / 1e12 / 157.3 * 100:4.1f}% of fp32 MFMA peak)")
