@@ -14,6 +14,8 @@ buffers.  torch.cat never materialises: convolutions read up to three source ten
 write into channel slices.  There is no eager/PyTorch fallback: without libfsraft.so, or
 on CPU tensors, forward raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -79,6 +81,9 @@ class BasicMotionEncoder(nn.Module):
 
 def _pad4(c):
     return (c + 3) // 4 * 4
+
+
+_WGRAD_SIDE_STREAM = os.environ.get("FSRAFT_WGRAD_STREAM", "1") != "0"
 
 
 # --------------------------------------------------------------------------- layer table
@@ -166,8 +171,18 @@ class _Engine:
                 st.dB[k] = st.arena[o:o + b]; o += (b + 3) // 4 * 4
         return st.dW, st.dB
 
+    def _side_stream(self, dev):
+        s = self.__dict__.get("_side")
+        if s is None or s.device != dev:
+            s = torch.cuda.Stream(device=dev)
+            self.__dict__["_side"] = s
+        return s
+
     def unpack_param_grads(self, st, P, params):
         """packed arena -> list of gradients in self.pnames order (fused layers split back)."""
+        if _WGRAD_SIDE_STREAM and st.arena is not None:
+            torch.cuda.current_stream(st.arena.device).wait_stream(self._side_stream(st.arena.device))
+        st.keep = None
         byname = dict(zip(self.pnames, params))
         grads = {}
         for k in self.order:
@@ -289,14 +304,33 @@ class _Engine:
             return f(B, H, W, ld, device=dev, dtype=torch.float32)
 
         dW, dB = self._grad_arena(st, P, dev)
+        if st.keep is None:
+            st.keep = []
 
         def relu_bwd(g, y):
             L.check(lib.fsraft_relu_bwd(L.c_void_p(g.ptr), g.ld, L.c_void_p(y.ptr), y.ld, M, g.C, L.stream()), "relu_bwd")
 
+        # Weight gradients run on a side stream, concurrently with the data-gradient chain on the
+        # main stream: the two only share read-only inputs, and co-scheduling them fills the CUs a
+        # single 220..880-workgroup GEMM leaves idle in its last wave.  Everything the side stream
+        # reads is kept alive in st.keep until the arena is unpacked (which joins the streams).
+        side = self._side_stream(dev) if _WGRAD_SIDE_STREAM else None
+        main = torch.cuda.current_stream(dev)
+        keep = st.keep if st.keep is not None else []
+
         def wgrad(k, dy, srcs):
             l = self.layers[k]
-            ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw)
-            ops.col_sum_v(dy, dB[k])
+            if side is None:
+                ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw)
+                ops.col_sum_v(dy, dB[k])
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            keep.append((dy.t, [v.t for v in srcs]))
+            with torch.cuda.stream(side):
+                ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw)
+                ops.col_sum_v(dy, dB[k])
 
         def dgrad(k, dy, dsts):
             l = self.layers[k]
@@ -391,10 +425,11 @@ class _Engine:
 
 
 class _ParamState:
-    __slots__ = ("key", "anchor", "arena", "dW", "dB", "consumed", "zero")
+    __slots__ = ("key", "anchor", "arena", "dW", "dB", "consumed", "zero", "keep")
 
     def __init__(self, key):
         self.key, self.anchor, self.arena, self.dW, self.dB, self.consumed, self.zero = key, None, None, None, None, False, None
+        self.keep = None
 
 
 class _ParamFn(torch.autograd.Function):

@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int n0 = blockIdx.x * Cfg::BN, m0 = blockIdx.y * Cfg::BM;
 
   ConvALoader<Cfg> la;
-  la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + Cfg::BK - 1) / Cfg::BK;
-  la.p1 = a.src[1].p; la.C1 = a.src[1].C; la.ld1 = a.src[1].ld; la.cpt1 = a.nsrc > 1 ? (a.src[1].C + Cfg::BK - 1) / Cfg::BK : 0;
-  la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + Cfg::BK - 1) / Cfg::BK : 0;
+  // k-tiles per tap: channel runs are packed in multiples of 32 whatever BK is
+  la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + 31) / 32 * (32 / Cfg::BK);
+  la.p1 = a.src[1].p; la.C1 = a.src[1].C; la.ld1 = a.src[1].ld; la.cpt1 = a.nsrc > 1 ? (a.src[1].C + 31) / 32 * (32 / Cfg::BK) : 0;
+  la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + 31) / 32 * (32 / Cfg::BK) : 0;
   if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
   if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
   la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.KH / 2; la.PW = a.KW / 2; la.H = a.H; la.W = a.W;
@@ -386,6 +387,8 @@ using Cfg64 = GemmCfg<128, 64, 32, 4, 1, 2, 2>;
 using CfgM64 = GemmCfg<64, 128, 32, 1, 4, 2, 2>;     // half-height tile: doubles the workgroup count for narrow N
 using Cfg6464 = GemmCfg<64, 64, 32, 2, 2, 2, 2>;     // small tile: 4 workgroups/CU, fine-grained balance over 256 CUs
 using WCfg6464 = GemmCfg<64, 64, 32, 2, 2, 0, 0>;
+using Cfg6464K16 = GemmCfg<64, 64, 16, 2, 2, 2, 2>;  // 17 KB of LDS: 8 workgroups/CU
+using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
 int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
@@ -460,6 +463,8 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   // fewer than ~2 workgroups per CU, halve the tile height
   const int M = d->B * d->H * d->W;
   if (g_conv_tile == 3) return launch_conv<Cfg6464>(a, d->epi, stream);
+  if (g_conv_tile == 4) return launch_conv<Cfg6464K16>(a, d->epi, stream);
+  if (g_conv_tile == 5) return launch_conv<CfgM64K16>(a, d->epi, stream);
   if (g_conv_tile == 2) return launch_conv<CfgM64>(a, d->epi, stream);
   if (g_conv_tile == 1) return launch_conv<Cfg128>(a, d->epi, stream);
   if ((int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 512) return launch_conv<CfgM64>(a, d->epi, stream);

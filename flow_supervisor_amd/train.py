@@ -17,13 +17,14 @@ def sequence_loss(flow_preds, flow_gt=None, gamma=0.8):
 
 
 class TrainStep:
-    def __init__(self, model, lr=4e-4, wdecay=1e-5, eps=1e-8, clip=1.0, iters=12):
+    def __init__(self, model, lr=4e-4, wdecay=1e-5, eps=1e-8, clip=1.0, iters=12, capturable=False):
         self.model = model
         self.iters = iters
         self.clip = clip
         self.grads = FlatGradients(model.parameters())
         fused = self.grads.flat.is_cuda
-        self.opt = torch.optim.AdamW(self.grads.params, lr=lr, weight_decay=wdecay, eps=eps, fused=fused)
+        self.opt = torch.optim.AdamW(self.grads.params, lr=lr, weight_decay=wdecay, eps=eps, fused=fused,
+                                     capturable=bool(capturable and fused))
 
     def __call__(self, image1, image2, flow_gt=None):
         self.grads.zero_()
