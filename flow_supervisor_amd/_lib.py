@@ -53,6 +53,7 @@ SIGNATURES = {
     "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_tuning": [c_int, c_int],
+    "fsraft_set_lookup_qb": [c_int],
     "fsraft_gemm_f32": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _S],
     "fsraft_nchw_to_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],

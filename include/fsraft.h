@@ -107,6 +107,8 @@ int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH
  * key 0: conv tile (0 auto, 1 128x128, 2 64x128, 3 64x64); key 1: wgrad tile (0 128x128, 3 64x64);
  * key 2: target workgroup count of the wgrad pixel split. */
 int fsraft_set_tuning(int key, int value);
+/* queries per workgroup of the lookup kernels: 0 auto, 8, 16 or 32 */
+int fsraft_set_lookup_qb(int qb);
 
 /* ---- batched fp32 GEMM (volume backward: autograd of torch.matmul, corr.py:57) ------- */
 int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
