@@ -22,7 +22,7 @@ class ConvDesc(Structure):
     """Mirror of struct fsraft_conv_desc (include/fsraft.h)."""
     _fields_ = [
         ("src", c_void_p * 3), ("srcC", c_int * 3), ("srcld", c_int * 3), ("nsrc", c_int),
-        ("wpk", c_void_p), ("bias", c_void_p),
+        ("wpk", c_void_p), ("bias", c_void_p), ("wpk_split", c_void_p),
         ("B", c_int), ("H", c_int), ("W", c_int), ("KH", c_int), ("KW", c_int), ("N", c_int),
         ("dst", c_void_p * 3), ("dst_bs", c_int64 * 3), ("dst_ps", c_int64 * 3), ("dst_cs", c_int64 * 3),
         ("dst_n0", c_int * 3), ("dst_acc", c_int * 3), ("ndst", c_int),
@@ -84,6 +84,12 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_int
     _lib = lib
+    # precision / tiling switches: FSRAFT_CONV_SPLIT=1 runs the forward and
+    # data-gradient GEMMs of the update block on the split-bf16 core (3 bf16 MFMAs per product,
+    # fp32 accumulation); 0 keeps them on exact-fp32 MFMA.
+    split = os.environ.get("FSRAFT_CONV_SPLIT")
+    if split is not None:
+        lib.fsraft_set_tuning(3, int(split))
     return lib
 
 

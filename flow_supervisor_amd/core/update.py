@@ -221,7 +221,8 @@ class _Engine:
                     w = w.reshape(w.shape[0], *l.view_as)
                 w = w.contiguous().float()
                 out[k] = (ops.pack_weight(w, l.src_c, 0), ops.pack_weight(w, l.src_c, 1), b.contiguous().float(),
-                          w.shape[0], tuple(w.shape))
+                          w.shape[0], tuple(w.shape),
+                          ops.pack_weight(w, l.src_c, 10), ops.pack_weight(w, l.src_c, 11))
         self._cache_key, self._cache = key, out
         return out
 
@@ -242,8 +243,9 @@ class _Engine:
 
         def conv(k, srcs, dsts, relu=False, alpha=1.0, **kw):
             l = self.layers[k]
-            wpk, _, bias, n, _ = P[k]
-            ops.conv_forward(srcs, wpk, bias, B, H, W, l.kh, l.kw, n, dsts, relu=relu, alpha=alpha, **kw)
+            wpk, _, bias, n = P[k][:4]
+            ops.conv_forward(srcs, wpk, bias, B, H, W, l.kh, l.kw, n, dsts, relu=relu, alpha=alpha,
+                             wpk_split=P[k][5], **kw)
 
         hid = self.hid
         cor1 = buf(self.c1) if self.c2 else None
@@ -335,7 +337,7 @@ class _Engine:
         def dgrad(k, dy, dsts):
             l = self.layers[k]
             n_in = sum(l.src_c)
-            ops.conv_forward([dy], P[k][1], None, B, H, W, l.kh, l.kw, n_in, dsts)
+            ops.conv_forward([dy], P[k][1], None, B, H, W, l.kh, l.kw, n_in, dsts, wpk_split=P[k][6])
 
         # ---- heads
         dhead = buf(self.head_c * (2 if self.has_mask else 1))

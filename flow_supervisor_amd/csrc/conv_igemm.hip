@@ -19,6 +19,7 @@
 // The weight-gradient kernel is the transposed product  dWpk[co][k] += sum_m dY[m,co] * Xg[m,k]
 // with the pixel dimension split across workgroups and fp32 atomics into the packed layout.
 #include "gemm_core.hpp"
+#include "gemm_core_split.hpp"
 
 namespace {
 
@@ -85,44 +86,60 @@ struct ConvALoader {
   }
 };
 
+// ---- loaders of the split-bf16 core ---------------------------------------------------------
+template <class Cfg>
+struct SplitConvALoader {                 // implicit-GEMM gather of fp32 activations, converted at staging time
+  static constexpr int NCH = Cfg::NCH_A, NREG = NCH * 4;
+  const float* p0; const float* p1; const float* p2;
+  int C0, C1, C2, ld0, ld1, ld2, cpt0, cpt1, cpt2;
+  int taps, KW, PH, PW, H, W;
+  int py[NCH], px[NCH];                   // pixel coordinates of this thread's rows (py < 0: row outside M)
+  int pofs[NCH];                          // pixel index b*H*W + y*W + x of the row
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int n0 = taps * cpt0, n1 = taps * cpt1;
+    const bool is1 = kt >= n0, is2 = kt >= n0 + n1;
+    const int k = kt - (is1 ? n0 : 0) - (is2 ? n1 : 0);
+    const int C = C0 + (is1 ? C1 - C0 : 0) + (is2 ? C2 - C1 : 0);
+    const int ld = ld0 + (is1 ? ld1 - ld0 : 0) + (is2 ? ld2 - ld1 : 0);
+    const int cpt = cpt0 + (is1 ? cpt1 - cpt0 : 0) + (is2 ? cpt2 - cpt1 : 0);
+    const float* p = p0 + (is1 ? p1 - p0 : 0) + (is2 ? p2 - p1 : 0);
+    const int tap = k / cpt, c0 = (k % cpt) * 32;
+    const int dy = tap / KW - PH, dx = tap % KW - PW;
+    const int kq = (threadIdx.x + 256 * j) & 7;
+    const int c = c0 + kq * 4;
+    const bool ok = ((unsigned)(py[j] + dy) < (unsigned)H) && ((unsigned)(px[j] + dx) < (unsigned)W) && c < C;
+    const float* src = ok ? p + (int64_t)(pofs[j] + dy * W + dx) * ld + c : g_fsraft_zero16;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+  }
+  __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+  }
+};
+
+template <class Cfg>
+struct SplitWeightLoader {                // pre-split packed weights: row n = Ktot/32 records of [32 hi | 32 lo] bf16
+  static constexpr int NCH = Cfg::NCH_B, NREG = NCH * 4;
+  const char* base;                       // row n0 of the packed matrix
+  int64_t row_bytes;                      // Ktot * 4
+  int rows_valid;
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int row = e >> 3, part = e & 7;
+    const char* src = row < rows_valid ? base + row * row_bytes + (int64_t)kt * 128 + part * 16
+                                       : reinterpret_cast<const char*>(g_fsraft_zero16);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+  }
+  __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
+    stage_copy<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+  }
+};
+
 template <class Cfg, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0) {
   const int HW = a.H * a.W;
   const int M = a.B * HW;
-  const int n0 = blockIdx.x * Cfg::BN, m0 = blockIdx.y * Cfg::BM;
-
-  ConvALoader<Cfg> la;
-  // k-tiles per tap: channel runs are packed in multiples of 32 whatever BK is
-  la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + 31) / 32 * (32 / Cfg::BK);
-  la.p1 = a.src[1].p; la.C1 = a.src[1].C; la.ld1 = a.src[1].ld; la.cpt1 = a.nsrc > 1 ? (a.src[1].C + 31) / 32 * (32 / Cfg::BK) : 0;
-  la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + 31) / 32 * (32 / Cfg::BK) : 0;
-  if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
-  if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
-  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.KH / 2; la.PW = a.KW / 2; la.H = a.H; la.W = a.W;
-#pragma unroll
-  for (int j = 0; j < ConvALoader<Cfg>::NF4; ++j) {
-    const int row = (threadIdx.x + 256 * j) / ConvALoader<Cfg>::F4;
-    const int m = m0 + row;
-    if (m < M) {
-      const int b = m / HW, pix = m % HW;
-      la.py[j] = pix / a.W; la.px[j] = pix % a.W; la.pb[j] = (int64_t)b * HW;
-    } else {
-      la.py[j] = -1; la.px[j] = 0; la.pb[j] = 0;
-    }
-  }
-  RowMajorTileLoader<Cfg::BN, Cfg::BK, Cfg::LDB> lb{a.wpk + (int64_t)n0 * a.Ktot, a.Ktot, a.N - n0, a.Ktot};
-
-  f32x16 acc[Cfg::TM][Cfg::TN];
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  gemm_mainloop<Cfg>(lds, a.Ktot / Cfg::BK, la, lb, acc);
-
   // Epilogue.  Everything is batched per 32x32 MFMA tile: 16 addresses, then (optionally) 16
   // loads in flight, then 16 stores, with no wait between consecutive stores.  Rows of one
   // accumulator tile are m = mbase + (r&3) + 8*(r>>2); a 128-row tile crosses at most one
@@ -216,6 +233,80 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
+}
+
+// exact-fp32 variant: v_mfma_f32_32x32x2_f32
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int HW = a.H * a.W;
+  const int M = a.B * HW;
+  const int n0 = blockIdx.x * Cfg::BN, m0 = blockIdx.y * Cfg::BM;
+  ConvALoader<Cfg> la;
+  // k-tiles per tap: channel runs are packed in multiples of 32 whatever BK is
+  la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + 31) / 32 * (32 / Cfg::BK);
+  la.p1 = a.src[1].p; la.C1 = a.src[1].C; la.ld1 = a.src[1].ld; la.cpt1 = a.nsrc > 1 ? (a.src[1].C + 31) / 32 * (32 / Cfg::BK) : 0;
+  la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + 31) / 32 * (32 / Cfg::BK) : 0;
+  if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
+  if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
+  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.KH / 2; la.PW = a.KW / 2; la.H = a.H; la.W = a.W;
+#pragma unroll
+  for (int j = 0; j < ConvALoader<Cfg>::NF4; ++j) {
+    const int row = (threadIdx.x + 256 * j) / ConvALoader<Cfg>::F4;
+    const int m = m0 + row;
+    if (m < M) {
+      const int b = m / HW, pix = m % HW;
+      la.py[j] = pix / a.W; la.px[j] = pix % a.W; la.pb[j] = (int64_t)b * HW;
+    } else {
+      la.py[j] = -1; la.px[j] = 0; la.pb[j] = 0;
+    }
+  }
+  RowMajorTileLoader<Cfg::BN, Cfg::BK, Cfg::LDB> lb{a.wpk + (int64_t)n0 * a.Ktot, a.Ktot, a.N - n0, a.Ktot};
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  gemm_mainloop<Cfg>(lds, a.Ktot / Cfg::BK, la, lb, acc);
+  conv_epilogue<Cfg, EPI>(a, acc, m0, n0);
+}
+
+// split-bf16 variant: 3 x v_mfma_f32_32x32x16_bf16 per product block, weights pre-split at pack time
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_split_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int HW = a.H * a.W;
+  const int M = a.B * HW;
+  const int n0 = blockIdx.x * Cfg::BN, m0 = blockIdx.y * Cfg::BM;
+  SplitConvALoader<Cfg> la;
+  la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + 31) / 32;
+  la.p1 = a.src[1].p; la.C1 = a.src[1].C; la.ld1 = a.src[1].ld; la.cpt1 = a.nsrc > 1 ? (a.src[1].C + 31) / 32 : 0;
+  la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + 31) / 32 : 0;
+  if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
+  if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
+  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.KH / 2; la.PW = a.KW / 2; la.H = a.H; la.W = a.W;
+#pragma unroll
+  for (int j = 0; j < SplitConvALoader<Cfg>::NCH; ++j) {
+    const int m = m0 + ((threadIdx.x + 256 * j) >> 3);
+    if (m < M) {
+      const int pix = m % HW;
+      la.py[j] = pix / a.W; la.px[j] = pix % a.W; la.pofs[j] = m;
+    } else {
+      la.py[j] = -(1 << 20); la.px[j] = 0; la.pofs[j] = 0;      // fails every (unsigned)(py+dy) < H test
+    }
+  }
+  SplitWeightLoader<Cfg> lb{reinterpret_cast<const char*>(a.wpk) + (int64_t)n0 * a.Ktot * 4, (int64_t)a.Ktot * 4, a.N - n0};
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  split_mainloop<Cfg>(lds, a.Ktot / 32, la, lb, acc);
+  conv_epilogue<Cfg, EPI>(a, acc, m0, n0);
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -349,7 +440,18 @@ struct PackArgs {
   int C[3]; int nsrc;  // forward source split of Cin (mode 0/2); ignored for mode 1
   int Ktot, rows;
   int mode, accumulate;
+  int split;           // modes 0/1: write [32 hi | 32 lo] bf16 records instead of fp32 (same byte size)
 };
+
+__device__ __forceinline__ void store_packed(const PackArgs& a, int64_t e, float v) {
+  if (!a.split) { a.wpk[e] = v; return; }
+  // element e = n*Ktot + k  ->  record (e / 32) of 64 shorts: hi at [k % 32], lo at [32 + k % 32]
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  __bf16* rec = reinterpret_cast<__bf16*>(a.wpk) + (e >> 5) * 64;
+  rec[e & 31] = h;
+  rec[32 + (e & 31)] = l;
+}
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
   const int64_t total = (int64_t)a.rows * a.Ktot;
@@ -361,7 +463,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
       const int tp = k / cpad, c = k % cpad;
       float v = 0.f;
       if (c < a.Cout && n < a.Cin) v = a.w[((int64_t)c * a.Cin + n) * a.taps + (a.taps - 1 - tp)];
-      a.wpk[e] = v;
+      store_packed(a, e, v);
     } else {
       int s = 0, coff = 0;
       for (; s < a.nsrc; ++s) {
@@ -373,7 +475,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
       const int t = k / cpad, c = k % cpad;
       const bool ok = c < a.C[s] && n < a.Cout;
       if (a.mode == 0) {
-        a.wpk[e] = ok ? a.w[((int64_t)n * a.Cin + coff + c) * a.taps + t] : 0.f;
+        store_packed(a, e, ok ? a.w[((int64_t)n * a.Cin + coff + c) * a.taps + t] : 0.f);
       } else if (ok) {
         float* d = a.w + ((int64_t)n * a.Cin + coff + c) * a.taps + t;
         *d = a.accumulate ? *d + a.wpk[e] : a.wpk[e];
@@ -390,6 +492,11 @@ using WCfg6464 = GemmCfg<64, 64, 32, 2, 2, 0, 0>;
 using Cfg6464K16 = GemmCfg<64, 64, 16, 2, 2, 2, 2>;  // 17 KB of LDS: 8 workgroups/CU
 using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 
+using SCfg128 = SplitCfg<128, 128, 2, 2>;
+using SCfgM64 = SplitCfg<64, 128, 1, 4>;
+using SCfg128S = SplitCfg<128, 128, 2, 2, 1>;   // single LDS image: 36 KB -> 4 workgroups per CU
+using SCfgM64S = SplitCfg<64, 128, 1, 4, 1>;
+int g_conv_split = 0;   // 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (fsraft_set_tuning key 3)
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
 int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
 int g_wgrad_blocks = 1024;  // target workgroup count of the pixel split              (key 2)
@@ -397,6 +504,16 @@ using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
 // weight-gradient tiles: LDS images are filled with float4 rows, so pitches stay multiples of 4
 using WCfg128 = GemmCfg<128, 128, 32, 2, 2, 0, 0>;
 using WCfg32 = GemmCfg<32, 128, 32, 1, 4, 0, 0>;
+
+template <class Cfg>
+int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
+  const int M = a.B * a.H * a.W;
+  dim3 grid(ceil_div(a.N, Cfg::BN), ceil_div(M, Cfg::BM));
+  if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN>), grid, dim3(256), 0, s, a);
+  else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q>), grid, dim3(256), 0, s, a);
+  return fs_launch_status();
+}
 
 template <class Cfg>
 int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
@@ -420,6 +537,7 @@ int conv_ktot(const int* C, int nsrc, int taps) {
 struct fsraft_conv_desc {
   const float* src[3]; int srcC[3]; int srcld[3]; int nsrc;
   const float* wpk; const float* bias;
+  const float* wpk_split;        // same matrix packed with mode 10/11 (or NULL): enables the split-bf16 core
   int B, H, W, KH, KW, N;
   float* dst[3]; int64_t dst_bs[3]; int64_t dst_ps[3]; int64_t dst_cs[3]; int dst_n0[3]; int dst_acc[3]; int ndst;
   int relu; float alpha;
@@ -462,6 +580,14 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   // one workgroup per CU is not enough to keep the matrix pipe busy: when the 128x128 grid has
   // fewer than ~2 workgroups per CU, halve the tile height
   const int M = d->B * d->H * d->W;
+  if (g_conv_split && d->wpk_split && d->N > 64) {
+    a.wpk = d->wpk_split;
+    const bool narrow = (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 512;
+    if (g_conv_split == 2) return narrow ? launch_conv_split<SCfgM64S>(a, d->epi, stream) : launch_conv_split<SCfg128S>(a, d->epi, stream);
+    if (g_conv_split == 3) return launch_conv_split<SCfg128S>(a, d->epi, stream);
+    if (g_conv_split == 4) return launch_conv_split<SCfg128>(a, d->epi, stream);
+    return narrow ? launch_conv_split<SCfgM64>(a, d->epi, stream) : launch_conv_split<SCfg128>(a, d->epi, stream);
+  }
   if (g_conv_tile == 3) return launch_conv<Cfg6464>(a, d->epi, stream);
   if (g_conv_tile == 4) return launch_conv<Cfg6464K16>(a, d->epi, stream);
   if (g_conv_tile == 5) return launch_conv<CfgM64K16>(a, d->epi, stream);
@@ -475,6 +601,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   if (key == 0) g_conv_tile = value;
   else if (key == 1) g_wgrad_tile = value;
   else if (key == 2) g_wgrad_blocks = value;
+  else if (key == 3) g_conv_split = value;
   else return FS_ERR_ARG;
   return FS_OK;
 }
@@ -520,8 +647,11 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
 // mode 2: packed (forward layout) -> OIHW, optionally accumulating.  srcC splits Cin for modes 0/2.
 extern "C" int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
                                        int nsrc, int mode, int accumulate, hipStream_t stream) {
-  if (!w_oihw || !wpk || mode < 0 || mode > 2) return FS_ERR_ARG;
+  if (!w_oihw || !wpk || mode < 0 || (mode > 2 && mode != 10 && mode != 11)) return FS_ERR_ARG;
   PackArgs a{};
+  a.split = mode >= 10;                      // modes 10 / 11: split-bf16 variants of modes 0 / 1
+  if (mode >= 10) mode -= 10;
+  if (a.split && mode > 1) return FS_ERR_ARG;
   a.w = w_oihw; a.wpk = wpk; a.Cout = Cout; a.Cin = Cin; a.taps = KH * KW; a.mode = mode; a.accumulate = accumulate;
   if (mode == 1) {
     a.nsrc = 1; a.C[0] = Cout; a.C[1] = a.C[2] = 0;

@@ -318,11 +318,12 @@ def conv_ktot(srcC, KH, KW):
 
 
 def pack_weight(w, srcC, mode):
-    """w: [Cout,Cin,KH,KW] contiguous.  mode 0 -> [Cout,Ktot]; mode 1 -> [Cin,Ktot'] (data gradient)."""
+    """w: [Cout,Cin,KH,KW] contiguous.  mode 0 -> [Cout,Ktot]; mode 1 -> [Cin,Ktot'] (data gradient);
+    modes 10 / 11: same matrices with every 32-k run stored as [32 hi | 32 lo] bf16 (split-bf16 core)."""
     L.require_cuda_f32(w)
     w = w.contiguous()
     Cout, Cin, KH, KW = w.shape
-    if mode == 0:
+    if mode % 10 == 0:
         rows, kt = Cout, conv_ktot(srcC, KH, KW)
     else:
         rows, kt = Cin, conv_ktot([Cout], KH, KW)
@@ -375,7 +376,7 @@ class Dst:
 
 
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
-                 aux1=None, aux2=None, hid=0):
+                 aux1=None, aux2=None, hid=0, wpk_split=None):
     """srcs: list of V (concatenated along channels).  dsts: list of Dst.
     GRU epilogues (epi 2: z|r, epi 3: q) take h, z, aux buffers as [B,H,W,ld] tensors."""
     d = L.ConvDesc()
@@ -383,6 +384,7 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
         d.src[i] = v.ptr; d.srcC[i] = v.C; d.srcld[i] = v.ld
     d.nsrc = len(srcs)
     d.wpk = wpk.data_ptr()
+    d.wpk_split = wpk_split.data_ptr() if wpk_split is not None else None
     d.bias = bias.data_ptr() if bias is not None else None
     d.B, d.H, d.W, d.KH, d.KW, d.N = B, H, W, KH, KW, N
     for i, ds in enumerate(dsts):

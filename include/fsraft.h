@@ -85,6 +85,7 @@ int fsraft_upflow8_bwd(const float* dup, float* dflow, int N, int C, int H, int 
 typedef struct fsraft_conv_desc {
   const float* src[3]; int srcC[3]; int srcld[3]; int nsrc;   /* concatenated inputs            */
   const float* wpk; const float* bias;                        /* packed weights, bias[N] or NULL */
+  const float* wpk_split;                                     /* same, packed split-bf16 (modes 10/11), or NULL */
   int B, H, W, KH, KW, N;                                     /* N = output channels             */
   float* dst[3]; int64_t dst_bs[3]; int64_t dst_ps[3]; int64_t dst_cs[3];
   int dst_n0[3]; int dst_acc[3]; int ndst;                    /* output channel ranges           */
@@ -99,13 +100,15 @@ int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream);
 int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
                       const int* srcld, int nsrc, float* dwpk, int B, int H, int W, int KH, int KW,
                       hipStream_t stream);
-/* mode 0: OIHW -> packed forward; 1: OIHW -> packed data-gradient; 2: packed -> OIHW (+=) */
+/* mode 0: OIHW -> packed forward; 1: OIHW -> packed data-gradient; 2: packed -> OIHW (+=);
+ * modes 10 / 11: as 0 / 1 but every 32-k run stored as [32 hi | 32 lo] bf16 (split-bf16 GEMM core) */
 int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
                             int nsrc, int mode, int accumulate, hipStream_t stream);
 
 /* Tuning knobs for experiments (tile selection); not part of the reference interface.
  * key 0: conv tile (0 auto, 1 128x128, 2 64x128, 3 64x64); key 1: wgrad tile (0 128x128, 3 64x64);
- * key 2: target workgroup count of the wgrad pixel split. */
+ * key 2: target workgroup count of the wgrad pixel split; key 3: 1 = split-bf16 (3 x bf16 MFMA,
+ * fp32 accumulate, ~2^-17 relative error per product) core for forward / data-gradient GEMMs with N > 64. */
 int fsraft_set_tuning(int key, int value);
 /* queries per workgroup of the lookup kernels: 0 auto, 8, 16 or 32 */
 int fsraft_set_lookup_qb(int qb);
