@@ -90,6 +90,9 @@ def load():
     split = os.environ.get("FSRAFT_CONV_SPLIT")
     if split is not None:
         lib.fsraft_set_tuning(3, int(split))
+    wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")
+    if wsplit is not None:
+        lib.fsraft_set_tuning(4, int(wsplit))
     return lib
 
 

@@ -375,6 +375,89 @@ struct DyLoader {                          // As[k = pixel][m = co] <- dY[pixel]
   }
 };
 
+// ---- split-bf16 weight gradient (k-major operands, transposed LDS reads) ---------------------
+template <class Cfg>
+struct SplitDyLoader {                    // chunk e: pixel k = e / 32, channels 4*(e % 32) .. +3 of the 128-wide co tile
+  static constexpr int NCH = Cfg::NCH_A, NREG = NCH * 4;
+  const float* p; int ld, cvalid; int64_t m_begin, m_end;
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / (Cfg::BM / 4), c4 = e % (Cfg::BM / 4);
+    const int64_t m = m_begin + (int64_t)kt * 32 + k;
+    const bool ok = m < m_end && c4 * 4 < cvalid;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p + m * ld + c4 * 4 : g_fsraft_zero16);
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+  }
+};
+template <class Cfg>
+struct SplitShiftedXLoader {
+  static constexpr int NCH = Cfg::NCH_B, NREG = NCH * 4;
+  const float* p; int ld, cvalid;
+  int dy, dx, H, W, HW; int64_t m_begin, m_end;
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int k = e / (Cfg::BN / 4), c4 = e % (Cfg::BN / 4);
+    const int64_t m = m_begin + (int64_t)kt * 32 + k;
+    const int64_t mm = m < m_end ? m : m_begin;
+    const int pix = (int)(mm % HW);
+    const int yy = pix / W + dy, xx = pix % W + dx;
+    const bool ok = m < m_end && c4 * 4 < cvalid && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p + (mm + dy * W + dx) * ld + c4 * 4 : g_fsraft_zero16);
+    r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+  }
+};
+
+using SWCfg128 = SplitTnCfg<128, 128, 2, 2, 2>;
+using SWCfg128S = SplitTnCfg<128, 128, 2, 2, 1>;
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int HW = a.H * a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int taps = a.KH * a.KW;
+  int t = blockIdx.x, s = 0, kofs = 0;
+  for (;; ++s) {
+    const int ct = (a.src[s].C + Cfg::BN - 1) / Cfg::BN;
+    if (t < taps * ct) break;
+    t -= taps * ct;
+    kofs += taps * ((a.src[s].C + 31) / 32) * 32;
+  }
+  const Src sc = s == 0 ? a.src[0] : s == 1 ? a.src[1] : a.src[2];
+  const int ct = (sc.C + Cfg::BN - 1) / Cfg::BN;
+  const int tap = t / ct, ci0 = (t % ct) * Cfg::BN;
+  const int cpad = ((sc.C + 31) / 32) * 32;
+  kofs += tap * cpad + ci0;
+  const int co0 = blockIdx.y * Cfg::BM;
+  const int64_t mb = (int64_t)blockIdx.z * a.kchunk;
+  const int64_t me = mb + a.kchunk < M ? mb + a.kchunk : M;
+  if (mb >= M) return;
+  SplitDyLoader<Cfg> la{a.dy + co0, a.ldy, a.ldy - co0 < Cfg::BM ? a.ldy - co0 : Cfg::BM, mb, me};
+  const int cleft = ((sc.C + 3) / 4) * 4 - ci0;
+  SplitShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN,
+                              tap / a.KW - a.KH / 2, tap % a.KW - a.KW / 2, a.H, a.W, HW, mb, me};
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  split_mainloop_tn<Cfg>(lds, (int)((me - mb + 31) / 32), la, lb, acc);
+#pragma unroll
+  for (int nt = 0; nt < Cfg::TN; ++nt) {
+    const int n = acc_col<Cfg>(nt);
+    if (ci0 + n >= cpad) continue;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + acc_row<Cfg>(mt, r);
+        if (co < a.Cout) atomicAdd(a.dwpk + (int64_t)co * a.Ktot + kofs + n, acc[mt][nt][r]);
+      }
+  }
+}
+
 // grid: x = packed-K tile (source, tap, 128-channel tile), y = Cout tile, z = pixel split
 template <class Cfg>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
@@ -496,7 +579,8 @@ using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgM64 = SplitCfg<64, 128, 1, 4>;
 using SCfg128S = SplitCfg<128, 128, 2, 2, 1>;   // single LDS image: 36 KB -> 4 workgroups per CU
 using SCfgM64S = SplitCfg<64, 128, 1, 4, 1>;
-int g_conv_split = 0;   // 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (fsraft_set_tuning key 3)
+int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_conv_split = 1;   // 0: exact fp32 MFMA; 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (key 3)
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
 int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
 int g_wgrad_blocks = 1024;  // target workgroup count of the pixel split              (key 2)
@@ -582,7 +666,9 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   const int M = d->B * d->H * d->W;
   if (g_conv_split && d->wpk_split && d->N > 64) {
     a.wpk = d->wpk_split;
-    const bool narrow = (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 512;
+    // 128x128 tiles unless that leaves fewer than ~1.5 workgroups per CU (measured crossover: N=128 layers
+    // at M=28160 run 1.3-1.4x faster on 64x128 tiles, N>=192 layers are faster on 128x128)
+    const bool narrow = (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
     if (g_conv_split == 2) return narrow ? launch_conv_split<SCfgM64S>(a, d->epi, stream) : launch_conv_split<SCfg128S>(a, d->epi, stream);
     if (g_conv_split == 3) return launch_conv_split<SCfg128S>(a, d->epi, stream);
     if (g_conv_split == 4) return launch_conv_split<SCfg128>(a, d->epi, stream);
@@ -602,6 +688,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 1) g_wgrad_tile = value;
   else if (key == 2) g_wgrad_blocks = value;
   else if (key == 3) g_conv_split = value;
+  else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;
   return FS_OK;
 }
@@ -637,6 +724,8 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   a.kchunk = (int)chunk;
   const int zs = (int)((M + chunk - 1) / chunk);
   dim3 grid(xt128, ytiles, zs);
+  if (!small_m && !t64 && g_wgrad_split == 1) { hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128>), grid, dim3(256), 0, stream, a); return fs_launch_status(); }
+  if (!small_m && !t64 && g_wgrad_split == 2) { hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S>), grid, dim3(256), 0, stream, a); return fs_launch_status(); }
   if (small_m) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg32>), grid, dim3(256), 0, stream, a);
   else if (t64) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg6464>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<WCfg128>), grid, dim3(256), 0, stream, a);

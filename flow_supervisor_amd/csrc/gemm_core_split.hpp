@@ -137,3 +137,108 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
     __syncthreads();
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// "TN" variant: both operands arrive k-major (element (k, m) at base[k*ld + m]), as in the weight
+// gradient dW[co][ci] = sum_pixels dY[pixel][co] * X[pixel][ci].  The MFMA wants 8 consecutive k of
+// one row per lane, i.e. the transpose of what a coalesced load delivers.  The tiles are staged
+// UN-transposed ([k][m] bf16 planes, hi and lo, straight 8-byte stores of converted float4s) and the
+// transpose happens for free in the LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane group
+// column m0+i of a 4-row block.  Row pitch 320 B (256 B of data + 64) puts the 4 rows of a block on
+// disjoint quarters of the 256-byte bank row, so the transposed reads are conflict free.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int BM_, int BN_, int WM_, int WN_, int NBUF_ = 2>
+struct SplitTnCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = 32, WM = WM_, WN = WN_, NBUF = NBUF_;
+  static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
+  static constexpr int PA = BM_ * 2 + 64, PB = BN_ * 2 + 64;         // row pitch in bytes
+  static constexpr int A_PLANE = 32 * PA, B_PLANE = 32 * PB;
+  static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+  static constexpr int LDS_BYTES = NBUF_ * STAGE;
+  static constexpr int NCH_A = 32 * (BM_ / 4) / 256, NCH_B = 32 * (BN_ / 4) / 256;
+  static_assert(WM_ * WN_ == 4, "4 waves per workgroup");
+};
+
+// chunk e of a [32][COLS] fp32 tile: k = e / (COLS/4), 4 consecutive columns from 4 * (e % (COLS/4))
+template <int COLS, int PITCH, int PLANE>
+__device__ __forceinline__ void stage_convert_kmajor(char* tile, int e, const float* r) {
+  uint2 hi, lo;
+  split4(r, hi, lo);
+  char* p = tile + (e / (COLS / 4)) * PITCH + (e % (COLS / 4)) * 8;
+  *reinterpret_cast<uint2*>(p) = hi;
+  *reinterpret_cast<uint2*>(p + PLANE) = lo;
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
+  // two transposed 4x16 blocks: k .. k+3 and k+4 .. k+7 of this lane's column
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * pitch));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
+                                                  f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  static_assert(LA::NCH == Cfg::NCH_A && LB::NCH == Cfg::NCH_B, "loader tile shape must match the config");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int lh = lane >> 5, gb = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
+
+  float ra[LA::NREG], rb[LB::NREG];
+  auto stage = [&](char* dst) {
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c)
+      stage_convert_kmajor<Cfg::BM, Cfg::PA, Cfg::A_PLANE>(dst, threadIdx.x + 256 * c, ra + 4 * c);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c)
+      stage_convert_kmajor<Cfg::BN, Cfg::PB, Cfg::B_PLANE>(dst + 2 * Cfg::A_PLANE, threadIdx.x + 256 * c, rb + 4 * c);
+  };
+  if (KT > 0) {
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(0, ra, c);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(0, rb, c);
+    stage(lds);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    char* cur = lds + (Cfg::NBUF == 2 ? (kt & 1) * Cfg::STAGE : 0);
+    char* nxt = lds + (Cfg::NBUF == 2 ? ((kt + 1) & 1) * Cfg::STAGE : 0);
+    const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(ktn, ra, c);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(ktn, rb, c);
+    // this lane's address inside a plane: row (8*lh + q) of the k-step, columns base + 16*gb + 4*p4
+    const char* As = cur + (8 * lh + q) * Cfg::PA + (wm * (Cfg::TM * 32) + 16 * gb + 4 * p4) * 2;
+    const char* Bs = cur + 2 * Cfg::A_PLANE + (8 * lh + q) * Cfg::PB + (wn * (Cfg::TN * 32) + 16 * gb + 4 * p4) * 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN];
+#pragma unroll
+      for (int mt = 0; mt < Cfg::TM; ++mt) {
+        ah[mt] = tr_frag(As + s * 16 * Cfg::PA + mt * 64, Cfg::PA);
+        al[mt] = tr_frag(As + s * 16 * Cfg::PA + mt * 64 + Cfg::A_PLANE, Cfg::PA);
+      }
+#pragma unroll
+      for (int nt = 0; nt < Cfg::TN; ++nt) {
+        bh[nt] = tr_frag(Bs + s * 16 * Cfg::PB + nt * 64, Cfg::PB);
+        bl[nt] = tr_frag(Bs + s * 16 * Cfg::PB + nt * 64 + Cfg::B_PLANE, Cfg::PB);
+      }
+#pragma unroll
+      for (int mt = 0; mt < Cfg::TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < Cfg::TN; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    if (Cfg::NBUF == 1) __syncthreads();
+    stage(nxt);
+    __syncthreads();
+  }
+}

@@ -19,6 +19,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=["exact", "split"])
+def precision(request):
+    """The update-block GEMMs have two arithmetic modes:
+    exact  -- v_mfma_f32_32x32x2_f32, a pure fp32 fmaf chain (tolerances = fp32 summation-order noise);
+    split  -- the default: every fp32 operand split into bf16 hi + lo, three bf16 MFMAs per product with fp32
+              accumulation, relative error ~2^-17 per product (tolerances widened accordingly; the contract
+              is the end-to-end EPE <= 1e-3 of BASELINE.json, checked in both modes)."""
+    from flow_supervisor_amd import _lib
+    lib = _lib.load()
+    on = request.param == "split"
+    lib.fsraft_set_tuning(3, 1 if on else 0)
+    lib.fsraft_set_tuning(4, 2 if on else 0)
+    yield request.param
+    lib.fsraft_set_tuning(3, 1)
+    lib.fsraft_set_tuning(4, 2)
+
+
 def _native():
     from flow_supervisor_amd import _lib
     _lib.load()
@@ -138,7 +155,8 @@ def test_upflow8_and_helpers():
 
 # ----------------------------------------------------------------------------- a6-a8
 @pytest.mark.parametrize("tag", ["basic", "small"])
-def test_update_block_vs_reference(tag):
+def test_update_block_vs_reference(tag, precision):
+    f = 1.0 if precision == "exact" else 8.0          # split-bf16: ~2^-17 per product, a few layers deep
     from flow_supervisor_amd.core.update import BasicUpdateBlock, SmallUpdateBlock
     g = load("update_" + tag)
     small = tag == "small"
@@ -156,25 +174,33 @@ def test_update_block_vs_reference(tag):
     corr = rand_tensor((B, cp, H, W), seed + 12, 2.0).to(DEV).requires_grad_(True)
     flow = rand_tensor((B, 2, H, W), seed + 13, 3.0).to(DEV).requires_grad_(True)
     net2, mask, delta = blk(net, inp, corr, flow)
-    close(net2, g["net_out"], 2e-5, what="net")
-    close(delta, g["delta"], 2e-5, what="delta")
+    close(net2, g["net_out"], 2e-5 * f, what="net")
+    close(delta, g["delta"], 2e-5 * f, what="delta")
     loss = (net2 * rand_tensor(tuple(net2.shape), seed + 20).to(DEV)).sum() + (delta * rand_tensor(tuple(delta.shape), seed + 21).to(DEV)).sum()
     if small:
         assert mask is None
     else:
-        close(mask, g["mask"], 2e-5, what="mask")
+        close(mask, g["mask"], 2e-5 * f, what="mask")
         loss = loss + (mask * rand_tensor(tuple(mask.shape), seed + 22).to(DEV)).sum()
     loss.backward()
-    close(net.grad, g["dnet"], 2e-4, what="dnet")
-    close(inp.grad, g["dinp"], 2e-4, what="dinp")
-    close(corr.grad, g["dcorr"], 2e-4, what="dcorr")
-    close(flow.grad, g["dflow"], 2e-4, what="dflow")
+    close(net.grad, g["dnet"], 2e-4 * f, what="dnet")
+    close(inp.grad, g["dinp"], 2e-4 * f, what="dinp")
+    close(corr.grad, g["dcorr"], 2e-4 * f, what="dcorr")
+    close(flow.grad, g["dflow"], 2e-4 * f, what="dflow")
     for k, p in blk.named_parameters():
         gr = p.grad.reshape(-1)
         ref_n = float(g["dparam_norm." + k])
-        assert abs(gr.norm().item() - ref_n) <= 2e-4 * ref_n + 1e-5, (k, gr.norm().item(), ref_n)
+        assert abs(gr.norm().item() - ref_n) <= 2e-4 * f * ref_n + 1e-5, (k, gr.norm().item(), ref_n)
         samp = gr if gr.numel() <= 4096 else gr[:: gr.numel() // 4096][:4096]
-        close(samp, g["dparam." + k], 2e-4, 1e-3, what="d" + k)
+        if precision == "exact":
+            close(samp, g["dparam." + k], 2e-4, 1e-3, what="d" + k)
+        else:
+            # A pre-activation that sits within ~1e-5 of zero can land on the other side of the ReLU in
+            # split-bf16 arithmetic; that flips one element of the mask and shows up as an isolated O(1e-2)
+            # difference in a few weight-gradient entries.  Judge those tensors by their L2 error.
+            ref = T(g["dparam." + k]).float()
+            rel = float((samp.detach().cpu() - ref).norm() / (ref.norm() + 1e-12))
+            assert rel <= 3e-3, ("d" + k, rel)
 
 
 # ----------------------------------------------------------------------------- end to end
@@ -186,7 +212,7 @@ def _model(small, seed):
 
 
 @pytest.mark.parametrize("name", ["e2e_small_128x256", "e2e_basic_368x496", "e2e_basic_440x1024"])
-def test_end_to_end_flow_epe(name):
+def test_end_to_end_flow_epe(name, precision):
     g = load(name)
     small, seed = bool(g["small"]), int(g["seed"])
     m = _model(small, seed).eval()
@@ -196,8 +222,9 @@ def test_end_to_end_flow_epe(name):
     s = int(g["stride"])
     e_low = O.epe(low.cpu(), T(g["flow_low"])).item()
     e_up = O.epe(up[:, :, ::s, ::s].cpu(), T(g["flow_up_strided"])).item()
-    print(name, "EPE low", e_low, "EPE up", e_up)
+    print(name, precision, "EPE low", e_low, "EPE up", e_up)
     assert e_low <= 1e-3 and e_up <= 1e-3, (e_low, e_up)      # BASELINE.json gate
+    assert e_up <= (5e-5 if precision == "exact" else 3e-4), (precision, e_up)   # what each mode actually delivers
 
 
 def test_end_to_end_alternate_corr_epe():
@@ -214,7 +241,7 @@ def test_end_to_end_alternate_corr_epe():
 
 
 @pytest.mark.parametrize("tag", ["basic", "small"])
-def test_train_step_loss_and_grads(tag):
+def test_train_step_loss_and_grads(tag, precision):
     g = load("train_step_" + tag)
     small, seed = tag == "small", int(g["seed"])
     m = _model(small, seed).train()
@@ -256,7 +283,7 @@ def test_gemm_and_layout_kernels():
 
 @pytest.mark.parametrize("kh,kw,cin,cout", [(1, 1, 324, 256), (3, 3, 256, 192), (1, 5, 384, 256), (5, 1, 384, 128),
                                             (3, 3, 256, 2), (3, 3, 128, 64), (3, 3, 256, 126), (3, 3, 242, 96)])
-def test_conv_igemm_fwd_dgrad_wgrad(kh, kw, cin, cout):
+def test_conv_igemm_fwd_dgrad_wgrad(kh, kw, cin, cout, precision):
     """One convolution through the C ABI against torch's CPU conv2d (fwd, data grad, weight grad)."""
     import torch.nn.functional as F
     from flow_supervisor_amd import ops
@@ -280,7 +307,7 @@ def test_conv_igemm_fwd_dgrad_wgrad(kh, kw, cin, cout):
     wd = w.to(DEV)
     wpk = ops.pack_weight(wd, split, 0)
     out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=DEV)
-    ops.conv_forward(srcs, wpk, b.to(DEV), B, H, W, kh, kw, cout, [Dst.nhwc(out)])
+    ops.conv_forward(srcs, wpk, b.to(DEV), B, H, W, kh, kw, cout, [Dst.nhwc(out)], wpk_split=ops.pack_weight(wd, split, 10))
     close(ops.nhwc_to_nchw(out, cout), y, 2e-4, what="conv fwd")
     gyc = ops.nchw_to_nhwc(gy.to(DEV))
     wpb = ops.pack_weight(wd, split, 1)
@@ -289,7 +316,7 @@ def test_conv_igemm_fwd_dgrad_wgrad(kh, kw, cin, cout):
     for t, c in zip(dxs, split):
         dsts.append(Dst.nhwc(t, 0, n0))
         n0 += c
-    ops.conv_forward([V(gyc, cout)], wpb, None, B, H, W, kh, kw, cin, dsts)
+    ops.conv_forward([V(gyc, cout)], wpb, None, B, H, W, kh, kw, cin, dsts, wpk_split=ops.pack_weight(wd, split, 11))
     dx = torch.cat([ops.nhwc_to_nchw(t, c) for t, c in zip(dxs, split)], 1)
     close(dx, xr.grad, 2e-4, what="conv dgrad")
     dwpk = torch.zeros_like(wpk)
