@@ -27,6 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# MIOpen's default find mode benchmarks every encoder convolution shape on first use (~35 s of start-up, measured);
+# the FAST mode picks the same kernels for these shapes without the search.  (The encoders are framework callers.)
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
 import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md

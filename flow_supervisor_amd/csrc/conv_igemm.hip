@@ -235,6 +235,115 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
   }
 }
 
+// Epilogue through LDS for channels-last destinations: the accumulator tile is parked in LDS (row
+// pitch BN+4 floats) and leaves as whole rows, 16 bytes per lane and 512 contiguous bytes per row of a
+// 128-wide tile, instead of 64 four-byte stores per lane.  GRU gate math runs on the float4s.
+template <class Cfg, int EPI>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
+                                                  float* __restrict__ tile) {
+  constexpr int LD = Cfg::BN + 4;
+  const int HW = a.H * a.W;
+  const int M = a.B * HW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();                                   // the k-loop's last LDS reads are done
+#pragma unroll
+  for (int nt = 0; nt < Cfg::TN; ++nt) {
+    const int nl = acc_col<Cfg>(nt);
+    const float bias = (n0 + nl < a.N && a.bias) ? a.bias[n0 + nl] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::TM; ++mt) {
+      const int rbase = (wave / Cfg::WN) * (Cfg::TM * 32) + mt * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[(rbase + (r & 3) + 8 * (r >> 2)) * LD + nl] = acc[mt][nt][r] + bias;
+    }
+  }
+  __syncthreads();
+  constexpr int C4 = Cfg::BN / 4;                    // float4 columns per row
+  constexpr int RPP = 256 / C4;                      // rows covered per pass
+  const int c4 = threadIdx.x % C4, rsub = threadIdx.x / C4;
+  const int n = n0 + c4 * 4;
+  if (n >= a.N) return;
+  if (EPI == EPI_PLAIN) {
+    int di = 0;
+    if (a.ndst > 1 && n >= a.dst[1].n0) di = 1;
+    if (a.ndst > 2 && n >= a.dst[2].n0) di = 2;
+    float* dp = di == 0 ? a.dst[0].p : di == 1 ? a.dst[1].p : a.dst[2].p;
+    const int64_t dps = di == 0 ? a.dst[0].ps : di == 1 ? a.dst[1].ps : a.dst[2].ps;
+    const int dn0 = di == 0 ? a.dst[0].n0 : di == 1 ? a.dst[1].n0 : a.dst[2].n0;
+    const bool dacc = (di == 0 ? a.dst[0].accumulate : di == 1 ? a.dst[1].accumulate : a.dst[2].accumulate) != 0;
+    const int nv = a.N - n < 4 ? a.N - n : 4;        // valid columns of this float4 (N need not be a multiple of 4)
+#pragma unroll 4
+    for (int row = rsub; row < Cfg::BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
+      float* o = dp + (int64_t)m * dps + (n - dn0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] *= a.alpha;
+        if (a.relu) v[i] = fmaxf(v[i], 0.f);
+      }
+      if (nv == 4) {
+        if (dacc) {
+          const f32x4 old = *reinterpret_cast<const f32x4*>(o);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += old[i];
+        }
+        *reinterpret_cast<f32x4*>(o) = v;
+      } else {
+        for (int i = 0; i < nv; ++i) o[i] = dacc ? o[i] + v[i] : v[i];
+      }
+    }
+  } else if (EPI == EPI_ZR) {
+    const bool isz = n < a.hid;
+    const int c = isz ? n : n - a.hid;
+#pragma unroll 4
+    for (int row = rsub; row < Cfg::BM; row += RPP) {
+      const int64_t m = m0 + row;
+      if (m >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
+      if (isz) {
+        *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + c) = v;                 // z
+      } else {
+        const f32x4 hh = *reinterpret_cast<const f32x4*>(a.h + m * a.ldh + c);
+        *reinterpret_cast<f32x4*>(a.aux2 + m * a.ld2 + c) = v;                            // r
+        f32x4 rh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rh[i] = v[i] * hh[i];
+        *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + c) = rh;                           // r*h
+      }
+    }
+  } else {   // EPI_Q
+#pragma unroll 4
+    for (int row = rsub; row < Cfg::BM; row += RPP) {
+      const int64_t m = m0 + row;
+      if (m >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
+      const f32x4 hh = *reinterpret_cast<const f32x4*>(a.h + m * a.ldh + n);
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(a.z + m * a.ldz + n);
+      f32x4 hn;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = tanhf(v[i]);
+        hn[i] = (1.f - zz[i]) * hh[i] + zz[i] * v[i];
+      }
+      *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + n) = v;                              // q
+      *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + n) = hn;                   // h'
+    }
+  }
+}
+
+// rows of every destination are 16-byte aligned and channels-last (column stride 1)?
+__device__ __forceinline__ bool epilogue_rows_ok(const ConvArgs& a) {
+  bool ok = true;
+  for (int i = 0; i < a.ndst; ++i)
+    ok = ok && a.dst[i].cs == 1 && (a.dst[i].ps & 3) == 0 && (a.dst[i].n0 & 3) == 0 && ((uintptr_t)a.dst[i].p & 15) == 0 &&
+         a.dst[i].bs == a.dst[i].ps * (int64_t)(a.H * a.W);
+  return ok;
+}
+
 // exact-fp32 variant: v_mfma_f32_32x32x2_f32
 template <class Cfg, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -306,6 +415,12 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   split_mainloop<Cfg>(lds, a.Ktot / 32, la, lb, acc);
+  if constexpr (Cfg::LDS_BYTES >= Cfg::BM * (Cfg::BN + 4) * 4) {     // the parked tile must fit the staging LDS
+    if (EPI != EPI_PLAIN || epilogue_rows_ok(a)) {
+      conv_epilogue_lds<Cfg, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(lds));
+      return;
+    }
+  }
   conv_epilogue<Cfg, EPI>(a, acc, m0, n0);
 }
 
@@ -577,8 +692,6 @@ using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 
 using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgM64 = SplitCfg<64, 128, 1, 4>;
-using SCfg128S = SplitCfg<128, 128, 2, 2, 1>;   // single LDS image: 36 KB -> 4 workgroups per CU
-using SCfgM64S = SplitCfg<64, 128, 1, 4, 1>;
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
 int g_conv_split = 1;   // 0: exact fp32 MFMA; 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (key 3)
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
@@ -669,8 +782,7 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // 128x128 tiles unless that leaves fewer than ~1.5 workgroups per CU (measured crossover: N=128 layers
     // at M=28160 run 1.3-1.4x faster on 64x128 tiles, N>=192 layers are faster on 128x128)
     const bool narrow = (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
-    if (g_conv_split == 2) return narrow ? launch_conv_split<SCfgM64S>(a, d->epi, stream) : launch_conv_split<SCfg128S>(a, d->epi, stream);
-    if (g_conv_split == 3) return launch_conv_split<SCfg128S>(a, d->epi, stream);
+    if (g_conv_split == 3) return launch_conv_split<SCfgM64>(a, d->epi, stream);
     if (g_conv_split == 4) return launch_conv_split<SCfg128>(a, d->epi, stream);
     return narrow ? launch_conv_split<SCfgM64>(a, d->epi, stream) : launch_conv_split<SCfg128>(a, d->epi, stream);
   }

@@ -78,36 +78,31 @@ template <class Cfg, class LA, class LB>
 __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
                                                f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
   static_assert(LA::NCH == Cfg::NCH_A && LB::NCH == Cfg::NCH_B, "loader tile shape must match the config");
+  static_assert(Cfg::NBUF == 2, "the two-deep prefetch schedule needs two LDS images");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  float ra[LA::NREG], rb[LB::NREG];
+  // Two register sets: while tile t is multiplied out of LDS, tile t+1 sits converted-on-arrival in one
+  // set and the loads of tile t+2 are in flight into the other.  With the bf16 matrix pipe a k-tile is
+  // only ~800 cycles of MFMA, less than one L2/HBM round trip, so a single tile of look-ahead (what the
+  // fp32 core uses) leaves the loads exposed; two tiles in flight per wave keep ~16 KB per wave moving.
+  float ra0[LA::NREG], rb0[LB::NREG], ra1[LA::NREG], rb1[LB::NREG];
 
-  auto stage = [&](char* dst) {
+  auto fetch = [&](int kt, float (&ra)[LA::NREG], float (&rb)[LB::NREG]) {
+    const int k = kt < KT ? kt : KT - 1;             // past the end: re-read the last tile (never staged)
+#pragma unroll
+    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(k, ra, c);
+#pragma unroll
+    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(k, rb, c);
+  };
+  auto stage = [&](char* dst, const float (&ra)[LA::NREG], const float (&rb)[LB::NREG]) {
 #pragma unroll
     for (int c = 0; c < LA::NCH; ++c) la.stage_chunk(dst, ra + 4 * c, c);
 #pragma unroll
     for (int c = 0; c < LB::NCH; ++c) lb.stage_chunk(dst + Cfg::A_BYTES, rb + 4 * c, c);
   };
-
-  if (KT > 0) {
-#pragma unroll
-    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(0, ra, c);
-#pragma unroll
-    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(0, rb, c);
-    stage(lds);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    char* cur = lds + (Cfg::NBUF == 2 ? (kt & 1) * Cfg::STAGE : 0);
-    char* nxt = lds + (Cfg::NBUF == 2 ? ((kt + 1) & 1) * Cfg::STAGE : 0);
-    const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
-#pragma unroll
-    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(ktn, ra, c);
-#pragma unroll
-    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(ktn, rb, c);
-
+  auto compute = [&](const char* cur) {
     const char* As = cur + (wm * (Cfg::TM * 32) + l31) * Cfg::PITCH + lh * 16;
     const char* Bs = cur + Cfg::A_BYTES + (wn * (Cfg::TN * 32) + l31) * Cfg::PITCH + lh * 16;
 #pragma unroll
@@ -132,8 +127,25 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
         }
     }
-    if (Cfg::NBUF == 1) __syncthreads();      // every wave is done reading the single image
-    stage(nxt);
+  };
+
+  if (KT <= 0) return;
+  char* buf0 = lds;
+  char* buf1 = lds + Cfg::STAGE;
+  fetch(0, ra0, rb0);
+  fetch(1, ra1, rb1);
+  stage(buf0, ra0, rb0);           // tile 0 -> LDS
+  fetch(2, ra0, rb0);              // tile 2 in flight, tile 1 waiting in set 1
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt += 2) {
+    compute(buf0);                                   // tile kt
+    if (kt + 1 < KT) stage(buf1, ra1, rb1);          // tile kt+1 -> other image
+    fetch(kt + 3, ra1, rb1);
+    __syncthreads();
+    if (kt + 1 >= KT) break;
+    compute(buf1);                                   // tile kt+1
+    if (kt + 2 < KT) stage(buf0, ra0, rb0);          // tile kt+2
+    fetch(kt + 4, ra0, rb0);
     __syncthreads();
   }
 }
