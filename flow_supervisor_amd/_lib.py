@@ -50,10 +50,11 @@ SIGNATURES = {
     "fsraft_upflow8_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_ktot": [_IP, c_int, c_int, c_int],
     "fsraft_conv_forward": [POINTER(ConvDesc), _S],
-    "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_tuning": [c_int, c_int],
     "fsraft_set_lookup_qb": [c_int],
+    "fsraft_set_build_split": [c_int],
     "fsraft_gemm_f32": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _S],
     "fsraft_nchw_to_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
@@ -90,6 +91,9 @@ def load():
     split = os.environ.get("FSRAFT_CONV_SPLIT")
     if split is not None:
         lib.fsraft_set_tuning(3, int(split))
+    bsplit = os.environ.get("FSRAFT_BUILD_SPLIT")
+    if bsplit is not None:
+        lib.fsraft_set_build_split(int(bsplit))
     wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")
     if wsplit is not None:
         lib.fsraft_set_tuning(4, int(wsplit))

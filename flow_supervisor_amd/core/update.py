@@ -325,16 +325,14 @@ class _Engine:
         def wgrad(k, dy, srcs):
             l = self.layers[k]
             if side is None:
-                ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw)
-                ops.col_sum_v(dy, dB[k])
+                ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
                 return
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
             keep.append((dy.t, [v.t for v in srcs]))
             with torch.cuda.stream(side):
-                ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw)
-                ops.col_sum_v(dy, dB[k])
+                ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
 
         def dgrad(k, dy, dsts):
             l = self.layers[k]

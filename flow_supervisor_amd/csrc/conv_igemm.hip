@@ -431,6 +431,7 @@ struct WgradArgs {
   float* dwpk; int Ktot;
   int B, H, W, KH, KW;
   int kchunk;                              // pixels per split (multiple of 32)
+  float* dbias;                            // optional: dbias[co] += sum_pixels dY[pixel][co] (fused in the split kernel)
 };
 
 template <class Cfg>
@@ -558,7 +559,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
     for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  split_mainloop_tn<Cfg>(lds, (int)((me - mb + 31) / 32), la, lb, acc);
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.dbias != nullptr && blockIdx.x == 0;        // one x-tile per (co tile, pixel split) owns the bias
+  if (want_bias) split_mainloop_tn<Cfg, SplitDyLoader<Cfg>, SplitShiftedXLoader<Cfg>, true>(lds, (int)((me - mb + 31) / 32), la, lb, acc, colsum);
+  else split_mainloop_tn<Cfg>(lds, (int)((me - mb + 31) / 32), la, lb, acc);
+  if (want_bias) {
+    // this thread's columns are co0 + 4*(tid % 32) .. +3; eight threads (tid / 32) share them
+    float* part = reinterpret_cast<float*>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[(threadIdx.x >> 5) * Cfg::BM + 4 * (threadIdx.x & 31) + q] = colsum[q];
+    __syncthreads();
+    if (threadIdx.x < Cfg::BM) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += part[g * Cfg::BM + threadIdx.x];
+      if (co0 + threadIdx.x < a.Cout) atomicAdd(a.dbias + co0 + threadIdx.x, s);
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < Cfg::TN; ++nt) {
     const int n = acc_col<Cfg>(nt);
@@ -806,9 +824,11 @@ extern "C" int fsraft_set_tuning(int key, int value) {
 }
 
 // dwpk[Cout][Ktot] += dY^T * im2col(X)   (same packed layout as the forward weights)
+extern "C" int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s);
+
 extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
-                                 const int* srcld, int nsrc, float* dwpk, int B, int H, int W, int KH, int KW,
-                                 hipStream_t stream) {
+                                 const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W, int KH,
+                                 int KW, hipStream_t stream) {
   if (!dy || !src || !dwpk || nsrc < 1 || nsrc > 3 || ldy % 4 != 0) return FS_ERR_ARG;
   WgradArgs a{};
   a.dy = dy; a.ldy = ldy; a.Cout = Cout;
@@ -836,8 +856,11 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   a.kchunk = (int)chunk;
   const int zs = (int)((M + chunk - 1) / chunk);
   dim3 grid(xt128, ytiles, zs);
+  a.dbias = dbias;
   if (!small_m && !t64 && g_wgrad_split == 1) { hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128>), grid, dim3(256), 0, stream, a); return fs_launch_status(); }
   if (!small_m && !t64 && g_wgrad_split == 2) { hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S>), grid, dim3(256), 0, stream, a); return fs_launch_status(); }
+  // the exact-fp32 kernels do not fuse the bias gradient: separate column-sum pass
+  if (dbias) { const int rc = fsraft_col_sum(dy, ldy, M, Cout, dbias, 1.0f, stream); if (rc) return rc; }
   if (small_m) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg32>), grid, dim3(256), 0, stream, a);
   else if (t64) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg6464>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<WCfg128>), grid, dim3(256), 0, stream, a);

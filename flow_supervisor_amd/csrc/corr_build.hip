@@ -14,6 +14,7 @@
 // HBM traffic per sample = read 2*N*C*4 + write N*P*4 (P = sum_l h_l*w_l): 275.7 MB at
 // 55x128, C=256.  FLOPs 2*N*N*C = 25.4 G => fp32-MFMA bound.
 #include "gemm_core.hpp"
+#include "gemm_core_split.hpp"
 
 namespace {
 
@@ -58,6 +59,8 @@ struct F2Loader {            // Bs[k][n(row,col)] <- f2[b][c][(py0+row)*W + px0+
   }
 };
 
+struct __attribute__((packed, aligned(4))) PF4 { float v[4]; };
+
 struct Levels {
   float* p[4];
   int h[4];
@@ -68,30 +71,10 @@ constexpr int S_LD = 256;
 constexpr int EPI_FLOATS = 32 * 256 + 32 * 64 + 32 * 16;
 constexpr int LDS_FLOATS = BuildCfg::LDS_FLOATS > EPI_FLOATS ? BuildCfg::LDS_FLOATS : EPI_FLOATS;
 
-__global__ __launch_bounds__(256) void corr_build_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                         Levels lv, int nlev, int C, int H, int W, float scale) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  const int N = H * W;
-  const int npx = ceil_div_dev(W, 32);
-  const int px0 = (blockIdx.x % npx) * 32, py0 = (blockIdx.x / npx) * 8;
-  const int i0 = blockIdx.y * 64;
-  const int b = blockIdx.z;
-
-  F1Loader la{f1 + (int64_t)b * C * N, N, i0, C};
-  const int prow = threadIdx.x >> 5, pcol = threadIdx.x & 31;
-  const bool pok = (py0 + prow < H) && (px0 + pcol < W);
-  F2Loader lb{f2 + (int64_t)b * C * N, N, C, (py0 + prow) * W + px0 + pcol, pok};
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-  gemm_mainloop<BuildCfg>(lds, ceil_div_dev(C, 16), la, lb, acc);
-
+// Shared epilogue: park the 64 x (8x32 patch) tile in LDS half by half, store level 0 as 128-byte row
+// segments and pool 2x2 / 4x4 / 8x8 out of LDS.
+__device__ __forceinline__ void build_epilogue(f32x16 (&acc)[2][2], float* lds, const Levels& lv, int nlev, int H, int W,
+                                               int N, int b, int i0, int px0, int py0, float scale) {
   float* S = lds;                 // [32][256]  scaled level-0 patch, patch-linear (row*32+col)
   float* P1 = lds + 32 * 256;     // [32][4*16]
   float* P2 = P1 + 32 * 64;       // [32][2*8]
@@ -111,16 +94,25 @@ __global__ __launch_bounds__(256) void corr_build_kernel(const float* __restrict
     }
     __syncthreads();
     const int qbase = i0 + mt * 32;
-    // level 0: 32 queries x 8 rows, 32 contiguous floats each
+    // level 0: 32 queries x 8 rows of 32 contiguous floats; 16 bytes per lane (dword-aligned vector
+    // stores: rows start at multiples of W floats, which need not be 16-byte aligned)
     {
-      const int col = threadIdx.x & 31, slot = threadIdx.x >> 5;
-      const bool cok = px0 + col < W;
+      const int c4 = threadIdx.x & 7, slot = threadIdx.x >> 3;       // 8 lanes per 128-byte row segment
+      const int x = px0 + 4 * c4;
 #pragma unroll 4
-      for (int jj = 0; jj < 32; ++jj) {
-        const int idx = slot + 8 * jj;
+      for (int jj = 0; jj < 8; ++jj) {
+        const int idx = slot + 32 * jj;
         const int i = idx >> 3, row = idx & 7;
-        if (cok && py0 + row < H && qbase + i < N)
-          lv.p[0][(((int64_t)b * N + qbase + i) * H + py0 + row) * W + px0 + col] = S[i * S_LD + row * 32 + col];
+        if (py0 + row < H && qbase + i < N && x < W) {
+          float* dst = lv.p[0] + (((int64_t)b * N + qbase + i) * H + py0 + row) * W + x;
+          const float* src = S + i * S_LD + row * 32 + 4 * c4;
+          if (x + 3 < W) {
+            PF4 v; v.v[0] = src[0]; v.v[1] = src[1]; v.v[2] = src[2]; v.v[3] = src[3];
+            *reinterpret_cast<PF4*>(dst) = v;
+          } else {
+            for (int q = 0; q < 4 && x + q < W; ++q) dst[q] = src[q];
+          }
+        }
       }
     }
     if (nlev > 1) {
@@ -163,6 +155,95 @@ __global__ __launch_bounds__(256) void corr_build_kernel(const float* __restrict
   }
 }
 
+__global__ __launch_bounds__(256) void corr_build_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         Levels lv, int nlev, int C, int H, int W, float scale) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int N = H * W;
+  const int npx = ceil_div_dev(W, 32);
+  const int px0 = (blockIdx.x % npx) * 32, py0 = (blockIdx.x / npx) * 8;
+  const int i0 = blockIdx.y * 64;
+  const int b = blockIdx.z;
+
+  F1Loader la{f1 + (int64_t)b * C * N, N, i0, C};
+  const int prow = threadIdx.x >> 5, pcol = threadIdx.x & 31;
+  const bool pok = (py0 + prow < H) && (px0 + pcol < W);
+  F2Loader lb{f2 + (int64_t)b * C * N, N, C, (py0 + prow) * W + px0 + pcol, pok};
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  gemm_mainloop<BuildCfg>(lds, ceil_div_dev(C, 16), la, lb, acc);
+
+  build_epilogue(acc, lds, lv, nlev, H, W, N, b, i0, px0, py0, scale);
+}
+
+// ---- split-bf16 build: both operands are k-major ([channel][pixel]), i.e. the transposed-read path ----
+using BuildSplitCfg = SplitTnCfg<64, 256, 1, 4, 1>;
+
+struct F1SplitLoader {        // chunk e: channel k = e / 16, queries i0 + 4*(e % 16) .. +3
+  static constexpr int NCH = BuildSplitCfg::NCH_A, NREG = NCH * 4;
+  const float* f1b; int N, i0, C;
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int c = kt * 32 + e / 16, i = i0 + 4 * (e % 16);
+    if (c < C && i + 3 < N) {
+      const PF4 v = *reinterpret_cast<const PF4*>(f1b + (int64_t)c * N + i);
+      r[4 * j + 0] = v.v[0]; r[4 * j + 1] = v.v[1]; r[4 * j + 2] = v.v[2]; r[4 * j + 3] = v.v[3];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[4 * j + q] = (c < C && i + q < N) ? f1b[(int64_t)c * N + i + q] : 0.f;
+    }
+  }
+};
+struct F2SplitLoader {        // chunk e: channel k = e / 64, tile columns n = 4*(e % 64) .. +3 = 4 consecutive patch columns
+  static constexpr int NCH = BuildSplitCfg::NCH_B, NREG = NCH * 4;
+  const float* f2b; int N, C, H, W, px0, py0;
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int e = threadIdx.x + 256 * j;
+    const int c = kt * 32 + e / 64, n = 4 * (e % 64);
+    const int rem = n & 63, row = ((rem >> 5) << 2) + ((rem & 31) >> 3), col = ((n >> 6) << 3) + (rem & 7);
+    const int y = py0 + row, x = px0 + col;
+    if (c < C && y < H && x + 3 < W) {
+      const PF4 v = *reinterpret_cast<const PF4*>(f2b + (int64_t)c * N + y * W + x);
+      r[4 * j + 0] = v.v[0]; r[4 * j + 1] = v.v[1]; r[4 * j + 2] = v.v[2]; r[4 * j + 3] = v.v[3];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[4 * j + q] = (c < C && y < H && x + q < W) ? f2b[(int64_t)c * N + y * W + x + q] : 0.f;
+    }
+  }
+};
+
+constexpr int LDS_SPLIT_BYTES = BuildSplitCfg::LDS_BYTES > EPI_FLOATS * 4 ? BuildSplitCfg::LDS_BYTES : EPI_FLOATS * 4;
+
+__global__ __launch_bounds__(256) void corr_build_split_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                               Levels lv, int nlev, int C, int H, int W, float scale) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_SPLIT_BYTES];
+  const int N = H * W;
+  const int npx = ceil_div_dev(W, 32);
+  const int px0 = (blockIdx.x % npx) * 32, py0 = (blockIdx.x / npx) * 8;
+  const int i0 = blockIdx.y * 64;
+  const int b = blockIdx.z;
+  F1SplitLoader la{f1 + (int64_t)b * C * N, N, i0, C};
+  F2SplitLoader lb{f2 + (int64_t)b * C * N, N, C, H, W, px0, py0};
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  split_mainloop_tn<BuildSplitCfg>(lds, ceil_div_dev(C, 32), la, lb, acc);
+  __syncthreads();
+  build_epilogue(acc, reinterpret_cast<float*>(lds), lv, nlev, H, W, N, b, i0, px0, py0, scale);
+}
+
+int g_build_split = 1;    // 0: exact fp32 MFMA build, 1: split-bf16 (fsraft_set_build_split)
+
 // Backward of the pooling chain, folded into level 0 in place:
 //   g0[y][x] += 1/4 * ( g1[y/2][x/2] + 1/4 * ( g2[y/4][x/4] + 1/4 * g3[y/8][x/8] ) )
 // where a level-l cell only feeds back if it exists (index < size of that level);
@@ -200,9 +281,18 @@ extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* 
   }
   const int N = H * W;
   dim3 grid(ceil_div(W, 32) * ceil_div(H, 8), ceil_div(N, 64), B);
-  hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, lv, num_levels, C, H, W,
-                     1.0f / sqrtf((float)C));
+  if (g_build_split)
+    hipLaunchKernelGGL(corr_build_split_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, lv, num_levels, C, H, W,
+                       1.0f / sqrtf((float)C));
+  else
+    hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, lv, num_levels, C, H, W,
+                       1.0f / sqrtf((float)C));
   return fs_launch_status();
+}
+
+extern "C" int fsraft_set_build_split(int on) {
+  g_build_split = on ? 1 : 0;
+  return FS_OK;
 }
 
 // In place: levels[0] += unpooled(levels[1..]).  levels[l] hold dL/dV_l on entry.

@@ -191,19 +191,27 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <class Cfg, class LA, class LB>
+// COLSUM: additionally accumulate, per thread, the column sums of the A operand (its 4 columns are the same
+// for every chunk: (tid + 256 c) % (BM/4) == tid % (BM/4)) -- the bias gradient falls out of the weight
+// gradient's own loads.
+template <class Cfg, class LA, class LB, bool COLSUM = false>
 __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
-                                                  f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+                                                  f32x16 (&acc)[Cfg::TM][Cfg::TN], float* colsum = nullptr) {
   static_assert(LA::NCH == Cfg::NCH_A && LB::NCH == Cfg::NCH_B, "loader tile shape must match the config");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int lh = lane >> 5, gb = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
 
   float ra[LA::NREG], rb[LB::NREG];
-  auto stage = [&](char* dst) {
+  auto stage = [&](char* dst, bool count) {
 #pragma unroll
-    for (int c = 0; c < LA::NCH; ++c)
+    for (int c = 0; c < LA::NCH; ++c) {
       stage_convert_kmajor<Cfg::BM, Cfg::PA, Cfg::A_PLANE>(dst, threadIdx.x + 256 * c, ra + 4 * c);
+      if (COLSUM && count) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) colsum[q] += ra[4 * c + q];
+      }
+    }
 #pragma unroll
     for (int c = 0; c < LB::NCH; ++c)
       stage_convert_kmajor<Cfg::BN, Cfg::PB, Cfg::B_PLANE>(dst + 2 * Cfg::A_PLANE, threadIdx.x + 256 * c, rb + 4 * c);
@@ -213,7 +221,7 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
     for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(0, ra, c);
 #pragma unroll
     for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(0, rb, c);
-    stage(lds);
+    stage(lds, true);
   }
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
@@ -250,7 +258,7 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
         }
     }
     if (Cfg::NBUF == 1) __syncthreads();
-    stage(nxt);
+    stage(nxt, kt + 1 < KT);        // the last iteration re-stages its own tile: do not count it twice
     __syncthreads();
   }
 }

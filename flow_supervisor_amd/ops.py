@@ -410,14 +410,15 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
         t.end("conv_igemm", e0, 2.0 * B * H * W * N * cin * KH * KW, 4.0 * B * H * W * (cin + N))
 
 
-def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW):
-    """dwpk [Cout,Ktot] += dy^T im2col(srcs).  dy: V over the (already act'-scaled) output gradient."""
+def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW, dbias=None):
+    """dwpk [Cout,Ktot] += dy^T im2col(srcs);  dbias [Cout] += column sums of dy (optional).
+    dy: V over the (already act'-scaled) output gradient."""
     arr = (ctypes.c_void_p * len(srcs))(*[v.ptr for v in srcs])
     pp = ctypes.cast(arr, L._PP)
     e0w = TIMER.begin() if TIMER else None
     L.check(_lib().fsraft_conv_wgrad(ctypes.c_void_p(dy.ptr), dy.ld, dy.C, pp, L.int_array([v.C for v in srcs]),
-                                     L.int_array([v.ld for v in srcs]), len(srcs), L.ptr(dwpk), B, H, W, KH, KW,
-                                     L.stream()), "conv_wgrad")
+                                     L.int_array([v.ld for v in srcs]), len(srcs), L.ptr(dwpk), L.ptr(dbias), B, H, W,
+                                     KH, KW, L.stream()), "conv_wgrad")
     if TIMER:
         cin = sum(v.C for v in srcs)
         TIMER.end("conv_wgrad", e0w, 2.0 * B * H * W * dy.C * cin * KH * KW, 4.0 * B * H * W * (cin + dy.C))

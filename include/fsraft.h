@@ -97,8 +97,9 @@ typedef struct fsraft_conv_desc {
 
 int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);
 int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream);
+/* dwpk[Cout][Ktot] += dY^T im2col(src);  dbias (nullable): dbias[co] += sum over pixels of dY[:, co] */
 int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
-                      const int* srcld, int nsrc, float* dwpk, int B, int H, int W, int KH, int KW,
+                      const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W, int KH, int KW,
                       hipStream_t stream);
 /* mode 0: OIHW -> packed forward; 1: OIHW -> packed data-gradient; 2: packed -> OIHW (+=);
  * modes 10 / 11: as 0 / 1 but every 32-k run stored as [32 hi | 32 lo] bf16 (split-bf16 GEMM core) */
@@ -110,6 +111,8 @@ int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH
  * key 2: target workgroup count of the wgrad pixel split; key 3: 1 = split-bf16 (3 x bf16 MFMA,
  * fp32 accumulate, ~2^-17 relative error per product) core for forward / data-gradient GEMMs with N > 64. */
 int fsraft_set_tuning(int key, int value);
+/* volume build arithmetic: 1 (default) split-bf16, 0 exact fp32 MFMA */
+int fsraft_set_build_split(int on);
 /* queries per workgroup of the lookup kernels: 0 auto, 8, 16 or 32 */
 int fsraft_set_lookup_qb(int qb);
 

@@ -31,9 +31,11 @@ def precision(request):
     on = request.param == "split"
     lib.fsraft_set_tuning(3, 1 if on else 0)
     lib.fsraft_set_tuning(4, 2 if on else 0)
+    lib.fsraft_set_build_split(1 if on else 0)
     yield request.param
     lib.fsraft_set_tuning(3, 1)
     lib.fsraft_set_tuning(4, 2)
+    lib.fsraft_set_build_split(1)
 
 
 def _native():
@@ -48,7 +50,7 @@ def ns(small):
 
 # ----------------------------------------------------------------------------- a1-a3
 @pytest.mark.parametrize("name", ["corr_tiny", "corr_odd", "corr_mid"])
-def test_corr_build_lookup_and_grads_vs_reference(name):
+def test_corr_build_lookup_and_grads_vs_reference(name, precision):
     from flow_supervisor_amd.core.corr import CorrBlock
     g = load(name)
     B, C, H, W, r, seed = (int(g[k]) for k in ("B", "C", "H", "W", "radius", "seed"))
@@ -72,7 +74,7 @@ def test_corr_build_lookup_and_grads_vs_reference(name):
     close(v.reshape(-1), T(g["pyr0"]).reshape(-1), 2e-5, what="CorrBlock.corr")
 
 
-def test_corr_lookup_matches_oracle_on_sintel_shape():
+def test_corr_lookup_matches_oracle_on_sintel_shape(precision):
     """Full 55x128 / C=256 shape against the oracle for a strip of queries (the oracle needs the
     whole volume, so B=1) plus an average-pool consistency property on every level."""
     from flow_supervisor_amd.core.corr import CorrBlock
@@ -320,9 +322,11 @@ def test_conv_igemm_fwd_dgrad_wgrad(kh, kw, cin, cout, precision):
     dx = torch.cat([ops.nhwc_to_nchw(t, c) for t, c in zip(dxs, split)], 1)
     close(dx, xr.grad, 2e-4, what="conv dgrad")
     dwpk = torch.zeros_like(wpk)
-    ops.conv_wgrad(V(gyc, cout), srcs, dwpk, B, H, W, kh, kw)
+    dbias = torch.zeros(cout, device=DEV)
+    ops.conv_wgrad(V(gyc, cout), srcs, dwpk, B, H, W, kh, kw, dbias=dbias)
     dw = ops.unpack_weight_grad(dwpk, tuple(w.shape), split)
     close(dw, wr.grad, 5e-4, what="conv wgrad")
+    close(dbias, gy.sum(dim=(0, 2, 3)), 2e-4, what="bias grad (fused into the weight-gradient kernel)")
 
 
 # ----------------------------------------------------------------------------- properties at full size
