@@ -192,7 +192,8 @@ def main():
     if timer is not None:
         kern = {}
         split = {"conv_igemm": os.environ.get("FSRAFT_CONV_SPLIT", "1") != "0",
-                 "conv_wgrad": os.environ.get("FSRAFT_WGRAD_SPLIT", "2") != "0"}
+                 "conv_wgrad": os.environ.get("FSRAFT_WGRAD_SPLIT", "2") != "0",
+                 "gemm_f32": True}
         for fam, s in timer.summary().items():
             mfma = fam in ("conv_igemm", "conv_wgrad", "gemm_f32")
             sec = s["ms_total"] * 1e-3

@@ -55,6 +55,8 @@ SIGNATURES = {
     "fsraft_set_tuning": [c_int, c_int],
     "fsraft_set_lookup_qb": [c_int],
     "fsraft_set_build_split": [c_int],
+    "fsraft_set_gemm_split": [c_int],
+    "fsraft_gemm_tn_split": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _S],
     "fsraft_gemm_f32": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _S],
     "fsraft_nchw_to_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],

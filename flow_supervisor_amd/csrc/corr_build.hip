@@ -266,6 +266,39 @@ __global__ __launch_bounds__(256) void corr_unpool_bwd_kernel(Levels lv, int nle
   }
 }
 
+// W % 4 == 0 fast path: one thread per 4 consecutive x (16-byte load/store of level 0); the 4 pixels share
+// their level >= 2 ancestors and touch two level-1 cells.
+__global__ __launch_bounds__(256) void corr_unpool_bwd_vec_kernel(Levels lv, int nlev, int64_t nrows) {
+  const int H = lv.h[0], W = lv.w[0], W4 = W >> 2;
+  const int64_t total = nrows * W4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % W4) * 4;
+    const int64_t row = e / W4;            // = q*H + y
+    const int y = (int)(row % H);
+    const int64_t q = row / H;
+    float up = 0.f;                        // common ancestors: levels >= 2 (cells of >= 4 pixels)
+    for (int l = nlev - 1; l >= 2; --l) {
+      const int yl = y >> l, xl = x >> l;
+      const bool ok = yl < lv.h[l] && xl < lv.w[l];
+      up = ok ? (lv.p[l][(q * lv.h[l] + yl) * lv.w[l] + xl] + 0.25f * up) : 0.f;
+    }
+    float g1[2] = {0.f, 0.f};
+    if (nlev > 1) {
+      const int y1 = y >> 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int x1 = (x >> 1) + i;
+        const bool ok = y1 < lv.h[1] && x1 < lv.w[1];
+        g1[i] = ok ? (lv.p[1][(q * lv.h[1] + y1) * lv.w[1] + x1] + 0.25f * up) : 0.f;
+      }
+    }
+    f32x4* p = reinterpret_cast<f32x4*>(lv.p[0] + row * W + x);
+    f32x4 v = *p;
+    v[0] += 0.25f * g1[0]; v[1] += 0.25f * g1[0]; v[2] += 0.25f * g1[1]; v[3] += 0.25f * g1[1];
+    *p = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* levels, int num_levels,
@@ -308,6 +341,12 @@ extern "C" int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int
   }
   const int64_t nq = (int64_t)B * H * W;
   const int64_t total = nq * H * W;
+  if (W % 4 == 0 && ((uintptr_t)dlevels[0] % 16) == 0) {
+    const int64_t work = total / 4;
+    int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+    hipLaunchKernelGGL(corr_unpool_bwd_vec_kernel, dim3(blocks), dim3(256), 0, stream, lv, num_levels, nq * H);
+    return fs_launch_status();
+  }
   int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(corr_unpool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, lv, num_levels, nq);
   return fs_launch_status();

@@ -144,6 +144,24 @@ def gemm(A, Bm, trans_b, alpha=1.0, out=None, accumulate=False):
     return out
 
 
+SPLIT_VOLUME_BWD = True     # dF2 through the k-major split-bf16 GEMM (needs H*W % 4 == 0)
+
+
+def gemm_tn_split(A, Bm, alpha=1.0):
+    """C[b] = alpha * A[b]^T @ Bm[b] with A [b,K,M], Bm [b,K,N] (both k-major), split-bf16 core."""
+    L.require_cuda_f32(A, Bm)
+    b, K, M = A.shape
+    N = Bm.shape[2]
+    out = torch.empty(b, M, N, device=A.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_gemm_tn_split(L.ptr(A), M, K * M, L.ptr(Bm), N, K * N, L.ptr(out), N, M * N, b, M, N, K,
+                                        float(alpha), 0, L.stream()), "gemm_tn_split")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
+    return out
+
+
 def corr_build_bwd(fmap1, fmap2, dlevels):
     """dlevels: accumulated dL/dV_l (modified in place).  Returns (dfmap1, dfmap2) as NCHW."""
     B, C, H, W = fmap1.shape
@@ -154,6 +172,12 @@ def corr_build_bwd(fmap1, fmap2, dlevels):
     f1 = fmap1.contiguous().view(B, C, N)
     f2 = fmap2.contiguous().view(B, C, N)
     d1 = gemm(f2, dV, True, s)     # [B,C,N]: sum_j f2[c][j] dV[i][j]
+    if SPLIT_VOLUME_BWD and N % 4 == 0 and C % 4 == 0:
+        # dF2^T[j][c] = sum_i dV[i][j] f1^T[i][c]: both operands k-major -> transposed-read split GEMM
+        f1t = nchw_to_nhwc(fmap1).view(B, N, C)
+        d2t = gemm_tn_split(dV, f1t, s)                       # [B, N(j), C]
+        d2 = nhwc_to_nchw(d2t.view(B, H, W, C), C)
+        return d1.view(B, C, H, W), d2
     d2 = gemm(f1, dV, False, s)    # [B,C,N]: sum_i f1[c][i] dV[i][j]
     return d1.view(B, C, H, W), d2.view(B, C, H, W)
 

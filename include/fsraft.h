@@ -121,6 +121,13 @@ int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, in
                     int64_t ldc, int64_t sC, int batch, int M, int N, int K, int trans_b, float alpha,
                     int accumulate, hipStream_t stream);
 
+/* C[b][m][n] = alpha * sum_k A[b][k][m] * Bm[b][k][n] (both k-major) on the split-bf16 core. */
+int fsraft_gemm_tn_split(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
+                         int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int accumulate,
+                         hipStream_t stream);
+/* 1 (default): fsraft_gemm_f32 with trans_b uses the split-bf16 core when its operands are 16-byte aligned */
+int fsraft_set_gemm_split(int on);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);

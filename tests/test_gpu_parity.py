@@ -32,7 +32,12 @@ def precision(request):
     lib.fsraft_set_tuning(3, 1 if on else 0)
     lib.fsraft_set_tuning(4, 2 if on else 0)
     lib.fsraft_set_build_split(1 if on else 0)
+    lib.fsraft_set_gemm_split(1 if on else 0)
+    from flow_supervisor_amd import ops as _ops
+    _ops.SPLIT_VOLUME_BWD = on
     yield request.param
+    _ops.SPLIT_VOLUME_BWD = True
+    lib.fsraft_set_gemm_split(1)
     lib.fsraft_set_tuning(3, 1)
     lib.fsraft_set_tuning(4, 2)
     lib.fsraft_set_build_split(1)
