@@ -68,6 +68,10 @@ SIGNATURES = {
     "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, _S],
     "fsraft_gru_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, _S],
     "fsraft_col_sum": [c_void_p, c_int, c_int64, c_int, c_void_p, c_float, _S],
+    "fsraft_softmax_rows": [c_void_p, c_int64, c_int, _S],
+    "fsraft_softmax_rows_bwd": [c_void_p, c_void_p, c_int64, c_int, _S],
+    "fsraft_gma_mix_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, _S],
+    "fsraft_gma_mix_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, _S],
     "fsraft_axpby": [c_void_p, c_void_p, c_float, c_float, c_int64, _S],
 }
 

@@ -1,0 +1,76 @@
+"""Flow-supervisor forward for the GMA variant (pytorch/core/gma_l2l.py:26-129).
+
+Same two-phase schedule as core/l2l.py.  As in the reference, the second phase keeps calling ``update_block``
+(gma_l2l.py:112); ``grad_update_block`` exists (and is part of the state_dict) but is not used by forward.
+"""
+import torch.nn.functional as F
+
+from .corr import CorrBlock
+from .gma_network import RAFTGMA
+from .raft import convex_upsample
+from .update import GMAUpdateBlock
+from .utils.utils import upflow8
+
+
+class GMAL2L(RAFTGMA):
+    def __init__(self, args):
+        super().__init__(args)
+        self.grad_update_block = GMAUpdateBlock(self.args, hidden_dim=self.hidden_dim)
+
+    def forward(self, image1, image2, ci1=None, ci2=None, ox=None, oy=None, iters=12, flow_init=None,
+                upsample=True, test_mode=False):
+        norm = lambda im: (2 * (im / 255.0) - 1.0).contiguous()
+        image1, image2 = norm(image1), norm(image2)
+        if ci1 is not None:
+            ci1, ci2 = norm(ci1), norm(ci2)
+        if not test_mode and ci1 is None:
+            raise NameError("GMAL2L.forward in training mode needs the uncropped pair ci1/ci2 and offsets ox/oy")
+
+        fmap1, fmap2 = self._features(image1, image2)
+        corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+        net, inp, attention = self._context(image1)
+        coords0, coords1 = self.initialize_flow(image1)
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+
+        flow_predictions = []
+        flow_up = None
+        half = iters // 2
+        crop = None
+        for itr in range(iters):
+            coords1 = coords1.detach()
+            corr = corr_fn(coords1, channels_last=True)
+            flow = coords1 - coords0
+            if not (test_mode or itr < half) and itr == half:
+                if ci1 is not None:
+                    orig_h, orig_w = image1.shape[-2:]
+                    targ_h, targ_w = ci1.shape[-2:]
+                    ox_, oy_ = int(ox[0]), int(oy[0])
+                    crop = (oy_, orig_h, ox_, orig_w)
+                    l, r = ox_ // 8, (targ_w - ox_ - orig_w) // 8
+                    t, b = oy_ // 8, (targ_h - oy_ - orig_h) // 8
+                    net = F.pad(net, (0, 0, l, r, t, b))
+                    flow = F.pad(flow, (l, r, t, b))
+                    coords0, _ = self.initialize_flow(ci1)
+                    coords1 = flow + coords0
+                    tfmap1, tfmap2 = self._features(ci1, ci2)
+                    corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)
+                    corr = corr_fn(coords1, channels_last=True)
+                    _, inp, attention = self._context(ci1)
+                net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
+                attention = attention.detach()
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention)
+
+            coords1 = coords1 + delta_flow
+            if up_mask is None:
+                flow_up = upflow8(coords1 - coords0)
+            else:
+                flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+            if not test_mode and itr >= half:
+                oy_, orig_h, ox_, orig_w = crop
+                flow_up = flow_up[:, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w]
+            flow_predictions.append(flow_up)
+
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions

@@ -1,0 +1,86 @@
+"""RAFT-GMA forward (pytorch/core/gma_network.py:26-129) on the HIP hot path (benchmark config 5)."""
+import torch
+import torch.nn as nn
+from torch.amp import autocast
+
+from .corr import CorrBlock
+from .extractor import BasicEncoder
+from .gma import Attention
+from .raft import convex_upsample
+from .update import GMAUpdateBlock, to_channels_last
+from .utils.utils import coords_grid, upflow8
+
+
+class RAFTGMA(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        args.corr_levels = 4
+        args.corr_radius = 4
+        if "dropout" not in self.args:
+            self.args.dropout = 0
+        if "mixed_precision" not in self.args:
+            self.args.mixed_precision = False
+        self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
+        self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
+        self.update_block = GMAUpdateBlock(self.args, hidden_dim=hdim)
+        self.att = Attention(args=self.args, dim=cdim, heads=self.args.num_heads, max_pos_size=160, dim_head=cdim)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def initialize_flow(self, img):
+        N, C, H, W = img.shape
+        c = coords_grid(N, H // 8, W // 8, device=img.device)
+        return c, c.clone()
+
+    def upsample_flow(self, flow, mask):
+        return convex_upsample(flow, mask)
+
+    # -- pieces shared with GMAL2L ------------------------------------------------------
+    def _features(self, a, b):
+        with autocast("cuda", enabled=bool(self.args.mixed_precision)):
+            f1, f2 = self.fnet([a, b])
+        return f1.float(), f2.float()
+
+    def _context(self, img):
+        """-> (net, inp) channels-last and the attention map of inp."""
+        with autocast("cuda", enabled=bool(self.args.mixed_precision)):
+            cnet = self.cnet(img)
+        net, inp = torch.split(cnet.float(), [self.hidden_dim, self.context_dim], dim=1)
+        net = to_channels_last(torch.tanh(net))
+        inp = to_channels_last(torch.relu(inp))
+        return net, inp, self.att.forward_cl(inp)
+
+    def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        fmap1, fmap2 = self._features(image1, image2)
+        corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+        net, inp, attention = self._context(image1)
+
+        coords0, coords1 = self.initialize_flow(image1)
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+
+        flow_predictions = []
+        flow_up = None
+        for _ in range(iters):
+            coords1 = coords1.detach()
+            corr = corr_fn(coords1, channels_last=True)
+            flow = coords1 - coords0
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention)
+            coords1 = coords1 + delta_flow
+            if up_mask is None:
+                flow_up = upflow8(coords1 - coords0)
+            else:
+                flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+            flow_predictions.append(flow_up)
+
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions

@@ -1,0 +1,107 @@
+"""Flow-supervisor two-phase forward (pytorch/core/l2l.py:24-133) on the HIP hot path.
+
+First half of the iterations: the student `update_block` refines flow on the augmented crop.  At the half-way
+point the hidden state and flow are zero-padded out to the uncropped frame, a second correlation volume is built
+from the uncropped pair, everything is detached, and `grad_update_block` (the supervisor) carries on; its
+predictions are cropped back to the student's window.  Both halves run the same kernels as RAFT.forward; the
+padding happens directly on the channels-last hidden state.
+"""
+import torch
+import torch.nn.functional as F
+from torch.amp import autocast
+
+from .corr import AlternateCorrBlock, CorrBlock
+from .raft import RAFT, convex_upsample
+from .update import BasicUpdateBlock, to_channels_last
+from .utils.utils import upflow8
+
+
+class L2L(RAFT):
+    def __init__(self, args):
+        super().__init__(args)
+        self.grad_update_block = BasicUpdateBlock(self.args, hidden_dim=self.hidden_dim)   # l2l.py:27
+
+    def forward(self, image1, image2, ci1=None, ci2=None, ox=None, oy=None, iters=24, flow_init=None,
+                upsample=True, test_mode=False):
+        norm = lambda im: (2 * (im / 255.0) - 1.0).contiguous()
+        image1, image2 = norm(image1), norm(image2)
+        if ci1 is not None:
+            ci1, ci2 = norm(ci1), norm(ci2)
+        hdim, cdim = self.hidden_dim, self.context_dim
+        amp = bool(self.args.mixed_precision)
+        if not test_mode and ci1 is None:
+            # the reference reads oy_/ox_ in the second half without having set them (l2l.py:124-125)
+            raise NameError("L2L.forward in training mode needs the uncropped pair ci1/ci2 and offsets ox/oy")
+
+        def features(a, b):
+            with autocast("cuda", enabled=amp):
+                f1, f2 = self.fnet([a, b])
+            return f1.float(), f2.float()
+
+        def context(a):
+            with autocast("cuda", enabled=amp):
+                c = self.cnet(a)
+            return torch.split(c.float(), [hdim, cdim], dim=1)
+
+        def lookup(fn, coords):
+            if isinstance(fn, AlternateCorrBlock):
+                return to_channels_last(fn(coords))
+            return fn(coords, channels_last=True)
+
+        fmap1, fmap2 = features(image1, image2)
+        if self.args.alternate_corr:
+            corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+        else:
+            corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+        net, inp = context(image1)
+        net = to_channels_last(torch.tanh(net))
+        inp = to_channels_last(torch.relu(inp))
+
+        coords0, coords1 = self.initialize_flow(image1)
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+
+        flow_predictions = []
+        flow_up = None
+        half = iters // 2
+        crop = None
+        for itr in range(iters):
+            coords1 = coords1.detach()
+            corr = lookup(corr_fn, coords1)
+            flow = coords1 - coords0
+            if test_mode or itr < half:
+                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow)
+            else:
+                if itr == half:
+                    if ci1 is not None:
+                        orig_h, orig_w = image1.shape[-2:]
+                        targ_h, targ_w = ci1.shape[-2:]
+                        ox_, oy_ = int(ox[0]), int(oy[0])
+                        crop = (oy_, orig_h, ox_, orig_w)
+                        l, r = ox_ // 8, (targ_w - ox_ - orig_w) // 8
+                        t, b = oy_ // 8, (targ_h - oy_ - orig_h) // 8
+                        net = F.pad(net, (0, 0, l, r, t, b))            # channels-last: pad W then H   (l2l.py:90)
+                        flow = F.pad(flow, (l, r, t, b))                #                               (l2l.py:92)
+                        coords0, _ = self.initialize_flow(ci1)
+                        coords1 = flow + coords0
+                        tfmap1, tfmap2 = features(ci1, ci2)
+                        corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)   # second volume (l2l.py:101)
+                        corr = lookup(corr_fn, coords1)
+                        _, inp = context(ci1)
+                        inp = to_channels_last(torch.relu(inp))
+                    net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
+                net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow)
+
+            coords1 = coords1 + delta_flow
+            if up_mask is None:
+                flow_up = upflow8(coords1 - coords0)
+            else:
+                flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+            if not test_mode and itr >= half:
+                oy_, orig_h, ox_, orig_w = crop
+                flow_up = flow_up[:, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w]
+            flow_predictions.append(flow_up)
+
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions

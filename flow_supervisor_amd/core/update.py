@@ -15,6 +15,7 @@ write into channel slices.  There is no eager/PyTorch fallback: without libfsraf
 on CPU tensors, forward raises.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -92,8 +93,9 @@ _WGRAD_SIDE_STREAM = os.environ.get("FSRAFT_WGRAD_STREAM", "0") != "0"
 class _Layer:
     """One GEMM of the block: which parameters form its weight, its taps and its inputs."""
 
-    def __init__(self, key, wnames, kh, kw, src_c, view_as=None):
+    def __init__(self, key, wnames, kh, kw, src_c, view_as=None, bias=True):
         self.key = key              # short id
+        self.bias = bias            # nn.Conv2d(bias=False) layers have no bias parameter
         self.wnames = wnames        # parameter prefixes concatenated along Cout (e.g. convz1+convr1)
         self.kh, self.kw = kh, kw
         self.src_c = src_c          # channel counts of the concatenated inputs
@@ -103,9 +105,10 @@ class _Layer:
 class _Engine:
     """Owns the packed-weight cache and runs the kernel sequences of one update block."""
 
-    def __init__(self, module, small):
+    def __init__(self, module, small, gma=False):
         self.m = module
         self.small = small
+        self.gma = gma              # GMAUpdateBlock: Aggregate between the motion encoder and the GRU
         if small:
             self.corr_c, self.c1, self.c2, self.f1, self.f2, self.cv = module.cor_planes, 96, 0, 64, 32, 80
             self.hid, self.inp_c, self.head_c, self.has_mask = 96, 64, 128, False
@@ -119,6 +122,8 @@ class _Engine:
         cor_out = self.c2 if self.c2 else self.c1                  # channels the corr branch contributes to cor_flo
         self.cf_c = cor_out + self.f2
         hid, inp_c, mot = self.hid, self.inp_c, self.mot_c
+        self.x_c = mot * (2 if gma else 1)                         # [motion | motion_global] share one buffer
+        mot = self.x_c
         ls = [_Layer("c1", ["encoder.convc1"], 1, 1, [self.corr_c])]
         if self.c2:
             ls.append(_Layer("c2", ["encoder.convc2"], 3, 3, [self.c1]))
@@ -127,6 +132,8 @@ class _Engine:
             _Layer("f2", ["encoder.convf2"], 3, 3, [self.f1]),
             _Layer("cv", ["encoder.conv"], 3, 3, [self.cf_c]),
         ]
+        if gma:
+            ls.append(_Layer("av", ["aggregator.to_v"], 1, 1, [self.mot_c], bias=False))
         for sfx, kh, kw in passes:
             ls.append(_Layer("zr" + sfx, ["gru.convz" + sfx, "gru.convr" + sfx], kh, kw, [hid, inp_c, mot]))
             ls.append(_Layer("q" + sfx, ["gru.convq" + sfx], kh, kw, [hid, inp_c, mot]))
@@ -141,7 +148,9 @@ class _Engine:
         self.pnames = []                                            # flat parameter order fed to the Function
         for l in ls:
             for w in l.wnames:
-                self.pnames += [w + ".weight", w + ".bias"]
+                self.pnames += [w + ".weight"] + ([w + ".bias"] if l.bias else [])
+        self.extra = ["aggregator.gamma"] if gma else []            # non-conv parameters
+        self.pnames += self.extra
         self._cache_key = None
         self._cache = None
         self._pstate = None
@@ -164,13 +173,15 @@ class _Engine:
 
     def _grad_arena(self, st, P, dev):
         if st.arena is None:
-            sizes = [(k, P[k][0].numel(), P[k][3]) for k in self.order]
-            total = sum((a + 3) // 4 * 4 + (b + 3) // 4 * 4 for _, a, b in sizes)
+            sizes = [(k, P[k][0].numel(), P[k][3] if self.layers[k].bias else 0) for k in self.order]
+            total = sum((a + 3) // 4 * 4 + (b + 3) // 4 * 4 for _, a, b in sizes) + 4 * len(self.extra)
             st.arena = torch.zeros(total, device=dev, dtype=torch.float32)
             st.dW, st.dB, o = {}, {}, 0
             for k, a, b in sizes:
                 st.dW[k] = st.arena[o:o + a].view_as(P[k][0]); o += (a + 3) // 4 * 4
-                st.dB[k] = st.arena[o:o + b]; o += (b + 3) // 4 * 4
+                st.dB[k] = st.arena[o:o + b] if b else None; o += (b + 3) // 4 * 4
+            for n in self.extra:
+                st.dB[n] = st.arena[o:o + 1]; o += 4
         return st.dW, st.dB
 
     def _side_stream(self, dev):
@@ -195,8 +206,11 @@ class _Engine:
                 p = byname[wname + ".weight"]
                 n = p.shape[0]
                 grads[wname + ".weight"] = gw[o:o + n].reshape(p.shape)
-                grads[wname + ".bias"] = st.dB[k][o:o + n].clone()
+                if l.bias:
+                    grads[wname + ".bias"] = st.dB[k][o:o + n].clone()
                 o += n
+        for n in self.extra:
+            grads[n] = st.dB[n].clone().reshape(byname[n].shape)
         st.arena = st.dW = st.dB = None
         return [grads[n] for n in self.pnames]
 
@@ -213,23 +227,27 @@ class _Engine:
         byname = dict(zip(self.pnames, params))
         out = {}
         with torch.no_grad():
+            for n in self.extra:
+                out[n] = byname[n].detach().float().reshape(-1)
             for k in self.order:
                 l = self.layers[k]
                 ws = [byname[w + ".weight"].detach() for w in l.wnames]
-                bs = [byname[w + ".bias"].detach() for w in l.wnames]
                 w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
-                b = bs[0] if len(bs) == 1 else torch.cat(bs, 0)
+                b = None
+                if l.bias:
+                    bs = [byname[w_ + ".bias"].detach() for w_ in l.wnames]
+                    b = (bs[0] if len(bs) == 1 else torch.cat(bs, 0)).contiguous().float()
                 if l.view_as is not None:
                     w = w.reshape(w.shape[0], *l.view_as)
                 w = w.contiguous().float()
-                out[k] = (ops.pack_weight(w, l.src_c, 0), ops.pack_weight(w, l.src_c, 1), b.contiguous().float(),
+                out[k] = (ops.pack_weight(w, l.src_c, 0), ops.pack_weight(w, l.src_c, 1), b,
                           w.shape[0], tuple(w.shape),
                           ops.pack_weight(w, l.src_c, 10), ops.pack_weight(w, l.src_c, 11))
         self._cache_key, self._cache = key, out
         return out
 
     # ---- forward ------------------------------------------------------------------
-    def forward(self, net, inp, corr, flow, params, save):
+    def forward(self, net, inp, corr, flow, params, save, attn=None):
         """net/inp/corr: channels-last [B,H,W,C]; flow: [B,2,H,W] (any pixel stride).
         Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
         a dict of the intermediates backward needs."""
@@ -254,7 +272,7 @@ class _Engine:
         corflo = buf(self.cf_c)
         cols = buf(98)
         flo1 = buf(self.f1)
-        motion = buf(self.mot_c)
+        motion = buf(self.x_c)           # GMA: channels [mot_c, 2 mot_c) hold motion_global
         if self.c2:
             conv("c1", [V(corr, self.corr_c)], [Dst.nhwc(cor1)], relu=True)
             conv("c2", [V(cor1, self.c1)], [Dst.nhwc(corflo)], relu=True)
@@ -267,12 +285,24 @@ class _Engine:
         conv("f2", [V(flo1, self.f1)], [Dst.nhwc(corflo, cor_out)], relu=True)
         conv("cv", [V(corflo, self.cf_c)], [Dst.nhwc(motion)], relu=True)
         ops.flow_to_nhwc(flow, motion, self.cv)
+        v = agg = None
+        if self.gma:
+            # Aggregate (gma.py:102-115, heads = 1): v = to_v(motion); motion_global = motion + gamma * (attn @ v)
+            N, mc = H * W, self.mot_c
+            if attn is None or attn.numel() != B * N * N:
+                raise RuntimeError("GMA update block needs the attention map [B,1,H*W,H*W] (single head)")
+            L.require_cuda_f32(attn)
+            attn = attn.contiguous()
+            v, agg = buf(mc), buf(mc)
+            conv("av", [V(motion, mc, 0)], [Dst.nhwc(v)])
+            ops.gemm_raw(attn.data_ptr(), N, N * N, v.data_ptr(), mc, N * mc, agg.data_ptr(), mc, N * mc, B, N, mc, N, False)
+            ops.gma_mix_fwd(V(motion, mc, 0), V(agg), P["aggregator.gamma"], V(motion, mc, mc))
 
         h = net
         gates = []
         for sfx, _, _ in self.passes:
             z, r, rh, q, hn = buf(hid), buf(hid), buf(hid), buf(hid), buf(hid)
-            xs = [V(inp, self.inp_c), V(motion, self.mot_c)]
+            xs = [V(inp, self.inp_c), V(motion, self.x_c)]
             conv("zr" + sfx, [V(h, hid)] + xs, [Dst.nhwc(z)], epi=2, h=h, aux1=rh, aux2=r, hid=hid)
             conv("q" + sfx, [V(rh, hid)] + xs, [Dst.nhwc(hn)], epi=3, h=h, z=z, aux1=q)
             gates.append((h, z, r, rh, q))
@@ -289,11 +319,11 @@ class _Engine:
         saved = None
         if save:
             saved = dict(B=B, H=H, W=W, corr=corr, inp=inp, cor1=cor1, corflo=corflo, cols=cols, flo1=flo1,
-                         motion=motion, gates=gates, hlast=h, head=head)
+                         motion=motion, gates=gates, hlast=h, head=head, attn=attn, v=v, agg=agg)
         return h, mask, delta, saved
 
     # ---- backward -----------------------------------------------------------------
-    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True):
+    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None):
         """Accumulates parameter gradients into the packed arena of `st`;
         returns (dnet, dinp, dcorr, dflow)."""
         B, H, W = S["B"], S["H"], S["W"]
@@ -370,13 +400,13 @@ class _Engine:
         # ---- GRU passes, last to first
         inp, motion = S["inp"], S["motion"]
         dinp = buf(self.inp_c, zero=True)
-        dmotion = buf(self.mot_c, zero=True)
+        dmotion = buf(self.x_c, zero=True)
         for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
             dzr = buf(2 * hid)
             dq = buf(hid)
             dhp = buf(hid)
             ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid)
-            xs = [V(inp, self.inp_c), V(motion, self.mot_c)]
+            xs = [V(inp, self.inp_c), V(motion, self.x_c)]
             wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
             drh = buf(hid)
             dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dinp, 0, hid, True),
@@ -386,6 +416,26 @@ class _Engine:
             dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), Dst.nhwc(dinp, 0, hid, True),
                                                 Dst.nhwc(dmotion, 0, hid + self.inp_c, True)])
             dh = dhp
+
+        # ---- Aggregate (GMA): motion_global = motion + gamma * (attn @ to_v(motion))
+        if self.gma:
+            N, mc = H * W, self.mot_c
+            attn, v, agg = S["attn"], S["v"], S["agg"]
+            dagg, dv = buf(mc), buf(mc)
+            ops.gma_mix_bwd(V(dmotion, mc, mc), V(agg), P["aggregator.gamma"], V(dmotion, mc, 0), V(dagg),
+                            dB["aggregator.gamma"])
+            if N % 4 == 0:       # dv = attn^T dagg: both operands k-major -> transposed-read split GEMM
+                ops.gemm_tn_raw(attn.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N)
+            else:
+                at = attn.view(B, N, N).transpose(1, 2).contiguous()
+                ops.gemm_raw(at.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N, False)
+            if ast is not None:  # dattn += dagg v^T, one buffer for all the iterations of the step
+                if ast.dattn is None:
+                    ast.dattn = torch.zeros(B, N, N, device=dev, dtype=torch.float32)
+                ops.gemm_raw(dagg.data_ptr(), mc, N * mc, v.data_ptr(), mc, N * mc, ast.dattn.data_ptr(), N, N * N, B, N, N, mc,
+                             True, 1.0, True)
+            wgrad("av", V(dv, mc), [V(motion, mc, 0)])
+            dgrad("av", V(dv, mc), [Dst.nhwc(dmotion, 0, 0, True)])
 
         # ---- motion encoder
         dflow = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
@@ -453,14 +503,40 @@ class _ParamFn(torch.autograd.Function):
         return (None, None) + tuple(ctx.engine.unpack_param_grads(st, ctx.P, ctx.params))
 
 
+class _AttnState:
+    """Per-step accumulator of dL/d attention (GMA): every iteration's `dagg v^T` lands in one buffer."""
+    __slots__ = ("key", "anchor", "dattn", "consumed", "zero")
+
+    def __init__(self, key):
+        self.key, self.anchor, self.dattn, self.consumed, self.zero = key, None, None, False, None
+
+
+class _AttnFn(torch.autograd.Function):
+    """attention -> 1-element anchor; backward hands the accumulated gradient to the attention's producer."""
+
+    @staticmethod
+    def forward(ctx, ast, attn):
+        ctx.ast, ctx.shape = ast, attn.shape
+        ast.zero = torch.zeros(1, device=attn.device)
+        return torch.zeros(1, device=attn.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        ast = ctx.ast
+        ast.consumed = True
+        d, ast.dattn = ast.dattn, None
+        return None, (d.view(ctx.shape) if d is not None else None)
+
+
 class _UpdateFn(torch.autograd.Function):
     """(anchor; net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
 
     @staticmethod
-    def forward(ctx, engine, st, params, anchor, net, inp, corr, flow):
+    def forward(ctx, engine, st, params, anchor, net, inp, corr, flow, ast=None, attn=None, aanchor=None):
         need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
-        h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need)
+        h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need, attn=attn)
         ctx.engine, ctx.st, ctx.saved = engine, st, saved
+        ctx.ast = ast
         ctx.P = engine._packed(params) if need else None
         ctx.has_mask = mask is not None
         if mask is None:
@@ -476,8 +552,9 @@ class _UpdateFn(torch.autograd.Function):
             raise RuntimeError("update block backward ran twice on the same graph (retain_graph is not supported)")
         dmask = dmask if ctx.has_mask else None
         dh = dh.contiguous() if dh is not None else None
-        dnet, dinp, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta)
-        return None, None, None, ctx.st.zero, dnet, dinp, dcorr, dflow
+        dnet, dinp, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta, ast=ctx.ast)
+        return (None, None, None, ctx.st.zero, dnet, dinp, dcorr, dflow, None, None,
+                ctx.ast.zero if ctx.ast is not None else None)
 
 
 class _ToCL(torch.autograd.Function):
@@ -515,31 +592,46 @@ def from_channels_last(x):
 
 class _UpdateBlockBase(nn.Module):
     small = False
+    gma = False
 
     def _engine(self):
         e = self.__dict__.get("_eng")
         if e is None:
-            e = _Engine(self, self.small)
+            e = _Engine(self, self.small, self.gma)
             self.__dict__["_eng"] = e
         return e
 
-    def forward_cl(self, net, inp, corr, flow):
+    def _attn_state(self, attention):
+        """(state, anchor) shared by all calls of one step that pass the same attention tensor."""
+        if attention is None or not (torch.is_grad_enabled() and attention.requires_grad):
+            return None, None
+        ast = self.__dict__.get("_ast")
+        if ast is None or ast.key() is not attention or ast.consumed:
+            ast = _AttnState(weakref.ref(attention))      # identity, not address: freed storage gets reused
+            ast.anchor = _AttnFn.apply(ast, attention)
+            self.__dict__["_ast"] = ast
+        return ast, ast.anchor
+
+    def forward_cl(self, net, inp, corr, flow, attention=None):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
-        net/inp/corr: [B,H,W,C]; flow: [B,2,H,W].  Returns (net', mask_cl or None, delta)."""
+        net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
+        Returns (net', mask_cl or None, delta)."""
         eng = self._engine()
         params = tuple(eng.params())
         st, anchor = eng.param_state(params)
+        ast, aanchor = self._attn_state(attention)
         if anchor is None:
-            if torch.is_grad_enabled() and any(t.requires_grad for t in (net, inp, corr, flow)):
+            if torch.is_grad_enabled() and (ast is not None or any(t.requires_grad for t in (net, inp, corr, flow))):
                 st, anchor = _ParamState(None), torch.zeros(1, device=net.device)   # inputs need grads, params frozen
                 st.zero = anchor
             else:
-                h, mask, delta, _ = eng.forward(net, inp, corr, flow, params, save=False)
+                h, mask, delta, _ = eng.forward(net, inp, corr, flow, params, save=False, attn=attention)
                 return h, mask, delta
-        h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, inp, corr, flow)
+        attn = attention.detach() if attention is not None else None
+        h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, inp, corr, flow, ast, attn, aanchor)
         return h, (mask if eng.has_mask else None), delta
 
-    def _forward_nchw(self, net, inp, corr, flow):
+    def _forward_nchw(self, net, inp, corr, flow, attention=None):
         cache = self.__dict__.setdefault("_inp_cache", [None, None])
         key = (inp.data_ptr(), inp._version, tuple(inp.shape))
         if cache[0] != key or (inp.requires_grad and torch.is_grad_enabled()):
@@ -548,7 +640,7 @@ class _UpdateBlockBase(nn.Module):
                 cache[0], cache[1] = key, inp_cl
         else:
             inp_cl = cache[1]
-        h, mask, delta = self.forward_cl(to_channels_last(net), inp_cl, to_channels_last(corr), flow)
+        h, mask, delta = self.forward_cl(to_channels_last(net), inp_cl, to_channels_last(corr), flow, attention)
         return from_channels_last(h), (from_channels_last(mask) if mask is not None else None), delta
 
 
@@ -567,6 +659,34 @@ class SmallUpdateBlock(_UpdateBlockBase):
 
     def forward(self, net, inp, corr, flow):
         return self._forward_nchw(net, inp, corr, flow)
+
+
+class GMAUpdateBlock(_UpdateBlockBase):
+    """gma_update.py:112-139.  forward(net, inp, corr, flow, attention) -> (net, mask, delta_flow).
+    Same kernels as BasicUpdateBlock with a 512-channel GRU input [h | inp | motion | motion_global];
+    the Aggregate step (to_v 1x1 conv, attn @ v, gamma mix) runs between the motion encoder and the GRU."""
+    gma = True
+
+    def __init__(self, args, hidden_dim=128):
+        super().__init__()
+        from .gma import Aggregate
+        self.args = args
+        self.cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.encoder = BasicMotionEncoder(args)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(
+            nn.Conv2d(128, 256, 3, padding=1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self.aggregator = Aggregate(args=self.args, dim=128, dim_head=128, heads=self.args.num_heads)
+        if hidden_dim != 128:
+            raise NotImplementedError("the HIP update block is built for hidden_dim=128 (RAFT-GMA's value)")
+        if self.args.num_heads != 1:
+            raise NotImplementedError("the fused Aggregate step is built for num_heads=1 (train_gma.py:354 default)")
+
+    def forward(self, net, inp, corr, flow, attention):
+        return self._forward_nchw(net, inp, corr, flow, attention)
 
 
 class BasicUpdateBlock(_UpdateBlockBase):

@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
   const int64_t mb = (int64_t)blockIdx.z * a.kchunk;
   const int64_t me = mb + a.kchunk < M ? mb + a.kchunk : M;
   if (mb >= M) return;
-  SplitDyLoader<Cfg> la{a.dy + co0, a.ldy, a.ldy - co0 < Cfg::BM ? a.ldy - co0 : Cfg::BM, mb, me};
+  const int coleft = ((a.Cout + 3) / 4) * 4 - co0;     // dy may be a channel slice of a wider buffer: never read past it
+  SplitDyLoader<Cfg> la{a.dy + co0, a.ldy, coleft < Cfg::BM ? coleft : Cfg::BM, mb, me};
   const int cleft = ((sc.C + 3) / 4) * 4 - ci0;
   SplitShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN,
                               tap / a.KW - a.KH / 2, tap % a.KW - a.KW / 2, a.H, a.W, HW, mb, me};
@@ -616,7 +617,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int64_t me = mb + a.kchunk < M ? mb + a.kchunk : M;
   if (mb >= M) return;
 
-  DyLoader<Cfg> la{a.dy + co0, a.ldy, a.ldy - co0 < Cfg::BM ? a.ldy - co0 : Cfg::BM, mb, me};
+  const int coleft = ((a.Cout + 3) / 4) * 4 - co0;     // dy may be a channel slice of a wider buffer: never read past it
+  DyLoader<Cfg> la{a.dy + co0, a.ldy, coleft < Cfg::BM ? coleft : Cfg::BM, mb, me};
   const int cleft = ((sc.C + 3) / 4) * 4 - ci0;
   ShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN,
                          tap / a.KW - a.KH / 2, tap % a.KW - a.KW / 2, a.H, a.W, HW, M, mb, me};

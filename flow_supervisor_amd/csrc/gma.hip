@@ -1,0 +1,174 @@
+// HBM-bound kernels of the GMA variant:
+//   * row softmax of the N x N similarity map and its backward  (Attention.forward, pytorch/core/gma.py:71-74)
+//   * motion_global = motion + gamma * (attn @ v) and its backward (Aggregate.forward, gma.py:113)
+// The GEMMs around them (q k^T, attn @ v and their transposes) run on fsraft_gemm_f32 / fsraft_gemm_tn_split.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 256 threads = 4 waves; reduce across the workgroup through 4 LDS slots
+template <bool MAX>
+__device__ __forceinline__ float block_reduce(float v, float* red) {
+  v = MAX ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return MAX ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One workgroup per row, in place.  The row is read once from HBM (float4), held in LDS (n <= 16384)
+// and written once: 8 bytes per element.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, int n) {
+  extern __shared__ float row[];
+  __shared__ float red[4];
+  float* p = S + (int64_t)blockIdx.x * n;
+  const int n4 = (n & 3) ? 0 : (n >> 2);      // rows are 16-byte aligned only when n % 4 == 0
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+    reinterpret_cast<f32x4*>(row)[i] = v;
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) { row[i] = p[i]; m = fmaxf(m, p[i]); }
+  m = block_reduce<true>(m, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { const float e = __expf(row[i] - m); row[i] = e; s += e; }
+  s = block_reduce<false>(s, red);
+  const float inv = 1.0f / s;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    f32x4 v = reinterpret_cast<f32x4*>(row)[i];
+    v *= inv;
+    reinterpret_cast<f32x4*>(p)[i] = v;
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) p[i] = row[i] * inv;
+}
+
+// dS = A * (dA - sum_j dA_j A_j), written over dA.  A and dA are read once (LDS keeps the row of dA*A inputs).
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ A, float* __restrict__ dA, int n) {
+  extern __shared__ float row[];          // [2][n]: A row, dA row
+  __shared__ float red[4];
+  const float* a = A + (int64_t)blockIdx.x * n;
+  float* d = dA + (int64_t)blockIdx.x * n;
+  float* ra = row;
+  float* rd = row + ((n + 3) & ~3);
+  const int n4 = (n & 3) ? 0 : (n >> 2);
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+    const f32x4 dv = reinterpret_cast<const f32x4*>(d)[i];
+    reinterpret_cast<f32x4*>(ra)[i] = av;
+    reinterpret_cast<f32x4*>(rd)[i] = dv;
+    dot += av[0] * dv[0] + av[1] * dv[1] + av[2] * dv[2] + av[3] * dv[3];
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) { ra[i] = a[i]; rd[i] = d[i]; dot += a[i] * d[i]; }
+  dot = block_reduce<false>(dot, red);
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 av = reinterpret_cast<f32x4*>(ra)[i];
+    f32x4 dv = reinterpret_cast<f32x4*>(rd)[i];
+    dv = av * (dv - dot);
+    reinterpret_cast<f32x4*>(d)[i] = dv;
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) d[i] = ra[i] * (rd[i] - dot);
+}
+
+// Rows too long for LDS: same arithmetic, the row is re-read from global memory (L2) instead.
+__global__ __launch_bounds__(256) void softmax_rows_big_kernel(float* __restrict__ S, int n) {
+  __shared__ float red[4];
+  float* p = S + (int64_t)blockIdx.x * n;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, p[i]);
+  m = block_reduce<true>(m, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += __expf(p[i] - m);
+  s = block_reduce<false>(s, red);
+  const float inv = 1.0f / s;
+  for (int i = threadIdx.x; i < n; i += 256) p[i] = __expf(p[i] - m) * inv;
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_big_kernel(const float* __restrict__ A, float* __restrict__ dA, int n) {
+  __shared__ float red[4];
+  const float* a = A + (int64_t)blockIdx.x * n;
+  float* d = dA + (int64_t)blockIdx.x * n;
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) dot += a[i] * d[i];
+  dot = block_reduce<false>(dot, red);
+  for (int i = threadIdx.x; i < n; i += 256) d[i] = a[i] * (d[i] - dot);
+}
+
+// dst[m][c] = x[m][c] + gamma * y[m][c]   (C % 4 == 0, 16-byte aligned rows)
+__global__ __launch_bounds__(256) void gma_mix_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y,
+                                                          int ldy, const float* __restrict__ gamma, float* __restrict__ dst,
+                                                          int ldd, int64_t M, int C) {
+  const float g = gamma[0];
+  const int c4n = C >> 2;
+  const int64_t total = M * c4n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / c4n; const int c = (int)(e % c4n) * 4;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * ldx + c);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ldy + c);
+    *reinterpret_cast<f32x4*>(dst + m * ldd + c) = xv + g * yv;
+  }
+}
+
+// d = dL/d dst:  dx[m][c] += d;  dy[m][c] = gamma * d;  dgamma += sum d * y
+__global__ __launch_bounds__(256) void gma_mix_bwd_kernel(const float* __restrict__ d, int ldd, const float* __restrict__ y,
+                                                          int ldy, const float* __restrict__ gamma, float* __restrict__ dx,
+                                                          int ldx, float* __restrict__ dy, int lddy,
+                                                          float* __restrict__ dgamma, int64_t M, int C) {
+  __shared__ float red[4];
+  const float g = gamma[0];
+  const int c4n = C >> 2;
+  const int64_t total = M * c4n;
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / c4n; const int c = (int)(e % c4n) * 4;
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(d + m * ldd + c);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ldy + c);
+    f32x4* px = reinterpret_cast<f32x4*>(dx + m * ldx + c);
+    *px = *px + dv;
+    *reinterpret_cast<f32x4*>(dy + m * lddy + c) = g * dv;
+    acc += dv[0] * yv[0] + dv[1] * yv[1] + dv[2] * yv[2] + dv[3] * yv[3];
+  }
+  acc = block_reduce<false>(acc, red);
+  if (threadIdx.x == 0) atomicAdd(dgamma, acc);
+}
+
+inline int grid_for(int64_t work) { int64_t g = (work + 255) / 256; return (int)(g < 1 ? 1 : g > 4096 ? 4096 : g); }
+
+}  // namespace
+
+extern "C" int fsraft_softmax_rows(float* S, int64_t rows, int n, hipStream_t s) {
+  if (!S || rows < 1 || n < 1 || rows > 0x7fffffff) return FS_ERR_ARG;
+  if (n > 16384) hipLaunchKernelGGL(softmax_rows_big_kernel, dim3((unsigned)rows), dim3(256), 0, s, S, n);
+  else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), (size_t)((n + 3) & ~3) * 4, s, S, n);
+  return fs_launch_status();
+}
+extern "C" int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, int n, hipStream_t s) {
+  if (!A || !dA || rows < 1 || n < 1 || rows > 0x7fffffff) return FS_ERR_ARG;
+  if (n > 8192) hipLaunchKernelGGL(softmax_rows_bwd_big_kernel, dim3((unsigned)rows), dim3(256), 0, s, A, dA, n);
+  else hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), (size_t)((n + 3) & ~3) * 8, s, A, dA, n);
+  return fs_launch_status();
+}
+extern "C" int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,
+                                  int64_t M, int C, hipStream_t s) {
+  if (!x || !y || !gamma || !dst || C % 4 || ldx % 4 || ldy % 4 || ldd % 4) return FS_ERR_ARG;
+  hipLaunchKernelGGL(gma_mix_fwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, x, ldx, y, ldy, gamma, dst, ldd, M, C);
+  return fs_launch_status();
+}
+extern "C" int fsraft_gma_mix_bwd(const float* d, int ldd, const float* y, int ldy, const float* gamma, float* dx, int ldx,
+                                  float* dy, int lddy, float* dgamma, int64_t M, int C, hipStream_t s) {
+  if (!d || !y || !gamma || !dx || !dy || !dgamma || C % 4 || ldd % 4 || ldy % 4 || ldx % 4 || lddy % 4) return FS_ERR_ARG;
+  hipLaunchKernelGGL(gma_mix_bwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, d, ldd, y, ldy, gamma, dx, ldx, dy,
+                     lddy, dgamma, M, C);
+  return fs_launch_status();
+}

@@ -144,6 +144,58 @@ def gemm(A, Bm, trans_b, alpha=1.0, out=None, accumulate=False):
     return out
 
 
+def gemm_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, trans_b, alpha=1.0, accumulate=False):
+    """fsraft_gemm_f32 on explicit (pointer, pitch, batch stride) triples; A/Bm/C are ints (device addresses)."""
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_gemm_f32(ctypes.c_void_p(A), lda, sA, ctypes.c_void_p(Bm), ldb, sB, ctypes.c_void_p(C), ldc, sC,
+                                   batch, M, N, K, int(trans_b), float(alpha), int(accumulate), L.stream()), "gemm_f32")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
+
+
+def gemm_tn_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, accumulate=False):
+    """C[b][m][n] (+)= alpha * sum_k A[b][k][m] Bm[b][k][n] on the split-bf16 core (M, N, pitches % 4 == 0)."""
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_gemm_tn_split(ctypes.c_void_p(A), lda, sA, ctypes.c_void_p(Bm), ldb, sB, ctypes.c_void_p(C), ldc,
+                                        sC, batch, M, N, K, float(alpha), int(accumulate), L.stream()), "gemm_tn_split")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
+
+
+# ------------------------------------------------------------------ GMA (attention / aggregate)
+def softmax_rows_(S):
+    """In-place softmax over the last dimension of a contiguous tensor (gma.py:74)."""
+    L.require_cuda_f32(S)
+    n = S.shape[-1]
+    L.check(_lib().fsraft_softmax_rows(L.ptr(S), S.numel() // n, n, L.stream()), "softmax_rows")
+    return S
+
+
+def softmax_rows_bwd_(A, dA):
+    """dA <- A * (dA - sum(dA * A, -1)) in place."""
+    L.require_cuda_f32(A, dA)
+    n = A.shape[-1]
+    L.check(_lib().fsraft_softmax_rows_bwd(L.ptr(A), L.ptr(dA), A.numel() // n, n, L.stream()), "softmax_rows_bwd")
+    return dA
+
+
+def gma_mix_fwd(x, y, gamma, dst):
+    """dst = x + gamma * y over V channel slices (gma.py:113); gamma: 1-element device tensor."""
+    M = x.t.numel() // x.ld
+    L.check(_lib().fsraft_gma_mix_fwd(ctypes.c_void_p(x.ptr), x.ld, ctypes.c_void_p(y.ptr), y.ld, L.ptr(gamma),
+                                      ctypes.c_void_p(dst.ptr), dst.ld, M, x.C, L.stream()), "gma_mix_fwd")
+
+
+def gma_mix_bwd(d, y, gamma, dx, dy, dgamma):
+    """dx += d; dy = gamma * d; dgamma += sum(d * y)."""
+    M = d.t.numel() // d.ld
+    L.check(_lib().fsraft_gma_mix_bwd(ctypes.c_void_p(d.ptr), d.ld, ctypes.c_void_p(y.ptr), y.ld, L.ptr(gamma),
+                                      ctypes.c_void_p(dx.ptr), dx.ld, ctypes.c_void_p(dy.ptr), dy.ld, L.ptr(dgamma), M, d.C,
+                                      L.stream()), "gma_mix_bwd")
+
+
 SPLIT_VOLUME_BWD = True     # dF2 through the k-major split-bf16 GEMM (needs H*W % 4 == 0)
 
 

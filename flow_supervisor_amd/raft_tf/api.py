@@ -1,0 +1,61 @@
+import torch
+
+from .. import ops
+from ..core import update as _upd
+from ..core.raft import convex_upsample
+
+
+def calc_all_field(a, b, num_pool=0):
+    """a, b: [B,H,W,C] feature maps -> list of num_pool+1 volumes [B,H,W,h_l,w_l] (raft/allfield.py:61-92)."""
+    B, H, W, C = a.shape
+    f1 = a.permute(0, 3, 1, 2).contiguous().float()
+    f2 = b.permute(0, 3, 1, 2).contiguous().float()
+    levels = ops.corr_build(f1, f2, num_pool + 1)
+    return [lv.view(B, H, W, lv.shape[-2], lv.shape[-1]) for lv in levels]
+
+
+class CorrBlock:
+    """Stateless lookup object (raft/corr.py:5-22): obj(corr_pyramid, coords[B,H,W,2]) -> [B,H,W,L*(2r+1)^2]."""
+
+    def __init__(self, num_levels=4, radius=4, is_max_disp=False):
+        self.num_levels, self.radius, self.is_max_disp = num_levels, radius, is_max_disp
+        self.corr_pyramid = []
+
+    def __call__(self, corr_pyramid, coords, is_coord=True):
+        B, H, W, _ = coords.shape
+        levels = [lv.reshape(B * H * W, 1, lv.shape[-2], lv.shape[-1]) for lv in corr_pyramid]
+        c = coords.permute(0, 3, 1, 2)                       # NCHW view of the NHWC coords: strides, no copy
+        return ops.corr_lookup_fwd(levels, c.float(), self.radius, nhwc=True)
+
+
+class UpsampleConvexWithMask:
+    """call([x, mask(, ref)]) with x [B,H,W,C=2], mask [B,H,W,576] -> [B,8H,8W,2] cropped to ref's H,W
+    (raft/upsample.py:11-41).  Unlike the PyTorch method the TF layer does not scale the flow by 8."""
+
+    def __init__(self, scale=8, **kwargs):
+        if scale != 8:
+            raise NotImplementedError("the HIP upsampler is built for the 8x factor RAFT uses")
+        self.scale = scale
+
+    def call(self, inputs, training=None, mask=None):
+        if not isinstance(inputs, (list, tuple)):
+            raise ValueError
+        x, m = inputs[0], inputs[1]
+        up = convex_upsample(x.permute(0, 3, 1, 2).contiguous() * 0.125, m.contiguous(), channels_last=True)
+        up = up.permute(0, 2, 3, 1)
+        if len(inputs) == 3:
+            up = up[:, : inputs[2].shape[1], : inputs[2].shape[2]]
+        return up
+
+    __call__ = call
+
+
+class BasicUpdateBlock(_upd.BasicUpdateBlock):
+    """Keras-style entry point: call([net, inp, corr, flow]) on NHWC tensors -> (net, mask, delta_flow) NHWC
+    (raft/smurf_models/raft_update.py:180-212).  Parameters keep the PyTorch names and OIHW shapes."""
+
+    def call(self, inputs, training=None):
+        net, inp, corr, flow = inputs
+        h, mask, delta = self.forward_cl(net.contiguous(), inp.contiguous(), corr.contiguous(),
+                                         flow.permute(0, 3, 1, 2))
+        return h, mask, delta.permute(0, 2, 3, 1)

@@ -128,6 +128,19 @@ int fsraft_gemm_tn_split(const float* A, int64_t lda, int64_t sA, const float* B
 /* 1 (default): fsraft_gemm_f32 with trans_b uses the split-bf16 core when its operands are 16-byte aligned */
 int fsraft_set_gemm_split(int on);
 
+/* ---- GMA variant (config 5) --------------------------------------------------------------
+ * Attention.forward, pytorch/core/gma.py:54-76: sim = scale * q k^T runs on fsraft_gemm_f32 (trans_b), then this
+ * in-place row softmax over the last dimension (rows = B*heads*N, n = N; rows up to 16384 floats are staged in LDS). */
+int fsraft_softmax_rows(float* S, int64_t rows, int n, hipStream_t stream);
+/* dA <- A * (dA - rowsum(dA * A))  (softmax backward, in place over dA) */
+int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, int n, hipStream_t stream);
+/* Aggregate.forward, gma.py:113: dst = x + gamma[0] * y with gamma a device scalar (the nn.Parameter). */
+int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,
+                       int64_t M, int C, hipStream_t stream);
+/* d = dL/d dst:  dx += d;  dy = gamma * d;  dgamma[0] += sum(d * y) */
+int fsraft_gma_mix_bwd(const float* d, int ldd, const float* y, int ldy, const float* gamma, float* dx, int ldx,
+                       float* dy, int lddy, float* dgamma, int64_t M, int C, hipStream_t stream);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);

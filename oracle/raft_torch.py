@@ -262,6 +262,37 @@ def small_update_block(sd, p, net, inp, corr, flow):
 
 
 # --------------------------------------------------------------------------
+# a11: GMA attention / aggregate / update block (single head, content only).
+# core/gma.py:54-76, 102-115; core/gma_update.py:127-139
+# --------------------------------------------------------------------------
+def gma_attention(sd, p, fmap, dim_head=128):
+    """softmax over all N positions of (scale*q) . k with q,k = chunk(to_qk(fmap)) -> [B,1,N,N]  (gma.py:54-76)."""
+    B, C, H, W = fmap.shape
+    qk = F.conv2d(fmap, sd[p + "to_qk.weight"])
+    q, k = qk[:, :dim_head].reshape(B, dim_head, H * W), qk[:, dim_head:].reshape(B, dim_head, H * W)
+    sim = torch.bmm((dim_head ** -0.5 * q).transpose(1, 2), k)            # [B, N(xy), N(uv)]
+    return torch.softmax(sim, dim=-1).unsqueeze(1)
+
+
+def gma_aggregate(sd, p, attn, fmap):
+    """fmap + gamma * (attn @ to_v(fmap))  (gma.py:102-115, heads=1 so no projection)."""
+    B, C, H, W = fmap.shape
+    v = F.conv2d(fmap, sd[p + "to_v.weight"]).reshape(B, C, H * W)        # [B, d, N(j)]
+    out = torch.bmm(attn[:, 0], v.transpose(1, 2))                        # [B, N(i), d]
+    return fmap + sd[p + "gamma"] * out.transpose(1, 2).reshape(B, C, H, W)
+
+
+def gma_update_block(sd, p, net, inp, corr, flow, attn):
+    """core/gma_update.py:127-139 -> (net, mask, delta_flow)."""
+    mf = basic_motion_encoder(sd, p + "encoder.", flow, corr)
+    mfg = gma_aggregate(sd, p + "aggregator.", attn, mf)
+    net = sep_conv_gru(sd, p + "gru.", net, torch.cat([inp, mf, mfg], 1))
+    delta = flow_head(sd, p + "flow_head.", net)
+    m = _conv(sd, p + "mask.2", F.relu(_conv(sd, p + "mask.0", net, 1)), 0)
+    return net, 0.25 * m, delta
+
+
+# --------------------------------------------------------------------------
 # a9: convex 8x upsampler.  core/raft.py:72-83
 # --------------------------------------------------------------------------
 def upsample_flow(flow, mask):
@@ -329,8 +360,8 @@ def encoder(sd, p, x, kind, small):
 # the model loop.  core/raft.py:86-144
 # --------------------------------------------------------------------------
 def raft_forward(sd, image1, image2, iters=12, small=False, alternate_corr=False,
-                 flow_init=None, test_mode=False):
-    """RAFT.forward with frozen BN and dropout 0."""
+                 flow_init=None, test_mode=False, gma=False):
+    """RAFT.forward (gma=True: RAFTGMA.forward, core/gma_network.py:72-129) with frozen BN and dropout 0."""
     hdim, cdim, radius = (96, 64, 3) if small else (128, 128, 4)
     image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
     image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
@@ -342,6 +373,7 @@ def raft_forward(sd, image1, image2, iters=12, small=False, alternate_corr=False
     cnet = encoder(sd, "cnet.", image1, "none" if small else "batch", small)
     net = torch.tanh(cnet[:, :hdim])
     inp = torch.relu(cnet[:, hdim:hdim + cdim])
+    attn = gma_attention(sd, "att.", inp) if gma else None
     H8, W8 = image1.shape[2] // 8, image1.shape[3] // 8
     coords0 = coords_grid(B, H8, W8, image1.device)
     coords1 = coords_grid(B, H8, W8, image1.device)
@@ -356,7 +388,9 @@ def raft_forward(sd, image1, image2, iters=12, small=False, alternate_corr=False
         else:
             corr = corr_lookup(pyr, coords1, radius)
         flow = coords1 - coords0
-        if small:
+        if gma:
+            net, up_mask, delta = gma_update_block(sd, "update_block.", net, inp, corr, flow, attn)
+        elif small:
             net, up_mask, delta = small_update_block(sd, "update_block.", net, inp, corr, flow)
         else:
             net, up_mask, delta = basic_update_block(sd, "update_block.", net, inp, corr, flow)

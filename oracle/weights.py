@@ -29,6 +29,8 @@ def procedural_state_dict(shapes, seed):
     for key in sorted(shapes):
         shp = tuple(shapes[key])
         leaf = key.rsplit(".", 1)[-1]
+        if leaf == "rel_ind":       # GMA RelPosEmb index buffer: keeps its constructed value (load with strict=False)
+            continue
         if leaf == "num_batches_tracked":
             out[key] = torch.zeros((), dtype=torch.long)
             continue

@@ -162,6 +162,148 @@ def gen_e2e():
              flow_up_absmean=flow_up.abs().mean())
 
 
+def gen_kitti():
+    """KITTI-shaped evaluation exactly as evaluate.py:133-148 runs it: pad (mode='kitti') -> 24 iters -> unpad."""
+    name, B, H, W, iters, seed, stride = "e2e_basic_kitti_375x1242", 1, 375, 1242, 24, 504, 6
+    model = RAFT(args_ns(False))
+    model.load_state_dict(procedural_state_dict(shapes_of(model), seed))
+    model.eval()
+    im1, im2 = synthetic_pair(B, H, W, seed + 1)
+    padder = InputPadder(im1.shape, mode="kitti")
+    p1, p2 = padder.pad(im1, im2)
+    with torch.no_grad():
+        flow_low, flow_up = model(p1, p2, iters=iters, test_mode=True)
+    flow = padder.unpad(flow_up)
+    save(name, small=False, B=B, H=H, W=W, iters=iters, seed=seed, stride=stride, padded=np.array(p1.shape[-2:]),
+         flow_low=flow_low, flow_strided=flow[:, :, ::stride, ::stride].contiguous(), flow_absmean=flow.abs().mean())
+
+
+def gen_l2l():
+    """Flow-supervisor two-phase forward (core/l2l.py): crop = window of the uncropped pair, fwd+bwd, frozen BN."""
+    from core.l2l import L2L
+    seed, H, W, h, w, oy, ox, iters, B = 701, 160, 256, 128, 192, 16, 40, 6, 2
+    model = L2L(args_ns(False))
+    shapes = shapes_of(model)
+    with open(os.path.join(HERE, "l2l_basic_shapes.json"), "w") as f:
+        json.dump({k: list(v) for k, v in shapes.items()}, f, indent=0)
+    model.load_state_dict(procedural_state_dict(shapes, seed))
+    model.train()
+    model.freeze_bn()
+    ci1, ci2 = synthetic_pair(B, H, W, seed + 1)
+    im1 = ci1[:, :, oy:oy + h, ox:ox + w].contiguous()
+    im2 = ci2[:, :, oy:oy + h, ox:ox + w].contiguous()
+    preds = model(im1, im2, ci1, ci2, torch.tensor([ox] * B), torch.tensor([oy] * B), iters=iters)
+    n = len(preds)
+    loss = 0.0
+    for i, p in enumerate(preds):
+        loss = loss + (0.8 ** (n - i - 1)) * torch.sqrt(p * p + 1e-6).mean()
+    loss.backward()
+    d = dict(seed=seed, H=H, W=W, h=h, w=w, oy=oy, ox=ox, iters=iters, B=B, loss=loss.detach(),
+             mid=preds[iters // 2 - 1].detach()[:, :, ::2, ::2], last=preds[-1].detach()[:, :, ::2, ::2])
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        d["gnorm." + k] = g.norm()
+    model.eval()
+    with torch.no_grad():
+        low, up = model(im1, im2, iters=iters, test_mode=True)
+    d["test_low"], d["test_up"] = low, up[:, :, ::2, ::2]
+    save("l2l_basic", **d)
+
+
+# ---------------------------------------------------------------- G7 (GMA, benchmark config 5)
+def gma_ns():
+    return argparse.Namespace(small=False, mixed_precision=False, dropout=0, num_heads=1, position_only=False,
+                              position_and_content=False, corr_levels=4, corr_radius=4)
+
+
+def _digest(d, named_params):
+    for k, p in named_params:
+        g = (p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+        d["dparam_norm." + k] = g.norm()
+        d["dparam." + k] = g if g.numel() <= 4096 else g[:: g.numel() // 4096][:4096].clone()
+
+
+def gen_gma():
+    from core.gma import Aggregate, Attention
+    from core.gma_network import RAFTGMA
+    from core.gma_update import GMAUpdateBlock
+    a = gma_ns()
+    # --- Attention / Aggregate ops
+    B, H, W, seed = 2, 12, 16, 800
+    att = Attention(args=a, dim=128, heads=1, max_pos_size=160, dim_head=128)
+    agg = Aggregate(args=a, dim=128, dim_head=128, heads=1)
+    sh = {"att." + k: tuple(v.shape) for k, v in att.state_dict().items()}
+    sh.update({"agg." + k: tuple(v.shape) for k, v in agg.state_dict().items()})
+    sd = procedural_state_dict(sh, seed)
+    att.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("att.")}, strict=False)
+    agg.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("agg.")})
+    ctx = torch.relu(rand_tensor((B, 128, H, W), seed + 1, 1.5)).requires_grad_(True)
+    fm = rand_tensor((B, 128, H, W), seed + 2).requires_grad_(True)
+    A = att(ctx)
+    out = agg(A, fm)
+    (out * rand_tensor(tuple(out.shape), seed + 3)).sum().backward()
+    d = dict(B=B, H=H, W=W, seed=seed, attn=A, out=out, dctx=ctx.grad, dfm=fm.grad)
+    _digest(d, [("att." + k, p) for k, p in att.named_parameters() if "pos_emb" not in k] +
+               [("agg." + k, p) for k, p in agg.named_parameters()])
+    with open(os.path.join(HERE, "gma_ops_shapes.json"), "w") as f:
+        json.dump({k: list(v) for k, v in sh.items()}, f, indent=0)
+    save("gma_ops", **d)
+
+    # --- GMAUpdateBlock fwd + grads
+    blk = GMAUpdateBlock(a, hidden_dim=128)
+    shapes = shapes_of(blk)
+    with open(os.path.join(HERE, "update_gma_shapes.json"), "w") as f:
+        json.dump({k: list(v) for k, v in shapes.items()}, f, indent=0)
+    seed = 810
+    blk.load_state_dict(procedural_state_dict(shapes, seed))
+    B, H, W = 1, 12, 16
+    net = torch.tanh(rand_tensor((B, 128, H, W), seed + 10)).requires_grad_(True)
+    inp = torch.relu(rand_tensor((B, 128, H, W), seed + 11)).requires_grad_(True)
+    corr = rand_tensor((B, 324, H, W), seed + 12, 2.0).requires_grad_(True)
+    flow = rand_tensor((B, 2, H, W), seed + 13, 3.0).requires_grad_(True)
+    attn = torch.softmax(rand_tensor((B, 1, H * W, H * W), seed + 14, 2.0), -1).requires_grad_(True)
+    net2, mask, delta = blk(net, inp, corr, flow, attn)
+    loss = ((net2 * rand_tensor(tuple(net2.shape), seed + 20)).sum() + (delta * rand_tensor(tuple(delta.shape), seed + 21)).sum()
+            + (mask * rand_tensor(tuple(mask.shape), seed + 22)).sum())
+    loss.backward()
+    d = dict(B=B, H=H, W=W, seed=seed, net_out=net2, delta=delta, mask=mask, dnet=net.grad, dinp=inp.grad,
+             dcorr=corr.grad, dflow=flow.grad, dattn=attn.grad[:, :, ::3, ::3].contiguous(), dattn_norm=attn.grad.norm())
+    _digest(d, blk.named_parameters())
+    save("update_gma", **d)
+
+    # --- end to end (eval) and one training step
+    model = RAFTGMA(gma_ns())
+    shapes = shapes_of(model)
+    with open(os.path.join(HERE, "raft_gma_shapes.json"), "w") as f:
+        json.dump({k: list(v) for k, v in shapes.items() if not k.endswith("rel_ind")}, f, indent=0)
+    seed, H, W, iters, stride = 820, 368, 496, 12, 4
+    model.load_state_dict(procedural_state_dict(shapes, seed), strict=False)
+    model.eval()
+    im1, im2 = synthetic_pair(1, H, W, seed + 1)
+    with torch.no_grad():
+        low, up = model(im1, im2, iters=iters, test_mode=True)
+    save("e2e_gma_368x496", B=1, H=H, W=W, iters=iters, seed=seed, stride=stride, flow_low=low,
+         flow_up_strided=up[:, :, ::stride, ::stride].contiguous(), flow_up_absmean=up.abs().mean())
+
+    seed, H, W, iters = 830, 128, 192, 3
+    model = RAFTGMA(gma_ns())
+    model.load_state_dict(procedural_state_dict(shapes, seed), strict=False)
+    model.train()
+    model.freeze_bn()
+    im1, im2 = synthetic_pair(2, H, W, seed + 1)
+    preds = model(im1, im2, iters=iters)
+    n = len(preds)
+    loss = 0.0
+    for i, p in enumerate(preds):
+        loss = loss + (0.8 ** (n - i - 1)) * torch.sqrt(p * p + 1e-6).mean()
+    loss.backward()
+    d = dict(H=H, W=W, iters=iters, seed=seed, loss=loss.detach(), last=preds[-1].detach())
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        d["gnorm." + k] = g.norm()
+    save("train_step_gma", **d)
+
+
 def gen_train_step():
     """fwd+bwd of the whole model (frozen BN), small shapes: loss + parameter-grad digests."""
     for small, H, W, iters, seed in ((False, 128, 192, 3, 601), (True, 128, 192, 3, 602)):
@@ -186,7 +328,7 @@ def gen_train_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "train"]
+    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "kitti", "l2l", "gma", "train"]
     if "corr" in which:
         gen_corr()
     if "update" in which:
@@ -195,5 +337,11 @@ if __name__ == "__main__":
         gen_upsample()
     if "e2e" in which:
         gen_e2e()
+    if "kitti" in which:
+        gen_kitti()
+    if "l2l" in which:
+        gen_l2l()
+    if "gma" in which:
+        gen_gma()
     if "train" in which:
         gen_train_step()

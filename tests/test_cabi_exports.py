@@ -83,6 +83,22 @@ def test_state_dict_keys_match_reference():
         assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref
 
 
+def test_l2l_and_gma_state_dict_keys_match_reference():
+    import json
+    from flow_supervisor_amd.core.gma_l2l import GMAL2L
+    from flow_supervisor_amd.core.gma_network import RAFTGMA
+    from flow_supervisor_amd.core.l2l import L2L
+    gd = os.path.join(ROOT, "tests", "golden")
+    m = L2L(argparse.Namespace(small=False))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == json.load(open(os.path.join(gd, "l2l_basic_shapes.json")))
+    a = argparse.Namespace(num_heads=1, position_only=False, position_and_content=False)
+    ref = json.load(open(os.path.join(gd, "raft_gma_shapes.json")))
+    got = {k: list(v.shape) for k, v in RAFTGMA(a).state_dict().items() if not k.endswith("rel_ind")}
+    assert got == ref
+    l2l = {k for k in GMAL2L(a).state_dict() if not k.endswith("rel_ind")}
+    assert l2l == set(ref) | {"grad_" + k for k in ref if k.startswith("update_block.")}
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure; nothing shipped may import it."""
     bad = []

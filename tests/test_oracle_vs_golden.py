@@ -158,3 +158,60 @@ def test_train_step_grads(tag):
         if abs(gn - ref) > 1e-3 * max(ref, 1e-6) + 1e-7:
             bad.append((name, gn, ref))
     assert not bad, bad[:5]
+
+
+# ----------------------------------------------------------------------------- GMA (config 5)
+def test_gma_attention_and_aggregate():
+    g = load("gma_ops")
+    sh = json.load(open(os.path.join(G, "gma_ops_shapes.json")))
+    seed, B, H, W = int(g["seed"]), int(g["B"]), int(g["H"]), int(g["W"])
+    sd = {k: v.requires_grad_(True) for k, v in procedural_state_dict(sh, seed).items()}
+    ctx = torch.relu(rand_tensor((B, 128, H, W), seed + 1, 1.5)).requires_grad_(True)
+    fm = rand_tensor((B, 128, H, W), seed + 2).requires_grad_(True)
+    A = O.gma_attention(sd, "att.", ctx)
+    out = O.gma_aggregate(sd, "agg.", A, fm)
+    close(A, g["attn"], 1e-6)
+    close(out, g["out"], 1e-5)
+    (out * rand_tensor(tuple(out.shape), seed + 3)).sum().backward()
+    close(ctx.grad, g["dctx"], 1e-5)
+    close(fm.grad, g["dfm"], 1e-5)
+    for k in ("att.to_qk.weight", "agg.to_v.weight", "agg.gamma"):
+        gr = sd[k].grad.reshape(-1)
+        samp = gr if gr.numel() <= 4096 else gr[:: gr.numel() // 4096][:4096]
+        close(samp, g["dparam." + k], 1e-4)
+
+
+def test_gma_update_block():
+    g = load("update_gma")
+    sh = json.load(open(os.path.join(G, "update_gma_shapes.json")))
+    seed, B, H, W = int(g["seed"]), int(g["B"]), int(g["H"]), int(g["W"])
+    sd = {k: v.requires_grad_(True) for k, v in procedural_state_dict(sh, seed).items()}
+    net = torch.tanh(rand_tensor((B, 128, H, W), seed + 10)).requires_grad_(True)
+    inp = torch.relu(rand_tensor((B, 128, H, W), seed + 11)).requires_grad_(True)
+    corr = rand_tensor((B, 324, H, W), seed + 12, 2.0).requires_grad_(True)
+    flow = rand_tensor((B, 2, H, W), seed + 13, 3.0).requires_grad_(True)
+    attn = torch.softmax(rand_tensor((B, 1, H * W, H * W), seed + 14, 2.0), -1).requires_grad_(True)
+    net2, mask, delta = O.gma_update_block(sd, "", net, inp, corr, flow, attn)
+    close(net2, g["net_out"], 1e-5); close(mask, g["mask"], 1e-5); close(delta, g["delta"], 1e-5)
+    loss = ((net2 * rand_tensor(tuple(net2.shape), seed + 20)).sum() + (delta * rand_tensor(tuple(delta.shape), seed + 21)).sum()
+            + (mask * rand_tensor(tuple(mask.shape), seed + 22)).sum())
+    loss.backward()
+    close(net.grad, g["dnet"], 1e-4); close(inp.grad, g["dinp"], 1e-4)
+    close(corr.grad, g["dcorr"], 1e-4); close(flow.grad, g["dflow"], 1e-4)
+    close(attn.grad[:, :, ::3, ::3], g["dattn"], 1e-4)
+    for k in sd:
+        ref_n = float(g["dparam_norm." + k])
+        assert abs(sd[k].grad.norm().item() - ref_n) <= 1e-4 * ref_n + 1e-5, k
+
+
+def test_gma_end_to_end_flow():
+    g = load("e2e_gma_368x496")
+    sh = json.load(open(os.path.join(G, "raft_gma_shapes.json")))
+    seed = int(g["seed"])
+    sd = procedural_state_dict(sh, seed)
+    im1, im2 = synthetic_pair(1, int(g["H"]), int(g["W"]), seed + 1)
+    with torch.no_grad():
+        low, up = O.raft_forward(sd, im1, im2, iters=int(g["iters"]), test_mode=True, gma=True)
+    s = int(g["stride"])
+    assert O.epe(low, T(g["flow_low"])).item() < 1e-4
+    assert O.epe(up[:, :, ::s, ::s], T(g["flow_up_strided"])).item() < 1e-4
