@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--height", type=int, default=440)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--variant", choices=["raft", "gma", "alt"], default="raft",
+                    help="raft: BASELINE.json config 3 (the default, the judged line); gma: config 5 (RAFT-GMA); "
+                         "alt: config 4 (AlternateCorrBlock, use --height 376 --width 1248 --batch-per-gpu 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", type=int, default=-1,
@@ -100,7 +103,15 @@ def main():
     torch.backends.cudnn.benchmark = False
 
     torch.manual_seed(0)
-    model = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(dev).train()
+    if a.variant == "gma":
+        from flow_supervisor_amd.core.gma_network import RAFTGMA
+        model = RAFTGMA(argparse.Namespace(mixed_precision=False, num_heads=1, position_only=False,
+                                           position_and_content=False)).to(dev).train()
+        with torch.no_grad():
+            model.update_block.aggregator.gamma.fill_(0.1)      # zero-init gamma would leave the aggregate path unexercised
+    else:
+        model = RAFT(argparse.Namespace(small=False, mixed_precision=False,
+                                        alternate_corr=a.variant == "alt")).to(dev).train()
     model.freeze_bn()                                 # pytorch/train.py:203-204
     broadcast_parameters(model)
     use_graph = a.graph == 1      # measured: no gain over eager once the step is GPU-bound (140 ms either way), so eager is the default
@@ -184,7 +195,8 @@ def main():
         "dtype": "f32 storage and accumulation; update-block GEMMs as split-bf16 (3 bf16 MFMA products per fp32 product)"
                  if os.environ.get("FSRAFT_CONV_SPLIT", "1") != "0" else "f32",
         "data": "synthetic",
-        "config": {"workload": f"RAFT full, {a.height}x{a.width} (Sintel 436x1024 padded), {a.iters} GRU iters, "
+        "config": {"workload": {"raft": "RAFT full", "gma": "RAFT-GMA (config 5)", "alt": "RAFT full, AlternateCorrBlock (config 4)"}[a.variant] +
+                               f", {a.height}x{a.width} (Sintel 436x1024 padded), {a.iters} GRU iters, "
                                f"{B} pairs/GPU, train step = fwd + sequence loss + bwd + RCCL all-reduce + clip + AdamW",
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v,
                    "launch": "hipGraph replay of the whole step" if graph is not None else "eager"},
@@ -226,7 +238,7 @@ def main():
                 if fam in kern:
                     kern[fam]["traffic"] = v
             out["roofline"]["traffic"] = kern[dom]["traffic"]
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.variant == "raft":
         out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters)
     print(json.dumps(out))
 

@@ -89,13 +89,15 @@ class _AttentionFn(torch.autograd.Function):
         dS = ops.softmax_rows_bwd_(attn, dA.contiguous().clone())
         dqk = torch.empty_like(qk)
         # dq = scale dS k ; dk = scale dS^T q
-        ops.gemm_raw(dS.data_ptr(), N, N * N, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, dqk.data_ptr(), 2 * D, N * 2 * D,
-                     B, N, D, N, False, scale)
-        if N % 4 == 0 and D % 4 == 0:
+        dSt = dS.view(B, N, N).transpose(1, 2).contiguous()
+        if N % 4 == 0 and D % 4 == 0:      # k-major operands on the transposed-read split-bf16 GEMM
+            ops.gemm_tn_raw(dSt.data_ptr(), N, N * N, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, dqk.data_ptr(), 2 * D,
+                            N * 2 * D, B, N, D, N, scale)
             ops.gemm_tn_raw(dS.data_ptr(), N, N * N, qk.data_ptr(), 2 * D, N * 2 * D, dqk.data_ptr() + 4 * D, 2 * D,
                             N * 2 * D, B, N, D, N, scale)
         else:
-            dSt = dS.view(B, N, N).transpose(1, 2).contiguous()
+            ops.gemm_raw(dS.data_ptr(), N, N * N, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, dqk.data_ptr(), 2 * D,
+                         N * 2 * D, B, N, D, N, False, scale)
             ops.gemm_raw(dSt.data_ptr(), N, N * N, qk.data_ptr(), 2 * D, N * 2 * D, dqk.data_ptr() + 4 * D, 2 * D,
                          N * 2 * D, B, N, D, N, False, scale)
         dw = _conv1x1_wgrad(dqk, x_cl, C, 2 * D, B, H, W) if ctx.needs_input_grad[1] else None

@@ -247,7 +247,7 @@ class _Engine:
         return out
 
     # ---- forward ------------------------------------------------------------------
-    def forward(self, net, inp, corr, flow, params, save, attn=None):
+    def forward(self, net, inp, corr, flow, params, save, attn=None, attn_t=None):
         """net/inp/corr: channels-last [B,H,W,C]; flow: [B,2,H,W] (any pixel stride).
         Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
         a dict of the intermediates backward needs."""
@@ -295,7 +295,12 @@ class _Engine:
             attn = attn.contiguous()
             v, agg = buf(mc), buf(mc)
             conv("av", [V(motion, mc, 0)], [Dst.nhwc(v)])
-            ops.gemm_raw(attn.data_ptr(), N, N * N, v.data_ptr(), mc, N * mc, agg.data_ptr(), mc, N * mc, B, N, mc, N, False)
+            if attn_t is not None and N % 4 == 0:
+                # attn @ v with attn^T resident (transposed once per pair): both operands k-major ->
+                # transposed-read split-bf16 GEMM instead of the exact-fp32 NN kernel
+                ops.gemm_tn_raw(attn_t.data_ptr(), N, N * N, v.data_ptr(), mc, N * mc, agg.data_ptr(), mc, N * mc, B, N, mc, N)
+            else:
+                ops.gemm_raw(attn.data_ptr(), N, N * N, v.data_ptr(), mc, N * mc, agg.data_ptr(), mc, N * mc, B, N, mc, N, False)
             ops.gma_mix_fwd(V(motion, mc, 0), V(agg), P["aggregator.gamma"], V(motion, mc, mc))
 
         h = net
@@ -429,11 +434,8 @@ class _Engine:
             else:
                 at = attn.view(B, N, N).transpose(1, 2).contiguous()
                 ops.gemm_raw(at.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N, False)
-            if ast is not None:  # dattn += dagg v^T, one buffer for all the iterations of the step
-                if ast.dattn is None:
-                    ast.dattn = torch.zeros(B, N, N, device=dev, dtype=torch.float32)
-                ops.gemm_raw(dagg.data_ptr(), mc, N * mc, v.data_ptr(), mc, N * mc, ast.dattn.data_ptr(), N, N * N, B, N, N, mc,
-                             True, 1.0, True)
+            if ast is not None:  # dattn = sum_t dagg_t v_t^T is formed once per step from the stashed factors
+                ast.stash.append((dagg.view(B, N, mc), v.view(B, N, mc)))
             wgrad("av", V(dv, mc), [V(motion, mc, 0)])
             dgrad("av", V(dv, mc), [Dst.nhwc(dmotion, 0, 0, True)])
 
@@ -504,11 +506,13 @@ class _ParamFn(torch.autograd.Function):
 
 
 class _AttnState:
-    """Per-step accumulator of dL/d attention (GMA): every iteration's `dagg v^T` lands in one buffer."""
-    __slots__ = ("key", "anchor", "dattn", "consumed", "zero")
+    """Per-step accumulator of dL/d attention (GMA).  dattn = sum_t dagg_t v_t^T over the iterations of a step is
+    ONE GEMM with K = T*128 over the stashed (dagg_t, v_t) factors (14 MB each at 4 x 55 x 128) instead of T
+    read-modify-write passes over the 0.8 GB map."""
+    __slots__ = ("key", "anchor", "stash", "consumed", "zero")
 
     def __init__(self, key):
-        self.key, self.anchor, self.dattn, self.consumed, self.zero = key, None, None, False, None
+        self.key, self.anchor, self.stash, self.consumed, self.zero = key, None, [], False, None
 
 
 class _AttnFn(torch.autograd.Function):
@@ -524,17 +528,24 @@ class _AttnFn(torch.autograd.Function):
     def backward(ctx, g):
         ast = ctx.ast
         ast.consumed = True
-        d, ast.dattn = ast.dattn, None
-        return None, (d.view(ctx.shape) if d is not None else None)
+        stash, ast.stash = ast.stash, []
+        if not stash:
+            return None, None
+        D = torch.cat([d for d, _ in stash], 2) if len(stash) > 1 else stash[0][0].contiguous()
+        Vc = torch.cat([v for _, v in stash], 2) if len(stash) > 1 else stash[0][1].contiguous()
+        B, N, K = D.shape
+        dattn = torch.empty(ctx.shape, device=D.device, dtype=torch.float32)
+        ops.gemm_raw(D.data_ptr(), K, N * K, Vc.data_ptr(), K, N * K, dattn.data_ptr(), N, N * N, B, N, N, K, True)
+        return None, dattn
 
 
 class _UpdateFn(torch.autograd.Function):
     """(anchor; net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
 
     @staticmethod
-    def forward(ctx, engine, st, params, anchor, net, inp, corr, flow, ast=None, attn=None, aanchor=None):
+    def forward(ctx, engine, st, params, anchor, net, inp, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None):
         need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
-        h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need, attn=attn)
+        h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need, attn=attn, attn_t=attn_t)
         ctx.engine, ctx.st, ctx.saved = engine, st, saved
         ctx.ast = ast
         ctx.P = engine._packed(params) if need else None
@@ -554,7 +565,7 @@ class _UpdateFn(torch.autograd.Function):
         dh = dh.contiguous() if dh is not None else None
         dnet, dinp, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta, ast=ctx.ast)
         return (None, None, None, ctx.st.zero, dnet, dinp, dcorr, dflow, None, None,
-                ctx.ast.zero if ctx.ast is not None else None)
+                ctx.ast.zero if ctx.ast is not None else None, None)
 
 
 class _ToCL(torch.autograd.Function):
@@ -612,6 +623,20 @@ class _UpdateBlockBase(nn.Module):
             self.__dict__["_ast"] = ast
         return ast, ast.anchor
 
+    def _attn_transposed(self, attention):
+        """attention^T [B,N,N], computed once per attention tensor (one pair / one step) and reused by every
+        iteration's `attn @ v`."""
+        if attention is None or not self._engine().gma or attention.shape[-1] % 4 or not ops.SPLIT_VOLUME_BWD:
+            return None         # (SPLIT_VOLUME_BWD off = exact-fp32 test mode: keep the exact NN GEMM)
+        c = self.__dict__.get("_attn_t")
+        if c is None or c[0]() is not attention or c[1] != attention._version:
+            with torch.no_grad():
+                B, N = attention.shape[0], attention.shape[-1]
+                t = attention.detach().reshape(B, N, N).transpose(1, 2).contiguous()
+            c = (weakref.ref(attention), attention._version, t)
+            self.__dict__["_attn_t"] = c
+        return c[2]
+
     def forward_cl(self, net, inp, corr, flow, attention=None):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
@@ -625,10 +650,12 @@ class _UpdateBlockBase(nn.Module):
                 st, anchor = _ParamState(None), torch.zeros(1, device=net.device)   # inputs need grads, params frozen
                 st.zero = anchor
             else:
-                h, mask, delta, _ = eng.forward(net, inp, corr, flow, params, save=False, attn=attention)
+                h, mask, delta, _ = eng.forward(net, inp, corr, flow, params, save=False, attn=attention,
+                                                attn_t=self._attn_transposed(attention))
                 return h, mask, delta
         attn = attention.detach() if attention is not None else None
-        h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, inp, corr, flow, ast, attn, aanchor)
+        h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, inp, corr, flow, ast, attn, aanchor,
+                                         self._attn_transposed(attention))
         return h, (mask if eng.has_mask else None), delta
 
     def _forward_nchw(self, net, inp, corr, flow, attention=None):
