@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsraft.so")
+LIB_PATH = os.environ.get("FSRAFT_LIB_PATH") or os.path.join(_HERE, "libfsraft.so")   # (override: experiment builds)
 _lib = None
 
 c_float_p = c_void_p      # device pointers travel as integers

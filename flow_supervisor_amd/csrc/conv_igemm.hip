@@ -20,6 +20,8 @@
 // with the pixel dimension split across workgroups and fp32 atomics into the packed layout.
 #include "gemm_core.hpp"
 #include "gemm_core_split.hpp"
+#include <cstddef>
+#include <type_traits>
 
 namespace {
 
@@ -39,6 +41,30 @@ struct ConvArgs {
   float* aux1; int ld1;          // ZR: r*h     Q: q
   float* aux2; int ld2;          // ZR: r
   int hid;
+  int swz;                       // 1: XCD-aware workgroup -> tile mapping (see tile_of_block)
+};
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  With the plain
+// (x = N tile, y = M tile) mapping the N tiles of one M tile -- which read the same activation rows -- land on
+// different XCDs.  This maps linear id i to logical tile t so that every XCD owns one contiguous run of tiles:
+// XCD x holds ids {x, x+8, ...}; its run starts at x*(T/8) + min(x, T%8).
+__device__ __forceinline__ void tile_of_block(int swz, int& bx, int& by) {
+  if (!swz) return;
+  const int nx = gridDim.x, T = nx * gridDim.y, i = by * nx + bx;
+  const int x = i & 7, q = T >> 3, r = T & 7;
+  const int t = x * q + (x < r ? x : r) + (i >> 3);
+  bx = t % nx; by = t / nx;
+}
+
+// Arguments of the buffer-addressed split kernels: ConvArgs plus one dword per k-tile, built on the host, that
+// says where the tile comes from -- bits 0..15: SGPR byte offset / 16 of (tap shift, channel chunk) inside the
+// source, 16..19: tap, 20..21: source, 22..27: channels left in the source from this chunk (1..32).  The kernel
+// reads it with one scalar load; without it the (source, tap, chunk) decode is two integer divisions per k-tile,
+// which the compiler can only do on the vector ALU (~50 instructions) even though the values are wave-uniform.
+constexpr int KTAB_MAX = 256;
+struct ConvArgsT {
+  ConvArgs a;
+  unsigned ktab[KTAB_MAX];
 };
 
 enum { EPI_PLAIN = 0, EPI_ZR = 2, EPI_Q = 3 };
@@ -74,7 +100,7 @@ struct ConvALoader {
     // unconditional load from a clamped address; the zero-select happens in store_chunk so that
     // nothing consumes the load result here (a use would force s_waitcnt right behind the load)
     const bool ok = py[j] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W && c < C;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p + (ok ? (pb[j] + (int64_t)yy * W + xx) * ld + c : 0));
+    const f32x4 v = gload4(p + (ok ? (pb[j] + (int64_t)yy * W + xx) * ld + c : 0));
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
     return ok;
   }
@@ -109,11 +135,87 @@ struct SplitConvALoader {                 // implicit-GEMM gather of fp32 activa
     const int c = c0 + kq * 4;
     const bool ok = ((unsigned)(py[j] + dy) < (unsigned)H) && ((unsigned)(px[j] + dx) < (unsigned)W) && c < C;
     const float* src = ok ? p + (int64_t)(pofs[j] + dy * W + dx) * ld + c : g_fsraft_zero16;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 v = gload4(src);
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
     stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+  }
+};
+
+// ---- buffer-addressed variants -----------------------------------------------------------------
+// Same tiles, but fetched with buffer_load_dwordx4: the per-lane part of the address is a 32-bit byte offset that
+// is constant over the whole k-loop (this thread's pixel row and 16-byte column), the per-k-tile part (tap shift,
+// channel chunk, source) is wave-uniform and travels in the SGPR offset, and "outside the image / outside the
+// matrix" is expressed by pointing the lane offset past num_records, which makes the hardware return zeros.
+// That removes the 64-bit per-lane address arithmetic and the bounds compares (about 15 VALU per 16-byte chunk)
+// from the k-loop; what is left per chunk is one mask test and one select.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define FS_RSRC_FLAGS 0x00020000            // raw buffer, 32-bit data format (gfx9 family word 3)
+#define FS_OOB 0x80000000u                  // lane offset that always fails the num_records check
+
+__device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ const T* uni_ptr(const T* p) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  return reinterpret_cast<const T*>((uint64_t)uni((unsigned)(u >> 32)) << 32 | uni((unsigned)u));
+}
+// p and bytes must be wave-uniform; the readfirstlanes state that (a descriptor the compiler believes to be
+// divergent is wrapped in a waterfall loop around every load).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  void* q = reinterpret_cast<void*>((uint64_t)hi << 32 | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), FS_RSRC_FLAGS);
+}
+
+template <class Cfg>
+struct BufConvALoader {
+  static constexpr int NCH = Cfg::NCH_A, NREG = NCH * 4;
+  // descriptor bases, biased down by (PH*W + PW) pixels so that tap shifts stay non-negative, and sizes in bytes.
+  // (Descriptors are rebuilt from these scalars at each use: a struct holding __amdgpu_buffer_rsrc_t members is not
+  // scalarised by the compiler and ends up in scratch, which turns every uniform value read back from it divergent.)
+  const float* b0; const float* b1; const float* b2; unsigned nb0, nb1, nb2;
+  unsigned ld0x4, ld1x4, ld2x4;           // row pitches in bytes
+  const unsigned __attribute__((address_space(4)))* ktab;   // table in the kernarg segment (constant address space -> s_load), see ConvArgsT
+  unsigned tapmask[NCH];                  // bit t: tap t of this thread's pixel row lies inside the image (0: row outside M)
+  unsigned pofs[NCH];                     // pixel index of the row
+  unsigned kq16;                          // byte offset of this thread's 16-byte column inside a 128-byte chunk row
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    // kt is wave-uniform; saying so explicitly lets the table entry come in with s_load_dword and keeps everything
+    // derived from it (descriptor, SGPR offset) in scalar registers instead of behind a waterfall loop
+    const unsigned e = ktab[__builtin_amdgcn_readfirstlane(kt)];
+    const unsigned soff = (e & 0xffffu) << 4, tap = (e >> 16) & 15u, src = (e >> 20) & 3u, crem = (e >> 22) & 63u;
+    const bool s1 = src >= 1, s2 = src >= 2;
+    // (sums of two-way selects: a three-way select chain over kernel arguments becomes a scratch lookup table)
+    const unsigned ldb = ld0x4 + (s1 ? ld1x4 - ld0x4 : 0u) + (s2 ? ld2x4 - ld1x4 : 0u);
+    const bool ok = ((tapmask[j] >> tap) & 1u) != 0 && kq16 < crem * 4u;
+    const unsigned voff = ok ? __umul24(pofs[j], ldb) + kq16 : FS_OOB;
+    const float* bp = b0 + (s1 ? b1 - b0 : 0) + (s2 ? b2 - b1 : 0);
+    const unsigned nb = nb0 + (s1 ? nb1 - nb0 : 0u) + (s2 ? nb2 - nb1 : 0u);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(bp, nb), voff, soff, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+  }
+  __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+  }
+};
+
+template <class Cfg>
+struct BufWeightLoader {                  // pre-split packed weights through one buffer descriptor
+  static constexpr int NCH = Cfg::NCH_B, NREG = NCH * 4;
+  const char* base; unsigned nbytes;
+  unsigned voff[NCH];                     // row * row_bytes + 16 * part, or FS_OOB for rows outside the matrix
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);            // kt < 0: zero tile
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, nbytes), ku < 0 ? FS_OOB : voff[j],
+                                                          ku < 0 ? 0u : (unsigned)ku * 128u, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+  }
+  __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
+    stage_copy<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
   }
 };
 
@@ -126,9 +228,9 @@ struct SplitWeightLoader {                // pre-split packed weights: row n = K
   __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
     const int e = threadIdx.x + 256 * j;
     const int row = e >> 3, part = e & 7;
-    const char* src = row < rows_valid ? base + row * row_bytes + (int64_t)kt * 128 + part * 16
-                                       : reinterpret_cast<const char*>(g_fsraft_zero16);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    const char* src = (row < rows_valid && kt >= 0) ? base + row * row_bytes + (int64_t)kt * 128 + part * 16
+                                                    : reinterpret_cast<const char*>(g_fsraft_zero16);   // kt < 0: zero tile
+    const f32x4 v = gload4(src);
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
@@ -285,13 +387,13 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       }
       if (nv == 4) {
         if (dacc) {
-          const f32x4 old = *reinterpret_cast<const f32x4*>(o);
+          const f32x4 old = gload4(o);
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] += old[i];
         }
-        *reinterpret_cast<f32x4*>(o) = v;
+        gstore4(o, v);
       } else {
-        for (int i = 0; i < nv; ++i) o[i] = dacc ? o[i] + v[i] : v[i];
+        for (int i = 0; i < nv; ++i) gstore1(o + i, dacc ? gload1(o + i) + v[i] : v[i]);
       }
     }
   } else if (EPI == EPI_ZR) {
@@ -307,7 +409,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       if (isz) {
         *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + c) = v;                 // z
       } else {
-        const f32x4 hh = *reinterpret_cast<const f32x4*>(a.h + m * a.ldh + c);
+        const f32x4 hh = gload4(a.h + m * a.ldh + c);
         *reinterpret_cast<f32x4*>(a.aux2 + m * a.ld2 + c) = v;                            // r
         f32x4 rh;
 #pragma unroll
@@ -321,8 +423,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       const int64_t m = m0 + row;
       if (m >= M) break;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
-      const f32x4 hh = *reinterpret_cast<const f32x4*>(a.h + m * a.ldh + n);
-      const f32x4 zz = *reinterpret_cast<const f32x4*>(a.z + m * a.ldz + n);
+      const f32x4 hh = gload4(a.h + m * a.ldh + n);
+      const f32x4 zz = gload4(a.z + m * a.ldz + n);
       f32x4 hn;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -383,12 +485,58 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // split-bf16 variant: 3 x v_mfma_f32_32x32x16_bf16 per product block, weights pre-split at pack time
-template <class Cfg, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm_split_kernel(ConvArgs a) {
+template <class Cfg, int EPI, bool BUF = false>
+__global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::conditional_t<BUF, ConvArgsT, ConvArgs> args) {
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const ConvArgs& a = [&]() -> const ConvArgs& { if constexpr (BUF) return args.a; else return args; }();
   const int HW = a.H * a.W;
   const int M = a.B * HW;
-  const int n0 = blockIdx.x * Cfg::BN, m0 = blockIdx.y * Cfg::BM;
+  int bx = blockIdx.x, by = blockIdx.y;
+  tile_of_block(a.swz, bx, by);
+  const int n0 = bx * Cfg::BN, m0 = by * Cfg::BM;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if constexpr (BUF) {
+    BufConvALoader<Cfg> la;
+    const int PH = a.KH / 2, PW = a.KW / 2, taps = a.KH * a.KW;
+    la.ld0x4 = uni(a.src[0].ld * 4); la.ld1x4 = uni(a.src[1].ld * 4); la.ld2x4 = uni(a.src[2].ld * 4);
+    // descriptor base = tensor base - (PH*W + PW) pixels, so the per-tap SGPR offset (dy*W + dx)*ld is >= 0
+    la.b0 = uni_ptr(a.src[0].p - (int64_t)(PH * a.W + PW) * a.src[0].ld); la.nb0 = 0x7fffffffu;
+    la.b1 = uni_ptr(a.src[1].p - (int64_t)(PH * a.W + PW) * a.src[1].ld); la.nb1 = 0x7fffffffu;
+    la.b2 = uni_ptr(a.src[2].p - (int64_t)(PH * a.W + PW) * a.src[2].ld); la.nb2 = 0x7fffffffu;
+    // Index the table where it lives, in the kernarg segment: going through the by-value struct would make the
+    // compiler copy it to scratch (dynamic index), and a scratch load is per-lane, i.e. no longer provably uniform.
+    la.ktab = (const unsigned __attribute__((address_space(4)))*)(
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvArgsT, ktab));
+    la.kq16 = (threadIdx.x & 7) * 16;
+#pragma unroll
+    for (int j = 0; j < BufConvALoader<Cfg>::NCH; ++j) {
+      const int m = m0 + ((threadIdx.x + 256 * j) >> 3);
+      unsigned mask = 0;
+      if (m < M) {
+        const int pix = m % HW, y = pix / a.W, x = pix % a.W;
+        for (int t = 0; t < taps; ++t) {
+          const int yy = y + t / a.KW - PH, xx = x + t % a.KW - PW;
+          if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) mask |= 1u << t;
+        }
+      }
+      la.tapmask[j] = mask; la.pofs[j] = m < M ? m : 0;
+    }
+    BufWeightLoader<Cfg> lb;
+    lb.base = uni_ptr(reinterpret_cast<const char*>(a.wpk) + (int64_t)n0 * a.Ktot * 4);
+    lb.nbytes = 0x7fffffffu;   // validity is carried by the lane offsets alone (FS_OOB), whatever the range check adds to them
+#pragma unroll
+    for (int j = 0; j < BufWeightLoader<Cfg>::NCH; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      lb.voff[j] = (e >> 3) < a.N - n0 ? (unsigned)((e >> 3) * a.Ktot * 4 + (e & 7) * 16) : FS_OOB;
+    }
+    split_mainloop<Cfg, BufConvALoader<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
+  } else {
   SplitConvALoader<Cfg> la;
   la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + 31) / 32;
   la.p1 = a.src[1].p; la.C1 = a.src[1].C; la.ld1 = a.src[1].ld; la.cpt1 = a.nsrc > 1 ? (a.src[1].C + 31) / 32 : 0;
@@ -407,14 +555,8 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(ConvArgs a) {
     }
   }
   SplitWeightLoader<Cfg> lb{reinterpret_cast<const char*>(a.wpk) + (int64_t)n0 * a.Ktot * 4, (int64_t)a.Ktot * 4, a.N - n0};
-  f32x16 acc[Cfg::TM][Cfg::TN];
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   split_mainloop<Cfg>(lds, a.Ktot / 32, la, lb, acc);
+  }
   if constexpr (Cfg::LDS_BYTES >= Cfg::BM * (Cfg::BN + 4) * 4) {     // the parked tile must fit the staging LDS
     if (EPI != EPI_PLAIN || epilogue_rows_ok(a)) {
       conv_epilogue_lds<Cfg, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(lds));
@@ -451,7 +593,7 @@ struct ShiftedXLoader {                    // Bs[k = pixel][n = ci] <- X[pixel +
     const int64_t b = mm / HW; const int pix = (int)(mm % HW);
     const int yy = pix / W + dy, xx = pix % W + dx;
     const bool ok = m < m_end && c4 * 4 < cvalid && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p + (ok ? (b * HW + (int64_t)yy * W + xx) * ld + c4 * 4 : 0));
+    const f32x4 v = gload4(p + (ok ? (b * HW + (int64_t)yy * W + xx) * ld + c4 * 4 : 0));
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
     return ok;
   }
@@ -478,7 +620,7 @@ struct DyLoader {                          // As[k = pixel][m = co] <- dY[pixel]
     const int k = e / F4, c4 = e % F4;
     const int64_t m = m_begin + (int64_t)kt * BK + k;
     const bool ok = m < m_end && c4 * 4 < cvalid;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p + (ok ? m * ld + c4 * 4 : 0));
+    const f32x4 v = gload4(p + (ok ? m * ld + c4 * 4 : 0));
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
     return ok;
   }
@@ -501,7 +643,7 @@ struct SplitDyLoader {                    // chunk e: pixel k = e / 32, channels
     const int k = e / (Cfg::BM / 4), c4 = e % (Cfg::BM / 4);
     const int64_t m = m_begin + (int64_t)kt * 32 + k;
     const bool ok = m < m_end && c4 * 4 < cvalid;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p + m * ld + c4 * 4 : g_fsraft_zero16);
+    const f32x4 v = gload4(ok ? p + m * ld + c4 * 4 : g_fsraft_zero16);
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
   }
 };
@@ -518,7 +660,7 @@ struct SplitShiftedXLoader {
     const int pix = (int)(mm % HW);
     const int yy = pix / W + dy, xx = pix % W + dx;
     const bool ok = m < m_end && c4 * 4 < cvalid && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p + (mm + dy * W + dx) * ld + c4 * 4 : g_fsraft_zero16);
+    const f32x4 v = gload4(ok ? p + (mm + dy * W + dx) * ld + c4 * 4 : g_fsraft_zero16);
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
   }
 };
@@ -713,6 +855,9 @@ using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgM64 = SplitCfg<64, 128, 1, 4>;
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_ktab_order = 0;   // experiment switch (key 6)
+int g_xcd_swizzle = 0;  // experiment switch (key 7)
+int g_conv_buf = 1;     // buffer-addressed loaders in the split conv kernels (key 5): 0 never, 1 on 64-row tiles, 2 always
 int g_conv_split = 1;   // 0: exact fp32 MFMA; 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (key 3)
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
 int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
@@ -722,10 +867,43 @@ using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
 using WCfg128 = GemmCfg<128, 128, 32, 2, 2, 0, 0>;
 using WCfg32 = GemmCfg<32, 128, 32, 1, 4, 0, 0>;
 
+// Fills the per-k-tile table of the buffer-addressed kernels; false when the shape does not fit its fields
+// (more than KTAB_MAX k-tiles, more than 15 taps, tap/channel offsets beyond 1 MiB, tensors of 2 GiB or more).
+bool build_ktab(const ConvArgs& a, ConvArgsT& t) {
+  const int taps = a.KH * a.KW, KT = a.Ktot / 32;
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  if (KT > KTAB_MAX || taps > 15) return false;
+  int kt = 0;
+  for (int s = 0; s < a.nsrc; ++s) {
+    const int C = a.src[s].C, ld = a.src[s].ld, cpt = (C + 31) / 32;
+    if (M * ld * 4 >= (int64_t)FS_OOB) return false;
+    for (int i = 0; i < taps * cpt; ++i, ++kt) {
+        // g_ktab_order 1 (EXPERIMENT, results are wrong: the weight pack is tap-major): taps innermost
+        const int tap = g_ktab_order ? i % taps : i / cpt, c = g_ktab_order ? i / taps : i % cpt;
+        const int64_t soff = ((int64_t)((tap / a.KW) * a.W + tap % a.KW) * ld + c * 32) * 4;
+        if (soff % 16 != 0 || soff / 16 > 0xffff) return false;
+        const int crem = C - c * 32 < 32 ? C - c * 32 : 32;
+        t.ktab[kt] = (unsigned)(soff / 16) | (unsigned)tap << 16 | (unsigned)s << 20 | (unsigned)crem << 22;
+      }
+  }
+  if (kt != KT) return false;
+  t.a = a;
+  return true;
+}
+
 template <class Cfg>
 int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   const int M = a.B * a.H * a.W;
   dim3 grid(ceil_div(a.N, Cfg::BN), ceil_div(M, Cfg::BM));
+  ConvArgsT t;
+  // buffer-addressed loaders + branch-free k-loop: measured faster on the 64-row tiles, slower on 128x128
+  const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64);
+  if (buf && build_ktab(a, t)) {
+    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, true>), grid, dim3(256), 0, s, t);
+    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, true>), grid, dim3(256), 0, s, t);
+    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, true>), grid, dim3(256), 0, s, t);
+    return fs_launch_status();
+  }
   if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN>), grid, dim3(256), 0, s, a);
   else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q>), grid, dim3(256), 0, s, a);
@@ -789,6 +967,7 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   a.ndst = d->ndst; a.relu = d->relu; a.alpha = d->alpha;
   a.h = d->h; a.ldh = d->ldh; a.z = d->z; a.ldz = d->ldz; a.aux1 = d->aux1; a.ld1 = d->ld1; a.aux2 = d->aux2; a.ld2 = d->ld2;
   a.hid = d->hid;
+  a.swz = g_xcd_swizzle;
   if (d->epi == EPI_ZR && (!d->h || !d->aux1 || !d->aux2 || d->hid * 2 != d->N)) return FS_ERR_ARG;
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
@@ -799,9 +978,11 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   const int M = d->B * d->H * d->W;
   if (g_conv_split && d->wpk_split && d->N > 64) {
     a.wpk = d->wpk_split;
-    // 128x128 tiles unless that leaves fewer than ~1.5 workgroups per CU (measured crossover: N=128 layers
-    // at M=28160 run 1.3-1.4x faster on 64x128 tiles, N>=192 layers are faster on 128x128)
-    const bool narrow = (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
+    // 64x128 tiles with the buffer-addressed loaders and the branch-free k-loop are the fastest variant on every
+    // update-block shape at M = 28160 (scripts/conv_micro.py: zr 129 us, hd 142 us, q 65 us, m2 61 us, c1 41 us;
+    // the 128x128 kernel needs 131 / 157 / 87 / 78 / 45 us); 128x128 stays selectable (key 3 = 4) and is the
+    // fallback for shapes the k-tile table cannot describe.
+    const bool narrow = g_conv_buf != 0 || (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
     if (g_conv_split == 3) return launch_conv_split<SCfgM64>(a, d->epi, stream);
     if (g_conv_split == 4) return launch_conv_split<SCfg128>(a, d->epi, stream);
     return narrow ? launch_conv_split<SCfgM64>(a, d->epi, stream) : launch_conv_split<SCfg128>(a, d->epi, stream);
@@ -815,11 +996,20 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   return launch_conv<Cfg128>(a, d->epi, stream);
 }
 
+#ifdef FSRAFT_ABLATE
+extern "C" int fsraft_set_ablate(int mask) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fsraft_ablate), &mask, sizeof(int)) == hipSuccess ? FS_OK : FS_ERR_LAUNCH;
+}
+#endif
+
 extern "C" int fsraft_set_tuning(int key, int value) {
   if (key == 0) g_conv_tile = value;
   else if (key == 1) g_wgrad_tile = value;
   else if (key == 2) g_wgrad_blocks = value;
   else if (key == 3) g_conv_split = value;
+  else if (key == 5) g_conv_buf = value;
+  else if (key == 6) g_ktab_order = value;
+  else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;
   return FS_OK;

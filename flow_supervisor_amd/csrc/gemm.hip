@@ -72,8 +72,8 @@ struct SplitRowLoader {          // chunk e: row e / 8, k = kt*32 + 4*(e % 8)
   __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
     const int e = threadIdx.x + 256 * j;
     const int row = e >> 3, k = kt * 32 + 4 * (e & 7);
-    const bool ok = row < rows_valid && k < K;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? base + row * ld + k : g_fsraft_zero16);
+    const bool ok = row < rows_valid && k < K && kt >= 0;          // kt < 0: zero tile (split_mainloop's padding)
+    const f32x4 v = gload4(ok ? base + row * ld + k : g_fsraft_zero16);
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {

@@ -148,7 +148,7 @@ struct RowMajorTileLoader {
     bool ok = true;
     if (vec) {
       ok = row < rows_valid && k < k_valid_total;
-      v = *reinterpret_cast<const f32x4*>(base + (ok ? (int64_t)row * ld + k : 0));
+      v = gload4(base + (ok ? (int64_t)row * ld + k : 0));
     } else if (row < rows_valid) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -188,7 +188,7 @@ struct KMajorTileLoader {
     bool ok = true;
     if (vec) {
       ok = kk < k_valid_total && c4 * 4 < cols_valid;
-      v = *reinterpret_cast<const f32x4*>(base + (ok ? (int64_t)kk * ld + c4 * 4 : 0));
+      v = gload4(base + (ok ? (int64_t)kk * ld + c4 * 4 : 0));
     } else if (kk < k_valid_total) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)

@@ -74,9 +74,26 @@ __device__ __forceinline__ void stage_copy(char* tile, int e, const float* r) {
   *reinterpret_cast<f32x4*>(tile + (e >> 3) * PITCH + (e & 7) * 16) = f32x4{r[0], r[1], r[2], r[3]};
 }
 
-template <class Cfg, class LA, class LB>
+#ifdef FSRAFT_ABLATE
+// Experiment build only (make ablate): a run-time mask removes pipeline stages so their cost can be measured.
+// bit 0: no LDS staging, bit 1: no MFMA, bit 2: no LDS fragment reads (and no MFMA), bit 3: no global loads.
+__device__ int g_fsraft_ablate;
+#endif
+
+// STRAIGHT selects the shape of the k-loop (both compute the same thing):
+//   false: tail conditions inside the body.  The compiler re-shapes that loop and waits for vmcnt(0) before each
+//          staging step -- effectively one tile of look-ahead -- which measures FASTER on the 128x128 tiles
+//          (zr 1x5 384->256 at M=28160: 131 us vs 157 us) and on short-K layers (no padded tile, shorter prologue);
+//   true:  branch-free body, two tiles per trip, an odd tile count runs one all-zero tile; the waits are the
+//          intended vmcnt(15..8) (two tiles in flight).  Faster on the 64x128 tiles (q 1x5 384->128: 76 -> 64 us).
+template <class Cfg, class LA, class LB, bool STRAIGHT = false>
 __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
                                                f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+#ifdef FSRAFT_ABLATE
+  const int abl = __builtin_amdgcn_readfirstlane(g_fsraft_ablate);
+#else
+  constexpr int abl = 0;
+#endif
   static_assert(LA::NCH == Cfg::NCH_A && LB::NCH == Cfg::NCH_B, "loader tile shape must match the config");
   static_assert(Cfg::NBUF == 2, "the two-deep prefetch schedule needs two LDS images");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -90,19 +107,24 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
   float ra0[LA::NREG], rb0[LB::NREG], ra1[LA::NREG], rb1[LB::NREG];
 
   auto fetch = [&](int kt, float (&ra)[LA::NREG], float (&rb)[LB::NREG]) {
-    const int k = kt < KT ? kt : KT - 1;             // past the end: re-read the last tile (never staged)
+    if (abl & 8) return;
+    // past the end: A re-reads the last tile, B is asked for tile -1, which every B loader answers with zeros --
+    // so a tile beyond K contributes nothing and the k-loop below needs no tail conditions
+    const int ka = kt < KT ? kt : KT - 1, kb = kt < KT ? kt : (STRAIGHT ? -1 : KT - 1);
 #pragma unroll
-    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(k, ra, c);
+    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(ka, ra, c);
 #pragma unroll
-    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(k, rb, c);
+    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(kb, rb, c);
   };
   auto stage = [&](char* dst, const float (&ra)[LA::NREG], const float (&rb)[LB::NREG]) {
+    if (abl & 1) return;
 #pragma unroll
     for (int c = 0; c < LA::NCH; ++c) la.stage_chunk(dst, ra + 4 * c, c);
 #pragma unroll
     for (int c = 0; c < LB::NCH; ++c) lb.stage_chunk(dst + Cfg::A_BYTES, rb + 4 * c, c);
   };
   auto compute = [&](const char* cur) {
+    if (abl & 4) return;
     const char* As = cur + (wm * (Cfg::TM * 32) + l31) * Cfg::PITCH + lh * 16;
     const char* Bs = cur + Cfg::A_BYTES + (wn * (Cfg::TN * 32) + l31) * Cfg::PITCH + lh * 16;
 #pragma unroll
@@ -117,6 +139,13 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
       for (int nt = 0; nt < Cfg::TN; ++nt) {
         bh[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + s * 32);
         bl[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + s * 32 + 64);
+      }
+      if (abl & 2) {      // keep the fragment reads alive without issuing MFMAs
+#pragma unroll
+        for (int mt = 0; mt < Cfg::TM; ++mt) asm volatile("" ::"v"(ah[mt]), "v"(al[mt]));
+#pragma unroll
+        for (int nt = 0; nt < Cfg::TN; ++nt) asm volatile("" ::"v"(bh[nt]), "v"(bl[nt]));
+        continue;
       }
 #pragma unroll
       for (int mt = 0; mt < Cfg::TM; ++mt)
@@ -137,14 +166,29 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
   stage(buf0, ra0, rb0);           // tile 0 -> LDS
   fetch(2, ra0, rb0);              // tile 2 in flight, tile 1 waiting in set 1
   __syncthreads();
+  if constexpr (!STRAIGHT) {
+    for (int kt = 0; kt < KT; kt += 2) {
+      compute(buf0);                                   // tile kt
+      if (kt + 1 < KT) stage(buf1, ra1, rb1);          // tile kt+1 -> other image
+      fetch(kt + 3, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= KT) break;
+      compute(buf1);                                   // tile kt+1
+      if (kt + 2 < KT) stage(buf0, ra0, rb0);          // tile kt+2
+      fetch(kt + 4, ra0, rb0);
+      __syncthreads();
+    }
+    return;
+  }
   for (int kt = 0; kt < KT; kt += 2) {
     compute(buf0);                                   // tile kt
-    if (kt + 1 < KT) stage(buf1, ra1, rb1);          // tile kt+1 -> other image
+    __builtin_amdgcn_sched_barrier(0);               // MFMAs first: a vmcnt wait hoisted between them would stall the matrix pipe
+    stage(buf1, ra1, rb1);                           // tile kt+1 -> other image
     fetch(kt + 3, ra1, rb1);
     __syncthreads();
-    if (kt + 1 >= KT) break;
-    compute(buf1);                                   // tile kt+1
-    if (kt + 2 < KT) stage(buf0, ra0, rb0);          // tile kt+2
+    compute(buf1);                                   // tile kt+1 (zeros when kt+1 == KT)
+    __builtin_amdgcn_sched_barrier(0);
+    stage(buf0, ra0, rb0);                           // tile kt+2
     fetch(kt + 4, ra0, rb0);
     __syncthreads();
   }

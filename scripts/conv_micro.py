@@ -23,13 +23,18 @@ LAYERS = [  # name, kh, kw, src channels, Cout
     ("hd 3x3 128->512", 3, 3, [128], 512),
     ("m2 1x1 256->576", 1, 1, [256], 576),
     ("fh2 3x3 256->2", 3, 3, [256], 2),
+    # diagnostics: same K as zr, different reuse structure
+    ("x1 1x1 1920->256", 1, 1, [1920], 256),
+    ("x5 1x5 384->256 one src", 1, 5, [384], 256),
+    ("x9 3x3 224->256", 3, 3, [224], 256),
+    ("xw 1x5 384->512", 1, 5, [384], 512),
 ]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
 from flow_supervisor_amd import _lib  # noqa: E402
-for i, v in enumerate(sys.argv[3:8]):
+for i, v in enumerate(sys.argv[3:9]):
     _lib.load().fsraft_set_tuning(i, int(v))
-print("tuning:", sys.argv[3:8])
+print("tuning:", sys.argv[3:9])
 for name, kh, kw, cs, cout in LAYERS:
     if only and not name.startswith(only):
         continue
