@@ -30,6 +30,7 @@ class ConvDesc(Structure):
         ("epi", c_int),
         ("h", c_void_p), ("ldh", c_int), ("z", c_void_p), ("ldz", c_int),
         ("aux1", c_void_p), ("ld1", c_int), ("aux2", c_void_p), ("ld2", c_int), ("hid", c_int),
+        ("pre", c_void_p), ("ldpre", c_int),
     ]
 
 
@@ -100,6 +101,9 @@ def load():
     bsplit = os.environ.get("FSRAFT_BUILD_SPLIT")
     if bsplit is not None:
         lib.fsraft_set_build_split(int(bsplit))
+    for key, env in ((0, "FSRAFT_CONV_TILE"), (2, "FSRAFT_WGRAD_BLOCKS"), (5, "FSRAFT_CONV_BUF"), (8, "FSRAFT_WGRAD_BUF")):
+        if os.environ.get(env) is not None:
+            lib.fsraft_set_tuning(key, int(os.environ[env]))
     wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")
     if wsplit is not None:
         lib.fsraft_set_tuning(4, int(wsplit))

@@ -93,8 +93,9 @@ _WGRAD_SIDE_STREAM = os.environ.get("FSRAFT_WGRAD_STREAM", "0") != "0"
 class _Layer:
     """One GEMM of the block: which parameters form its weight, its taps and its inputs."""
 
-    def __init__(self, key, wnames, kh, kw, src_c, view_as=None, bias=True):
+    def __init__(self, key, wnames, kh, kw, src_c, view_as=None, bias=True, cin_sel=None):
         self.key = key              # short id
+        self.cin_sel = cin_sel      # [(start, stop), ...] input-channel ranges of the OIHW weight this GEMM uses (None: all)
         self.bias = bias            # nn.Conv2d(bias=False) layers have no bias parameter
         self.wnames = wnames        # parameter prefixes concatenated along Cout (e.g. convz1+convr1)
         self.kh, self.kw = kh, kw
@@ -134,9 +135,17 @@ class _Engine:
         ]
         if gma:
             ls.append(_Layer("av", ["aggregator.to_v"], 1, 1, [self.mot_c], bias=False))
+        # GRU gates: conv(cat(h, inp, motion)) = conv_hm(cat(h, motion)) + conv_i(inp) + b.  The context features inp do
+        # not change over the iterations of a step, so conv_i(inp) + b is evaluated once per step ("zi*", "qi*") and
+        # enters every iteration's epilogue as a per-pixel addend; its backward runs once on the summed gate gradients.
+        hm = [(0, hid), (hid + inp_c, hid + inp_c + mot)]
+        ii = [(hid, hid + inp_c)]
         for sfx, kh, kw in passes:
-            ls.append(_Layer("zr" + sfx, ["gru.convz" + sfx, "gru.convr" + sfx], kh, kw, [hid, inp_c, mot]))
-            ls.append(_Layer("q" + sfx, ["gru.convq" + sfx], kh, kw, [hid, inp_c, mot]))
+            zr, qq = ["gru.convz" + sfx, "gru.convr" + sfx], ["gru.convq" + sfx]
+            ls.append(_Layer("zr" + sfx, zr, kh, kw, [hid, mot], bias=False, cin_sel=hm))
+            ls.append(_Layer("q" + sfx, qq, kh, kw, [hid, mot], bias=False, cin_sel=hm))
+            ls.append(_Layer("zi" + sfx, zr, kh, kw, [inp_c], cin_sel=ii))
+            ls.append(_Layer("qi" + sfx, qq, kh, kw, [inp_c], cin_sel=ii))
         if self.has_mask:
             ls.append(_Layer("hd", ["flow_head.conv1", "mask.0"], 3, 3, [hid]))
             ls.append(_Layer("m2", ["mask.2"], 1, 1, [self.head_c]))
@@ -146,9 +155,12 @@ class _Engine:
         self.layers = {l.key: l for l in ls}
         self.order = [l.key for l in ls]
         self.pnames = []                                            # flat parameter order fed to the Function
+        self.ctx_keys = [k + sfx for sfx, _, _ in passes for k in ("zi", "qi")]
         for l in ls:
             for w in l.wnames:
-                self.pnames += [w + ".weight"] + ([w + ".bias"] if l.bias else [])
+                for n in [w + ".weight"] + ([w + ".bias"] if l.bias else []):
+                    if n not in self.pnames:
+                        self.pnames.append(n)
         self.extra = ["aggregator.gamma"] if gma else []            # non-conv parameters
         self.pnames += self.extra
         self._cache_key = None
@@ -205,7 +217,16 @@ class _Engine:
             for wname in l.wnames:
                 p = byname[wname + ".weight"]
                 n = p.shape[0]
-                grads[wname + ".weight"] = gw[o:o + n].reshape(p.shape)
+                if l.cin_sel is None:
+                    grads[wname + ".weight"] = gw[o:o + n].reshape(p.shape)
+                else:                       # this GEMM saw only some input channels of the parameter
+                    full = grads.get(wname + ".weight")
+                    if full is None:
+                        full = grads[wname + ".weight"] = torch.zeros_like(p, dtype=torch.float32)
+                    c = 0
+                    for a, b in l.cin_sel:
+                        full[:, a:b] = gw[o:o + n, c:c + b - a]
+                        c += b - a
                 if l.bias:
                     grads[wname + ".bias"] = st.dB[k][o:o + n].clone()
                 o += n
@@ -239,6 +260,8 @@ class _Engine:
                     b = (bs[0] if len(bs) == 1 else torch.cat(bs, 0)).contiguous().float()
                 if l.view_as is not None:
                     w = w.reshape(w.shape[0], *l.view_as)
+                if l.cin_sel is not None:
+                    w = torch.cat([w[:, a:b] for a, b in l.cin_sel], 1)
                 w = w.contiguous().float()
                 out[k] = (ops.pack_weight(w, l.src_c, 0), ops.pack_weight(w, l.src_c, 1), b,
                           w.shape[0], tuple(w.shape),
@@ -247,11 +270,43 @@ class _Engine:
         return out
 
     # ---- forward ------------------------------------------------------------------
-    def forward(self, net, inp, corr, flow, params, save, attn=None, attn_t=None):
-        """net/inp/corr: channels-last [B,H,W,C]; flow: [B,2,H,W] (any pixel stride).
+    def context(self, inp, params):
+        """Once per step: {"zi*"/"qi*": conv_i(inp) + bias as [B,H,W,N]} for the GRU gate convolutions."""
+        L.require_cuda_f32(inp)
+        B, H, W, _ = inp.shape
+        P = self._packed(params)
+        out = {}
+        for k in self.ctx_keys:
+            l = self.layers[k]
+            buf = torch.empty(B, H, W, P[k][3], device=inp.device, dtype=torch.float32)
+            ops.conv_forward([V(inp, self.inp_c)], P[k][0], P[k][2], B, H, W, l.kh, l.kw, P[k][3], [Dst.nhwc(buf)],
+                             wpk_split=P[k][5])
+            out[k] = buf
+        return out
+
+    def context_backward(self, cst, P, st):
+        """Backward of context(): weight / bias gradients of the inp part into the arena, returns dL/d inp."""
+        inp = cst.inp
+        B, H, W, _ = inp.shape
+        dW, dB = self._grad_arena(st, P, inp.device)
+        dinp = torch.zeros(B, H, W, _pad4(self.inp_c), device=inp.device, dtype=torch.float32)
+        for k in self.ctx_keys:
+            g = cst.dsum.get(k)
+            if g is None:
+                continue
+            l = self.layers[k]
+            n = P[k][3]
+            ops.conv_wgrad(V(g, n), [V(inp, self.inp_c)], dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
+            ops.conv_forward([V(g, n)], P[k][1], None, B, H, W, l.kh, l.kw, self.inp_c, [Dst.nhwc(dinp, 0, 0, True)],
+                             wpk_split=P[k][6])
+        cst.dsum = {}
+        return dinp
+
+    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None):
+        """net/corr: channels-last [B,H,W,C]; ctxb: context() of the context features; flow: [B,2,H,W] (any pixel stride).
         Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
         a dict of the intermediates backward needs."""
-        L.require_cuda_f32(net, inp, corr, flow)
+        L.require_cuda_f32(net, corr, flow)
         B, H, W, _ = net.shape
         dev = net.device
         P = self._packed(params)
@@ -307,9 +362,9 @@ class _Engine:
         gates = []
         for sfx, _, _ in self.passes:
             z, r, rh, q, hn = buf(hid), buf(hid), buf(hid), buf(hid), buf(hid)
-            xs = [V(inp, self.inp_c), V(motion, self.x_c)]
-            conv("zr" + sfx, [V(h, hid)] + xs, [Dst.nhwc(z)], epi=2, h=h, aux1=rh, aux2=r, hid=hid)
-            conv("q" + sfx, [V(rh, hid)] + xs, [Dst.nhwc(hn)], epi=3, h=h, z=z, aux1=q)
+            xs = [V(motion, self.x_c)]
+            conv("zr" + sfx, [V(h, hid)] + xs, [Dst.nhwc(z)], epi=2, h=h, aux1=rh, aux2=r, hid=hid, pre=ctxb["zi" + sfx])
+            conv("q" + sfx, [V(rh, hid)] + xs, [Dst.nhwc(hn)], epi=3, h=h, z=z, aux1=q, pre=ctxb["qi" + sfx])
             gates.append((h, z, r, rh, q))
             h = hn
         nhead = self.head_c * (2 if self.has_mask else 1)
@@ -323,14 +378,14 @@ class _Engine:
             conv("m2", [V(head, self.head_c, self.head_c)], [Dst.nhwc(mask)], alpha=0.25)
         saved = None
         if save:
-            saved = dict(B=B, H=H, W=W, corr=corr, inp=inp, cor1=cor1, corflo=corflo, cols=cols, flo1=flo1,
+            saved = dict(B=B, H=H, W=W, corr=corr, cor1=cor1, corflo=corflo, cols=cols, flo1=flo1,
                          motion=motion, gates=gates, hlast=h, head=head, attn=attn, v=v, agg=agg)
         return h, mask, delta, saved
 
     # ---- backward -----------------------------------------------------------------
-    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None):
-        """Accumulates parameter gradients into the packed arena of `st`;
-        returns (dnet, dinp, dcorr, dflow)."""
+    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None, cst=None):
+        """Accumulates parameter gradients into the packed arena of `st` and the gate gradients into `cst.dsum`
+        (the context part's backward runs once per step, context_backward); returns (dnet, dcorr, dflow)."""
         B, H, W = S["B"], S["H"], S["W"]
         dev = S["corr"].device
         lib = L.load()
@@ -403,23 +458,31 @@ class _Engine:
             dgrad("hd", V(dhead), [Dst.nhwc(dh)])
 
         # ---- GRU passes, last to first
-        inp, motion = S["inp"], S["motion"]
-        dinp = buf(self.inp_c, zero=True)
+        motion = S["motion"]
         dmotion = buf(self.x_c, zero=True)
+
+        def to_context(k, g):
+            if cst is None:
+                return
+            if k in cst.dsum:
+                ops.axpby_(g, cst.dsum[k], 1.0, 1.0)
+            else:
+                cst.dsum[k] = g          # first contribution: adopt the buffer (it is not touched again by this call)
+
         for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
             dzr = buf(2 * hid)
             dq = buf(hid)
             dhp = buf(hid)
             ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid)
-            xs = [V(inp, self.inp_c), V(motion, self.x_c)]
+            xs = [V(motion, self.x_c)]
             wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
             drh = buf(hid)
-            dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dinp, 0, hid, True),
-                                          Dst.nhwc(dmotion, 0, hid + self.inp_c, True)])
+            dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dmotion, 0, hid, True)])
             ops.gru_bwd2(drh, r, h, dzr, dhp, hid)
             wgrad("zr" + sfx, V(dzr, 2 * hid), [V(h, hid)] + xs)
-            dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), Dst.nhwc(dinp, 0, hid, True),
-                                                Dst.nhwc(dmotion, 0, hid + self.inp_c, True)])
+            dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), Dst.nhwc(dmotion, 0, hid, True)])
+            to_context("qi" + sfx, dq)
+            to_context("zi" + sfx, dzr)
             dh = dhp
 
         # ---- Aggregate (GMA): motion_global = motion + gamma * (attn @ to_v(motion))
@@ -475,7 +538,34 @@ class _Engine:
             if need_input_grads:
                 dgrad("c1", V(dcorflo, self.c1, 0), [Dst.nhwc(dcorr)])
 
-        return dh, dinp, dcorr, dflow
+        return dh, dcorr, dflow
+
+
+class _CtxState:
+    """Per-step state of the context convolution: its outputs (forward) and the summed gate gradients (backward)."""
+    __slots__ = ("key", "inp", "bufs", "dsum", "anchor", "consumed", "zero")
+
+    def __init__(self, key, inp, bufs):
+        self.key, self.inp, self.bufs, self.dsum, self.anchor, self.consumed, self.zero = key, inp, bufs, {}, None, False, None
+
+
+class _CtxFn(torch.autograd.Function):
+    """(param anchor, inp) -> 1-element anchor standing for conv_i(inp) + b of all GRU gate convolutions."""
+
+    @staticmethod
+    def forward(ctx, engine, st, cst, params, anchor, inp):
+        ctx.engine, ctx.st, ctx.cst = engine, st, cst
+        ctx.P = engine._packed(params)
+        cst.zero = torch.zeros(1, device=inp.device)
+        return torch.zeros(1, device=inp.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        cst = ctx.cst
+        cst.consumed = True
+        dinp = ctx.engine.context_backward(cst, ctx.P, ctx.st)
+        cst.bufs = None
+        return None, None, None, None, ctx.st.zero, dinp
 
 
 class _ParamState:
@@ -543,11 +633,11 @@ class _UpdateFn(torch.autograd.Function):
     """(anchor; net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
 
     @staticmethod
-    def forward(ctx, engine, st, params, anchor, net, inp, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None):
+    def forward(ctx, engine, st, params, anchor, net, cst, canchor, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None):
         need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
-        h, mask, delta, saved = engine.forward(net, inp, corr, flow, params, save=need, attn=attn, attn_t=attn_t)
+        h, mask, delta, saved = engine.forward(net, cst.bufs, corr, flow, params, save=need, attn=attn, attn_t=attn_t)
         ctx.engine, ctx.st, ctx.saved = engine, st, saved
-        ctx.ast = ast
+        ctx.ast, ctx.cst = ast, cst
         ctx.P = engine._packed(params) if need else None
         ctx.has_mask = mask is not None
         if mask is None:
@@ -563,9 +653,11 @@ class _UpdateFn(torch.autograd.Function):
             raise RuntimeError("update block backward ran twice on the same graph (retain_graph is not supported)")
         dmask = dmask if ctx.has_mask else None
         dh = dh.contiguous() if dh is not None else None
-        dnet, dinp, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta, ast=ctx.ast)
-        return (None, None, None, ctx.st.zero, dnet, dinp, dcorr, dflow, None, None,
-                ctx.ast.zero if ctx.ast is not None else None, None)
+        cst = ctx.cst
+        dnet, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta, ast=ctx.ast,
+                                          cst=cst if cst.anchor is not None else None)
+        return (None, None, None, ctx.st.zero, dnet, None, cst.zero if cst.anchor is not None else None, dcorr, dflow,
+                None, None, ctx.ast.zero if ctx.ast is not None else None, None)
 
 
 class _ToCL(torch.autograd.Function):
@@ -637,6 +729,23 @@ class _UpdateBlockBase(nn.Module):
             self.__dict__["_attn_t"] = c
         return c[2]
 
+    def _ctx_state(self, eng, st, params, anchor, inp, track):
+        """Context convolution of `inp`, shared by every call of a step that passes the same inp tensor (and the
+        same parameter values).  With `track`, its backward is threaded through a 1-element anchor."""
+        pkey = tuple((p.data_ptr(), p._version) for p in params)
+        cst = self.__dict__.get("_cst")
+        stale = (cst is None or cst.key[0]() is not inp or cst.key[1] != inp._version or cst.key[2] != pkey
+                 or cst.consumed or cst.bufs is None or (cst.anchor is not None) != track
+                 or (track and cst.key[3] is not st))
+        if stale:
+            with torch.no_grad():
+                bufs = eng.context(inp.detach(), params)
+            cst = _CtxState((weakref.ref(inp), inp._version, pkey, st), inp.detach(), bufs)
+            if track:
+                cst.anchor = _CtxFn.apply(eng, st, cst, params, anchor, inp)
+            self.__dict__["_cst"] = cst
+        return cst
+
     def forward_cl(self, net, inp, corr, flow, attention=None):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
@@ -647,14 +756,21 @@ class _UpdateBlockBase(nn.Module):
         ast, aanchor = self._attn_state(attention)
         if anchor is None:
             if torch.is_grad_enabled() and (ast is not None or any(t.requires_grad for t in (net, inp, corr, flow))):
-                st, anchor = _ParamState(None), torch.zeros(1, device=net.device)   # inputs need grads, params frozen
-                st.zero = anchor
+                st = self.__dict__.get("_frozen_st")       # inputs need grads, params frozen: one state per step
+                if st is None or st.consumed:
+                    st = _ParamState(None)
+                    st.zero = torch.zeros(1, device=net.device)
+                    self.__dict__["_frozen_st"] = st
+                anchor = st.zero
             else:
-                h, mask, delta, _ = eng.forward(net, inp, corr, flow, params, save=False, attn=attention,
+                cst = self._ctx_state(eng, None, params, None, inp, False)
+                h, mask, delta, _ = eng.forward(net, cst.bufs, corr, flow, params, save=False, attn=attention,
                                                 attn_t=self._attn_transposed(attention))
                 return h, mask, delta
+        track = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params))
+        cst = self._ctx_state(eng, st, params, anchor, inp, track)
         attn = attention.detach() if attention is not None else None
-        h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, inp, corr, flow, ast, attn, aanchor,
+        h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, cst, cst.anchor, corr, flow, ast, attn, aanchor,
                                          self._attn_transposed(attention))
         return h, (mask if eng.has_mask else None), delta
 

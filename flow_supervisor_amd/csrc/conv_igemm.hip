@@ -41,6 +41,7 @@ struct ConvArgs {
   float* aux1; int ld1;          // ZR: r*h     Q: q
   float* aux2; int ld2;          // ZR: r
   int hid;
+  const float* pre; int ldpre;   // GRU epilogues: per-pixel addend to the pre-activation, [M][ldpre] (NULL: none)
   int swz;                       // 1: XCD-aware workgroup -> tile mapping (see tile_of_block)
 };
 
@@ -303,7 +304,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
-          const float sg = 1.0f / (1.0f + expf(-(acc[mt][nt][r] + bias)));
+          const float pre = (a.pre && ok[r]) ? a.pre[m * a.ldpre + n] : 0.f;
+          const float sg = 1.0f / (1.0f + expf(-(acc[mt][nt][r] + bias + pre)));
           if (ok[r]) {
             if (isz) {
               a.dst[0].p[m * a.dst[0].ps + c] = sg;                 // z
@@ -326,7 +328,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
-          const float q = tanhf(acc[mt][nt][r] + bias);
+          const float pre = (a.pre && ok[r]) ? a.pre[m * a.ldpre + n] : 0.f;
+          const float q = tanhf(acc[mt][nt][r] + bias + pre);
           if (ok[r]) {
             a.aux1[m * a.ld1 + n] = q;
             a.dst[0].p[m * a.dst[0].ps + n] = (1.f - zz[r]) * hh[r] + zz[r] * q;
@@ -404,6 +407,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       const int64_t m = m0 + row;
       if (m >= M) break;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
+      if (a.pre) v += gload4(a.pre + m * a.ldpre + n);
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
       if (isz) {
@@ -423,6 +427,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       const int64_t m = m0 + row;
       if (m >= M) break;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
+      if (a.pre) v += gload4(a.pre + m * a.ldpre + n);
       const f32x4 hh = gload4(a.h + m * a.ldh + n);
       const f32x4 zz = gload4(a.z + m * a.ldz + n);
       f32x4 hn;
@@ -665,12 +670,48 @@ struct SplitShiftedXLoader {
   }
 };
 
+// buffer-addressed variants of the two loaders above (see BufConvALoader): per-lane offsets are fixed for the whole
+// k-loop, the k-tile advance is one SGPR offset, and the "shifted pixel inside the image" test -- three integer
+// divisions per 16-byte chunk in the loaders above, ~300 VALU instructions per k-tile -- is a bit test against a
+// per-workgroup pixel mask that is computed once (one word per k-tile, in LDS).
+constexpr int WGRAD_MASK_WORDS = 2048;     // pixels per workgroup / 32 (host caps the pixel split at 65536)
+template <class Cfg>
+struct BufDyLoader {
+  static constexpr int NCH = Cfg::NCH_A, NREG = NCH * 4;
+  const float* base; unsigned ld4; int npix;
+  unsigned voff[NCH]; int krow[NCH];
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);
+    const bool ok = ku * 32 + krow[j] < npix;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, 0x7fffffffu), ok ? voff[j] : FS_OOB,
+                                                          (unsigned)ku * 32u * ld4, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+  }
+};
+template <class Cfg>
+struct BufShiftedXLoader {
+  static constexpr int NCH = Cfg::NCH_B, NREG = NCH * 4;
+  const float* base; unsigned ld4; const unsigned* mask;       // mask: LDS, bit k of word kt = pixel mb + 32 kt + k usable
+  unsigned voff[NCH]; int krow[NCH];
+  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);
+    const unsigned w = __builtin_amdgcn_readfirstlane(mask[ku]);
+    const bool ok = ((w >> krow[j]) & 1u) != 0;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, 0x7fffffffu), ok ? voff[j] : FS_OOB,
+                                                          (unsigned)ku * 32u * ld4, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+  }
+};
+
 using SWCfg128 = SplitTnCfg<128, 128, 2, 2, 2>;
 using SWCfg128S = SplitTnCfg<128, 128, 2, 2, 1>;
 
-template <class Cfg>
+template <class Cfg, bool BUF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  __shared__ unsigned pixmask[BUF ? WGRAD_MASK_WORDS : 1];
   const int HW = a.H * a.W;
   const int64_t M = (int64_t)a.B * HW;
   const int taps = a.KH * a.KW;
@@ -691,10 +732,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
   const int64_t me = mb + a.kchunk < M ? mb + a.kchunk : M;
   if (mb >= M) return;
   const int coleft = ((a.Cout + 3) / 4) * 4 - co0;     // dy may be a channel slice of a wider buffer: never read past it
-  SplitDyLoader<Cfg> la{a.dy + co0, a.ldy, coleft < Cfg::BM ? coleft : Cfg::BM, mb, me};
   const int cleft = ((sc.C + 3) / 4) * 4 - ci0;
-  SplitShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN,
-                              tap / a.KW - a.KH / 2, tap % a.KW - a.KW / 2, a.H, a.W, HW, mb, me};
+  const int dyy = tap / a.KW - a.KH / 2, dxx = tap % a.KW - a.KW / 2;
+  const int KT = (int)((me - mb + 31) / 32);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -704,8 +744,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.dbias != nullptr && blockIdx.x == 0;        // one x-tile per (co tile, pixel split) owns the bias
-  if (want_bias) split_mainloop_tn<Cfg, SplitDyLoader<Cfg>, SplitShiftedXLoader<Cfg>, true>(lds, (int)((me - mb + 31) / 32), la, lb, acc, colsum);
-  else split_mainloop_tn<Cfg>(lds, (int)((me - mb + 31) / 32), la, lb, acc);
+  if constexpr (BUF) {
+    // pixel mask: bit k of word w <=> pixel mb + 32 w + k exists and its (dy, dx)-shifted neighbour is inside the image
+    for (int i = threadIdx.x; i < KT * 32; i += 256) {
+      const int64_t m = mb + i;
+      bool ok = m < me;
+      if (ok) {
+        const int pix = (int)(m % HW), yy = pix / a.W + dyy, xx = pix % a.W + dxx;
+        ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      }
+      const unsigned long long bal = __ballot(ok);
+      if ((threadIdx.x & 63) == 0) { pixmask[i >> 5] = (unsigned)bal; pixmask[(i >> 5) + 1] = (unsigned)(bal >> 32); }
+    }
+    __syncthreads();
+    BufDyLoader<Cfg> la;
+    la.base = uni_ptr(a.dy + co0 + mb * a.ldy); la.ld4 = uni((unsigned)a.ldy * 4u); la.npix = (int)(me - mb);
+    const int cva = coleft < Cfg::BM ? coleft : Cfg::BM;
+#pragma unroll
+    for (int j = 0; j < BufDyLoader<Cfg>::NCH; ++j) {
+      const int e = threadIdx.x + 256 * j, k = e / (Cfg::BM / 4), c4 = e % (Cfg::BM / 4);
+      la.krow[j] = k; la.voff[j] = c4 * 4 < cva ? (unsigned)(k * a.ldy + c4 * 4) * 4u : FS_OOB;
+    }
+    BufShiftedXLoader<Cfg> lb;
+    lb.base = uni_ptr(sc.p + ci0 + (mb + dyy * a.W + dxx) * sc.ld); lb.ld4 = uni((unsigned)sc.ld * 4u); lb.mask = pixmask;
+    const int cvb = cleft < Cfg::BN ? cleft : Cfg::BN;
+#pragma unroll
+    for (int j = 0; j < BufShiftedXLoader<Cfg>::NCH; ++j) {
+      const int e = threadIdx.x + 256 * j, k = e / (Cfg::BN / 4), c4 = e % (Cfg::BN / 4);
+      lb.krow[j] = k; lb.voff[j] = c4 * 4 < cvb ? (unsigned)(k * sc.ld + c4 * 4) * 4u : FS_OOB;
+    }
+    if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
+    else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
+  } else {
+  SplitDyLoader<Cfg> la{a.dy + co0, a.ldy, coleft < Cfg::BM ? coleft : Cfg::BM, mb, me};
+  SplitShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN, dyy, dxx, a.H, a.W, HW, mb, me};
+  if (want_bias) split_mainloop_tn<Cfg, SplitDyLoader<Cfg>, SplitShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
+  else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
+  }
   if (want_bias) {
     // this thread's columns are co0 + 4*(tid % 32) .. +3; eight threads (tid / 32) share them
     float* part = reinterpret_cast<float*>(lds);
@@ -855,6 +930,7 @@ using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgM64 = SplitCfg<64, 128, 1, 4>;
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_wgrad_buf = 1;    // buffer-addressed loaders + pixel mask in the split weight-gradient kernel (key 8)
 int g_ktab_order = 0;   // experiment switch (key 6)
 int g_xcd_swizzle = 0;  // experiment switch (key 7)
 int g_conv_buf = 1;     // buffer-addressed loaders in the split conv kernels (key 5): 0 never, 1 on 64-row tiles, 2 always
@@ -942,6 +1018,7 @@ struct fsraft_conv_desc {
   float* aux1; int ld1;
   float* aux2; int ld2;
   int hid;
+  const float* pre; int ldpre;   // GRU epilogues: addend to the pre-activation (e.g. the context part of the conv), or NULL
 };
 
 extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
@@ -967,6 +1044,8 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   a.ndst = d->ndst; a.relu = d->relu; a.alpha = d->alpha;
   a.h = d->h; a.ldh = d->ldh; a.z = d->z; a.ldz = d->ldz; a.aux1 = d->aux1; a.ld1 = d->ld1; a.aux2 = d->aux2; a.ld2 = d->ld2;
   a.hid = d->hid;
+  a.pre = d->epi == EPI_PLAIN ? nullptr : d->pre; a.ldpre = d->ldpre;
+  if (a.pre && (d->ldpre % 4 != 0 || ((uintptr_t)d->pre & 15))) return FS_ERR_ARG;
   a.swz = g_xcd_swizzle;
   if (d->epi == EPI_ZR && (!d->h || !d->aux1 || !d->aux2 || d->hid * 2 != d->N)) return FS_ERR_ARG;
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
@@ -1009,6 +1088,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 3) g_conv_split = value;
   else if (key == 5) g_conv_buf = value;
   else if (key == 6) g_ktab_order = value;
+  else if (key == 8) g_wgrad_buf = value;
   else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;
@@ -1044,13 +1124,23 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   if (want < 1) want = 1;
   int64_t chunk = (M + want - 1) / want;
   if (chunk < 256) chunk = 256;
+  if (chunk > 32 * (WGRAD_MASK_WORDS - 2)) chunk = 32 * (WGRAD_MASK_WORDS - 2);   // pixel-mask capacity of the buffer-addressed kernel
   chunk = (chunk + 31) / 32 * 32;
   a.kchunk = (int)chunk;
   const int zs = (int)((M + chunk - 1) / chunk);
   dim3 grid(xt128, ytiles, zs);
   a.dbias = dbias;
-  if (!small_m && !t64 && g_wgrad_split == 1) { hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128>), grid, dim3(256), 0, stream, a); return fs_launch_status(); }
-  if (!small_m && !t64 && g_wgrad_split == 2) { hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S>), grid, dim3(256), 0, stream, a); return fs_launch_status(); }
+  const bool wbuf = g_wgrad_buf && chunk <= 32 * (WGRAD_MASK_WORDS - 2) && (int64_t)chunk * 4 * 2048 < 0x7fffffff;
+  if (!small_m && !t64 && g_wgrad_split == 1) {
+    if (wbuf) hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128>), grid, dim3(256), 0, stream, a);
+    return fs_launch_status();
+  }
+  if (!small_m && !t64 && g_wgrad_split == 2) {
+    if (wbuf) hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S>), grid, dim3(256), 0, stream, a);
+    return fs_launch_status();
+  }
   // the exact-fp32 kernels do not fuse the bias gradient: separate column-sum pass
   if (dbias) { const int rc = fsraft_col_sum(dy, ldy, M, Cout, dbias, 1.0f, stream); if (rc) return rc; }
   if (small_m) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg32>), grid, dim3(256), 0, stream, a);

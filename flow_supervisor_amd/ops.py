@@ -452,7 +452,7 @@ class Dst:
 
 
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
-                 aux1=None, aux2=None, hid=0, wpk_split=None):
+                 aux1=None, aux2=None, hid=0, wpk_split=None, pre=None):
     """srcs: list of V (concatenated along channels).  dsts: list of Dst.
     GRU epilogues (epi 2: z|r, epi 3: q) take h, z, aux buffers as [B,H,W,ld] tensors."""
     d = L.ConvDesc()
@@ -478,6 +478,8 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     if aux2 is not None:
         d.aux2 = aux2.data_ptr(); d.ld2 = aux2.shape[-1]
     d.hid = hid
+    if pre is not None:
+        d.pre = pre.data_ptr(); d.ldpre = pre.shape[-1]
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_conv_forward(ctypes.byref(d), L.stream()), "conv_forward")

@@ -93,6 +93,7 @@ typedef struct fsraft_conv_desc {
   int epi;                                                    /* 0 plain, 2 GRU z|r, 3 GRU q     */
   const float* h; int ldh; const float* z; int ldz;
   float* aux1; int ld1; float* aux2; int ld2; int hid;
+  const float* pre; int ldpre;                                /* epi 2/3: [M][ldpre] addend to the pre-activation, or NULL */
 } fsraft_conv_desc;
 
 int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);
