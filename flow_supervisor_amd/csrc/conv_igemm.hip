@@ -182,21 +182,27 @@ struct BufConvALoader {
   unsigned tapmask[NCH];                  // bit t: tap t of this thread's pixel row lies inside the image (0: row outside M)
   unsigned pofs[NCH];                     // pixel index of the row
   unsigned kq16;                          // byte offset of this thread's 16-byte column inside a 128-byte chunk row
-  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+  __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
     // kt is wave-uniform; saying so explicitly lets the table entry come in with s_load_dword and keeps everything
-    // derived from it (descriptor, SGPR offset) in scalar registers instead of behind a waterfall loop
+    // derived from it (descriptor, SGPR offset) in scalar registers -- once per tile, not once per chunk
     const unsigned e = ktab[__builtin_amdgcn_readfirstlane(kt)];
     const unsigned soff = (e & 0xffffu) << 4, tap = (e >> 16) & 15u, src = (e >> 20) & 3u, crem = (e >> 22) & 63u;
     const bool s1 = src >= 1, s2 = src >= 2;
     // (sums of two-way selects: a three-way select chain over kernel arguments becomes a scratch lookup table)
     const unsigned ldb = ld0x4 + (s1 ? ld1x4 - ld0x4 : 0u) + (s2 ? ld2x4 - ld1x4 : 0u);
-    const bool ok = ((tapmask[j] >> tap) & 1u) != 0 && kq16 < crem * 4u;
-    const unsigned voff = ok ? __umul24(pofs[j], ldb) + kq16 : FS_OOB;
     const float* bp = b0 + (s1 ? b1 - b0 : 0) + (s2 ? b2 - b1 : 0);
-    const unsigned nb = nb0 + (s1 ? nb1 - nb0 : 0u) + (s2 ? nb2 - nb1 : 0u);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(bp, nb), voff, soff, 0);
-    const f32x4 f = __builtin_bit_cast(f32x4, v);
-    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(bp, 0x7fffffffu);
+    const unsigned cok = kq16 < crem * 4u ? 1u : 0u;              // this lane's 16-byte column holds channels of the source
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      // branch-free: lanes whose tap falls outside the image (or whose column is padding) get bit 31 set in their
+      // offset, which fails the descriptor's range check and reads as zeros
+      const unsigned bad = (__builtin_amdgcn_ubfe(tapmask[j], tap, 1u) & cok) ^ 1u;
+      const unsigned voff = (bad << 31) | (__umul24(pofs[j], ldb) + kq16);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
     stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
@@ -208,12 +214,16 @@ struct BufWeightLoader {                  // pre-split packed weights through on
   static constexpr int NCH = Cfg::NCH_B, NREG = NCH * 4;
   const char* base; unsigned nbytes;
   unsigned voff[NCH];                     // row * row_bytes + 16 * part, or FS_OOB for rows outside the matrix
-  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
-    const int ku = __builtin_amdgcn_readfirstlane(kt);            // kt < 0: zero tile
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, nbytes), ku < 0 ? FS_OOB : voff[j],
-                                                          ku < 0 ? 0u : (unsigned)ku * 128u, 0);
-    const f32x4 f = __builtin_bit_cast(f32x4, v);
-    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+  __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);            // kt < 0: zero tile = a descriptor with no records
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ku < 0 ? 0u : nbytes);
+    const unsigned soff = ku < 0 ? 0u : (unsigned)ku * 128u;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], soff, 0);
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
     stage_copy<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
@@ -680,13 +690,18 @@ struct BufDyLoader {
   static constexpr int NCH = Cfg::NCH_A, NREG = NCH * 4;
   const float* base; unsigned ld4; int npix;
   unsigned voff[NCH]; int krow[NCH];
-  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+  __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
     const int ku = __builtin_amdgcn_readfirstlane(kt);
-    const bool ok = ku * 32 + krow[j] < npix;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, 0x7fffffffu), ok ? voff[j] : FS_OOB,
-                                                          (unsigned)ku * 32u * ld4, 0);
-    const f32x4 f = __builtin_bit_cast(f32x4, v);
-    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, 0x7fffffffu);
+    const unsigned soff = (unsigned)ku * 32u * ld4;
+    const int left = npix - ku * 32;                              // rows of this tile that exist
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const unsigned voffj = voff[j] | (krow[j] < left ? 0u : FS_OOB);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voffj, soff, 0);
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    }
   }
 };
 template <class Cfg>
@@ -694,14 +709,18 @@ struct BufShiftedXLoader {
   static constexpr int NCH = Cfg::NCH_B, NREG = NCH * 4;
   const float* base; unsigned ld4; const unsigned* mask;       // mask: LDS, bit k of word kt = pixel mb + 32 kt + k usable
   unsigned voff[NCH]; int krow[NCH];
-  __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
+  __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
     const int ku = __builtin_amdgcn_readfirstlane(kt);
     const unsigned w = __builtin_amdgcn_readfirstlane(mask[ku]);
-    const bool ok = ((w >> krow[j]) & 1u) != 0;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, 0x7fffffffu), ok ? voff[j] : FS_OOB,
-                                                          (unsigned)ku * 32u * ld4, 0);
-    const f32x4 f = __builtin_bit_cast(f32x4, v);
-    r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, 0x7fffffffu);
+    const unsigned soff = (unsigned)ku * 32u * ld4;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const unsigned voffj = voff[j] | ((__builtin_amdgcn_ubfe(w, (unsigned)krow[j], 1u) ^ 1u) << 31);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voffj, soff, 0);
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    }
   }
 };
 
@@ -928,7 +947,7 @@ using Cfg6464K16 = GemmCfg<64, 64, 16, 2, 2, 2, 2>;  // 17 KB of LDS: 8 workgrou
 using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 
 using SCfg128 = SplitCfg<128, 128, 2, 2>;
-using SCfgM64 = SplitCfg<64, 128, 1, 4>;
+using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
 int g_wgrad_buf = 1;    // buffer-addressed loaders + pixel mask in the split weight-gradient kernel (key 8)
 int g_ktab_order = 0;   // experiment switch (key 6)
@@ -937,7 +956,7 @@ int g_conv_buf = 1;     // buffer-addressed loaders in the split conv kernels (k
 int g_conv_split = 1;   // 0: exact fp32 MFMA; 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (key 3)
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
 int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
-int g_wgrad_blocks = 1024;  // target workgroup count of the pixel split              (key 2)
+int g_wgrad_blocks = 512;   // target workgroup count of the pixel split (key 2); measured 256: 12.9, 512: 11.5, 1024: 12.9, 2048: 14.1 ms/step
 using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
 // weight-gradient tiles: LDS images are filled with float4 rows, so pitches stay multiples of 4
 using WCfg128 = GemmCfg<128, 128, 32, 2, 2, 0, 0>;

@@ -20,15 +20,37 @@
 // Chunk c of a 256-thread tile is e = tid + 256 c: row e / 8, sixteen-byte column e % 8.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM_, int BN_, int WM_, int WN_, int NBUF_ = 2>
+// SWZ_ = true: rows are stored unpadded (128 B) and the eight 16-byte slots of row r are permuted by
+// slot ^ ((r >> 1) & 7) instead -- the 16 rows of a ds_read_b128 lane group then still cover all 64 banks once,
+// and a 64x128 tile pair needs 48 KB instead of 54 KB, so THREE workgroups fit the 160 KB of a CU instead of two.
+// Loaders may provide fetch_tile(kt, regs) -- all chunks of a k-tile in one call, so that per-tile wave-uniform work
+// (table lookup, descriptor, SGPR offset) is done once instead of once per 16-byte chunk; otherwise the main loops
+// call fetch_chunk(kt, regs, c) for every chunk.
+template <class L, class = void>
+struct has_fetch_tile : std::false_type {};
+template <class L>
+struct has_fetch_tile<L, std::void_t<decltype(&L::fetch_tile)>> : std::true_type {};
+template <class L, int N>
+__device__ __forceinline__ void fetch_all(const L& l, int kt, float (&r)[N]) {
+  if constexpr (has_fetch_tile<L>::value) {
+    l.fetch_tile(kt, r);
+  } else {
+#pragma unroll
+    for (int c = 0; c < L::NCH; ++c) l.fetch_chunk(kt, r, c);
+  }
+}
+
+template <int BM_, int BN_, int WM_, int WN_, int NBUF_ = 2, bool SWZ_ = false>
 struct SplitCfg {
   static constexpr int NBUF = NBUF_;                              // 2: double-buffered LDS; 1: one image, two barriers per k-tile
   static constexpr int BM = BM_, BN = BN_, BK = 32, WM = WM_, WN = WN_;
-  static constexpr int PITCH = 144;                               // bytes per row
+  static constexpr bool SWZ = SWZ_;
+  static constexpr int PITCH = SWZ_ ? 128 : 144;                  // bytes per row
   static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
   static constexpr int A_BYTES = BM_ * PITCH, B_BYTES = BN_ * PITCH;
   static constexpr int STAGE = A_BYTES + B_BYTES;
@@ -59,19 +81,24 @@ __device__ __forceinline__ void split4(const float* r, uint2& hi, uint2& lo) {
   lo = make_uint2(l[0], l[1]);
 }
 
+// byte offset of 16-byte slot `slot` (0..7: hi k 0-7, 8-15, 16-23, 24-31, then the same for lo) of row `row`
+template <int PITCH>
+__device__ __forceinline__ int slot_offset(int row, int slot) {
+  return PITCH == 128 ? row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) : row * PITCH + (slot << 4);
+}
 // staging of one 16-byte chunk e (row = e / 8, k = 4 * (e % 8)) of fp32 data into a [row][hi 32 | lo 32] image
 template <int PITCH>
 __device__ __forceinline__ void stage_convert(char* tile, int e, const float* r) {
   uint2 hi, lo;
   split4(r, hi, lo);
-  char* p = tile + (e >> 3) * PITCH + (e & 7) * 8;
-  *reinterpret_cast<uint2*>(p) = hi;
-  *reinterpret_cast<uint2*>(p + 64) = lo;
+  const int row = e >> 3, kq = e & 7;                 // 8 bytes of hi at slot kq / 2, half kq % 2; lo four slots further
+  *reinterpret_cast<uint2*>(tile + slot_offset<PITCH>(row, kq >> 1) + (kq & 1) * 8) = hi;
+  *reinterpret_cast<uint2*>(tile + slot_offset<PITCH>(row, 4 + (kq >> 1)) + (kq & 1) * 8) = lo;
 }
 // staging of pre-split data: chunk e is 16 bytes number (e % 8) of row e / 8's 128-byte [hi | lo] record
 template <int PITCH>
 __device__ __forceinline__ void stage_copy(char* tile, int e, const float* r) {
-  *reinterpret_cast<f32x4*>(tile + (e >> 3) * PITCH + (e & 7) * 16) = f32x4{r[0], r[1], r[2], r[3]};
+  *reinterpret_cast<f32x4*>(tile + slot_offset<PITCH>(e >> 3, e & 7)) = f32x4{r[0], r[1], r[2], r[3]};
 }
 
 #ifdef FSRAFT_ABLATE
@@ -111,10 +138,8 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
     // past the end: A re-reads the last tile, B is asked for tile -1, which every B loader answers with zeros --
     // so a tile beyond K contributes nothing and the k-loop below needs no tail conditions
     const int ka = kt < KT ? kt : KT - 1, kb = kt < KT ? kt : (STRAIGHT ? -1 : KT - 1);
-#pragma unroll
-    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(ka, ra, c);
-#pragma unroll
-    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(kb, rb, c);
+    fetch_all(la, ka, ra);
+    fetch_all(lb, kb, rb);
   };
   auto stage = [&](char* dst, const float (&ra)[LA::NREG], const float (&rb)[LB::NREG]) {
     if (abl & 1) return;
@@ -125,20 +150,25 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
   };
   auto compute = [&](const char* cur) {
     if (abl & 4) return;
-    const char* As = cur + (wm * (Cfg::TM * 32) + l31) * Cfg::PITCH + lh * 16;
-    const char* Bs = cur + Cfg::A_BYTES + (wn * (Cfg::TN * 32) + l31) * Cfg::PITCH + lh * 16;
+    // this lane's row in the A / B images; slot of (k-step s, hi/lo) = 2 s + lh (+ 4 for lo).  Rows mt*32 apart share
+    // (row >> 1) & 7, so the swizzled slot offsets are per-lane constants
+    const int ra = wm * (Cfg::TM * 32) + l31, rb = wn * (Cfg::TN * 32) + l31;
+    const char* As = cur + ra * Cfg::PITCH;
+    const char* Bs = cur + Cfg::A_BYTES + rb * Cfg::PITCH;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN];
+      const int oah = slot_offset<Cfg::PITCH>(ra, 2 * s + lh) - ra * Cfg::PITCH, oal = slot_offset<Cfg::PITCH>(ra, 4 + 2 * s + lh) - ra * Cfg::PITCH;
+      const int obh = slot_offset<Cfg::PITCH>(rb, 2 * s + lh) - rb * Cfg::PITCH, obl = slot_offset<Cfg::PITCH>(rb, 4 + 2 * s + lh) - rb * Cfg::PITCH;
 #pragma unroll
       for (int mt = 0; mt < Cfg::TM; ++mt) {
-        ah[mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * Cfg::PITCH + s * 32);
-        al[mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * Cfg::PITCH + s * 32 + 64);
+        ah[mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * Cfg::PITCH + oah);
+        al[mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * Cfg::PITCH + oal);
       }
 #pragma unroll
       for (int nt = 0; nt < Cfg::TN; ++nt) {
-        bh[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + s * 32);
-        bl[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + s * 32 + 64);
+        bh[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + obh);
+        bl[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + obl);
       }
       if (abl & 2) {      // keep the fragment reads alive without issuing MFMAs
 #pragma unroll
@@ -261,10 +291,8 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
       stage_convert_kmajor<Cfg::BN, Cfg::PB, Cfg::B_PLANE>(dst + 2 * Cfg::A_PLANE, threadIdx.x + 256 * c, rb + 4 * c);
   };
   if (KT > 0) {
-#pragma unroll
-    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(0, ra, c);
-#pragma unroll
-    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(0, rb, c);
+    fetch_all(la, 0, ra);
+    fetch_all(lb, 0, rb);
     stage(lds, true);
   }
   __syncthreads();
@@ -272,10 +300,8 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
     char* cur = lds + (Cfg::NBUF == 2 ? (kt & 1) * Cfg::STAGE : 0);
     char* nxt = lds + (Cfg::NBUF == 2 ? ((kt + 1) & 1) * Cfg::STAGE : 0);
     const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
-#pragma unroll
-    for (int c = 0; c < LA::NCH; ++c) la.fetch_chunk(ktn, ra, c);
-#pragma unroll
-    for (int c = 0; c < LB::NCH; ++c) lb.fetch_chunk(ktn, rb, c);
+    fetch_all(la, ktn, ra);
+    fetch_all(lb, ktn, rb);
     // this lane's address inside a plane: row (8*lh + q) of the k-step, columns base + 16*gb + 4*p4
     const char* As = cur + (8 * lh + q) * Cfg::PA + (wm * (Cfg::TM * 32) + 16 * gb + 4 * p4) * 2;
     const char* Bs = cur + 2 * Cfg::A_PLANE + (8 * lh + q) * Cfg::PB + (wn * (Cfg::TN * 32) + 16 * gb + 4 * p4) * 2;
