@@ -947,8 +947,10 @@ using Cfg6464K16 = GemmCfg<64, 64, 16, 2, 2, 2, 2>;  // 17 KB of LDS: 8 workgrou
 using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 
 using SCfg128 = SplitCfg<128, 128, 2, 2>;
+using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_conv_n256 = 0;    // 64x256 tiles for layers whose N fills them (key 9); measured slower than 64x128 (zr 139 vs 119 us, hd 182 vs 125 us)
 int g_wgrad_buf = 1;    // buffer-addressed loaders + pixel mask in the split weight-gradient kernel (key 8)
 int g_ktab_order = 0;   // experiment switch (key 6)
 int g_xcd_swizzle = 0;  // experiment switch (key 7)
@@ -992,7 +994,7 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   dim3 grid(ceil_div(a.N, Cfg::BN), ceil_div(M, Cfg::BM));
   ConvArgsT t;
   // buffer-addressed loaders + branch-free k-loop: measured faster on the 64-row tiles, slower on 128x128
-  const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64);
+  const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256;
   if (buf && build_ktab(a, t)) {
     if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, true>), grid, dim3(256), 0, s, t);
     else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, true>), grid, dim3(256), 0, s, t);
@@ -1081,6 +1083,9 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // the 128x128 kernel needs 131 / 157 / 87 / 78 / 45 us); 128x128 stays selectable (key 3 = 4) and is the
     // fallback for shapes the k-tile table cannot describe.
     const bool narrow = g_conv_buf != 0 || (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
+    if (g_conv_split == 5 || (g_conv_split == 1 && g_conv_n256 && d->N >= 256 &&
+                              ceil_div(d->N, 256) * 256 <= ceil_div(d->N, 128) * 128))
+      return launch_conv_split<SCfgN256>(a, d->epi, stream);
     if (g_conv_split == 3) return launch_conv_split<SCfgM64>(a, d->epi, stream);
     if (g_conv_split == 4) return launch_conv_split<SCfg128>(a, d->epi, stream);
     return narrow ? launch_conv_split<SCfgM64>(a, d->epi, stream) : launch_conv_split<SCfg128>(a, d->epi, stream);
@@ -1108,6 +1113,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 5) g_conv_buf = value;
   else if (key == 6) g_ktab_order = value;
   else if (key == 8) g_wgrad_buf = value;
+  else if (key == 9) g_conv_n256 = value;
   else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;
