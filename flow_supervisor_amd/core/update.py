@@ -87,6 +87,8 @@ def _pad4(c):
 # measured: +2 % at best, and it makes per-kernel event timing meaningless (kernels of the two streams
 # overlap), so weight gradients stay on the main stream unless asked for
 _WGRAD_SIDE_STREAM = os.environ.get("FSRAFT_WGRAD_STREAM", "0") != "0"
+# one weight-gradient launch per layer per step (all iterations' operands stashed) instead of one per iteration
+_DEFER_WGRAD = os.environ.get("FSRAFT_DEFER_WGRAD", "1") != "0"
 
 
 # --------------------------------------------------------------------------- layer table
@@ -208,6 +210,13 @@ class _Engine:
         if _WGRAD_SIDE_STREAM and st.arena is not None:
             torch.cuda.current_stream(st.arena.device).wait_stream(self._side_stream(st.arena.device))
         st.keep = None
+        if st.pending:
+            dW, dB = self._grad_arena(st, P, params[0].device)
+            for (k, B, H, W), lst in st.pending.items():
+                l = self.layers[k]
+                ops.conv_wgrad_multi([dy for dy, _ in lst], [srcs for _, srcs in lst], dW[k], B, H, W, l.kh, l.kw,
+                                     dbias=dB[k])
+            st.pending = {}
         byname = dict(zip(self.pnames, params))
         grads = {}
         for k in self.order:
@@ -414,6 +423,11 @@ class _Engine:
 
         def wgrad(k, dy, srcs):
             l = self.layers[k]
+            if st.pending is not None:
+                # deferred: dW = sum over the iterations of a step is one launch per layer, issued when the arena is
+                # unpacked (the operands stay alive, and are not written again, until then)
+                st.pending.setdefault((k, B, H, W), []).append((dy, srcs))
+                return
             if side is None:
                 ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
                 return
@@ -467,7 +481,7 @@ class _Engine:
             if k in cst.dsum:
                 ops.axpby_(g, cst.dsum[k], 1.0, 1.0)
             else:
-                cst.dsum[k] = g          # first contribution: adopt the buffer (it is not touched again by this call)
+                cst.dsum[k] = g.clone()  # (g itself stays untouched: its weight-gradient GEMM is deferred)
 
         for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
             dzr = buf(2 * hid)
@@ -569,11 +583,12 @@ class _CtxFn(torch.autograd.Function):
 
 
 class _ParamState:
-    __slots__ = ("key", "anchor", "arena", "dW", "dB", "consumed", "zero", "keep")
+    __slots__ = ("key", "anchor", "arena", "dW", "dB", "consumed", "zero", "keep", "pending")
 
     def __init__(self, key):
         self.key, self.anchor, self.arena, self.dW, self.dB, self.consumed, self.zero = key, None, None, None, None, False, None
         self.keep = None
+        self.pending = {} if (key is not None and _DEFER_WGRAD) else None     # frozen-parameter states compute nothing
 
 
 class _ParamFn(torch.autograd.Function):

@@ -591,6 +591,17 @@ struct WgradArgs {
   float* dbias;                            // optional: dbias[co] += sum_pixels dY[pixel][co] (fused in the split kernel)
 };
 
+// Several (dY, X) pairs of identical shape in one launch -- the 12 iterations of a step: dW = sum_t dY_t^T X_t is one
+// reduction over 12 x M pixels, so the per-launch prologue / atomic epilogue is paid once per step instead of once
+// per iteration.  blockIdx.z = segment * zs + pixel split.  The pointer tables are read from the kernarg segment.
+constexpr int WGRAD_MAX_SEG = 16;
+struct WgradArgsM {
+  WgradArgs a;
+  int nseg, zs;
+  const float* dys[WGRAD_MAX_SEG];
+  const float* srcs[3][WGRAD_MAX_SEG];
+};
+
 template <class Cfg>
 struct ShiftedXLoader {                    // Bs[k = pixel][n = ci] <- X[pixel + off][ci0 + n]
   static constexpr int BN = Cfg::BN, BK = Cfg::BK, LD = Cfg::LDB;
@@ -727,10 +738,13 @@ struct BufShiftedXLoader {
 using SWCfg128 = SplitTnCfg<128, 128, 2, 2, 2>;
 using SWCfg128S = SplitTnCfg<128, 128, 2, 2, 1>;
 
-template <class Cfg, bool BUF = false>
-__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
+template <class Cfg, bool BUF = false, bool MULTI = false>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const std::conditional_t<MULTI, WgradArgsM, WgradArgs> args) {
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
   __shared__ unsigned pixmask[BUF ? WGRAD_MASK_WORDS : 1];
+  const WgradArgs& a = [&]() -> const WgradArgs& { if constexpr (MULTI) return args.a; else return args; }();
+  int zblock = blockIdx.z, seg = 0;
+  if constexpr (MULTI) { seg = zblock / args.zs; zblock -= seg * args.zs; seg = __builtin_amdgcn_readfirstlane(seg); }
   const int HW = a.H * a.W;
   const int64_t M = (int64_t)a.B * HW;
   const int taps = a.KH * a.KW;
@@ -741,13 +755,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
     t -= taps * ct;
     kofs += taps * ((a.src[s].C + 31) / 32) * 32;
   }
-  const Src sc = s == 0 ? a.src[0] : s == 1 ? a.src[1] : a.src[2];
+  Src sc = s == 0 ? a.src[0] : s == 1 ? a.src[1] : a.src[2];
+  const float* dyp = a.dy;
+  if constexpr (MULTI) {       // this segment's tensors, read from the kernarg tables with a uniform index
+    typedef const float* fptr;
+    const auto* karg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    dyp = ((const fptr __attribute__((address_space(4)))*)(karg + offsetof(WgradArgsM, dys)))[seg];
+    sc.p = ((const fptr __attribute__((address_space(4)))*)(karg + offsetof(WgradArgsM, srcs)))[s * WGRAD_MAX_SEG + seg];
+  }
   const int ct = (sc.C + Cfg::BN - 1) / Cfg::BN;
   const int tap = t / ct, ci0 = (t % ct) * Cfg::BN;
   const int cpad = ((sc.C + 31) / 32) * 32;
   kofs += tap * cpad + ci0;
   const int co0 = blockIdx.y * Cfg::BM;
-  const int64_t mb = (int64_t)blockIdx.z * a.kchunk;
+  const int64_t mb = (int64_t)zblock * a.kchunk;
   const int64_t me = mb + a.kchunk < M ? mb + a.kchunk : M;
   if (mb >= M) return;
   const int coleft = ((a.Cout + 3) / 4) * 4 - co0;     // dy may be a channel slice of a wider buffer: never read past it
@@ -777,7 +798,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
     }
     __syncthreads();
     BufDyLoader<Cfg> la;
-    la.base = uni_ptr(a.dy + co0 + mb * a.ldy); la.ld4 = uni((unsigned)a.ldy * 4u); la.npix = (int)(me - mb);
+    la.base = uni_ptr(dyp + co0 + mb * a.ldy); la.ld4 = uni((unsigned)a.ldy * 4u); la.npix = (int)(me - mb);
     const int cva = coleft < Cfg::BM ? coleft : Cfg::BM;
 #pragma unroll
     for (int j = 0; j < BufDyLoader<Cfg>::NCH; ++j) {
@@ -795,7 +816,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgradArgs a) {
     if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
     else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
   } else {
-  SplitDyLoader<Cfg> la{a.dy + co0, a.ldy, coleft < Cfg::BM ? coleft : Cfg::BM, mb, me};
+  SplitDyLoader<Cfg> la{dyp + co0, a.ldy, coleft < Cfg::BM ? coleft : Cfg::BM, mb, me};
   SplitShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN, dyy, dxx, a.H, a.W, HW, mb, me};
   if (want_bias) split_mainloop_tn<Cfg, SplitDyLoader<Cfg>, SplitShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
   else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
@@ -950,6 +971,7 @@ using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_wgrad_multi = 1;  // one weight-gradient launch per layer per step over all stashed iterations (key 10)
 int g_conv_n256 = 0;    // 64x256 tiles for layers whose N fills them (key 9); measured slower than 64x128 (zr 139 vs 119 us, hd 182 vs 125 us)
 int g_wgrad_buf = 1;    // buffer-addressed loaders + pixel mask in the split weight-gradient kernel (key 8)
 int g_ktab_order = 0;   // experiment switch (key 6)
@@ -1114,6 +1136,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 6) g_ktab_order = value;
   else if (key == 8) g_wgrad_buf = value;
   else if (key == 9) g_conv_n256 = value;
+  else if (key == 10) g_wgrad_multi = value;
   else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;
@@ -1172,6 +1195,65 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   else if (t64) hipLaunchKernelGGL((conv_wgrad_kernel<WCfg6464>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<WCfg128>), grid, dim3(256), 0, stream, a);
   return fs_launch_status();
+}
+
+// nseg (dY, X) pairs of identical shape in one launch; src[seg * nsrc + s].  Falls back to one launch per segment when
+// the buffer-addressed split kernel cannot take the shape.
+extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy, int Cout, const float* const* src,
+                                       const int* srcC, const int* srcld, int nsrc, float* dwpk, float* dbias, int B,
+                                       int H, int W, int KH, int KW, hipStream_t stream) {
+  if (!dy || !src || !dwpk || nseg < 1 || nsrc < 1 || nsrc > 3 || ldy % 4 != 0) return FS_ERR_ARG;
+  const int64_t M = (int64_t)B * H * W;
+  const bool fast = g_wgrad_multi && nseg > 1 && Cout > 32 && g_wgrad_tile != 3 && g_wgrad_split == 2 && g_wgrad_buf;
+  for (int base = 0; base < nseg; base += WGRAD_MAX_SEG) {
+    const int n = nseg - base < WGRAD_MAX_SEG ? nseg - base : WGRAD_MAX_SEG;
+    if (!fast || n == 1) {
+      for (int i = 0; i < n; ++i) {
+        const int rc = fsraft_conv_wgrad(dy[base + i], ldy, Cout, src + (size_t)(base + i) * nsrc, srcC, srcld, nsrc, dwpk,
+                                         dbias, B, H, W, KH, KW, stream);
+        if (rc) return rc;
+      }
+      continue;
+    }
+    WgradArgsM m{};
+    WgradArgs& a = m.a;
+    a.dy = dy[base]; a.ldy = ldy; a.Cout = Cout;
+    int xt128 = 0;
+    for (int s = 0; s < 3; ++s) {
+      a.src[s] = Src{s < nsrc ? src[(size_t)base * nsrc + s] : src[(size_t)base * nsrc], s < nsrc ? srcC[s] : 0, s < nsrc ? srcld[s] : 4};
+      if (s < nsrc) {
+        if (srcld[s] % 4 != 0) return FS_ERR_ARG;
+        xt128 += KH * KW * ceil_div(srcC[s], 128);
+      }
+    }
+    for (int i = 0; i < n; ++i) {
+      if (!dy[base + i]) return FS_ERR_ARG;
+      m.dys[i] = dy[base + i];
+      for (int s = 0; s < nsrc; ++s) {
+        if (!src[(size_t)(base + i) * nsrc + s]) return FS_ERR_ARG;
+        m.srcs[s][i] = src[(size_t)(base + i) * nsrc + s];
+      }
+    }
+    a.nsrc = nsrc; a.dwpk = dwpk; a.Ktot = conv_ktot(srcC, nsrc, KH * KW);
+    a.B = B; a.H = H; a.W = W; a.KH = KH; a.KW = KW; a.dbias = dbias;
+    const int ytiles = ceil_div(Cout, 128);
+    // ~g_wgrad_blocks workgroups in total, a whole number of pixel splits per segment
+    int64_t zs = (g_wgrad_blocks + (int64_t)xt128 * ytiles * n - 1) / ((int64_t)xt128 * ytiles * n);
+    if (zs < 1) zs = 1;
+    int64_t chunk = (M + zs - 1) / zs;
+    if (chunk < 256) chunk = 256;
+    if (chunk > 32 * (WGRAD_MASK_WORDS - 2)) chunk = 32 * (WGRAD_MASK_WORDS - 2);
+    chunk = (chunk + 31) / 32 * 32;
+    if ((int64_t)chunk * 4 * 2048 >= 0x7fffffff) return FS_ERR_ARG;
+    a.kchunk = (int)chunk;
+    m.zs = (int)((M + chunk - 1) / chunk);
+    m.nseg = n;
+    dim3 grid(xt128, ytiles, m.zs * n);
+    hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S, true, true>), grid, dim3(256), 0, stream, m);
+    const int rc = fs_launch_status();
+    if (rc) return rc;
+  }
+  return FS_OK;
 }
 
 // mode 0: OIHW -> forward packed; mode 1: OIHW -> data-gradient packed (rows = Cin);

@@ -364,6 +364,7 @@ template <int R>
 int dispatch_fwd(int qb, const Pyr& pyr, const Coords& co, float* out, int nhwc, int64_t nq, int HW, hipStream_t s) {
   if (nhwc && g_lookup_cl) {
     if (qb == 8 && g_lookup_nt == 128) return launch_fwd_cl<R, 8, 128>(pyr, co, out, nq, HW, s);
+    if (qb == 8 && g_lookup_nt == 320) return launch_fwd_cl<R, 8, 320>(pyr, co, out, nq, HW, s);
     if (qb == 8) return launch_fwd_cl<R, 8>(pyr, co, out, nq, HW, s);
     if (qb == 32) return launch_fwd_cl<R, 32>(pyr, co, out, nq, HW, s);
     return launch_fwd_cl<R, 16>(pyr, co, out, nq, HW, s);
@@ -376,6 +377,7 @@ template <int R>
 int dispatch_bwd(int qb, const Pyr& pyr, const Coords& co, const float* dout, int nhwc, int64_t nq, int HW, hipStream_t s) {
   if (nhwc && g_lookup_cl) {
     if (qb == 8 && g_lookup_nt == 128) return launch_bwd_cl<R, 8, 128>(pyr, co, dout, nq, HW, s);
+    if (qb == 8 && g_lookup_nt == 320) return launch_bwd_cl<R, 8, 320>(pyr, co, dout, nq, HW, s);
     if (qb == 8) return launch_bwd_cl<R, 8>(pyr, co, dout, nq, HW, s);
     if (qb == 32) return launch_bwd_cl<R, 32>(pyr, co, dout, nq, HW, s);
     return launch_bwd_cl<R, 16>(pyr, co, dout, nq, HW, s);
@@ -403,6 +405,7 @@ bool fill_pyr(Pyr& pyr, float* const* levels, int num_levels, int H, int W) {
 
 extern "C" int fsraft_set_lookup_qb(int qb) {
   g_lookup_nt = 256;
+  if (qb >= 300) { g_lookup_nt = 320; qb -= 300; }      // 8 queries x 4 levels x 10 rows = 320 row loads: one per thread
   if (qb >= 200) { g_lookup_nt = 128; qb -= 200; }
   g_lookup_cl = qb < 100;
   if (qb >= 100) qb -= 100;

@@ -502,6 +502,22 @@ def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW, dbias=None):
         TIMER.end("conv_wgrad", e0w, 2.0 * B * H * W * dy.C * cin * KH * KW, 4.0 * B * H * W * (cin + dy.C))
 
 
+def conv_wgrad_multi(dys, srcs, dwpk, B, H, W, KH, KW, dbias=None):
+    """One launch for several (dy, srcs) pairs of identical shape: dwpk += sum_t dy_t^T im2col(srcs_t).
+    dys: list of V; srcs: list (same length) of lists of V."""
+    n, nsrc = len(dys), len(srcs[0])
+    dy0 = dys[0]
+    a_dy = (ctypes.c_void_p * n)(*[v.ptr for v in dys])
+    a_src = (ctypes.c_void_p * (n * nsrc))(*[v.ptr for sl in srcs for v in sl])
+    e0w = TIMER.begin() if TIMER else None
+    L.check(_lib().fsraft_conv_wgrad_multi(ctypes.cast(a_dy, L._PP), n, dy0.ld, dy0.C, ctypes.cast(a_src, L._PP),
+                                           L.int_array([v.C for v in srcs[0]]), L.int_array([v.ld for v in srcs[0]]), nsrc,
+                                           L.ptr(dwpk), L.ptr(dbias), B, H, W, KH, KW, L.stream()), "conv_wgrad_multi")
+    if TIMER:
+        cin = sum(v.C for v in srcs[0])
+        TIMER.end("conv_wgrad", e0w, 2.0 * n * B * H * W * dy0.C * cin * KH * KW, 4.0 * n * B * H * W * (cin + dy0.C))
+
+
 def col_sum_v(v, out, scale=1.0):
     M = v.t.numel() // v.ld
     L.check(_lib().fsraft_col_sum(ctypes.c_void_p(v.ptr), v.ld, M, v.C, L.ptr(out), float(scale), L.stream()), "col_sum")

@@ -102,6 +102,11 @@ int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream);
 int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
                       const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W, int KH, int KW,
                       hipStream_t stream);
+/* The same reduction over nseg (dY, X) pairs of identical shape -- the iterations of one training step -- in one launch:
+ * dwpk += sum_t dY_t^T im2col(X_t).  src[t * nsrc + s] is source s of pair t. */
+int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy, int Cout, const float* const* src,
+                            const int* srcC, const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W,
+                            int KH, int KW, hipStream_t stream);
 /* mode 0: OIHW -> packed forward; 1: OIHW -> packed data-gradient; 2: packed -> OIHW (+=);
  * modes 10 / 11: as 0 / 1 but every 32-k run stored as [32 hi | 32 lo] bf16 (split-bf16 GEMM core) */
 int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,

@@ -14,7 +14,7 @@ dlv = [torch.zeros_like(l) for l in levels]
 nq = B * H * W
 fwd_b = 4.0 * nq * (400 + 2 + 324); bwd_b = 4.0 * nq * (324 + 2 + 800)
 for nhwc in (True, False):
-    for qb in ((8, 16, 208) if nhwc else (8, 32)):
+    for qb in ((8, 16, 208, 308) if nhwc else (8, 32)):
         _lib.load().fsraft_set_lookup_qb(qb)
         out = ops.corr_lookup_fwd(levels, coords, r, nhwc=nhwc)
         g = torch.randn_like(out)
