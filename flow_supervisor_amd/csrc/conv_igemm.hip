@@ -971,6 +971,7 @@ using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_wgrad_blocks_multi = 2048;   // workgroup target of the multi-segment launch (key 11); measured 512: 9.0, 1024: 8.5, 2048: 8.35 ms/step
 int g_wgrad_multi = 1;  // one weight-gradient launch per layer per step over all stashed iterations (key 10)
 int g_conv_n256 = 0;    // 64x256 tiles for layers whose N fills them (key 9); measured slower than 64x128 (zr 139 vs 119 us, hd 182 vs 125 us)
 int g_wgrad_buf = 1;    // buffer-addressed loaders + pixel mask in the split weight-gradient kernel (key 8)
@@ -1137,6 +1138,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 8) g_wgrad_buf = value;
   else if (key == 9) g_conv_n256 = value;
   else if (key == 10) g_wgrad_multi = value;
+  else if (key == 11) g_wgrad_blocks_multi = value;
   else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;
@@ -1238,7 +1240,7 @@ extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy
     a.B = B; a.H = H; a.W = W; a.KH = KH; a.KW = KW; a.dbias = dbias;
     const int ytiles = ceil_div(Cout, 128);
     // ~g_wgrad_blocks workgroups in total, a whole number of pixel splits per segment
-    int64_t zs = (g_wgrad_blocks + (int64_t)xt128 * ytiles * n - 1) / ((int64_t)xt128 * ytiles * n);
+    int64_t zs = (g_wgrad_blocks_multi + (int64_t)xt128 * ytiles * n - 1) / ((int64_t)xt128 * ytiles * n);
     if (zs < 1) zs = 1;
     int64_t chunk = (M + zs - 1) / zs;
     if (chunk < 256) chunk = 256;
