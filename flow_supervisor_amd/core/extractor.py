@@ -5,6 +5,18 @@ pytorch/core/extractor.py are reproduced so reference checkpoints load (state_di
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv_norm(conv, norm, x):
+    """norm(conv(x)).  A per-channel constant added before a non-affine InstanceNorm is removed again by its mean
+    subtraction, so in that case the convolution runs without its bias: same output (to rounding), one bias-add
+    kernel less forward and one [N,H,W] reduction less backward per convolution.  The bias then receives no
+    gradient (mathematically it is exactly zero; the flat gradient buffer of parallel.FlatGradients keeps a zero
+    for it, so the optimizer treats it as the reference does)."""
+    if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats and conv.bias is not None:
+        return norm(F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups))
+    return norm(conv(x))
 
 
 def _make_norm(kind, ch, groups):
@@ -47,9 +59,9 @@ class _Block(nn.Module):
     def forward(self, x):
         y = x
         for i in range(1, self.n + 1):
-            y = self.relu(getattr(self, f"norm{i}")(getattr(self, f"conv{i}")(y)))
+            y = self.relu(_conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y))
         if self.downsample is not None:
-            x = self.downsample(x)
+            x = _conv_norm(self.downsample[0], self.downsample[1], x)
         return self.relu(x + y)
 
 
@@ -90,7 +102,7 @@ class _Encoder(nn.Module):
         if pair:
             n = x[0].shape[0]
             x = torch.cat(x, dim=0)
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.relu1(_conv_norm(self.conv1, self.norm1, x))
         x = self.layer3(self.layer2(self.layer1(x)))
         x = self.conv2(x)
         if self.training and self.dropout is not None:
