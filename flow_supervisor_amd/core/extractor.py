@@ -8,15 +8,86 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-def _conv_norm(conv, norm, x):
-    """norm(conv(x)).  A per-channel constant added before a non-affine InstanceNorm is removed again by its mean
-    subtraction, so in that case the convolution runs without its bias: same output (to rounding), one bias-add
-    kernel less forward and one [N,H,W] reduction less backward per convolution.  The bias then receives no
-    gradient (mathematically it is exactly zero; the flat gradient buffer of parallel.FlatGradients keeps a zero
-    for it, so the optimizer treats it as the reference does)."""
-    if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats and conv.bias is not None:
-        return norm(F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups))
-    return norm(conv(x))
+class _InstNormRelu(torch.autograd.Function):
+    """relu?(instance_norm(x)) for NCHW fp32 on the fsraft kernels (two passes over the data each way)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, relu):
+        from .. import _lib as L
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(N * C, 2, device=x.device, dtype=torch.float32)
+        L.check(L.load().fsraft_inorm_relu_fwd(L.ptr(x), L.ptr(y), L.ptr(stats), N * C, H * W, float(eps), int(relu),
+                                               L.stream()), "inorm_relu_fwd")
+        ctx.save_for_backward(x, stats)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib as L
+        x, stats = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.load().fsraft_inorm_relu_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(dx), N * C, H * W, int(ctx.relu),
+                                               L.stream()), "inorm_relu_bwd")
+        return dx, None, None
+
+
+class _FrozenBNRelu(torch.autograd.Function):
+    """relu?(batch_norm(x)) with running statistics (eval mode / freeze_bn): y = x * scale[c] + shift[c]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rm, rv, eps, relu):
+        from .. import _lib as L
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        rs = torch.rsqrt(rv.float() + eps)
+        scale = (weight.float() * rs).contiguous()
+        shift = (bias.float() - rm.float() * scale).contiguous()
+        y = torch.empty_like(x)
+        L.check(L.load().fsraft_affine_relu_fwd(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(y), N * C, C, H * W, int(relu),
+                                                L.stream()), "affine_relu_fwd")
+        ctx.save_for_backward(x, scale, shift, rs, rm)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib as L
+        x, scale, shift, rs, rm = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        sums = torch.zeros(2, C, device=x.device, dtype=torch.float32)
+        L.check(L.load().fsraft_affine_relu_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dx), L.ptr(sums[0]),
+                                                L.ptr(sums[1]), N * C, C, H * W, int(ctx.relu), L.stream()), "affine_relu_bwd")
+        dweight = rs * (sums[1] - rm.float() * sums[0])       # sum g' * (x - rm) * rs
+        return dx, dweight, sums[0], None, None, None, None
+
+
+def _conv_norm(conv, norm, x, relu):
+    """relu?(norm(conv(x))) of pytorch/core/extractor.py.  The convolution stays a PyTorch-ROCm (MIOpen) call; for fp32
+    CUDA tensors the normalisation + ReLU around it runs on the fused fsraft kernels:
+      * non-affine InstanceNorm2d (feature encoder).  A per-channel constant added before it is removed again by its
+        mean subtraction, so the convolution runs without its bias: same output (to rounding), one bias-add kernel less
+        forward and one [N,H,W] reduction less backward.  The bias then receives no gradient (mathematically it is
+        exactly zero; parallel.FlatGradients keeps a zero for it, so the optimizer treats it as the reference does);
+      * BatchNorm2d using running statistics (context encoder after freeze_bn, or eval mode).
+    Everything else (training-mode BatchNorm, GroupNorm, autocast dtypes, CPU) is the framework's own modules."""
+    fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+    if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)
+        if fused:
+            return _InstNormRelu.apply(y, norm.eps, relu)
+        y = norm(y)
+    elif isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats and norm.affine and fused:
+        return _FrozenBNRelu.apply(conv(x), norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
+    else:
+        y = norm(conv(x))
+    return F.relu(y, inplace=True) if relu else y
 
 
 def _make_norm(kind, ch, groups):
@@ -59,9 +130,9 @@ class _Block(nn.Module):
     def forward(self, x):
         y = x
         for i in range(1, self.n + 1):
-            y = self.relu(_conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y))
+            y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True)
         if self.downsample is not None:
-            x = _conv_norm(self.downsample[0], self.downsample[1], x)
+            x = _conv_norm(self.downsample[0], self.downsample[1], x, False)
         return self.relu(x + y)
 
 
@@ -102,7 +173,7 @@ class _Encoder(nn.Module):
         if pair:
             n = x[0].shape[0]
             x = torch.cat(x, dim=0)
-        x = self.relu1(_conv_norm(self.conv1, self.norm1, x))
+        x = _conv_norm(self.conv1, self.norm1, x, True)
         x = self.layer3(self.layer2(self.layer1(x)))
         x = self.conv2(x)
         if self.training and self.dropout is not None:

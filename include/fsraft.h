@@ -147,6 +147,19 @@ int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const f
 int fsraft_gma_mix_bwd(const float* d, int ldd, const float* y, int ldy, const float* gamma, float* dx, int ldx,
                        float* dy, int lddy, float* dgamma, int64_t M, int C, hipStream_t stream);
 
+/* ---- normalisation + ReLU around the encoder convolutions (callers of the path) ------------------------------
+ * pytorch/core/extractor.py:6-57: relu(norm(conv(x))) with norm = InstanceNorm2d (feature net) or a frozen
+ * BatchNorm2d (context net).  The convolutions stay MIOpen; these fuse what surrounds them.  NCHW, one (n,c) plane
+ * of HW floats per workgroup; stats[plane] = (mean, rstd). */
+int fsraft_inorm_relu_fwd(const float* x, float* y, float* stats, int64_t planes, int HW, float eps, int relu, hipStream_t stream);
+int fsraft_inorm_relu_bwd(const float* g, const float* x, const float* stats, float* dx, int64_t planes, int HW, int relu,
+                          hipStream_t stream);
+/* y = relu?(x * scale[c] + shift[c]);  backward: dx = g' * scale[c], dsum_g[c] += sum g', dsum_gx[c] += sum g' * x */
+int fsraft_affine_relu_fwd(const float* x, const float* scale, const float* shift, float* y, int64_t planes, int C, int HW,
+                           int relu, hipStream_t stream);
+int fsraft_affine_relu_bwd(const float* g, const float* x, const float* scale, const float* shift, float* dx, float* dsum_g,
+                           float* dsum_gx, int64_t planes, int C, int HW, int relu, hipStream_t stream);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);

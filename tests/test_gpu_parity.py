@@ -598,3 +598,32 @@ def test_tf_shaped_api_matches_pytorch_shaped_api():
         n1, m1, d1 = blk(net, inp, corr, flow)
         n2, m2, d2 = tfb.call([t.permute(0, 2, 3, 1).contiguous() for t in (net, inp, corr, flow)])
     close(n2.permute(0, 3, 1, 2), n1, 1e-6); close(m2.permute(0, 3, 1, 2), m1, 1e-6); close(d2.permute(0, 3, 1, 2), d1, 1e-6)
+
+
+# ----------------------------------------------------------------------------- encoder-side fused norm + ReLU
+@pytest.mark.parametrize("shape", [(2, 8, 20, 32), (1, 5, 7, 9)])
+def test_fused_norm_relu_kernels_match_torch(shape):
+    from flow_supervisor_amd.core.extractor import _FrozenBNRelu, _InstNormRelu
+    torch.manual_seed(3)
+    N, C, H, W = shape
+    for relu in (True, False):
+        x = (torch.randn(N, C, H, W, device=DEV) * 2 + 0.5).requires_grad_(True)
+        g = torch.randn(N, C, H, W, device=DEV)
+        y = _InstNormRelu.apply(x, 1e-5, relu)
+        y.backward(g)
+        xr = x.detach().clone().requires_grad_(True)
+        yr = torch.nn.functional.instance_norm(xr, eps=1e-5)
+        yr = torch.relu(yr) if relu else yr
+        yr.backward(g)
+        close(y, yr, 1e-5, what="instance norm fwd"); close(x.grad, xr.grad, 1e-5, what="instance norm bwd")
+        w = (torch.rand(C, device=DEV) + 0.5).requires_grad_(True); b = torch.randn(C, device=DEV).requires_grad_(True)
+        rm, rv = torch.randn(C, device=DEV), torch.rand(C, device=DEV) + 0.5
+        x2 = x.detach().clone().requires_grad_(True)
+        y = _FrozenBNRelu.apply(x2, w, b, rm, rv, 1e-5, relu)
+        y.backward(g)
+        x3 = x.detach().clone().requires_grad_(True); w3 = w.detach().clone().requires_grad_(True); b3 = b.detach().clone().requires_grad_(True)
+        yr = torch.nn.functional.batch_norm(x3, rm, rv, w3, b3, False, 0.0, 1e-5)
+        yr = torch.relu(yr) if relu else yr
+        yr.backward(g)
+        close(y, yr, 1e-5, what="frozen bn fwd"); close(x2.grad, x3.grad, 1e-5, what="frozen bn dx")
+        close(w.grad, w3.grad, 1e-4, 1e-4, what="frozen bn dweight"); close(b.grad, b3.grad, 1e-4, 1e-4, what="frozen bn dbias")
