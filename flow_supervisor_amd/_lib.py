@@ -53,6 +53,8 @@ SIGNATURES = {
     "fsraft_conv_forward": [POINTER(ConvDesc), _S],
     "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_wgrad_multi": [_PP, c_int, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_conv_small_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_conv_small_wgrad": [_PP, _PP, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_tuning": [c_int, c_int],
     "fsraft_set_lookup_qb": [c_int],

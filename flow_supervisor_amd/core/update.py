@@ -214,6 +214,9 @@ class _Engine:
             dW, dB = self._grad_arena(st, P, params[0].device)
             for (k, B, H, W), lst in st.pending.items():
                 l = self.layers[k]
+                if k == "fh2" and self.head_c % 4 == 0 and self.head_c <= 512:
+                    ops.conv_small_wgrad([dy for dy, _ in lst], [srcs[0] for _, srcs in lst], dW[k], dB[k], B, H, W)
+                    continue
                 ops.conv_wgrad_multi([dy for dy, _ in lst], [srcs for _, srcs in lst], dW[k], B, H, W, l.kh, l.kw,
                                      dbias=dB[k])
             st.pending = {}
@@ -259,6 +262,9 @@ class _Engine:
         with torch.no_grad():
             for n in self.extra:
                 out[n] = byname[n].detach().float().reshape(-1)
+            # the 2-output flow-head convolution runs on the dot-product kernels straight from the OIHW weight
+            out["fh2.raw"] = (byname["flow_head.conv2.weight"].detach().contiguous().float(),
+                              byname["flow_head.conv2.bias"].detach().contiguous().float())
             for k in self.order:
                 l = self.layers[k]
                 ws = [byname[w + ".weight"].detach() for w in l.wnames]
@@ -380,7 +386,10 @@ class _Engine:
         head = buf(nhead)
         conv("hd", [V(h, hid)], [Dst.nhwc(head)], relu=True)
         delta = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
-        conv("fh2", [V(head, self.head_c)], [Dst.nchw(delta)])
+        if self.head_c % 4 == 0 and self.head_c <= 512:
+            ops.conv_small_fwd(V(head, self.head_c), P["fh2.raw"][0], P["fh2.raw"][1], delta)
+        else:
+            conv("fh2", [V(head, self.head_c)], [Dst.nchw(delta)])
         mask = None
         if self.has_mask:
             mask = buf(576)

@@ -1095,11 +1095,12 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
   if (d->N <= 32 && d->epi == EPI_PLAIN) return launch_conv<Cfg32>(a, d->epi, stream);
-  if (d->N <= 64 && d->epi == EPI_PLAIN) return launch_conv<Cfg64>(a, d->epi, stream);
+  // 33..64 outputs: half of a 64x128 split tile is padding, still ~2x faster than the exact 64-wide kernel
+  if (d->N <= 64 && d->epi == EPI_PLAIN && !(g_conv_split && d->wpk_split && g_conv_buf)) return launch_conv<Cfg64>(a, d->epi, stream);
   // one workgroup per CU is not enough to keep the matrix pipe busy: when the 128x128 grid has
   // fewer than ~2 workgroups per CU, halve the tile height
   const int M = d->B * d->H * d->W;
-  if (g_conv_split && d->wpk_split && d->N > 64) {
+  if (g_conv_split && d->wpk_split && d->N > 32) {
     a.wpk = d->wpk_split;
     // 64x128 tiles with the buffer-addressed loaders and the branch-free k-loop are the fastest variant on every
     // update-block shape at M = 28160 (scripts/conv_micro.py: zr 129 us, hd 142 us, q 65 us, m2 61 us, c1 41 us;

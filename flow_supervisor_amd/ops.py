@@ -518,6 +518,26 @@ def conv_wgrad_multi(dys, srcs, dwpk, B, H, W, KH, KW, dbias=None):
         TIMER.end("conv_wgrad", e0w, 2.0 * n * B * H * W * dy0.C * cin * KH * KW, 4.0 * n * B * H * W * (cin + dy0.C))
 
 
+def conv_small_fwd(x, w_oihw, bias, out_nchw):
+    """3x3 convolution to 2 output channels as per-pixel dot products; x: V (channels-last), out: [B,2,H,W]."""
+    B, N, H, W = out_nchw.shape
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_conv_small_fwd(ctypes.c_void_p(x.ptr), x.ld, x.C, L.ptr(w_oihw), L.ptr(bias), L.ptr(out_nchw),
+                                         N * H * W, H * W, 1, N, B, H, W, 3, 3, L.stream()), "conv_small_fwd")
+    if t:
+        t.end("conv_small", e0, 2.0 * B * H * W * N * x.C * 9, 4.0 * B * H * W * (x.C + N))
+
+
+def conv_small_wgrad(dys, xs, dwpk, dbias, B, H, W):
+    """dwpk (packed [2][9*ceil32(C)]) += sum over the (dy, x) pairs; dys/xs: lists of V."""
+    n = len(dys)
+    a_dy = (ctypes.c_void_p * n)(*[v.ptr for v in dys])
+    a_x = (ctypes.c_void_p * n)(*[v.ptr for v in xs])
+    L.check(_lib().fsraft_conv_small_wgrad(ctypes.cast(a_dy, L._PP), ctypes.cast(a_x, L._PP), n, dys[0].ld, xs[0].ld, xs[0].C,
+                                           L.ptr(dwpk), L.ptr(dbias), dys[0].C, B, H, W, 3, 3, L.stream()), "conv_small_wgrad")
+
+
 def col_sum_v(v, out, scale=1.0):
     M = v.t.numel() // v.ld
     L.check(_lib().fsraft_col_sum(ctypes.c_void_p(v.ptr), v.ld, M, v.C, L.ptr(out), float(scale), L.stream()), "col_sum")

@@ -112,6 +112,16 @@ int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy, int Cout,
 int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
                             int nsrc, int mode, int accumulate, hipStream_t stream);
 
+/* Convolutions with 2 output channels (FlowHead.conv2, pytorch/core/update.py:10: 3x3, hidden -> 2) as per-pixel dot
+ * products instead of a padded GEMM tile.  x channels-last [M][ld]; w_oihw [2][C][3][3]; out element (b,o,pix) at
+ * out[b*obs + o*ocs + pix*ops].  C % 4 == 0, C <= 512. */
+int fsraft_conv_small_fwd(const float* x, int ld, int C, const float* w_oihw, const float* bias, float* out, int64_t obs,
+                          int64_t ocs, int64_t ops, int N, int B, int H, int W, int KH, int KW, hipStream_t stream);
+/* dwpk[o][tap*ceil32(C) + c] += sum over nseg (dy_t, x_t) pairs and pixels of dy_t[pix][o] * x_t[pix+shift][c];
+ * dbias[o] += sum dy (nullable) */
+int fsraft_conv_small_wgrad(const float* const* dy, const float* const* x, int nseg, int ldy, int ldx, int C, float* dwpk,
+                            float* dbias, int N, int B, int H, int W, int KH, int KW, hipStream_t stream);
+
 /* Tuning knobs for experiments (tile selection); not part of the reference interface.
  * key 0: conv tile (0 auto, 1 128x128, 2 64x128, 3 64x64); key 1: wgrad tile (0 128x128, 3 64x64);
  * key 2: target workgroup count of the wgrad pixel split; key 3: 1 = split-bf16 (3 x bf16 MFMA,
