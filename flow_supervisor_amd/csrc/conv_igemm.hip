@@ -205,6 +205,10 @@ struct BufConvALoader {
     }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
+#ifdef FSRAFT_ABLATE
+    // experiment: bit 4 stages A as if it were stored pre-split (copy, no conversion) -- wrong numbers, right cost
+    if (__builtin_amdgcn_readfirstlane(g_fsraft_ablate) & 16) { stage_copy<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4); return; }
+#endif
     stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
   }
 };

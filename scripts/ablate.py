@@ -29,7 +29,7 @@ for name, kh, kw, cs, cout in (("zr 1x5 3x128->256", 1, 5, [128, 128, 128], 256)
     wpk, wps = ops.pack_weight(w, cs, 0), ops.pack_weight(w, cs, 10)
     out = torch.zeros(B, H, W, cout, device=dev)
     for mask, what in ((0, "full"), (1, "no staging"), (2, "no MFMA"), (4, "no frag reads, no MFMA"), (8, "no global loads"),
-                       (9, "no loads, no staging"), (6, "no reads/MFMA (=4|2)"), (5, "loads only"), (13, "nothing but loop")):
+                       (9, "no loads, no staging"), (6, "no reads/MFMA (=4|2)"), (5, "loads only"), (13, "nothing but loop"), (16, "A staged by copy (pre-split emulation)")):
         if MASKS is not None and mask not in MASKS:
             continue
         lib.fsraft_set_ablate(mask)
