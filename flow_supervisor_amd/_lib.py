@@ -31,6 +31,7 @@ class ConvDesc(Structure):
         ("h", c_void_p), ("ldh", c_int), ("z", c_void_p), ("ldz", c_int),
         ("aux1", c_void_p), ("ld1", c_int), ("aux2", c_void_p), ("ld2", c_int), ("hid", c_int),
         ("pre", c_void_p), ("ldpre", c_int),
+        ("rmask", c_void_p * 3), ("ldmask", c_int * 3), ("maskc", c_int * 3),
     ]
 
 
@@ -69,8 +70,8 @@ SIGNATURES = {
     "fsraft_flow_to_nhwc": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_nhwc_to_flow": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, _S],
     "fsraft_relu_bwd": [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, _S],
-    "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, _S],
-    "fsraft_gru_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, _S],
+    "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, _S],
+    "fsraft_gru_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, _S],
     "fsraft_col_sum": [c_void_p, c_int, c_int64, c_int, c_void_p, c_float, _S],
     "fsraft_softmax_rows": [c_void_p, c_int64, c_int, _S],
     "fsraft_softmax_rows_bwd": [c_void_p, c_void_p, c_int64, c_int, _S],

@@ -460,17 +460,17 @@ class _Engine:
                 g = torch.empty(B, H, W, 576, device=dev, dtype=torch.float32)
                 ops.axpby_(dmask.contiguous(), g, 0.25, 0.0)      # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask
                 wgrad("m2", V(g, 576), [V(head, self.head_c, self.head_c)])
-                dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c)])
+                dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))])
             else:
                 dhead[..., self.head_c:].zero_()
         dd = torch.zeros(B, H, W, 4, device=dev, dtype=torch.float32)
         if ddelta is not None:
             ops.flow_to_nhwc(ddelta, dd, 0)
             wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
-            dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0)])
+            dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0).masked(V(head, self.head_c, 0))])
         else:
             dhead[..., : self.head_c].zero_()
-        relu_bwd(V(dhead), V(head))
+        # (no separate ReLU-backward pass: the two data-gradient epilogues above wrote dhead already masked by head > 0)
         hlast = S["hlast"]
         wgrad("hd", V(dhead), [V(hlast, hid)])
         dh = buf(hid)
@@ -484,28 +484,33 @@ class _Engine:
         motion = S["motion"]
         dmotion = buf(self.x_c, zero=True)
 
-        def to_context(k, g):
+        def ctx_sum(k, like):
+            """Running sum of the gate gradients over the iterations of the step (filled by the gru_bwd kernels)."""
             if cst is None:
-                return
-            if k in cst.dsum:
-                ops.axpby_(g, cst.dsum[k], 1.0, 1.0)
-            else:
-                cst.dsum[k] = g.clone()  # (g itself stays untouched: its weight-gradient GEMM is deferred)
+                return None
+            if k not in cst.dsum:
+                cst.dsum[k] = torch.zeros_like(like)
+            return cst.dsum[k]
 
+        first_pass = self.passes[0][0]
         for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
             dzr = buf(2 * hid)
             dq = buf(hid)
             dhp = buf(hid)
-            ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid)
+            zsum, qsum = ctx_sum("zi" + sfx, dzr), ctx_sum("qi" + sfx, dq)
+            ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid, zsum, qsum)
             xs = [V(motion, self.x_c)]
             wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
             drh = buf(hid)
             dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dmotion, 0, hid, True)])
-            ops.gru_bwd2(drh, r, h, dzr, dhp, hid)
+            ops.gru_bwd2(drh, r, h, dzr, dhp, hid, zsum)
             wgrad("zr" + sfx, V(dzr, 2 * hid), [V(h, hid)] + xs)
-            dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), Dst.nhwc(dmotion, 0, hid, True)])
-            to_context("qi" + sfx, dq)
-            to_context("zi" + sfx, dzr)
+            dm = Dst.nhwc(dmotion, 0, hid, True)
+            if sfx == first_pass and not self.gma:
+                # last accumulation into dmotion: its epilogue applies the motion encoder's ReLU backward to the conv
+                # channels [0, cv) (the two flow channels behind them pass through)
+                dm = dm.masked(V(motion, self.cv))
+            dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), dm])
             dh = dhp
 
         # ---- Aggregate (GMA): motion_global = motion + gamma * (attn @ to_v(motion))
@@ -528,18 +533,17 @@ class _Engine:
         # ---- motion encoder
         dflow = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
         ops.nhwc_to_flow(dmotion, self.cv, dflow, False)
-        relu_bwd(V(dmotion, self.cv), V(motion, self.cv))
+        if self.gma:      # (GMA adds to dmotion after the GRU, so the mask cannot ride on a GRU epilogue)
+            relu_bwd(V(dmotion, self.cv), V(motion, self.cv))
         corflo = S["corflo"]
         wgrad("cv", V(dmotion, self.cv), [V(corflo, self.cf_c)])
         dcorflo = buf(self.cf_c)
-        dgrad("cv", V(dmotion, self.cv), [Dst.nhwc(dcorflo)])
-        relu_bwd(V(dcorflo, self.cf_c), V(corflo, self.cf_c))
+        dgrad("cv", V(dmotion, self.cv), [Dst.nhwc(dcorflo).masked(V(corflo, self.cf_c))])
         cor_out = self.c2 if self.c2 else self.c1
         flo1 = S["flo1"]
         wgrad("f2", V(dcorflo, self.f2, cor_out), [V(flo1, self.f1)])
         dflo1 = buf(self.f1)
-        dgrad("f2", V(dcorflo, self.f2, cor_out), [Dst.nhwc(dflo1)])
-        relu_bwd(V(dflo1, self.f1), V(flo1, self.f1))
+        dgrad("f2", V(dcorflo, self.f2, cor_out), [Dst.nhwc(dflo1).masked(V(flo1, self.f1))])
         cols = S["cols"]
         wgrad("f1", V(dflo1, self.f1), [V(cols, 98)])
         dcols = buf(98)
@@ -551,8 +555,7 @@ class _Engine:
             cor1 = S["cor1"]
             wgrad("c2", V(dcorflo, self.c2, 0), [V(cor1, self.c1)])
             dcor1 = buf(self.c1)
-            dgrad("c2", V(dcorflo, self.c2, 0), [Dst.nhwc(dcor1)])
-            relu_bwd(V(dcor1, self.c1), V(cor1, self.c1))
+            dgrad("c2", V(dcorflo, self.c2, 0), [Dst.nhwc(dcor1).masked(V(cor1, self.c1))])
             wgrad("c1", V(dcor1, self.c1), [V(corr, self.corr_c)])
             if need_input_grads:
                 dgrad("c1", V(dcor1, self.c1), [Dst.nhwc(dcorr)])

@@ -42,6 +42,10 @@ struct ConvArgs {
   float* aux2; int ld2;          // ZR: r
   int hid;
   const float* pre; int ldpre;   // GRU epilogues: per-pixel addend to the pre-activation, [M][ldpre] (NULL: none)
+  // plain epilogue, per destination: ReLU-backward mask.  After scaling / accumulation, column j of the destination
+  // range (j < maskc) is zeroed where rmask[m*ldmask + j] <= 0 -- the data gradient of a layer whose input came
+  // out of a ReLU leaves the kernel already masked, instead of a separate pass over the tensor.
+  const float* rmask[3]; int ldmask[3]; int maskc[3];
   int swz;                       // 1: XCD-aware workgroup -> tile mapping (see tile_of_block)
 };
 
@@ -276,6 +280,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
     const int64_t dcs = di == 0 ? a.dst[0].cs : di == 1 ? a.dst[1].cs : a.dst[2].cs;
     const int dn0 = di == 0 ? a.dst[0].n0 : di == 1 ? a.dst[1].n0 : a.dst[2].n0;
     const bool dacc = (di == 0 ? a.dst[0].accumulate : di == 1 ? a.dst[1].accumulate : a.dst[2].accumulate) != 0;
+    const float* mk = di == 0 ? a.rmask[0] : di == 1 ? a.rmask[1] : a.rmask[2];
+    const int ldm = di == 0 ? a.ldmask[0] : di == 1 ? a.ldmask[1] : a.ldmask[2];
+    const int mkc = di == 0 ? a.maskc[0] : di == 1 ? a.maskc[1] : a.maskc[2];
 #pragma unroll
     for (int mt = 0; mt < Cfg::TM; ++mt) {
       const int mbase = m0 + (wave / Cfg::WN) * (Cfg::TM * 32) + mt * 32 + 4 * (lane >> 5);
@@ -301,7 +308,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
           for (int q = 0; q < 8; ++q) {
             float v = (acc[mt][nt][hb * 8 + q] + bias) * a.alpha;
             if (a.relu) v = fmaxf(v, 0.f);
-            if (off[q] >= 0) dp[off[q]] = v + old[q];
+            v += old[q];
+            if (off[q] >= 0 && mk && n - dn0 < mkc) {
+              const int r = hb * 8 + q;
+              const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+              if (mk[m * ldm + (n - dn0)] <= 0.f) v = 0.f;
+            }
+            if (off[q] >= 0) dp[off[q]] = v;
           }
         }
       } else if (EPI == EPI_ZR) {
@@ -390,6 +403,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
     const int64_t dps = di == 0 ? a.dst[0].ps : di == 1 ? a.dst[1].ps : a.dst[2].ps;
     const int dn0 = di == 0 ? a.dst[0].n0 : di == 1 ? a.dst[1].n0 : a.dst[2].n0;
     const bool dacc = (di == 0 ? a.dst[0].accumulate : di == 1 ? a.dst[1].accumulate : a.dst[2].accumulate) != 0;
+    const float* mk = di == 0 ? a.rmask[0] : di == 1 ? a.rmask[1] : a.rmask[2];
+    const int ldm = di == 0 ? a.ldmask[0] : di == 1 ? a.ldmask[1] : a.ldmask[2];
+    const int mkc = di == 0 ? a.maskc[0] : di == 1 ? a.maskc[1] : a.maskc[2];
     const int nv = a.N - n < 4 ? a.N - n : 4;        // valid columns of this float4 (N need not be a multiple of 4)
 #pragma unroll 4
     for (int row = rsub; row < Cfg::BM; row += RPP) {
@@ -408,9 +424,18 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] += old[i];
         }
+        if (mk) {
+          const f32x4 y = gload4(mk + (int64_t)m * ldm + (n - dn0));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (n - dn0 + i < mkc && y[i] <= 0.f) v[i] = 0.f;
+        }
         gstore4(o, v);
       } else {
-        for (int i = 0; i < nv; ++i) gstore1(o + i, dacc ? gload1(o + i) + v[i] : v[i]);
+        for (int i = 0; i < nv; ++i) {
+          float r = dacc ? gload1(o + i) + v[i] : v[i];
+          if (mk && n - dn0 + i < mkc && gload1(mk + (int64_t)m * ldm + (n - dn0) + i) <= 0.f) r = 0.f;
+          gstore1(o + i, r);
+        }
       }
     }
   } else if (EPI == EPI_ZR) {
@@ -1067,6 +1092,7 @@ struct fsraft_conv_desc {
   float* aux2; int ld2;
   int hid;
   const float* pre; int ldpre;   // GRU epilogues: addend to the pre-activation (e.g. the context part of the conv), or NULL
+  const float* rmask[3]; int ldmask[3]; int maskc[3];   // epi 0, per destination: zero column j < maskc where rmask[m*ldmask+j] <= 0
 };
 
 extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
@@ -1094,6 +1120,11 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   a.hid = d->hid;
   a.pre = d->epi == EPI_PLAIN ? nullptr : d->pre; a.ldpre = d->ldpre;
   if (a.pre && (d->ldpre % 4 != 0 || ((uintptr_t)d->pre & 15))) return FS_ERR_ARG;
+  for (int i = 0; i < 3; ++i) {
+    const bool on = d->epi == EPI_PLAIN && i < d->ndst && d->rmask[i] != nullptr;
+    a.rmask[i] = on ? d->rmask[i] : nullptr; a.ldmask[i] = d->ldmask[i]; a.maskc[i] = d->maskc[i];
+    if (on && (d->ldmask[i] % 4 != 0 || ((uintptr_t)d->rmask[i] & 15))) return FS_ERR_ARG;
+  }
   a.swz = g_xcd_swizzle;
   if (d->epi == EPI_ZR && (!d->h || !d->aux1 || !d->aux2 || d->hid * 2 != d->N)) return FS_ERR_ARG;
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;

@@ -132,27 +132,33 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, in
 __global__ __launch_bounds__(256) void gru_bwd1_kernel(const float* __restrict__ dhn, const float* __restrict__ z,
                                                        const float* __restrict__ q, const float* __restrict__ h,
                                                        float* __restrict__ dzr, int ldzr, float* __restrict__ dq,
-                                                       float* __restrict__ dh, int64_t M, int hid) {
+                                                       float* __restrict__ dh, float* __restrict__ dzr_sum,
+                                                       float* __restrict__ dq_sum, int64_t M, int hid) {
   const int64_t total = M * hid;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / hid; const int c = (int)(e % hid);
     const float g = dhn[e], zz = z[e], qq = q[e], hh = h[e];
-    dzr[m * ldzr + c] = g * (qq - hh) * zz * (1.f - zz);
-    dq[e] = g * zz * (1.f - qq * qq);
+    const float dz = g * (qq - hh) * zz * (1.f - zz), dqv = g * zz * (1.f - qq * qq);
+    dzr[m * ldzr + c] = dz;
+    dq[e] = dqv;
     dh[e] = g * (1.f - zz);
+    if (dzr_sum) dzr_sum[m * ldzr + c] += dz;       // running sums over the iterations of a step (context part's backward)
+    if (dq_sum) dq_sum[e] += dqv;
   }
 }
 
 // stage 2 (input of the q conv was r*h):  dzr[:, hid:2hid] = d(rh) * h * r (1-r);   dh += d(rh) * r
 __global__ __launch_bounds__(256) void gru_bwd2_kernel(const float* __restrict__ drh, const float* __restrict__ r,
                                                        const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
-                                                       float* __restrict__ dh, int64_t M, int hid) {
+                                                       float* __restrict__ dh, float* __restrict__ dzr_sum, int64_t M, int hid) {
   const int64_t total = M * hid;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / hid; const int c = (int)(e % hid);
     const float g = drh[e], rr = r[e];
-    dzr[m * ldzr + hid + c] = g * h[e] * rr * (1.f - rr);
+    const float dr = g * h[e] * rr * (1.f - rr);
+    dzr[m * ldzr + hid + c] = dr;
     dh[e] += g * rr;
+    if (dzr_sum) dzr_sum[m * ldzr + hid + c] += dr;
   }
 }
 
@@ -227,15 +233,15 @@ extern "C" int fsraft_relu_bwd(float* g, int ldg, const float* y, int ldy, int64
   return fs_launch_status();
 }
 extern "C" int fsraft_gru_bwd1(const float* dhn, const float* z, const float* q, const float* h, float* dzr, int ldzr,
-                               float* dq, float* dh, int64_t M, int hid, hipStream_t s) {
+                               float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid, hipStream_t s) {
   if (!dhn || !z || !q || !h || !dzr || !dq || !dh) return FS_ERR_ARG;
-  hipLaunchKernelGGL(gru_bwd1_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, dhn, z, q, h, dzr, ldzr, dq, dh, M, hid);
+  hipLaunchKernelGGL(gru_bwd1_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, dhn, z, q, h, dzr, ldzr, dq, dh, dzr_sum, dq_sum, M, hid);
   return fs_launch_status();
 }
 extern "C" int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh,
-                               int64_t M, int hid, hipStream_t s) {
+                               float* dzr_sum, int64_t M, int hid, hipStream_t s) {
   if (!drh || !r || !h || !dzr || !dh) return FS_ERR_ARG;
-  hipLaunchKernelGGL(gru_bwd2_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, M, hid);
+  hipLaunchKernelGGL(gru_bwd2_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid);
   return fs_launch_status();
 }
 extern "C" int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s) {

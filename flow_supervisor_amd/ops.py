@@ -367,15 +367,15 @@ def relu_bwd_(g, y, C):
     L.check(_lib().fsraft_relu_bwd(L.ptr(g), g.shape[-1], L.ptr(y), y.shape[-1], M, C, L.stream()), "relu_bwd")
 
 
-def gru_bwd1(dhn, z, q, h, dzr, dq, dh, hid):
+def gru_bwd1(dhn, z, q, h, dzr, dq, dh, hid, dzr_sum=None, dq_sum=None):
     M = dhn.numel() // hid
     L.check(_lib().fsraft_gru_bwd1(L.ptr(dhn), L.ptr(z), L.ptr(q), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dq),
-                                   L.ptr(dh), M, hid, L.stream()), "gru_bwd1")
+                                   L.ptr(dh), L.ptr(dzr_sum), L.ptr(dq_sum), M, hid, L.stream()), "gru_bwd1")
 
 
-def gru_bwd2(drh, r, h, dzr, dh, hid):
+def gru_bwd2(drh, r, h, dzr, dh, hid, dzr_sum=None):
     M = drh.numel() // hid
-    L.check(_lib().fsraft_gru_bwd2(L.ptr(drh), L.ptr(r), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dh), M, hid,
+    L.check(_lib().fsraft_gru_bwd2(L.ptr(drh), L.ptr(r), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dh), L.ptr(dzr_sum), M, hid,
                                    L.stream()), "gru_bwd2")
 
 
@@ -435,10 +435,16 @@ class V:
 
 class Dst:
     """Output channel range starting at GEMM column n0 -> strided destination."""
-    __slots__ = ("t", "off", "bs", "ps", "cs", "n0", "acc")
+    __slots__ = ("t", "off", "bs", "ps", "cs", "n0", "acc", "mask")
 
     def __init__(self, t, off, bs, ps, cs, n0=0, acc=False):
         self.t, self.off, self.bs, self.ps, self.cs, self.n0, self.acc = t, off, bs, ps, cs, n0, acc
+        self.mask = None            # optional V: ReLU-backward mask applied to this range by the epilogue
+
+    def masked(self, v):
+        """Zero the written values where the forward activation v (a V over the same channels) is <= 0."""
+        self.mask = v
+        return self
 
     @staticmethod
     def nhwc(buf, coff=0, n0=0, acc=False):
@@ -467,6 +473,8 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
         d.dst[i] = ds.t.data_ptr() + 4 * ds.off
         d.dst_bs[i], d.dst_ps[i], d.dst_cs[i] = ds.bs, ds.ps, ds.cs
         d.dst_n0[i] = ds.n0; d.dst_acc[i] = int(ds.acc)
+        if ds.mask is not None:
+            d.rmask[i] = ds.mask.ptr; d.ldmask[i] = ds.mask.ld; d.maskc[i] = ds.mask.C
     d.ndst = len(dsts)
     d.relu = int(relu); d.alpha = float(alpha); d.epi = epi
     if h is not None:
