@@ -66,9 +66,14 @@ __device__ __forceinline__ void tile_of_block(int swz, int& bx, int& by) {
 // source, 16..19: tap, 20..21: source, 22..27: channels left in the source from this chunk (1..32).  The kernel
 // reads it with one scalar load; without it the (source, tap, chunk) decode is two integer divisions per k-tile,
 // which the compiler can only do on the vector ALU (~50 instructions) even though the values are wave-uniform.
-constexpr int KTAB_MAX = 256;
+// "Uniform" form (BUF = 2), used when all sources share one row pitch and lie within 2 GiB of each other: two dwords
+// per k-tile -- the complete SGPR byte offset from ONE base pointer (source delta + tap shift + channel chunk), and
+// tap | channels-left << 4.  One descriptor and one pitch for the whole k-loop: the per-tile scalar work shrinks from
+// ~30 instructions (source selects, 64-bit base arithmetic) to a two-dword load and two bit-field extracts.
+constexpr int KTAB_MAX = 512;
 struct ConvArgsT {
   ConvArgs a;
+  const float* ubase; int uld;   // uniform form: biased base pointer and the common pitch (floats)
   unsigned ktab[KTAB_MAX];
 };
 
@@ -213,6 +218,33 @@ struct BufConvALoader {
     // experiment: bit 4 stages A as if it were stored pre-split (copy, no conversion) -- wrong numbers, right cost
     if (__builtin_amdgcn_readfirstlane(g_fsraft_ablate) & 16) { stage_copy<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4); return; }
 #endif
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+  }
+};
+
+template <class Cfg>
+struct BufConvALoaderU {                  // uniform form: one base, one pitch, two table dwords per k-tile
+  static constexpr int NCH = Cfg::NCH_A, NREG = NCH * 4;
+  const float* base;
+  const unsigned __attribute__((address_space(4)))* ktab;
+  unsigned tapmask[NCH];                  // bit t: tap t of this thread's pixel row lies inside the image (0: row outside M)
+  unsigned voff0[NCH];                    // pixel * pitch + 16-byte column, in bytes (constant over the k-loop)
+  unsigned kq16;
+  __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);
+    const unsigned soff = ktab[2 * ku], e = ktab[2 * ku + 1];
+    const unsigned tap = e & 15u, crem4 = (e >> 4) * 4u;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, 0x7fffffffu);
+    const unsigned cok = kq16 < crem4 ? 1u : 0u;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const unsigned bad = (__builtin_amdgcn_ubfe(tapmask[j], tap, 1u) & cok) ^ 1u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (bad << 31) | voff0[j], soff, 0);
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    }
+  }
+  __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
     stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
   }
 };
@@ -529,10 +561,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // split-bf16 variant: 3 x v_mfma_f32_32x32x16_bf16 per product block, weights pre-split at pack time
-template <class Cfg, int EPI, bool BUF = false>
-__global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::conditional_t<BUF, ConvArgsT, ConvArgs> args) {
+template <class Cfg, int EPI, int BUF = 0>       // BUF 0: flat 64-bit addressing, 1: buffer loads + k-tile table, 2: uniform-pitch table
+__global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::conditional_t<BUF != 0, ConvArgsT, ConvArgs> args) {
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
-  const ConvArgs& a = [&]() -> const ConvArgs& { if constexpr (BUF) return args.a; else return args; }();
+  const ConvArgs& a = [&]() -> const ConvArgs& { if constexpr (BUF != 0) return args.a; else return args; }();
   const int HW = a.H * a.W;
   const int M = a.B * HW;
   int bx = blockIdx.x, by = blockIdx.y;
@@ -545,21 +577,15 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::condit
     for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  if constexpr (BUF) {
-    BufConvALoader<Cfg> la;
+  if constexpr (BUF != 0) {
     const int PH = a.KH / 2, PW = a.KW / 2, taps = a.KH * a.KW;
-    la.ld0x4 = uni(a.src[0].ld * 4); la.ld1x4 = uni(a.src[1].ld * 4); la.ld2x4 = uni(a.src[2].ld * 4);
-    // descriptor base = tensor base - (PH*W + PW) pixels, so the per-tap SGPR offset (dy*W + dx)*ld is >= 0
-    la.b0 = uni_ptr(a.src[0].p - (int64_t)(PH * a.W + PW) * a.src[0].ld); la.nb0 = 0x7fffffffu;
-    la.b1 = uni_ptr(a.src[1].p - (int64_t)(PH * a.W + PW) * a.src[1].ld); la.nb1 = 0x7fffffffu;
-    la.b2 = uni_ptr(a.src[2].p - (int64_t)(PH * a.W + PW) * a.src[2].ld); la.nb2 = 0x7fffffffu;
     // Index the table where it lives, in the kernarg segment: going through the by-value struct would make the
     // compiler copy it to scratch (dynamic index), and a scratch load is per-lane, i.e. no longer provably uniform.
-    la.ktab = (const unsigned __attribute__((address_space(4)))*)(
+    const auto* ktab = (const unsigned __attribute__((address_space(4)))*)(
         (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvArgsT, ktab));
-    la.kq16 = (threadIdx.x & 7) * 16;
+    unsigned tapmask[Cfg::NCH_A], pofs[Cfg::NCH_A];
 #pragma unroll
-    for (int j = 0; j < BufConvALoader<Cfg>::NCH; ++j) {
+    for (int j = 0; j < Cfg::NCH_A; ++j) {
       const int m = m0 + ((threadIdx.x + 256 * j) >> 3);
       unsigned mask = 0;
       if (m < M) {
@@ -569,7 +595,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::condit
           if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) mask |= 1u << t;
         }
       }
-      la.tapmask[j] = mask; la.pofs[j] = m < M ? m : 0;
+      tapmask[j] = mask; pofs[j] = m < M ? m : 0;
     }
     BufWeightLoader<Cfg> lb;
     lb.base = uni_ptr(reinterpret_cast<const char*>(a.wpk) + (int64_t)n0 * a.Ktot * 4);
@@ -579,7 +605,26 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::condit
       const int e = threadIdx.x + 256 * j;
       lb.voff[j] = (e >> 3) < a.N - n0 ? (unsigned)((e >> 3) * a.Ktot * 4 + (e & 7) * 16) : FS_OOB;
     }
-    split_mainloop<Cfg, BufConvALoader<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
+    if constexpr (BUF == 2) {
+      BufConvALoaderU<Cfg> la;
+      la.base = uni_ptr(args.ubase); la.ktab = ktab; la.kq16 = (threadIdx.x & 7) * 16;
+      const unsigned ldb = uni((unsigned)args.uld * 4u);
+#pragma unroll
+      for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.voff0[j] = pofs[j] * ldb + la.kq16; }
+      split_mainloop<Cfg, BufConvALoaderU<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
+    } else {
+      BufConvALoader<Cfg> la;
+      la.ld0x4 = uni(a.src[0].ld * 4); la.ld1x4 = uni(a.src[1].ld * 4); la.ld2x4 = uni(a.src[2].ld * 4);
+      // descriptor base = tensor base - (PH*W + PW) pixels, so the per-tap SGPR offset (dy*W + dx)*ld is >= 0
+      la.b0 = uni_ptr(a.src[0].p - (int64_t)(PH * a.W + PW) * a.src[0].ld); la.nb0 = 0x7fffffffu;
+      la.b1 = uni_ptr(a.src[1].p - (int64_t)(PH * a.W + PW) * a.src[1].ld); la.nb1 = 0x7fffffffu;
+      la.b2 = uni_ptr(a.src[2].p - (int64_t)(PH * a.W + PW) * a.src[2].ld); la.nb2 = 0x7fffffffu;
+      la.ktab = ktab;
+      la.kq16 = (threadIdx.x & 7) * 16;
+#pragma unroll
+      for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.pofs[j] = pofs[j]; }
+      split_mainloop<Cfg, BufConvALoader<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
+    }
   } else {
   SplitConvALoader<Cfg> la;
   la.p0 = a.src[0].p; la.C0 = a.src[0].C; la.ld0 = a.src[0].ld; la.cpt0 = (a.src[0].C + 31) / 32;
@@ -1000,6 +1045,7 @@ using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_conv_uniform = 1;   // uniform-pitch k-tile table when the sources allow it (key 12)
 int g_wgrad_blocks_multi = 2048;   // workgroup target of the multi-segment launch (key 11); measured 512: 9.0, 1024: 8.5, 2048: 8.35 ms/step
 int g_wgrad_multi = 1;  // one weight-gradient launch per layer per step over all stashed iterations (key 10)
 int g_conv_n256 = 0;    // 64x256 tiles for layers whose N fills them (key 9); measured slower than 64x128 (zr 139 vs 119 us, hd 182 vs 125 us)
@@ -1040,6 +1086,37 @@ bool build_ktab(const ConvArgs& a, ConvArgsT& t) {
   return true;
 }
 
+// Uniform form of the table (see ConvArgsT): possible when every source has the same pitch and all of them, shifted
+// taps included, lie inside one 2 GiB window.
+bool build_ktab_uniform(const ConvArgs& a, ConvArgsT& t) {
+  const int taps = a.KH * a.KW, KT = a.Ktot / 32, PH = a.KH / 2, PW = a.KW / 2;
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  if (!g_conv_uniform || 2 * KT > KTAB_MAX || taps > 15) return false;
+  const int ld = a.src[0].ld;
+  const float* lo = a.src[0].p;
+  for (int s = 0; s < a.nsrc; ++s) {
+    if (a.src[s].ld != ld) return false;
+    if (a.src[s].p < lo) lo = a.src[s].p;
+  }
+  const float* base = lo - (int64_t)(PH * a.W + PW) * ld;      // tap shifts become non-negative offsets
+  int kt = 0;
+  for (int s = 0; s < a.nsrc; ++s) {
+    const int C = a.src[s].C, cpt = (C + 31) / 32;
+    const int64_t delta = (a.src[s].p - lo) * 4;                  // bytes
+    for (int tap = 0; tap < taps; ++tap)
+      for (int c = 0; c < cpt; ++c, ++kt) {
+        const int64_t soff = delta + ((int64_t)((tap / a.KW) * a.W + tap % a.KW) * ld + c * 32) * 4;
+        if (soff + M * ld * 4 + 256 >= (int64_t)FS_OOB) return false;
+        const int crem = C - c * 32 < 32 ? C - c * 32 : 32;
+        t.ktab[2 * kt] = (unsigned)soff;
+        t.ktab[2 * kt + 1] = (unsigned)tap | (unsigned)crem << 4;
+      }
+  }
+  if (kt != KT) return false;
+  t.a = a; t.ubase = base; t.uld = ld;
+  return true;
+}
+
 template <class Cfg>
 int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   const int M = a.B * a.H * a.W;
@@ -1047,10 +1124,16 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   ConvArgsT t;
   // buffer-addressed loaders + branch-free k-loop: measured faster on the 64-row tiles, slower on 128x128
   const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256;
+  if (buf && build_ktab_uniform(a, t)) {
+    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(256), 0, s, t);
+    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 2>), grid, dim3(256), 0, s, t);
+    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(256), 0, s, t);
+    return fs_launch_status();
+  }
   if (buf && build_ktab(a, t)) {
-    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, true>), grid, dim3(256), 0, s, t);
-    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, true>), grid, dim3(256), 0, s, t);
-    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, true>), grid, dim3(256), 0, s, t);
+    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), grid, dim3(256), 0, s, t);
+    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 1>), grid, dim3(256), 0, s, t);
+    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 1>), grid, dim3(256), 0, s, t);
     return fs_launch_status();
   }
   if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN>), grid, dim3(256), 0, s, a);
@@ -1175,6 +1258,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 9) g_conv_n256 = value;
   else if (key == 10) g_wgrad_multi = value;
   else if (key == 11) g_wgrad_blocks_multi = value;
+  else if (key == 12) g_conv_uniform = value;
   else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;

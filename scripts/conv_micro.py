@@ -23,6 +23,21 @@ LAYERS = [  # name, kh, kw, src channels, Cout
     ("hd 3x3 128->512", 3, 3, [128], 512),
     ("m2 1x1 256->576", 1, 1, [256], 576),
     ("fh2 3x3 256->2", 3, 3, [256], 2),
+    # data-gradient shapes of the same layers (K = Cout * taps of the forward layer, N = its input channels)
+    ("dg m2 1x1 576->256", 1, 1, [576], 256),
+    ("dg fh2 3x3 2->256", 3, 3, [2], 256),
+    ("dg hd 3x3 512->128", 3, 3, [512], 128),
+    ("dg q 1x5 128->256", 1, 5, [128], 256),
+    ("dg zr 1x5 256->256", 1, 5, [256], 256),
+    ("dg cv 3x3 126->256", 3, 3, [126], 256),
+    ("dg f2 3x3 64->128", 3, 3, [64], 128),
+    ("dg f1 1x1 128->98", 1, 1, [128], 98),
+    ("dg c2 3x3 192->256", 3, 3, [192], 256),
+    ("dg c1 1x1 256->324", 1, 1, [256], 324),
+    ("f2 3x3 128->64", 3, 3, [128], 64),
+    ("f1 1x1 98->128", 1, 1, [98], 128),
+    ("zrc 1x5 256->256 (ctx split)", 1, 5, [128, 128], 256),
+    ("qc 1x5 256->128 (ctx split)", 1, 5, [128, 128], 128),
     # diagnostics: same K as zr, different reuse structure
     ("x1 1x1 1920->256", 1, 1, [1920], 256),
     ("x5 1x5 384->256 one src", 1, 5, [384], 256),
