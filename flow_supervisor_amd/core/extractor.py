@@ -37,21 +37,26 @@ class _InstNormRelu(torch.autograd.Function):
 
 
 class _FrozenBNRelu(torch.autograd.Function):
-    """relu?(batch_norm(x)) with running statistics (eval mode / freeze_bn): y = x * scale[c] + shift[c]."""
+    """relu?(batch_norm(x + cbias[c])) with running statistics (eval mode / freeze_bn): y = x * scale[c] + shift[c].
+    `cbias` is the bias of the convolution that produced x (or None): the convolution runs without it, the constant is
+    folded into the shift, and its gradient -- the per-channel sum of the convolution's output gradient -- falls out of
+    the sums this backward computes anyway, instead of a separate [N,H,W] reduction inside the convolution backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, rm, rv, eps, relu):
+    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu):
         from .. import _lib as L
         x = x.contiguous()
         N, C, H, W = x.shape
         rs = torch.rsqrt(rv.float() + eps)
         scale = (weight.float() * rs).contiguous()
-        shift = (bias.float() - rm.float() * scale).contiguous()
+        rmc = rm.float() - cbias.float() if cbias is not None else rm.float()       # effective mean seen by x
+        shift = (bias.float() - rmc * scale).contiguous()
         y = torch.empty_like(x)
         L.check(L.load().fsraft_affine_relu_fwd(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(y), N * C, C, H * W, int(relu),
                                                 L.stream()), "affine_relu_fwd")
-        ctx.save_for_backward(x, scale, shift, rs, rm)
+        ctx.save_for_backward(x, scale, shift, rs, rmc)
         ctx.relu = relu
+        ctx.has_cbias = cbias is not None
         return y
 
     @staticmethod
@@ -64,8 +69,9 @@ class _FrozenBNRelu(torch.autograd.Function):
         sums = torch.zeros(2, C, device=x.device, dtype=torch.float32)
         L.check(L.load().fsraft_affine_relu_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dx), L.ptr(sums[0]),
                                                 L.ptr(sums[1]), N * C, C, H * W, int(ctx.relu), L.stream()), "affine_relu_bwd")
-        dweight = rs * (sums[1] - rm.float() * sums[0])       # sum g' * (x - rm) * rs
-        return dx, dweight, sums[0], None, None, None, None
+        dweight = rs * (sums[1] - rm * sums[0])               # sum g' * (x + cbias - rm) * rs
+        dcbias = scale * sums[0] if ctx.has_cbias else None   # = sum over pixels of dx
+        return dx, dcbias, dweight, sums[0], None, None, None, None
 
 
 def _conv_norm(conv, norm, x, relu):
@@ -84,7 +90,8 @@ def _conv_norm(conv, norm, x, relu):
             return _InstNormRelu.apply(y, norm.eps, relu)
         y = norm(y)
     elif isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats and norm.affine and fused:
-        return _FrozenBNRelu.apply(conv(x), norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return _FrozenBNRelu.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
     else:
         y = norm(conv(x))
     return F.relu(y, inplace=True) if relu else y

@@ -619,14 +619,17 @@ def test_fused_norm_relu_kernels_match_torch(shape):
         w = (torch.rand(C, device=DEV) + 0.5).requires_grad_(True); b = torch.randn(C, device=DEV).requires_grad_(True)
         rm, rv = torch.randn(C, device=DEV), torch.rand(C, device=DEV) + 0.5
         x2 = x.detach().clone().requires_grad_(True)
-        y = _FrozenBNRelu.apply(x2, w, b, rm, rv, 1e-5, relu)
+        cb = torch.randn(C, device=DEV).requires_grad_(True)          # bias of the convolution in front, folded in
+        y = _FrozenBNRelu.apply(x2, cb, w, b, rm, rv, 1e-5, relu)
         y.backward(g)
         x3 = x.detach().clone().requires_grad_(True); w3 = w.detach().clone().requires_grad_(True); b3 = b.detach().clone().requires_grad_(True)
-        yr = torch.nn.functional.batch_norm(x3, rm, rv, w3, b3, False, 0.0, 1e-5)
+        cb3 = cb.detach().clone().requires_grad_(True)
+        yr = torch.nn.functional.batch_norm(x3 + cb3.view(1, C, 1, 1), rm, rv, w3, b3, False, 0.0, 1e-5)
         yr = torch.relu(yr) if relu else yr
         yr.backward(g)
         close(y, yr, 1e-5, what="frozen bn fwd"); close(x2.grad, x3.grad, 1e-5, what="frozen bn dx")
         close(w.grad, w3.grad, 1e-4, 1e-4, what="frozen bn dweight"); close(b.grad, b3.grad, 1e-4, 1e-4, what="frozen bn dbias")
+        close(cb.grad, cb3.grad, 1e-4, 1e-4, what="folded conv bias grad")
 
 
 # ----------------------------------------------------------------------------- ragged / odd shapes against the oracle
