@@ -113,6 +113,28 @@ __device__ int g_fsraft_ablate;
 //          (zr 1x5 384->256 at M=28160: 131 us vs 157 us) and on short-K layers (no padded tile, shorter prologue);
 //   true:  branch-free body, two tiles per trip, an odd tile count runs one all-zero tile; the waits are the
 //          intended vmcnt(15..8) (two tiles in flight).  Faster on the 64x128 tiles (q 1x5 384->128: 76 -> 64 us).
+// Experiment hook (-DFSRAFT_SCHED_PATTERN): ask the scheduler for "fragment reads, then one MFMA followed by a few
+// VALU / LDS-store / VMEM instructions, repeated" inside each half of the k-loop body.
+#ifdef FSRAFT_SCHED_PATTERN
+#define FSRAFT_SCHED_GROUPS()                                                            \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                   \
+    _Pragma("unroll") for (int sg = 0; sg < 6; ++sg) {                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                 \
+    }                                                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                   \
+    _Pragma("unroll") for (int sg = 0; sg < 6; ++sg) {                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+    }                                                                                    \
+  } while (0)
+#else
+#define FSRAFT_SCHED_GROUPS() do {} while (0)
+#endif
+
 template <class Cfg, class LA, class LB, bool STRAIGHT = false>
 __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
                                                f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
@@ -211,15 +233,17 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
     return;
   }
   for (int kt = 0; kt < KT; kt += 2) {
+    // No scheduling barrier between the MFMA block and the staging code: left alone, the compiler overlaps part of the
+    // conversion / LDS-store work with the matrix instructions (measured 2-3 % faster than pinning "MFMAs first").
     compute(buf0);                                   // tile kt
-    __builtin_amdgcn_sched_barrier(0);               // MFMAs first: a vmcnt wait hoisted between them would stall the matrix pipe
     stage(buf1, ra1, rb1);                           // tile kt+1 -> other image
     fetch(kt + 3, ra1, rb1);
+    FSRAFT_SCHED_GROUPS();
     __syncthreads();
     compute(buf1);                                   // tile kt+1 (zeros when kt+1 == KT)
-    __builtin_amdgcn_sched_barrier(0);
     stage(buf0, ra0, rb0);                           // tile kt+2
     fetch(kt + 4, ra0, rb0);
+    FSRAFT_SCHED_GROUPS();
     __syncthreads();
   }
 }
