@@ -5,15 +5,66 @@ import torch
 from .parallel import FlatGradients
 
 
-def sequence_loss(flow_preds, flow_gt=None, gamma=0.8):
-    """sum_i gamma^(n-1-i) * mean(sqrt((pred_i - gt)^2 + 1e-6)): the Charbonnier sequence loss of
-    pytorch/train.py:60-96 with every pixel valid (gt defaults to zero flow)."""
+MAX_FLOW = 400          # pytorch/train.py:55
+
+
+class _SeqLossFn(torch.autograd.Function):
+    """All predictions in one fsraft_sequence_loss launch: loss, its gradients and the EPE statistics."""
+
+    @staticmethod
+    def forward(ctx, weights, gt, valid, max_flow, eps, metric_idx, *preds):
+        import ctypes
+        from . import _lib as L
+        preds = [p.contiguous() for p in preds]
+        L.require_cuda_f32(*preds)
+        B, _, H, W = preds[0].shape
+        n = len(preds)
+        need = [ctx.needs_input_grad[6 + i] for i in range(n)]
+        dps = [torch.empty_like(p) if nd else None for p, nd in zip(preds, need)]
+        out = torch.zeros(6, device=preds[0].device, dtype=torch.float32)
+        a_p = (ctypes.c_void_p * n)(*[p.data_ptr() for p in preds])
+        a_d = (ctypes.c_void_p * n)(*[d.data_ptr() if d is not None else None for d in dps])
+        a_w = (ctypes.c_float * n)(*[float(w) for w in weights])
+        gt = gt.contiguous().float() if gt is not None else None
+        valid = valid.contiguous().float() if valid is not None else None
+        L.check(L.load().fsraft_sequence_loss(ctypes.cast(a_p, L._PP), ctypes.cast(a_d, L._PP), a_w, n,
+                                              -1 if metric_idx is None else int(metric_idx), L.ptr(gt), L.ptr(valid),
+                                              float(max_flow), float(eps), B, H, W, L.ptr(out), L.stream()), "sequence_loss")
+        ctx.dps = dps
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        dps, ctx.dps = ctx.dps, None
+        return (None,) * 6 + tuple(d * g if d is not None else None for d in dps)
+
+
+def weighted_sequence_loss(flow_preds, weights, flow_gt=None, valid=None, max_flow=MAX_FLOW, eps=1e-3, metric_idx=None):
+    """sum_i weights[i] * mean(mask * sqrt((pred_i - gt)^2 + eps^2)) on the fused kernel.  Returns (loss, stats) with
+    stats = [loss, epe_sum, n<1px, n<3px, n<5px, n_valid] of prediction `metric_idx` (device tensor, no sync)."""
+    return _SeqLossFn.apply(list(weights), flow_gt, valid, max_flow, eps, metric_idx, *flow_preds)
+
+
+def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8, gamma2=1.0, max_flow=MAX_FLOW):
+    """pytorch/train.py:60-96, same signature and return value (loss, metrics dict).  The first half of the predictions
+    (the student's, in the flow-supervisor forward) is weighted gamma^(n-i-1), the second half (the supervisor's)
+    gamma2^(n-i-1) with n = len(flow_preds) // 2; Charbonnier penalty with eps = 1e-3; pixels with valid < 0.5 or
+    |gt| >= max_flow are excluded; metrics (epe, 1px, 3px, 5px) come from prediction n-1 over valid > 0.5."""
+    nm = len(flow_preds)
+    n = nm // 2
+    weights = [gamma ** (n - i - 1) for i in range(n)] + [gamma2 ** (n - i - 1) for i in range(nm - n)]
+    loss, stats = weighted_sequence_loss(flow_preds, weights, flow_gt, valid, max_flow, 1e-3, n - 1)
+    _, epe_sum, n1, n3, n5, nv = stats.tolist()
+    nv = max(nv, 1.0)
+    return loss, {"epe": epe_sum / nv, "1px": n1 / nv, "3px": n3 / nv, "5px": n5 / nv}
+
+
+def raft_sequence_loss(flow_preds, flow_gt=None, gamma=0.8):
+    """The benchmark objective: sum_i gamma^(n-1-i) * mean(sqrt((pred_i - gt)^2 + 1e-6)), every pixel valid,
+    gt defaulting to zero flow."""
     n = len(flow_preds)
-    loss = 0.0
-    for i, p in enumerate(flow_preds):
-        d = p if flow_gt is None else p - flow_gt
-        loss = loss + (gamma ** (n - i - 1)) * torch.sqrt(d * d + 1e-6).mean()
-    return loss
+    return weighted_sequence_loss(flow_preds, [gamma ** (n - i - 1) for i in range(n)], flow_gt, None, float("inf"), 1e-3)[0]
 
 
 class TrainStep:
@@ -29,7 +80,7 @@ class TrainStep:
     def __call__(self, image1, image2, flow_gt=None):
         self.grads.zero_()
         preds = self.model(image1, image2, iters=self.iters)
-        loss = sequence_loss(preds, flow_gt)
+        loss = raft_sequence_loss(preds, flow_gt)
         loss.backward()
         self.grads.all_reduce_mean_()
         self.grads.clip_norm_(self.clip)

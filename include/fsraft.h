@@ -172,6 +172,15 @@ int fsraft_affine_relu_fwd(const float* x, const float* scale, const float* shif
 int fsraft_affine_relu_bwd(const float* g, const float* x, const float* scale, const float* shift, float* dx, float* dsum_g,
                            float* dsum_gx, int64_t planes, int C, int HW, int relu, hipStream_t stream);
 
+/* ---- sequence loss (a step next to the path: pytorch/train.py:60-96) -----------------------------------------------
+ * loss = sum_i weights[i] * mean(mask * sqrt((pred_i - gt)^2 + eps^2)), mask = valid >= 0.5 && |gt| < max_flow, over n
+ * predictions [B,2,H,W] in one pass; dpred[i] (nullable) receives d loss / d pred_i; out[0] = loss, out[1..5] = EPE sum,
+ * counts < 1 / 3 / 5 px and valid (> 0.5) count of prediction metric_idx.  gt / valid may be NULL (zero flow / all valid).
+ * out[6] must be zero on entry. */
+int fsraft_sequence_loss(const float* const* pred, float* const* dpred, const float* weights, int n, int metric_idx,
+                         const float* gt, const float* valid, float max_flow, float eps, int B, int H, int W, float* out,
+                         hipStream_t stream);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);

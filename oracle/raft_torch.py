@@ -415,6 +415,23 @@ def sequence_loss_zero_gt(preds, gamma=0.8):
     return loss
 
 
+def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8, gamma2=1.0, max_flow=400.0):
+    """pytorch/train.py:60-96 restated.  PARITY UNPINNED: pytorch/train.py cannot be imported in the build container (it
+    needs cv2), so no golden vector exists for this function; the formula is short enough to read against the source."""
+    nm = len(flow_preds)
+    n = nm // 2
+    mag = torch.sum(flow_gt ** 2, dim=1).sqrt()
+    mask = (valid >= 0.5) & (mag < max_flow)
+    loss = 0.0
+    for i in range(nm):
+        w = gamma ** (n - i - 1) if i < n else gamma2 ** (n - (i - n) - 1)
+        diff = flow_preds[i] - flow_gt
+        loss = loss + w * (mask[:, None] * (diff ** 2 + 0.001 ** 2) ** 0.5).mean()
+    e = torch.sum((flow_preds[n - 1] - flow_gt) ** 2, dim=1).sqrt().view(-1)[(valid > 0.5).view(-1)]
+    return loss, {"epe": e.mean().item(), "1px": (e < 1).float().mean().item(), "3px": (e < 3).float().mean().item(),
+                  "5px": (e < 5).float().mean().item()}
+
+
 def epe(a, b):
     """Mean end-point error, raft/metric.py:23-31."""
     return torch.sqrt(((a - b) ** 2).sum(dim=1)).mean()

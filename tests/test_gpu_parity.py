@@ -708,3 +708,27 @@ def test_gma_update_block_unaligned_pixel_count(precision):
     (n_g * wn.to(DEV)).sum().backward()
     close(a_g, a_r, 2e-6 * f, what="attention"); close(n_g, n_r, 2e-5 * f, what="net"); close(d_g, d_r, 2e-5 * f, what="delta")
     close(ctx_g.grad, ctx_c.grad, 1e-4 * f, what="d context through attention")
+
+
+# ----------------------------------------------------------------------------- fused sequence loss (step next to the path)
+def test_sequence_loss_matches_restatement():
+    """pytorch/train.py:60-96 on the fused kernel vs the oracle restatement (unpinned: train.py is not importable here)."""
+    from flow_supervisor_amd.train import raft_sequence_loss, sequence_loss
+    torch.manual_seed(5)
+    B, H, W, n = 2, 24, 40, 6
+    preds_c = [(torch.randn(B, 2, H, W) * 3).requires_grad_(True) for _ in range(n)]
+    gt = torch.randn(B, 2, H, W) * 4
+    gt[0, :, :3, :5] = 500.0                                     # beyond max_flow: excluded
+    valid = (torch.rand(B, H, W) > 0.2).float()
+    l_r, m_r = O.sequence_loss(preds_c, gt, valid, 0.8, 1.0, 400.0)
+    l_r.backward()
+    preds_g = [p.detach().to(DEV).requires_grad_(True) for p in preds_c]
+    l_g, m_g = sequence_loss(preds_g, gt.to(DEV), valid.to(DEV), 0.8, 1.0, 400.0)
+    l_g.backward()
+    assert abs(l_g.item() - l_r.item()) <= 1e-5 * abs(l_r.item())
+    for k in m_r:
+        assert abs(m_g[k] - m_r[k]) <= 1e-5 + 1e-5 * abs(m_r[k]), (k, m_g[k], m_r[k])
+    for a, b in zip(preds_g, preds_c):
+        close(a.grad, b.grad, 1e-8, 1e-4, what="d loss / d prediction")
+    z = raft_sequence_loss([p.detach() for p in preds_g])
+    assert abs(z.item() - O.sequence_loss_zero_gt([p.detach() for p in preds_c]).item()) <= 1e-5 * abs(z.item())
