@@ -245,7 +245,7 @@ struct BufConvALoaderU {                  // uniform form: one base, one pitch, 
     }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
-    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
   }
 };
 
@@ -266,7 +266,7 @@ struct BufWeightLoader {                  // pre-split packed weights through on
     }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
-    stage_copy<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+    stage_copy<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
   }
 };
 
@@ -423,7 +423,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
   }
   __syncthreads();
   constexpr int C4 = Cfg::BN / 4;                    // float4 columns per row
-  constexpr int RPP = 256 / C4;                      // rows covered per pass
+  constexpr int RPP = Cfg::NT / C4;                  // rows covered per pass
   const int c4 = threadIdx.x % C4, rsub = threadIdx.x / C4;
   const int n = n0 + c4 * 4;
   if (n >= a.N) return;
@@ -562,8 +562,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
 // split-bf16 variant: 3 x v_mfma_f32_32x32x16_bf16 per product block, weights pre-split at pack time
 template <class Cfg, int EPI, int BUF = 0>       // BUF 0: flat 64-bit addressing, 1: buffer loads + k-tile table, 2: uniform-pitch table
-__global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::conditional_t<BUF != 0, ConvArgsT, ConvArgs> args) {
-  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+__global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::conditional_t<BUF != 0, ConvArgsT, ConvArgs> args) {
+  static_assert(Cfg::NT == 256 || BUF == 2, "only the uniform-table path is written for 512-thread workgroups");
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_ALLOC];
   const ConvArgs& a = [&]() -> const ConvArgs& { if constexpr (BUF != 0) return args.a; else return args; }();
   const int HW = a.H * a.W;
   const int M = a.B * HW;
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::condit
     unsigned tapmask[Cfg::NCH_A], pofs[Cfg::NCH_A];
 #pragma unroll
     for (int j = 0; j < Cfg::NCH_A; ++j) {
-      const int m = m0 + ((threadIdx.x + 256 * j) >> 3);
+      const int m = m0 + ((threadIdx.x + Cfg::NT * j) >> 3);
       unsigned mask = 0;
       if (m < M) {
         const int pix = m % HW, y = pix / a.W, x = pix % a.W;
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::condit
     lb.nbytes = 0x7fffffffu;   // validity is carried by the lane offsets alone (FS_OOB), whatever the range check adds to them
 #pragma unroll
     for (int j = 0; j < BufWeightLoader<Cfg>::NCH; ++j) {
-      const int e = threadIdx.x + 256 * j;
+      const int e = threadIdx.x + Cfg::NT * j;
       lb.voff[j] = (e >> 3) < a.N - n0 ? (unsigned)((e >> 3) * a.Ktot * 4 + (e & 7) * 16) : FS_OOB;
     }
     if constexpr (BUF == 2) {
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const std::condit
   SplitWeightLoader<Cfg> lb{reinterpret_cast<const char*>(a.wpk) + (int64_t)n0 * a.Ktot * 4, (int64_t)a.Ktot * 4, a.N - n0};
   split_mainloop<Cfg>(lds, a.Ktot / 32, la, lb, acc);
   }
-  if constexpr (Cfg::LDS_BYTES >= Cfg::BM * (Cfg::BN + 4) * 4) {     // the parked tile must fit the staging LDS
+  if constexpr (Cfg::LDS_ALLOC >= Cfg::BM * (Cfg::BN + 4) * 4) {     // the parked tile must fit the LDS allocation
     if (EPI != EPI_PLAIN || epilogue_rows_ok(a)) {
       conv_epilogue_lds<Cfg, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(lds));
       return;
@@ -1043,8 +1044,11 @@ using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 
 using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
+using SCfg128W8 = SplitCfg<128, 128, 2, 4, 2, true, 512>;   // eight waves per workgroup, 66 KB of LDS: two workgroups per CU
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_conv_w8 = 1;        // 512-thread 128x128 tiles for wide layers (key 13); g_conv_w8_min: minimum workgroup count (key 14)
+int g_conv_w8_min = 64;      // (measured faster than 64x128 four-wave tiles on every update-block shape, N = 64 .. 576)
 int g_conv_uniform = 1;   // uniform-pitch k-tile table when the sources allow it (key 12)
 int g_wgrad_blocks_multi = 2048;   // workgroup target of the multi-segment launch (key 11); measured 512: 9.0, 1024: 8.5, 2048: 8.35 ms/step
 int g_wgrad_multi = 1;  // one weight-gradient launch per layer per step over all stashed iterations (key 10)
@@ -1123,13 +1127,16 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   dim3 grid(ceil_div(a.N, Cfg::BN), ceil_div(M, Cfg::BM));
   ConvArgsT t;
   // buffer-addressed loaders + branch-free k-loop: measured faster on the 64-row tiles, slower on 128x128
-  const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256;
+  const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256 || Cfg::NT != 256;
   if (buf && build_ktab_uniform(a, t)) {
-    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(256), 0, s, t);
-    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 2>), grid, dim3(256), 0, s, t);
-    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(256), 0, s, t);
+    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(Cfg::NT), 0, s, t);
+    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 2>), grid, dim3(Cfg::NT), 0, s, t);
+    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(Cfg::NT), 0, s, t);
     return fs_launch_status();
   }
+  if constexpr (Cfg::NT != 256) {
+    return -1;          // the 512-thread configuration exists for the uniform-table path only: caller falls back
+  } else {
   if (buf && build_ktab(a, t)) {
     if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), grid, dim3(256), 0, s, t);
     else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 1>), grid, dim3(256), 0, s, t);
@@ -1140,6 +1147,7 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q>), grid, dim3(256), 0, s, a);
   return fs_launch_status();
+  }
 }
 
 template <class Cfg>
@@ -1228,6 +1236,11 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     if (g_conv_split == 5 || (g_conv_split == 1 && g_conv_n256 && d->N >= 256 &&
                               ceil_div(d->N, 256) * 256 <= ceil_div(d->N, 128) * 128))
       return launch_conv_split<SCfgN256>(a, d->epi, stream);
+    // eight-wave 128x128 tiles where they fill the machine in one round (N >= 256 at M ~ 28 K): key 13
+    if (g_conv_w8 && g_conv_split == 1 && (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) >= g_conv_w8_min) {
+      const int rc = launch_conv_split<SCfg128W8>(a, d->epi, stream);
+      if (rc >= 0) return rc;
+    }
     if (g_conv_split == 3) return launch_conv_split<SCfgM64>(a, d->epi, stream);
     if (g_conv_split == 4) return launch_conv_split<SCfg128>(a, d->epi, stream);
     return narrow ? launch_conv_split<SCfgM64>(a, d->epi, stream) : launch_conv_split<SCfg128>(a, d->epi, stream);
@@ -1259,6 +1272,8 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 10) g_wgrad_multi = value;
   else if (key == 11) g_wgrad_blocks_multi = value;
   else if (key == 12) g_conv_uniform = value;
+  else if (key == 13) g_conv_w8 = value;
+  else if (key == 14) g_conv_w8_min = value;
   else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;

@@ -45,8 +45,12 @@ __device__ __forceinline__ void fetch_all(const L& l, int kt, float (&r)[N]) {
   }
 }
 
-template <int BM_, int BN_, int WM_, int WN_, int NBUF_ = 2, bool SWZ_ = false>
+// NT_ = threads per workgroup (256 or 512).  128x128 tiles with EIGHT waves (each still owning 64x32) need 440 workgroups
+// for an N = 256 layer at M = 28160 -- one round on 512 resident slots -- where the 64x128 / four-wave tiles need 880 on
+// 768 slots, i.e. a second round that is 15 % full; and every operand byte staged is shared by twice as many MFMAs.
+template <int BM_, int BN_, int WM_, int WN_, int NBUF_ = 2, bool SWZ_ = false, int NT_ = 256>
 struct SplitCfg {
+  static constexpr int NT = NT_;
   static constexpr int NBUF = NBUF_;                              // 2: double-buffered LDS; 1: one image, two barriers per k-tile
   static constexpr int BM = BM_, BN = BN_, BK = 32, WM = WM_, WN = WN_;
   static constexpr bool SWZ = SWZ_;
@@ -55,8 +59,10 @@ struct SplitCfg {
   static constexpr int A_BYTES = BM_ * PITCH, B_BYTES = BN_ * PITCH;
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NBUF_ * STAGE;
-  static constexpr int NCH_A = BM_ * 8 / 256, NCH_B = BN_ * 8 / 256;
-  static_assert(WM_ * WN_ == 4, "4 waves per workgroup");
+  static constexpr int EPI_BYTES = BM_ * (BN_ + 4) * 4;                         // fp32 tile parked for the row-wise epilogue
+  static constexpr int LDS_ALLOC = LDS_BYTES > EPI_BYTES ? LDS_BYTES : EPI_BYTES;
+  static constexpr int NCH_A = BM_ * 8 / NT_, NCH_B = BN_ * 8 / NT_;
+  static_assert(WM_ * WN_ * 64 == NT_, "one 64-lane wave per (WM, WN) cell");
 };
 
 // 16 bytes of zeros that out-of-range chunks are loaded from instead of being masked afterwards
