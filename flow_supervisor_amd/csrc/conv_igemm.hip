@@ -812,9 +812,11 @@ struct BufShiftedXLoader {
 
 using SWCfg128 = SplitTnCfg<128, 128, 2, 2, 2>;
 using SWCfg128S = SplitTnCfg<128, 128, 2, 2, 1>;
+using SWCfg128W8 = SplitTnCfg<128, 128, 2, 4, 1, 512>;   // eight waves per workgroup (multi-segment launches)
 
 template <class Cfg, bool BUF = false, bool MULTI = false>
-__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const std::conditional_t<MULTI, WgradArgsM, WgradArgs> args) {
+__global__ __launch_bounds__(Cfg::NT) void conv_wgrad_split_kernel(const std::conditional_t<MULTI, WgradArgsM, WgradArgs> args) {
+  static_assert(Cfg::NT == 256 || BUF, "512-thread workgroups use the buffer-addressed loaders");
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
   __shared__ unsigned pixmask[BUF ? WGRAD_MASK_WORDS : 1];
   const WgradArgs& a = [&]() -> const WgradArgs& { if constexpr (MULTI) return args.a; else return args; }();
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const std::condit
   const bool want_bias = a.dbias != nullptr && blockIdx.x == 0;        // one x-tile per (co tile, pixel split) owns the bias
   if constexpr (BUF) {
     // pixel mask: bit k of word w <=> pixel mb + 32 w + k exists and its (dy, dx)-shifted neighbour is inside the image
-    for (int i = threadIdx.x; i < KT * 32; i += 256) {
+    for (int i = threadIdx.x; i < KT * 32; i += Cfg::NT) {
       const int64_t m = mb + i;
       bool ok = m < me;
       if (ok) {
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const std::condit
     const int cva = coleft < Cfg::BM ? coleft : Cfg::BM;
 #pragma unroll
     for (int j = 0; j < BufDyLoader<Cfg>::NCH; ++j) {
-      const int e = threadIdx.x + 256 * j, k = e / (Cfg::BM / 4), c4 = e % (Cfg::BM / 4);
+      const int e = threadIdx.x + Cfg::NT * j, k = e / (Cfg::BM / 4), c4 = e % (Cfg::BM / 4);
       la.krow[j] = k; la.voff[j] = c4 * 4 < cva ? (unsigned)(k * a.ldy + c4 * 4) * 4u : FS_OOB;
     }
     BufShiftedXLoader<Cfg> lb;
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const std::condit
     const int cvb = cleft < Cfg::BN ? cleft : Cfg::BN;
 #pragma unroll
     for (int j = 0; j < BufShiftedXLoader<Cfg>::NCH; ++j) {
-      const int e = threadIdx.x + 256 * j, k = e / (Cfg::BN / 4), c4 = e % (Cfg::BN / 4);
+      const int e = threadIdx.x + Cfg::NT * j, k = e / (Cfg::BN / 4), c4 = e % (Cfg::BN / 4);
       lb.krow[j] = k; lb.voff[j] = c4 * 4 < cvb ? (unsigned)(k * sc.ld + c4 * 4) * 4u : FS_OOB;
     }
     if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const std::condit
   else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
   }
   if (want_bias) {
-    // this thread's columns are co0 + 4*(tid % 32) .. +3; eight threads (tid / 32) share them
+    // this thread's columns are co0 + 4*(tid % 32) .. +3; NT/32 threads (tid / 32) share them
     float* part = reinterpret_cast<float*>(lds);
     __syncthreads();
 #pragma unroll
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const std::condit
     if (threadIdx.x < Cfg::BM) {
       float s = 0.f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) s += part[g * Cfg::BM + threadIdx.x];
+      for (int g = 0; g < Cfg::NT / 32; ++g) s += part[g * Cfg::BM + threadIdx.x];
       if (co0 + threadIdx.x < a.Cout) atomicAdd(a.dbias + co0 + threadIdx.x, s);
     }
   }
@@ -1047,6 +1049,7 @@ using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgr
 using SCfg128W8 = SplitCfg<128, 128, 2, 4, 2, true, 512>;   // eight waves per workgroup, 66 KB of LDS: two workgroups per CU
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
+int g_wgrad_w8 = 0;       // 512-thread workgroups in the multi-segment weight gradient (key 15); measured slower (7.96 vs 7.32 ms/step): its grid is large already
 int g_conv_w8 = 1;        // 512-thread 128x128 tiles for wide layers (key 13); g_conv_w8_min: minimum workgroup count (key 14)
 int g_conv_w8_min = 64;      // (measured faster than 64x128 four-wave tiles on every update-block shape, N = 64 .. 576)
 int g_conv_uniform = 1;   // uniform-pitch k-tile table when the sources allow it (key 12)
@@ -1274,6 +1277,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 12) g_conv_uniform = value;
   else if (key == 13) g_conv_w8 = value;
   else if (key == 14) g_conv_w8_min = value;
+  else if (key == 15) g_wgrad_w8 = value;
   else if (key == 7) g_xcd_swizzle = value;
   else if (key == 4) g_wgrad_split = value;
   else return FS_ERR_ARG;
@@ -1386,7 +1390,8 @@ extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy
     m.zs = (int)((M + chunk - 1) / chunk);
     m.nseg = n;
     dim3 grid(xt128, ytiles, m.zs * n);
-    hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S, true, true>), grid, dim3(256), 0, stream, m);
+    if (g_wgrad_w8) hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128W8, true, true>), grid, dim3(512), 0, stream, m);
+    else hipLaunchKernelGGL((conv_wgrad_split_kernel<SWCfg128S, true, true>), grid, dim3(256), 0, stream, m);
     const int rc = fs_launch_status();
     if (rc) return rc;
   }

@@ -264,16 +264,16 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
 // disjoint quarters of the 256-byte bank row, so the transposed reads are conflict free.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM_, int BN_, int WM_, int WN_, int NBUF_ = 2>
+template <int BM_, int BN_, int WM_, int WN_, int NBUF_ = 2, int NT_ = 256>
 struct SplitTnCfg {
-  static constexpr int BM = BM_, BN = BN_, BK = 32, WM = WM_, WN = WN_, NBUF = NBUF_;
+  static constexpr int BM = BM_, BN = BN_, BK = 32, WM = WM_, WN = WN_, NBUF = NBUF_, NT = NT_;
   static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
   static constexpr int PA = BM_ * 2 + 64, PB = BN_ * 2 + 64;         // row pitch in bytes
   static constexpr int A_PLANE = 32 * PA, B_PLANE = 32 * PB;
   static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
   static constexpr int LDS_BYTES = NBUF_ * STAGE;
-  static constexpr int NCH_A = 32 * (BM_ / 4) / 256, NCH_B = 32 * (BN_ / 4) / 256;
-  static_assert(WM_ * WN_ == 4, "4 waves per workgroup");
+  static constexpr int NCH_A = 32 * (BM_ / 4) / NT_, NCH_B = 32 * (BN_ / 4) / NT_;
+  static_assert(WM_ * WN_ * 64 == NT_, "one 64-lane wave per (WM, WN) cell");
 };
 
 // chunk e of a [32][COLS] fp32 tile: k = e / (COLS/4), 4 consecutive columns from 4 * (e % (COLS/4))
@@ -310,7 +310,7 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
   auto stage = [&](char* dst, bool count) {
 #pragma unroll
     for (int c = 0; c < LA::NCH; ++c) {
-      stage_convert_kmajor<Cfg::BM, Cfg::PA, Cfg::A_PLANE>(dst, threadIdx.x + 256 * c, ra + 4 * c);
+      stage_convert_kmajor<Cfg::BM, Cfg::PA, Cfg::A_PLANE>(dst, threadIdx.x + Cfg::NT * c, ra + 4 * c);
       if (COLSUM && count) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) colsum[q] += ra[4 * c + q];
@@ -318,7 +318,7 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
     }
 #pragma unroll
     for (int c = 0; c < LB::NCH; ++c)
-      stage_convert_kmajor<Cfg::BN, Cfg::PB, Cfg::B_PLANE>(dst + 2 * Cfg::A_PLANE, threadIdx.x + 256 * c, rb + 4 * c);
+      stage_convert_kmajor<Cfg::BN, Cfg::PB, Cfg::B_PLANE>(dst + 2 * Cfg::A_PLANE, threadIdx.x + Cfg::NT * c, rb + 4 * c);
   };
   if (KT > 0) {
     fetch_all(la, 0, ra);
