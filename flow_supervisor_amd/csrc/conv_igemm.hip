@@ -1046,6 +1046,7 @@ using CfgM64K16 = GemmCfg<64, 128, 16, 1, 4, 2, 2>;  // 25 KB: 6 workgroups/CU
 
 using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
+using SCfg256W16 = SplitCfg<256, 128, 4, 4, 2, true, 1024>;  // sixteen waves, one workgroup per CU
 using SCfg128W8 = SplitCfg<128, 128, 2, 4, 2, true, 512>;   // eight waves per workgroup, 66 KB of LDS: two workgroups per CU
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
@@ -1240,6 +1241,11 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
                               ceil_div(d->N, 256) * 256 <= ceil_div(d->N, 128) * 128))
       return launch_conv_split<SCfgN256>(a, d->epi, stream);
     // eight-wave 128x128 tiles where they fill the machine in one round (N >= 256 at M ~ 28 K): key 13
+    // sixteen-wave 256x128 tiles: a further 3-6 % on the 192..512-output layers (zr 93 -> 87 us), slower on m2 (N = 576)
+    if (g_conv_split == 1 && ((g_conv_w8 == 1 && d->N >= 192 && d->N <= 512 && M >= 16384) || g_conv_w8 == 2) && d->N >= 192) {
+      const int rc = launch_conv_split<SCfg256W16>(a, d->epi, stream);
+      if (rc >= 0) return rc;
+    }
     if (g_conv_w8 && g_conv_split == 1 && (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) >= g_conv_w8_min) {
       const int rc = launch_conv_split<SCfg128W8>(a, d->epi, stream);
       if (rc >= 0) return rc;
