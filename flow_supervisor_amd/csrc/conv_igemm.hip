@@ -216,9 +216,9 @@ struct BufConvALoader {
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
 #ifdef FSRAFT_ABLATE
     // experiment: bit 4 stages A as if it were stored pre-split (copy, no conversion) -- wrong numbers, right cost
-    if (__builtin_amdgcn_readfirstlane(g_fsraft_ablate) & 16) { stage_copy<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4); return; }
+    if (__builtin_amdgcn_readfirstlane(g_fsraft_ablate) & 16) { stage_copy<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4); return; }
 #endif
-    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
   }
 };
 
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // split-bf16 variant: 3 x v_mfma_f32_32x32x16_bf16 per product block, weights pre-split at pack time
 template <class Cfg, int EPI, int BUF = 0>       // BUF 0: flat 64-bit addressing, 1: buffer loads + k-tile table, 2: uniform-pitch table
 __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::conditional_t<BUF != 0, ConvArgsT, ConvArgs> args) {
-  static_assert(Cfg::NT == 256 || BUF == 2, "only the uniform-table path is written for 512-thread workgroups");
+  static_assert(Cfg::NT == 256 || BUF != 0, "wider workgroups use the buffer-addressed loaders");
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_ALLOC];
   const ConvArgs& a = [&]() -> const ConvArgs& { if constexpr (BUF != 0) return args.a; else return args; }();
   const int HW = a.H * a.W;
@@ -1138,15 +1138,15 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
     else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(Cfg::NT), 0, s, t);
     return fs_launch_status();
   }
-  if constexpr (Cfg::NT != 256) {
-    return -1;          // the 512-thread configuration exists for the uniform-table path only: caller falls back
-  } else {
   if (buf && build_ktab(a, t)) {
-    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), grid, dim3(256), 0, s, t);
-    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 1>), grid, dim3(256), 0, s, t);
-    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 1>), grid, dim3(256), 0, s, t);
+    if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), grid, dim3(Cfg::NT), 0, s, t);
+    else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 1>), grid, dim3(Cfg::NT), 0, s, t);
+    else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 1>), grid, dim3(Cfg::NT), 0, s, t);
     return fs_launch_status();
   }
+  if constexpr (Cfg::NT != 256) {
+    return -1;          // the wide configurations exist for the buffer-addressed paths only: caller falls back
+  } else {
   if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN>), grid, dim3(256), 0, s, a);
   else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q>), grid, dim3(256), 0, s, a);
