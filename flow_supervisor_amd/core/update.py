@@ -220,6 +220,9 @@ class _Engine:
                 ops.conv_wgrad_multi([dy for dy, _ in lst], [srcs for _, srcs in lst], dW[k], B, H, W, l.kh, l.kw,
                                      dbias=dB[k])
             st.pending = {}
+        if self.has_mask and st.dW is not None:
+            st.dW["m2"].mul_(0.25)
+            st.dB["m2"].mul_(0.25)
         byname = dict(zip(self.pnames, params))
         grads = {}
         for k in self.order:
@@ -447,20 +450,21 @@ class _Engine:
             with torch.cuda.stream(side):
                 ops.conv_wgrad(dy, srcs, dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
 
-        def dgrad(k, dy, dsts):
+        def dgrad(k, dy, dsts, alpha=1.0):
             l = self.layers[k]
             n_in = sum(l.src_c)
-            ops.conv_forward([dy], P[k][1], None, B, H, W, l.kh, l.kw, n_in, dsts, wpk_split=P[k][6])
+            ops.conv_forward([dy], P[k][1], None, B, H, W, l.kh, l.kw, n_in, dsts, alpha=alpha, wpk_split=P[k][6])
 
         # ---- heads
         dhead = buf(self.head_c * (2 if self.has_mask else 1))
         head = S["head"]
         if self.has_mask:
             if dmask is not None:
-                g = torch.empty(B, H, W, 576, device=dev, dtype=torch.float32)
-                ops.axpby_(dmask.contiguous(), g, 0.25, 0.0)      # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask
+                # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask: the data gradient applies the factor in its
+                # epilogue, the weight / bias gradients once per step when the arena is unpacked
+                g = dmask.contiguous()
                 wgrad("m2", V(g, 576), [V(head, self.head_c, self.head_c)])
-                dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))])
+                dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))], alpha=0.25)
             else:
                 dhead[..., self.head_c:].zero_()
         dd = torch.zeros(B, H, W, 4, device=dev, dtype=torch.float32)
