@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from flow_supervisor_amd import ops  # noqa: E402
 from flow_supervisor_amd.ops import Dst, V  # noqa: E402
 
-B, H, W = 4, 55, 128
+B, H, W = (int(v) for v in os.environ.get("CONV_MICRO_BHW", "4,55,128").split(","))
 M = B * H * W
 dev = "cuda"
 LAYERS = [  # name, kh, kw, src channels, Cout
@@ -35,6 +35,9 @@ LAYERS = [  # name, kh, kw, src channels, Cout
     ("dg c2 3x3 192->256", 3, 3, [192], 256),
     ("dg c1 1x1 256->324", 1, 1, [256], 324),
     ("f2 3x3 128->64", 3, 3, [128], 64),
+    ("e1 3x3 64->64 (encoder layer1)", 3, 3, [64], 64),
+    ("e2 3x3 96->96 (encoder layer2)", 3, 3, [96], 96),
+    ("e3 3x3 128->128 (encoder layer3)", 3, 3, [128], 128),
     ("f1 1x1 98->128", 1, 1, [98], 128),
     ("zrc 1x5 256->256 (ctx split)", 1, 5, [128, 128], 256),
     ("qc 1x5 256->128 (ctx split)", 1, 5, [128, 128], 128),
