@@ -74,7 +74,155 @@ class _FrozenBNRelu(torch.autograd.Function):
         return dx, dcbias, dweight, sums[0], None, None, None, None
 
 
-def _conv_norm(conv, norm, x, relu):
+def _is_cl(x):
+    return x.dim() == 4 and x.shape[1] > 1 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
+def _cl_norm_ok(x):
+    return x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 256
+
+
+def _as_cl(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+class _InstNormReluCL(torch.autograd.Function):
+    """_InstNormRelu for channels_last tensors (storage [N][H*W][C]): csrc/norm_cl.hip."""
+
+    @staticmethod
+    def forward(ctx, x, eps, relu):
+        from .. import _lib as L
+        ctx.in_cl = _is_cl(x)
+        x = _as_cl(x)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)                                   # preserves channels_last
+        acc = torch.zeros(2, N, C, device=x.device, dtype=torch.float32)
+        stats = torch.empty(N, C, 2, device=x.device, dtype=torch.float32)
+        L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W, C,
+                                                  float(eps), int(relu), L.stream()), "inorm_relu_cl_fwd")
+        ctx.save_for_backward(x, stats)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib as L
+        x, stats = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = _as_cl(g)
+        dx = torch.empty_like(x)
+        acc = torch.zeros(2, N, C, device=x.device, dtype=torch.float32)
+        L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
+                                                  N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
+        return dx if ctx.in_cl else dx.contiguous(), None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
+
+
+class _FrozenBNReluCL(torch.autograd.Function):
+    """_FrozenBNRelu for channels_last tensors."""
+
+    @staticmethod
+    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu):
+        from .. import _lib as L
+        ctx.in_cl = _is_cl(x)
+        x = _as_cl(x)
+        N, C, H, W = x.shape
+        rs = torch.rsqrt(rv.float() + eps)
+        scale = (weight.float() * rs).contiguous()
+        rmc = rm.float() - cbias.float() if cbias is not None else rm.float()
+        shift = (bias.float() - rmc * scale).contiguous()
+        y = torch.empty_like(x)
+        L.check(L.load().fsraft_affine_relu_cl_fwd(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(y), N * H * W, C, int(relu),
+                                                   L.stream()), "affine_relu_cl_fwd")
+        ctx.save_for_backward(x, scale, shift, rs, rmc)
+        ctx.relu = relu
+        ctx.has_cbias = cbias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib as L
+        x, scale, shift, rs, rm = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = _as_cl(g)
+        dx = torch.empty_like(x)
+        part = torch.zeros(2, N * 8, C, device=x.device, dtype=torch.float32)      # partial rows (see norm_cl.hip)
+        L.check(L.load().fsraft_affine_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dx), L.ptr(part[0]),
+                                                   L.ptr(part[1]), N, H * W, C, int(ctx.relu), L.stream()), "affine_relu_cl_bwd")
+        sums = part.sum(dim=1)
+        dweight = rs * (sums[1] - rm * sums[0])
+        dcbias = scale * sums[0] if ctx.has_cbias else None
+        return dx if ctx.in_cl else dx.contiguous(), dcbias, dweight, sums[0], None, None, None, None
+
+
+def _weight_packs(conv):
+    """Packed forward / data-gradient matrices of a 3x3 convolution for the split-bf16 implicit GEMM, cached on the module
+    and rebuilt whenever the weight tensor changes (optimizer step, load_state_dict)."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version)
+    c = conv.__dict__.get("_fs_packs")
+    if c is None or c[0] != key:
+        from .. import ops
+        wd = w.detach()
+        cin = [wd.shape[1]]
+        c = (key, ops.pack_weight(wd, cin, 0), ops.pack_weight(wd, cin, 10), ops.pack_weight(wd, cin, 1), ops.pack_weight(wd, cin, 11))
+        conv.__dict__["_fs_packs"] = c
+    return c
+
+
+class _ConvCL(torch.autograd.Function):
+    """Stride-1 'same' convolution (1x1 or 3x3) of a channels_last tensor on the update block's implicit-GEMM kernels
+    (csrc/conv_igemm.hip): forward and data gradient on fsraft_conv_forward, weight (+ bias) gradient on
+    fsraft_conv_wgrad -- whose few-channel variant packs several taps into one tile for these 64/96-channel layers.
+    The storage of a channels_last [B,C,H,W] tensor IS the kernels' [B,H,W,C] layout, so nothing is transposed."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packs):
+        from .. import ops
+        x = _as_cl(x)
+        B, C, H, W = x.shape
+        N, _, KH, KW = weight.shape
+        out = torch.empty(B, H, W, N, device=x.device, dtype=torch.float32)
+        ops.conv_forward([ops.V(x.permute(0, 2, 3, 1), C)], packs[1], bias, B, H, W, KH, KW, N, [ops.Dst.nhwc(out)], wpk_split=packs[2])
+        ctx.save_for_backward(x, weight)
+        ctx.packs = packs
+        ctx.has_bias = bias is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        x, weight = ctx.saved_tensors
+        B, C, H, W = x.shape
+        N, _, KH, KW = weight.shape
+        g = _as_cl(g)
+        gv = ops.V(g.permute(0, 2, 3, 1), N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxb = torch.empty(B, H, W, C, device=x.device, dtype=torch.float32)
+            ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dxb)], wpk_split=ctx.packs[4])
+            dx = dxb.permute(0, 3, 1, 2)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dwpk = torch.zeros(N, ops.conv_ktot([C], KH, KW), device=x.device, dtype=torch.float32)
+            db = torch.zeros(N, device=x.device, dtype=torch.float32) if want_b else None
+            ops.conv_wgrad(gv, [ops.V(x.permute(0, 2, 3, 1), C)], dwpk, B, H, W, KH, KW, dbias=db)
+            dw = ops.unpack_weight_grad(dwpk, tuple(weight.shape), [C])
+        return dx, dw, db, None
+
+
+def _conv(conv, x, bias):
+    """conv(x) with the given bias (None: without).  A channels_last fp32 input of a stride-1 1x1 / 3x3 convolution takes
+    the fsraft kernels; anything else is MIOpen on an NCHW tensor (its NHWC fp32 kernels are far slower than its NCHW
+    ones on gfx950 -- the backward-weights one by two orders of magnitude -- so a channels_last input is converted)."""
+    k = conv.kernel_size
+    if (_is_cl(x) and x.is_cuda and x.dtype == torch.float32 and k in ((3, 3), (1, 1)) and conv.stride == (1, 1)
+            and conv.padding == (k[0] // 2, k[1] // 2) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros" and x.shape[1] % 4 == 0 and not torch.is_autocast_enabled()):
+        return _ConvCL.apply(x, conv.weight, bias, _weight_packs(conv))
+    return F.conv2d(x.contiguous(), conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _conv_norm(conv, norm, x, relu, to_cl=False):
     """relu?(norm(conv(x))) of pytorch/core/extractor.py.  The convolution stays a PyTorch-ROCm (MIOpen) call; for fp32
     CUDA tensors the normalisation + ReLU around it runs on the fused fsraft kernels:
       * non-affine InstanceNorm2d (feature encoder).  A per-channel constant added before it is removed again by its
@@ -82,16 +230,22 @@ def _conv_norm(conv, norm, x, relu):
         forward and one [N,H,W] reduction less backward.  The bias then receives no gradient (mathematically it is
         exactly zero; parallel.FlatGradients keeps a zero for it, so the optimizer treats it as the reference does);
       * BatchNorm2d using running statistics (context encoder after freeze_bn, or eval mode).
-    Everything else (training-mode BatchNorm, GroupNorm, autocast dtypes, CPU) is the framework's own modules."""
+    Everything else (training-mode BatchNorm, GroupNorm, autocast dtypes, CPU) is the framework's own modules.
+    A channels_last input (or to_cl) keeps the chain channels_last: the convolution output is converted if the library
+    handed back NCHW, and the [N][HW][C] twins of the norm kernels are used."""
     fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
     if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)
         if fused:
+            y = _conv(conv, x, None)
+            if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
+                return _InstNormReluCL.apply(y, norm.eps, relu)
             return _InstNormRelu.apply(y, norm.eps, relu)
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)
         y = norm(y)
     elif isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats and norm.affine and fused:
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-        return _FrozenBNRelu.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
+        y = _conv(conv, x, None)
+        fn = _FrozenBNReluCL if (to_cl or _is_cl(x)) and _cl_norm_ok(y) else _FrozenBNRelu
+        return fn.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
     else:
         y = norm(conv(x))
     return F.relu(y, inplace=True) if relu else y
@@ -135,11 +289,14 @@ class _Block(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, stride=stride), short)
 
     def forward(self, x):
+        cl = _is_cl(x)
+        if cl and self.downsample is not None:
+            x = x.contiguous()          # the strided convolutions (first 3x3 / shortcut 1x1) are MIOpen NCHW calls: one copy for both
         y = x
         for i in range(1, self.n + 1):
-            y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True)
+            y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True, to_cl=cl)
         if self.downsample is not None:
-            x = _conv_norm(self.downsample[0], self.downsample[1], x, False)
+            x = _conv_norm(self.downsample[0], self.downsample[1], x, False, to_cl=cl)
         return self.relu(x + y)
 
 
@@ -151,6 +308,23 @@ class ResidualBlock(_Block):
 class BottleneckBlock(_Block):
     def __init__(self, in_planes, planes, norm_fn="group", stride=1):
         super().__init__(in_planes, planes, norm_fn, stride, bottleneck=True)
+
+
+def _channels_last_ok(enc, x):
+    """Channels_last encoder path: fp32 CUDA, no autocast, norms that the fused channels_last kernels cover (non-affine
+    InstanceNorm, BatchNorm on running statistics).  FSRAFT_ENCODER_CL=0 keeps the encoder NCHW on MIOpen throughout."""
+    import os
+    mode = int(os.environ.get("FSRAFT_ENCODER_CL", "1"))
+    if mode == 0:
+        return 0
+    if not (x.is_cuda and x.dtype == torch.float32) or torch.is_autocast_enabled():
+        return 0
+    n = enc.norm1
+    if isinstance(n, nn.InstanceNorm2d):
+        return mode if not n.affine and not n.track_running_stats else 0
+    if isinstance(n, nn.BatchNorm2d):
+        return mode if not n.training and n.track_running_stats and n.affine else 0
+    return 0
 
 
 class _Encoder(nn.Module):
@@ -180,9 +354,12 @@ class _Encoder(nn.Module):
         if pair:
             n = x[0].shape[0]
             x = torch.cat(x, dim=0)
-        x = _conv_norm(self.conv1, self.norm1, x, True)
+        # channels_last after the stem (an NCHW MIOpen call: 3 input channels): the stride-1 convolutions then run on the
+        # fsraft implicit-GEMM kernels and the norm + ReLU kernels read and write [N][HW][C] directly
+        cl = _channels_last_ok(self, x)
+        x = _conv_norm(self.conv1, self.norm1, x, True, to_cl=bool(cl))
         x = self.layer3(self.layer2(self.layer1(x)))
-        x = self.conv2(x)
+        x = _conv(self.conv2, x, self.conv2.bias).contiguous() if cl else self.conv2(x)
         if self.training and self.dropout is not None:
             x = self.dropout(x)
         if pair:

@@ -926,6 +926,135 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_split_kernel(const std::co
   }
 }
 
+// ---- few-channel layers (encoder residual stages, C = 32 / 64 / 96) -----------------------------------------------
+// A 128-column x tile holding one tap of a 64-channel source is half empty, and so is a 128-row dY tile of a 64-channel
+// output: the kernel above then spends 4x the useful MFMA work.  Here the x tile packs TP = BN / cpad CONSECUTIVE taps
+// side by side (the packed-K layout is tap-major, so the tile's columns are one contiguous run of dW columns) and the
+// dY tile is 64 wide.  A lane's chunk belongs to one tap for the whole k-loop: the tap's pixel shift is folded into its
+// fixed buffer offset and its "neighbour inside the image" bit comes from that tap's own pixel mask.
+constexpr int WGRAD_PACK_WORDS = 256;      // pixel-mask words per tap slot (pixel split <= 32 * 254)
+constexpr int WGRAD_PACK_SLOTS = 8;
+using SWCfgPack = SplitTnCfg<64, 192, 2, 2, 1>;
+
+template <class Cfg>
+struct BufPackedXLoader {
+  static constexpr int NCH = Cfg::NCH_B, NREG = NCH * 4;
+  const float* base; unsigned ld4; const unsigned* mask;       // mask[word * SLOTS + slot]
+  unsigned voff[NCH]; int krow[NCH]; int slot[NCH];
+  __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, 0x7fffffffu);
+    const unsigned soff = (unsigned)ku * 32u * ld4;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const unsigned w = mask[ku * WGRAD_PACK_SLOTS + slot[j]];
+      const unsigned voffj = voff[j] | ((__builtin_amdgcn_ubfe(w, (unsigned)krow[j], 1u) ^ 1u) << 31);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voffj, soff, 0);
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      r[4 * j + 0] = f[0]; r[4 * j + 1] = f[1]; r[4 * j + 2] = f[2]; r[4 * j + 3] = f[3];
+    }
+  }
+};
+
+// grid: x = tap group, y = 64-row Cout tile, z = pixel split.  Single source, split-bf16 arithmetic.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void conv_wgrad_pack_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  __shared__ unsigned pixmask[WGRAD_PACK_WORDS * WGRAD_PACK_SLOTS];
+  const int HW = a.H * a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int taps = a.KH * a.KW;
+  const Src sc = a.src[0];
+  const int cpad = ((sc.C + 31) / 32) * 32;
+  int TP = Cfg::BN / cpad;
+  if (TP > WGRAD_PACK_SLOTS) TP = WGRAD_PACK_SLOTS;
+  const int tap0 = blockIdx.x * TP;
+  const int ntap = taps - tap0 < TP ? taps - tap0 : TP;
+  const int kofs = tap0 * cpad;
+  const int co0 = blockIdx.y * Cfg::BM;
+  const int64_t mb = (int64_t)blockIdx.z * a.kchunk;
+  const int64_t me = mb + a.kchunk < M ? mb + a.kchunk : M;
+  if (mb >= M) return;
+  const int coleft = ((a.Cout + 3) / 4) * 4 - co0;
+  const int cva = coleft < Cfg::BM ? coleft : Cfg::BM;
+  const int cvb = ((sc.C + 3) / 4) * 4;
+  const int KT = (int)((me - mb + 31) / 32);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.dbias != nullptr && blockIdx.x == 0;
+  // pixel masks, one per tap slot: bit k of word w <=> pixel mb + 32 w + k exists and its shifted neighbour is inside the image
+  for (int i = threadIdx.x; i < KT * 32; i += Cfg::NT) {
+    const int64_t m = mb + i;
+    const int pix = (int)(m % HW), py = pix / a.W, px = pix % a.W;
+    for (int tp = 0; tp < ntap; ++tp) {
+      const int tap = tap0 + tp;
+      const int yy = py + tap / a.KW - a.KH / 2, xx = px + tap % a.KW - a.KW / 2;
+      const bool ok = m < me && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      const unsigned long long bal = __ballot(ok);
+      if ((threadIdx.x & 63) == 0) {
+        pixmask[(i >> 5) * WGRAD_PACK_SLOTS + tp] = (unsigned)bal;
+        pixmask[((i >> 5) + 1) * WGRAD_PACK_SLOTS + tp] = (unsigned)(bal >> 32);
+      }
+    }
+  }
+  __syncthreads();
+  BufDyLoader<Cfg> la;
+  la.base = uni_ptr(a.dy + co0 + mb * a.ldy); la.ld4 = uni((unsigned)a.ldy * 4u); la.npix = (int)(me - mb);
+#pragma unroll
+  for (int j = 0; j < BufDyLoader<Cfg>::NCH; ++j) {
+    const int e = threadIdx.x + Cfg::NT * j, k = e / (Cfg::BM / 4), c4 = e % (Cfg::BM / 4);
+    la.krow[j] = k; la.voff[j] = c4 * 4 < cva ? (unsigned)(k * a.ldy + c4 * 4) * 4u : FS_OOB;
+  }
+  // taps ascend in (dy, dx), so the group's first tap has the smallest pixel shift: every lane offset is >= 0
+  const int shift0 = (tap0 / a.KW - a.KH / 2) * a.W + (tap0 % a.KW - a.KW / 2);
+  BufPackedXLoader<Cfg> lb;
+  lb.base = uni_ptr(sc.p + (mb + shift0) * sc.ld); lb.ld4 = uni((unsigned)sc.ld * 4u); lb.mask = pixmask;
+#pragma unroll
+  for (int j = 0; j < BufPackedXLoader<Cfg>::NCH; ++j) {
+    const int e = threadIdx.x + Cfg::NT * j, k = e / (Cfg::BN / 4), col = (e % (Cfg::BN / 4)) * 4;
+    const int tp = col / cpad, cc = col - tp * cpad, tap = tap0 + tp;
+    const int shift = (tap / a.KW - a.KH / 2) * a.W + (tap % a.KW - a.KW / 2) - shift0;
+    const bool valid = tp < ntap && cc < cvb;
+    lb.krow[j] = k; lb.slot[j] = valid ? tp : 0;
+    lb.voff[j] = valid ? (unsigned)((k + shift) * sc.ld + cc) * 4u : FS_OOB;
+  }
+  if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufPackedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
+  else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
+  if (want_bias) {
+    // this thread's dY columns are co0 + 4*(tid % (BM/4)) .. +3; NT / (BM/4) threads share them
+    constexpr int Q = Cfg::BM / 4, G = Cfg::NT / Q;
+    float* part = reinterpret_cast<float*>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[(threadIdx.x / Q) * Cfg::BM + 4 * (threadIdx.x % Q) + q] = colsum[q];
+    __syncthreads();
+    if (threadIdx.x < Cfg::BM) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) s += part[g * Cfg::BM + threadIdx.x];
+      if (co0 + threadIdx.x < a.Cout) atomicAdd(a.dbias + co0 + threadIdx.x, s);
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < Cfg::TN; ++nt) {
+    const int n = acc_col<Cfg>(nt);
+    if (n >= ntap * cpad) continue;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + acc_row<Cfg>(mt, r);
+        if (co < a.Cout) atomicAdd(a.dwpk + (int64_t)co * a.Ktot + kofs + n, acc[mt][nt][r]);
+      }
+  }
+}
+
 // grid: x = packed-K tile (source, tap, 128-channel tile), y = Cout tile, z = pixel split
 template <class Cfg>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
@@ -1064,6 +1193,8 @@ int g_conv_buf = 1;     // buffer-addressed loaders in the split conv kernels (k
 int g_conv_split = 1;   // 0: exact fp32 MFMA; 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (key 3)
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
 int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
+int g_wgrad_pack = 1;          // few-channel single-source layers on conv_wgrad_pack_kernel (key 16)
+int g_wgrad_blocks_pack = 1024;   // its workgroup target (key 17)
 int g_wgrad_blocks = 512;   // target workgroup count of the pixel split (key 2); measured 256: 12.9, 512: 11.5, 1024: 12.9, 2048: 14.1 ms/step
 using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
 // weight-gradient tiles: LDS images are filled with float4 rows, so pitches stay multiples of 4
@@ -1280,6 +1411,8 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 9) g_conv_n256 = value;
   else if (key == 10) g_wgrad_multi = value;
   else if (key == 11) g_wgrad_blocks_multi = value;
+  else if (key == 16) g_wgrad_pack = value;
+  else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;
   else if (key == 13) g_conv_w8 = value;
   else if (key == 14) g_conv_w8_min = value;
@@ -1313,6 +1446,25 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   a.nsrc = nsrc; a.dwpk = dwpk; a.Ktot = conv_ktot(srcC, nsrc, KH * KW);
   a.B = B; a.H = H; a.W = W; a.KH = KH; a.KW = KW;
   const int64_t M = (int64_t)B * H * W;
+  if (g_wgrad_pack && g_wgrad_split != 0 && g_wgrad_buf && nsrc == 1 && srcC[0] <= 96 && KH * KW > 1 &&
+      (int64_t)(32 * (WGRAD_PACK_WORDS - 2) + 2 * W + 2) * srcld[0] * 4 < 0x7fffffff) {
+    // few input channels: several taps per x tile, 64-row dY tiles (conv_wgrad_pack_kernel)
+    const int cpad = ceil_div(srcC[0], 32) * 32;
+    int tp = SWCfgPack::BN / cpad;
+    if (tp > WGRAD_PACK_SLOTS) tp = WGRAD_PACK_SLOTS;
+    const int xt = ceil_div(KH * KW, tp), yt = ceil_div(Cout, SWCfgPack::BM);
+    int64_t want = (g_wgrad_blocks_pack + (int64_t)xt * yt - 1) / ((int64_t)xt * yt);
+    if (want < 1) want = 1;
+    int64_t chunk = (M + want - 1) / want;
+    if (chunk < 256) chunk = 256;
+    if (chunk > 32 * (WGRAD_PACK_WORDS - 2)) chunk = 32 * (WGRAD_PACK_WORDS - 2);
+    chunk = (chunk + 31) / 32 * 32;
+    a.kchunk = (int)chunk;
+    a.dbias = dbias;
+    dim3 grid(xt, yt, (unsigned)((M + chunk - 1) / chunk));
+    hipLaunchKernelGGL((conv_wgrad_pack_kernel<SWCfgPack>), grid, dim3(SWCfgPack::NT), 0, stream, a);
+    return fs_launch_status();
+  }
   const int ytiles = ceil_div(Cout, bm);
   // aim for ~4 workgroups per CU; each split handles a multiple of 32 pixels, at least 256
   int64_t want = (g_wgrad_blocks + (int64_t)xt128 * ytiles - 1) / ((int64_t)xt128 * ytiles);

@@ -1,0 +1,214 @@
+// Channels-last ([B][HW][C], C % 4 == 0, C <= 256) variants of the encoder normalisation + ReLU kernels of norm.hip, for
+// the encoder stages whose 3x3 convolutions run on the split-bf16 implicit-GEMM kernels (which produce and consume
+// channels-last tensors).  A per-(sample, channel) statistic is a column reduction here: every workgroup walks a strip
+// of pixels with one float4 of channels per lane, reduces across its pixel lanes in LDS and adds its partial sums to
+// [B][C] accumulators with atomics (the caller zeroes them).
+#include "common.hpp"
+
+namespace {
+
+// pixels per workgroup: a few thousand workgroups per launch, so that every CU holds several and the strided walks
+// (one 16-byte load per lane and step, unrolled by four) hide each other's latency
+constexpr int CL_NSLOT = 8;
+__host__ __device__ inline int pix_per_wg(int B, int HW) {
+  int64_t p = ((int64_t)B * HW + 4095) / 4096;
+  p = (p + 63) / 64 * 64;
+  return p < 128 ? 128 : p > 1024 ? 1024 : (int)p;
+}
+
+// sums[b][c] += sum_pix x, sumsq[b][c] += sum_pix x^2
+__global__ __launch_bounds__(256) void cl_stats_kernel(const float* __restrict__ x, float* __restrict__ sums,
+                                                       float* __restrict__ sumsq, int HW, int C, int PIX_PER_WG) {
+  __shared__ f32x4 red[2][256];
+  const int c4n = C >> 2, lanes_p = 256 / c4n;            // pixels covered per step
+  const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * PIX_PER_WG, p1 = min(p0 + PIX_PER_WG, HW);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (pl < lanes_p)
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += lanes_p) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((int64_t)b * HW + p) * C + cl * 4);
+      s += v; q += v * v;
+    }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < c4n) {
+    f32x4 ts = {0.f, 0.f, 0.f, 0.f}, tq = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < lanes_p; ++k) { ts += red[0][k * c4n + threadIdx.x]; tq += red[1][k * c4n + threadIdx.x]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      atomicAdd(sums + b * C + threadIdx.x * 4 + i, ts[i]);
+      atomicAdd(sumsq + b * C + threadIdx.x * 4 + i, tq[i]);
+    }
+  }
+}
+
+// y = relu?((x - mean) * rstd) with mean / rstd from the accumulated sums; stats[b][c] = (mean, rstd) written by block (0, b)
+__global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ sums,
+                                                             const float* __restrict__ sumsq, float* __restrict__ y,
+                                                             float* __restrict__ stats, int HW, int C, float eps, int relu, int PIX_PER_WG) {
+  const int c4n = C >> 2, lanes_p = 256 / c4n;
+  const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int b = blockIdx.y;
+  f32x4 mean, rstd;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = cl * 4 + i;
+    const float m = sums[b * C + c] / (float)HW;
+    const float var = fmaxf(sumsq[b * C + c] / (float)HW - m * m, 0.f);
+    mean[i] = m; rstd[i] = rsqrtf(var + eps);
+    if (blockIdx.x == 0 && pl == 0) { stats[(b * C + c) * 2] = m; stats[(b * C + c) * 2 + 1] = rstd[i]; }
+  }
+  const int p0 = blockIdx.x * PIX_PER_WG, p1 = min(p0 + PIX_PER_WG, HW);
+  if (pl < lanes_p)
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += lanes_p) {
+      const int64_t o = ((int64_t)b * HW + p) * C + cl * 4;
+      f32x4 v = (*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd;
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(y + o) = v;
+    }
+}
+
+// MODE 0 (instance norm): xhat = (x - mean) * rstd, g' = g * (xhat > 0 | !relu); s1[b][c] += sum g', s2[b][c] += sum g' xhat
+// MODE 1 (affine):        t = x * scale + shift,    g' = g * (t > 0 | !relu);    s1[c]    += sum g', s2[c]    += sum g' x; dx = g' * scale
+template <int MODE>
+__global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                          const float* __restrict__ pa, const float* __restrict__ pb,
+                                                          float* __restrict__ s1, float* __restrict__ s2,
+                                                          float* __restrict__ dx, int HW, int C, int relu, int PIX_PER_WG) {
+  __shared__ f32x4 red[2][256];
+  const int c4n = C >> 2, lanes_p = 256 / c4n;
+  const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int b = blockIdx.y;
+  f32x4 A, Bv;                                             // MODE 0: mean, rstd (per b,c)   MODE 1: scale, shift (per c)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = cl * 4 + i;
+    if (MODE == 0) { A[i] = pa[(b * C + c) * 2]; Bv[i] = pa[(b * C + c) * 2 + 1]; }
+    else { A[i] = pa[c]; Bv[i] = pb[c]; }
+  }
+  const int p0 = blockIdx.x * PIX_PER_WG, p1 = min(p0 + PIX_PER_WG, HW);
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  if (pl < lanes_p)
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += lanes_p) {
+      const int64_t o = ((int64_t)b * HW + p) * C + cl * 4;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o), xv = *reinterpret_cast<const f32x4*>(x + o);
+      f32x4 dv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t = MODE == 0 ? (xv[i] - A[i]) * Bv[i] : xv[i] * A[i] + Bv[i];
+        const float gg = (relu && t <= 0.f) ? 0.f : gv[i];
+        a1[i] += gg;
+        a2[i] += gg * (MODE == 0 ? t : xv[i]);
+        dv[i] = gg * A[i];
+      }
+      if (MODE == 1) *reinterpret_cast<f32x4*>(dx + o) = dv;
+    }
+  red[0][threadIdx.x] = a1; red[1][threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x < c4n) {
+    f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < lanes_p; ++k) { t1 += red[0][k * c4n + threadIdx.x]; t2 += red[1][k * c4n + threadIdx.x]; }
+    // MODE 1 sums over the whole batch: spread the workgroups over gridDim.y * NSLOT partial rows ([B * NSLOT][C],
+    // summed by the caller) -- thousands of atomics on the same C addresses serialise in L2 otherwise
+    const int base = (MODE == 0 ? b * C : (b * CL_NSLOT + (int)(blockIdx.x % CL_NSLOT)) * C) + threadIdx.x * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { atomicAdd(s1 + base + i, t1[i]); atomicAdd(s2 + base + i, t2[i]); }
+  }
+}
+
+// dx = rstd * (g' - mean(g') - xhat * mean(g' xhat))
+__global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                 const float* __restrict__ stats, const float* __restrict__ s1,
+                                                                 const float* __restrict__ s2, float* __restrict__ dx, int HW,
+                                                                 int C, int relu, int PIX_PER_WG) {
+  const int c4n = C >> 2, lanes_p = 256 / c4n;
+  const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int b = blockIdx.y;
+  f32x4 mean, rstd, m1, m2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = cl * 4 + i;
+    mean[i] = stats[(b * C + c) * 2]; rstd[i] = stats[(b * C + c) * 2 + 1];
+    m1[i] = s1[b * C + c] / (float)HW; m2[i] = s2[b * C + c] / (float)HW;
+  }
+  const int p0 = blockIdx.x * PIX_PER_WG, p1 = min(p0 + PIX_PER_WG, HW);
+  if (pl < lanes_p)
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += lanes_p) {
+      const int64_t o = ((int64_t)b * HW + p) * C + cl * 4;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o), xv = *reinterpret_cast<const f32x4*>(x + o);
+      f32x4 dv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (xv[i] - mean[i]) * rstd[i];
+        const float gg = (relu && xh <= 0.f) ? 0.f : gv[i];
+        dv[i] = rstd[i] * (gg - m1[i] - xh * m2[i]);
+      }
+      *reinterpret_cast<f32x4*>(dx + o) = dv;
+    }
+}
+
+// y = relu?(x * scale[c] + shift[c])
+__global__ __launch_bounds__(256) void cl_affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ y,
+                                                            int64_t M, int C, int relu) {
+  const int c4n = C >> 2;
+  const int64_t total = M * c4n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % c4n) * 4;
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = v[i] * scale[c + i] + shift[c + i]; if (relu) v[i] = fmaxf(v[i], 0.f); }
+    reinterpret_cast<f32x4*>(y)[e] = v;
+  }
+}
+
+inline bool cl_ok(int C) { return C >= 4 && C <= 256 && C % 4 == 0; }      // (threads beyond (256 / (C/4)) * (C/4) idle)
+
+}  // namespace
+
+// x, y: [B][HW][C].  sums / sumsq: [B][C] scratch that must be ZERO on entry; stats: [B][C][2] = (mean, rstd) out.
+extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, float* y, float* sums, float* sumsq, float* stats, int B, int HW, int C,
+                                        float eps, int relu, hipStream_t s) {
+  if (!x || !y || !sums || !sumsq || !stats || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
+  const int ppw = pix_per_wg(B, HW);
+  dim3 grid(ceil_div(HW, ppw), B);
+  hipLaunchKernelGGL(cl_stats_kernel, grid, dim3(256), 0, s, x, sums, sumsq, HW, C, ppw);
+  hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw);
+  return fs_launch_status();
+}
+// s1, s2: [B][C] scratch, ZERO on entry.
+extern "C" int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, float* s1, float* s2, float* dx,
+                                        int B, int HW, int C, int relu, hipStream_t s) {
+  if (!g || !x || !stats || !s1 || !s2 || !dx || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
+  const int ppw = pix_per_wg(B, HW);
+  dim3 grid(ceil_div(HW, ppw), B);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw);
+  hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw);
+  return fs_launch_status();
+}
+extern "C" int fsraft_affine_relu_cl_fwd(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C,
+                                         int relu, hipStream_t s) {
+  if (!x || !scale || !shift || !y || M < 1 || C < 4 || C % 4) return FS_ERR_ARG;
+  int64_t blocks = (M * (C / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cl_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, y, M, C, relu);
+  return fs_launch_status();
+}
+// dx = g' * scale[c]; partial sums of g' and g' * x over pixels, spread over B * 8 rows to keep the atomics apart:
+// dsum_g, dsum_gx: [B * 8][C], ZERO on entry; the caller adds the rows up.
+extern "C" int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, float* dx,
+                                         float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, hipStream_t s) {
+  if (!g || !x || !scale || !shift || !dx || !dsum_g || !dsum_gx || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
+  const int ppw = pix_per_wg(B, HW);
+  dim3 grid(ceil_div(HW, ppw), B);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw);
+  return fs_launch_status();
+}

@@ -181,6 +181,18 @@ int fsraft_sequence_loss(const float* const* pred, float* const* dpred, const fl
                          const float* gt, const float* valid, float max_flow, float eps, int B, int H, int W, float* out,
                          hipStream_t stream);
 
+/* Channels-last ([B][HW][C], C % 4 == 0, C <= 256) variants, for the encoder stages whose convolutions run on
+ * fsraft_conv_forward.  sums/sumsq/s1/s2: [B][C] scratch; dsum_g/dsum_gx: [B * 8][C] partial rows (the per-channel sums
+ * are the column sums of these rows); all must be ZERO on entry.  stats: [B][C][2] = (mean, rstd). */
+int fsraft_inorm_relu_cl_fwd(const float* x, float* y, float* sums, float* sumsq, float* stats, int B, int HW, int C, float eps,
+                             int relu, hipStream_t stream);
+int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, float* s1, float* s2, float* dx, int B, int HW,
+                             int C, int relu, hipStream_t stream);
+int fsraft_affine_relu_cl_fwd(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C, int relu,
+                              hipStream_t stream);
+int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, float* dx, float* dsum_g,
+                              float* dsum_gx, int B, int HW, int C, int relu, hipStream_t stream);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);

@@ -50,7 +50,7 @@ LAYERS = [  # name, kh, kw, src channels, Cout
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
 from flow_supervisor_amd import _lib  # noqa: E402
-for i, v in enumerate(sys.argv[3:18]):
+for i, v in enumerate(sys.argv[3:21]):
     _lib.load().fsraft_set_tuning(i, int(v))
 print("tuning:", sys.argv[3:9])
 for name, kh, kw, cs, cout in LAYERS:
