@@ -32,6 +32,7 @@ class ConvDesc(Structure):
         ("aux1", c_void_p), ("ld1", c_int), ("aux2", c_void_p), ("ld2", c_int), ("hid", c_int),
         ("pre", c_void_p), ("ldpre", c_int),
         ("rmask", c_void_p * 3), ("ldmask", c_int * 3), ("maskc", c_int * 3),
+        ("wpk_frag", c_void_p),
     ]
 
 

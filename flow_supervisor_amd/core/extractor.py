@@ -165,6 +165,10 @@ def _weight_packs(conv):
         wd = w.detach()
         cin = [wd.shape[1]]
         c = (key, ops.pack_weight(wd, cin, 0), ops.pack_weight(wd, cin, 10), ops.pack_weight(wd, cin, 1), ops.pack_weight(wd, cin, 11))
+        if tuple(wd.shape[2:]) == (3, 3):     # the resident-patch kernel takes the 33..64-channel layers; the data gradient swaps the roles
+            c = c + (ops.fragment_order(c[2]), ops.fragment_order(c[4]))
+        else:
+            c = c + (None, None)
         conv.__dict__["_fs_packs"] = c
     return c
 
@@ -182,7 +186,8 @@ class _ConvCL(torch.autograd.Function):
         B, C, H, W = x.shape
         N, _, KH, KW = weight.shape
         out = torch.empty(B, H, W, N, device=x.device, dtype=torch.float32)
-        ops.conv_forward([ops.V(x.permute(0, 2, 3, 1), C)], packs[1], bias, B, H, W, KH, KW, N, [ops.Dst.nhwc(out)], wpk_split=packs[2])
+        ops.conv_forward([ops.V(x.permute(0, 2, 3, 1), C)], packs[1], bias, B, H, W, KH, KW, N, [ops.Dst.nhwc(out)], wpk_split=packs[2],
+                         wpk_frag=packs[5])
         ctx.save_for_backward(x, weight)
         ctx.packs = packs
         ctx.has_bias = bias is not None
@@ -199,7 +204,8 @@ class _ConvCL(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dxb = torch.empty(B, H, W, C, device=x.device, dtype=torch.float32)
-            ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dxb)], wpk_split=ctx.packs[4])
+            ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dxb)], wpk_split=ctx.packs[4],
+                             wpk_frag=ctx.packs[6])
             dx = dxb.permute(0, 3, 1, 2)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:

@@ -656,6 +656,151 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
   conv_epilogue<Cfg, EPI>(a, acc, m0, n0);
 }
 
+// ---------------------------------------------------------------- 3x3 convolution over a resident input patch
+// The implicit GEMM above re-reads every input pixel once per tap: a few-channel 3x3 layer at encoder resolution
+// (64 -> 64 at 8 x 220 x 512) moves 9 x 231 MB through the load path for 2 x 0.2 GB of unique data and is bound by
+// bytes in flight, not by the matrix pipe.  Here a workgroup owns a 4 x 32 patch of output pixels: it loads the
+// 6 x 34 input patch (halo included) ONCE, splits it to [hi | lo] bf16 and keeps it in LDS (one 128-byte record per
+// pixel and 32-channel group, same swizzle as the A image of split_mainloop); the k-loop then walks (tap, channel
+// group), reading the A fragments straight out of the patch at the tap's row shift, and streams only the weight
+// tiles.  Global traffic per output pixel drops from 9 to 1.6 input pixels and the per-k-tile staging to the B tile.
+constexpr int HALO_TH = 4, HALO_TW = 32, HALO_PW = HALO_TW + 2, HALO_ROWS = (HALO_TH + 2) * HALO_PW;
+struct HaloArgs {
+  const float* x; int ldx, C;
+  const char* wpk;                    // fragment-order split pack (fsraft_conv_desc.wpk_frag)
+  const float* bias;
+  float* out; int64_t obs, ops;       // batch / pixel strides of the destination (floats), channels contiguous
+  int N, B, H, W, relu;
+};
+
+template <int CG, int TN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
+  constexpr int PLANE = HALO_ROWS * 128;
+  constexpr int NCHH = (HALO_ROWS * CG * 8 + 255) / 256, KT = 9 * CG;
+  __shared__ __attribute__((aligned(16))) char lds[CG * PLANE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int x0 = blockIdx.x * HALO_TW, y0 = blockIdx.y * HALO_TH, b = blockIdx.z;
+
+  // Weight fragments come straight from the packed matrix (L1/L2-resident: 4 * N * Ktot bytes for the whole grid): lane
+  // (n, k half) reads its 16 bytes of hi and of lo for both k-steps of a k-tile.  No B image in LDS, hence no barrier in
+  // the k-loop: once the patch is staged the waves run independently.
+  // (a.wpk is the FRAGMENT-ORDER pack: [k-tile][32-column block][hi s0, hi s1, lo s0, lo s1][lane][16 B], so that one
+  // wave-load is 1 KB of consecutive bytes -- read out of the row-major pack the same fragment touches 32 cache lines
+  // and the kernel becomes L1-bound: 352 us instead of 270 us with an LDS-staged B on the 64 -> 64 encoder layer.)
+  const int NB = (a.N + 31) >> 5;
+  const char* wbase = uni_ptr(a.wpk);
+  struct BFrag { u32x4 v[TN][4]; };             // [nt][hi s0, hi s1, lo s0, lo s1]
+  auto fetch_b = [&](int kt, BFrag& f) {
+    const int ku = __builtin_amdgcn_readfirstlane(kt < KT ? kt : KT - 1);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(wbase, 0x7fffffffu);
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int nb = wn * TN + nt;
+      const unsigned soff = (unsigned)((ku * NB + (nb < NB ? nb : 0)) * 4096);
+      const unsigned voff = nb < NB ? (unsigned)lane * 16u : FS_OOB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f.v[nt][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 1024u * q, 0);
+    }
+  };
+  BFrag f0, f1;
+  fetch_b(0, f0);
+
+  // the input patch: chunk e = (patch row, channel group, 16-byte part); consecutive lanes read consecutive bytes
+  {
+    const float* img = uni_ptr(a.x + (int64_t)b * a.H * a.W * a.ldx);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(img, 0x7fffffffu);
+    float rh[NCHH * 4];
+#pragma unroll
+    for (int j = 0; j < NCHH; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int row = e / (CG * 8), rem = e % (CG * 8), ch = (rem >> 3) * 32 + (rem & 7) * 4;
+      const int y = y0 - 1 + row / HALO_PW, x = x0 - 1 + row % HALO_PW;
+      const bool ok = row < HALO_ROWS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && ch < a.C;
+      const unsigned voff = ok ? (unsigned)((y * a.W + x) * a.ldx + ch) * 4u : FS_OOB;
+      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+      rh[4 * j + 0] = f[0]; rh[4 * j + 1] = f[1]; rh[4 * j + 2] = f[2]; rh[4 * j + 3] = f[3];
+    }
+#pragma unroll
+    for (int j = 0; j < NCHH; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int row = e / (CG * 8), rem = e % (CG * 8);
+      if (row < HALO_ROWS) stage_convert<128>(lds + (rem >> 3) * PLANE, row * 8 + (rem & 7), rh + 4 * j);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int kt, const BFrag& f) {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);
+    const int tap = ku / CG, g = ku - tap * CG, dy = tap / 3, dx = tap - dy * 3;
+    const char* Ap = lds + g * PLANE;
+    const int rowa = (2 * wm + dy) * HALO_PW + dx + l31;          // patch row of this lane for mt = 0; mt = 1 is one patch line down
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[2], al[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = rowa + mt * HALO_PW;
+        ah[mt] = *reinterpret_cast<const bf16x8*>(Ap + slot_offset<128>(row, 2 * s + lh));
+        al[mt] = *reinterpret_cast<const bf16x8*>(Ap + slot_offset<128>(row, 4 + 2 * s + lh));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, f.v[nt][s]), bl = __builtin_bit_cast(bf16x8, f.v[nt][2 + s]);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+        }
+    }
+  };
+  static_assert(KT % 2 == 0 || KT > 2, "k-loop below handles an odd tail");
+  for (int kt = 0; kt + 1 < KT; kt += 2) {
+    fetch_b(kt + 1, f1);
+    compute(kt, f0);
+    fetch_b(kt + 2, f0);                  // (re-reads the last tile past the end; unused)
+    compute(kt + 1, f1);
+  }
+  if (KT & 1) compute(KT - 1, f0);
+
+  float* outb = a.out + (int64_t)b * a.obs;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int py = y0 + 2 * wm + mt;
+    if (py >= a.H) continue;
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int n = wn * (32 * TN) + nt * 32 + l31;
+      if (n >= a.N) continue;
+      const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (px >= a.W) continue;
+        float v = acc[mt][nt][r] + bv;
+        if (a.relu) v = fmaxf(v, 0.f);
+        outb[(int64_t)(py * a.W + px) * a.ops + n] = v;
+      }
+    }
+  }
+}
+
+template <int CG, int TN>
+int launch_halo(const HaloArgs& h, hipStream_t s) {
+  dim3 grid(ceil_div(h.W, HALO_TW), ceil_div(h.H, HALO_TH), h.B);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<CG, TN>), grid, dim3(256), 0, s, h);
+  return fs_launch_status();
+}
+
 // ---------------------------------------------------------------- weight gradient
 struct WgradArgs {
   const float* dy; int ldy; int Cout;     // dY (already multiplied by act'), [M][ldy]
@@ -1177,6 +1322,7 @@ using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
 using SCfg256W16 = SplitCfg<256, 128, 4, 4, 2, true, 1024>;  // sixteen waves, one workgroup per CU
 using SCfg128W8 = SplitCfg<128, 128, 2, 4, 2, true, 512>;   // eight waves per workgroup, 66 KB of LDS: two workgroups per CU
+using SCfg256N64 = SplitCfg<256, 64, 4, 2, 2, true, 512>;   // N <= 64 layers at large M (encoder layer1, f2): a 128-wide tile would be half empty
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
 int g_wgrad_w8 = 0;       // 512-thread workgroups in the multi-segment weight gradient (key 15); measured slower (7.96 vs 7.32 ms/step): its grid is large already
@@ -1193,6 +1339,10 @@ int g_conv_buf = 1;     // buffer-addressed loaders in the split conv kernels (k
 int g_conv_split = 1;   // 0: exact fp32 MFMA; 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (key 3)
 int g_conv_tile = 0;    // 0 auto, 1 force 128x128, 2 force 64x128, 3 force 64x64   (fsraft_set_tuning key 0)
 int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                           (key 1)
+int g_conv_n64 = 1;            // 256x64 tiles for N <= 64 (key 18) once M reaches g_conv_n64_min_m (key 19)
+int g_conv_n64_min_m = 65536;
+int g_conv_halo = 1;           // resident-patch 3x3 kernel for few-channel layers at large M (key 20; threshold key 21)
+int g_conv_halo_min_m = 65536;
 int g_wgrad_pack = 1;          // few-channel single-source layers on conv_wgrad_pack_kernel (key 16)
 int g_wgrad_blocks_pack = 1024;   // its workgroup target (key 17)
 int g_wgrad_blocks = 512;   // target workgroup count of the pixel split (key 2); measured 256: 12.9, 512: 11.5, 1024: 12.9, 2048: 14.1 ms/step
@@ -1285,6 +1435,23 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   }
 }
 
+// plain-epilogue-only launcher of a wide configuration (the narrow-N tiles never carry a GRU epilogue)
+template <class Cfg>
+int launch_conv_split_plain(const ConvArgs& a, hipStream_t s) {
+  const int M = a.B * a.H * a.W;
+  dim3 grid(ceil_div(a.N, Cfg::BN), ceil_div(M, Cfg::BM));
+  ConvArgsT t;
+  if (build_ktab_uniform(a, t)) {
+    hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(Cfg::NT), 0, s, t);
+    return fs_launch_status();
+  }
+  if (build_ktab(a, t)) {
+    hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), grid, dim3(Cfg::NT), 0, s, t);
+    return fs_launch_status();
+  }
+  return -1;
+}
+
 template <class Cfg>
 int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
   const int M = a.B * a.H * a.W;
@@ -1319,6 +1486,7 @@ struct fsraft_conv_desc {
   int hid;
   const float* pre; int ldpre;   // GRU epilogues: addend to the pre-activation (e.g. the context part of the conv), or NULL
   const float* rmask[3]; int ldmask[3]; int maskc[3];   // epi 0, per destination: zero column j < maskc where rmask[m*ldmask+j] <= 0
+  const float* wpk_frag;         // wpk_split in fragment order (or NULL): enables the resident-patch 3x3 kernel
 };
 
 extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
@@ -1355,6 +1523,17 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (d->epi == EPI_ZR && (!d->h || !d->aux1 || !d->aux2 || d->hid * 2 != d->N)) return FS_ERR_ARG;
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
+  if (g_conv_halo && g_conv_split == 1 && d->wpk_frag && d->epi == EPI_PLAIN && d->nsrc == 1 && d->KH == 3 && d->KW == 3 &&
+      d->srcC[0] % 4 == 0 && d->srcC[0] > 32 && d->srcC[0] <= 64 && d->N <= 128 && d->N > 32 && d->ndst == 1 &&
+      d->dst_cs[0] == 1 && d->dst_n0[0] == 0 && !d->dst_acc[0] && !a.rmask[0] && d->alpha == 1.0f &&
+      (int64_t)d->B * d->H * d->W >= g_conv_halo_min_m && (int64_t)d->H * d->W * d->srcld[0] * 4 < 0x7fffffff) {
+    HaloArgs h{d->src[0], d->srcld[0], d->srcC[0], reinterpret_cast<const char*>(d->wpk_frag), d->bias,
+               d->dst[0], d->dst_bs[0], d->dst_ps[0], d->N, d->B, d->H, d->W, d->relu};
+    // Measured (scripts/conv_micro.py, halo on / off): 64 -> 64 at 8x220x512 238 vs 442 us.  With three or four channel
+    // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
+    // GEMM (96 -> 96 at 8x110x256: 249 vs 165 us; 128 -> 128 at 8x55x128: 93 vs 65 us), so only two-group layers come here.
+    return d->N > 64 ? launch_halo<2, 2>(h, stream) : launch_halo<2, 1>(h, stream);
+  }
   if (d->N <= 32 && d->epi == EPI_PLAIN) return launch_conv<Cfg32>(a, d->epi, stream);
   // 33..64 outputs: half of a 64x128 split tile is padding, still ~2x faster than the exact 64-wide kernel
   if (d->N <= 64 && d->epi == EPI_PLAIN && !(g_conv_split && d->wpk_split && g_conv_buf)) return launch_conv<Cfg64>(a, d->epi, stream);
@@ -1371,6 +1550,10 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     if (g_conv_split == 5 || (g_conv_split == 1 && g_conv_n256 && d->N >= 256 &&
                               ceil_div(d->N, 256) * 256 <= ceil_div(d->N, 128) * 128))
       return launch_conv_split<SCfgN256>(a, d->epi, stream);
+    if (g_conv_split == 1 && g_conv_n64 && d->N <= 64 && d->epi == EPI_PLAIN && M >= g_conv_n64_min_m) {
+      const int rc = launch_conv_split_plain<SCfg256N64>(a, stream);
+      if (rc >= 0) return rc;
+    }
     // eight-wave 128x128 tiles where they fill the machine in one round (N >= 256 at M ~ 28 K): key 13
     // sixteen-wave 256x128 tiles: a further 3-6 % on the 192..512-output layers (zr 93 -> 87 us), slower on m2 (N = 576)
     if (g_conv_split == 1 && ((g_conv_w8 == 1 && d->N >= 192 && d->N <= 512 && M >= 16384) || g_conv_w8 == 2) && d->N >= 192) {
@@ -1411,6 +1594,10 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 9) g_conv_n256 = value;
   else if (key == 10) g_wgrad_multi = value;
   else if (key == 11) g_wgrad_blocks_multi = value;
+  else if (key == 18) g_conv_n64 = value;
+  else if (key == 19) g_conv_n64_min_m = value;
+  else if (key == 20) g_conv_halo = value;
+  else if (key == 21) g_conv_halo_min_m = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;

@@ -409,6 +409,18 @@ def pack_weight(w, srcC, mode):
     return wpk
 
 
+def fragment_order(wps):
+    """Split pack [N, Ktot] (modes 10 / 11) -> fragment order for fsraft_conv_desc.wpk_frag: [k-tile][32-row block]
+    [hi k0-15, hi k16-31, lo k0-15, lo k16-31][lane = 32 * (k half) + row][4 dwords], rows zero-padded to a multiple of 32."""
+    N, ktot = wps.shape
+    kt, nb = ktot // 32, (N + 31) // 32
+    w = wps.contiguous().view(torch.int32)
+    if nb * 32 != N:
+        w = torch.cat([w, w.new_zeros(nb * 32 - N, ktot)])
+    w = w.view(nb, 32, kt, 2, 2, 2, 4).permute(2, 0, 3, 4, 5, 1, 6).contiguous()      # kt, nb, hi/lo, s, k half, row, dword
+    return w.view(torch.float32).view(kt, nb, 4, 64, 4)
+
+
 def unpack_weight_grad(dwpk, shape, srcC, out=None, accumulate=False):
     Cout, Cin, KH, KW = shape
     if out is None:
@@ -458,7 +470,7 @@ class Dst:
 
 
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
-                 aux1=None, aux2=None, hid=0, wpk_split=None, pre=None):
+                 aux1=None, aux2=None, hid=0, wpk_split=None, pre=None, wpk_frag=None):
     """srcs: list of V (concatenated along channels).  dsts: list of Dst.
     GRU epilogues (epi 2: z|r, epi 3: q) take h, z, aux buffers as [B,H,W,ld] tensors."""
     d = L.ConvDesc()
@@ -467,6 +479,7 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     d.nsrc = len(srcs)
     d.wpk = wpk.data_ptr()
     d.wpk_split = wpk_split.data_ptr() if wpk_split is not None else None
+    d.wpk_frag = wpk_frag.data_ptr() if wpk_frag is not None else None
     d.bias = bias.data_ptr() if bias is not None else None
     d.B, d.H, d.W, d.KH, d.KW, d.N = B, H, W, KH, KW, N
     for i, ds in enumerate(dsts):

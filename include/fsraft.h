@@ -96,6 +96,11 @@ typedef struct fsraft_conv_desc {
   const float* pre; int ldpre;                                /* epi 2/3: [M][ldpre] addend to the pre-activation, or NULL */
   const float* rmask[3]; int ldmask[3]; int maskc[3];         /* epi 0, per destination: ReLU-backward mask (zero column
                                                                  j < maskc of the range where rmask[m*ldmask+j] <= 0), or NULL */
+  const float* wpk_frag;                                      /* optional: wpk_split re-ordered for direct fragment loads --
+                                                                 [k-tile][32-row block][hi k0-15, hi k16-31, lo k0-15, lo k16-31]
+                                                                 [lane = 32 * (k half) + row][16 B], rows zero-padded to 32;
+                                                                 enables the resident-patch 3x3 kernel (one source, 33..64
+                                                                 channels in, N <= 64, large B*H*W).  NULL: never used */
 } fsraft_conv_desc;
 
 int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);

