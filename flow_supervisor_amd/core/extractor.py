@@ -82,8 +82,42 @@ def _cl_norm_ok(x):
     return x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 256
 
 
+def _fast(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+
+
 def _as_cl(x):
+    """x as a channels_last tensor (no autograd: for use inside Functions).  The tiled fsraft transposes move an NCHW
+    activation at 4-6 TB/s; the framework's strided copy reaches 1.4-2 TB/s on the same tensors (scripts/layout_micro.py)."""
+    if _is_cl(x):
+        return x
+    if _fast(x) and x.is_contiguous():
+        from .. import ops
+        B, C, H, W = x.shape
+        return ops.nchw_to_nhwc(x, torch.empty(B, H, W, C, device=x.device, dtype=torch.float32)).permute(0, 3, 1, 2)
     return x.contiguous(memory_format=torch.channels_last)
+
+
+def _as_nchw(x):
+    if x.is_contiguous():
+        return x
+    if _fast(x) and _is_cl(x):
+        from .. import ops
+        return ops.nhwc_to_nchw(x.permute(0, 2, 3, 1))
+    return x.contiguous()
+
+
+class _ToNCHW(torch.autograd.Function):
+    """x.contiguous() for a channels_last activation whose consumer is an NCHW MIOpen call; the gradient goes back
+    channels_last, the layout its producer works in."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _as_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _as_cl(g)
 
 
 class _InstNormReluCL(torch.autograd.Function):
@@ -114,7 +148,7 @@ class _InstNormReluCL(torch.autograd.Function):
         acc = torch.zeros(2, N, C, device=x.device, dtype=torch.float32)
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
                                                   N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
-        return dx if ctx.in_cl else dx.contiguous(), None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
+        return dx if ctx.in_cl else _as_nchw(dx), None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
 
 
 class _FrozenBNReluCL(torch.autograd.Function):
@@ -151,7 +185,7 @@ class _FrozenBNReluCL(torch.autograd.Function):
         sums = part.sum(dim=1)
         dweight = rs * (sums[1] - rm * sums[0])
         dcbias = scale * sums[0] if ctx.has_cbias else None
-        return dx if ctx.in_cl else dx.contiguous(), dcbias, dweight, sums[0], None, None, None, None
+        return dx if ctx.in_cl else _as_nchw(dx), dcbias, dweight, sums[0], None, None, None, None
 
 
 def _weight_packs(conv):
@@ -225,7 +259,7 @@ def _conv(conv, x, bias):
             and conv.padding == (k[0] // 2, k[1] // 2) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.padding_mode == "zeros" and x.shape[1] % 4 == 0 and not torch.is_autocast_enabled()):
         return _ConvCL.apply(x, conv.weight, bias, _weight_packs(conv))
-    return F.conv2d(x.contiguous(), conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return F.conv2d(_ToNCHW.apply(x) if _is_cl(x) else x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 def _conv_norm(conv, norm, x, relu, to_cl=False):
@@ -297,7 +331,7 @@ class _Block(nn.Module):
     def forward(self, x):
         cl = _is_cl(x)
         if cl and self.downsample is not None:
-            x = x.contiguous()          # the strided convolutions (first 3x3 / shortcut 1x1) are MIOpen NCHW calls: one copy for both
+            x = _ToNCHW.apply(x)        # the strided convolutions (first 3x3 / shortcut 1x1) are MIOpen NCHW calls: one copy for both
         y = x
         for i in range(1, self.n + 1):
             y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True, to_cl=cl)
@@ -365,7 +399,7 @@ class _Encoder(nn.Module):
         cl = _channels_last_ok(self, x)
         x = _conv_norm(self.conv1, self.norm1, x, True, to_cl=bool(cl))
         x = self.layer3(self.layer2(self.layer1(x)))
-        x = _conv(self.conv2, x, self.conv2.bias).contiguous() if cl else self.conv2(x)
+        x = _ToNCHW.apply(_conv(self.conv2, x, self.conv2.bias)) if cl else self.conv2(x)
         if self.training and self.dropout is not None:
             x = self.dropout(x)
         if pair:

@@ -761,7 +761,8 @@ def test_encoder_channels_last_path_matches_nchw_path(kind, norm, precision, mon
     # random-init, squared-output objective) amplify it to ~6e-3 in the image gradient (scripts/encoder_grad_noise.py measures it).
     # The bottleneck (small) encoder has half as many channels again per norm and measures 2.8e-2.  The wiring of the path is
     # what the exact-mode run pins down; the split arithmetic itself is bounded per layer by the convolution tests above.
-    gtol = 2e-3 if precision == "exact" else 6e-2
+    # (atomic accumulation order makes the flips differ from run to run: the exact-mode bound leaves room for them)
+    gtol = 1e-2 if precision == "exact" else 6e-2
     close(outs["1"][0], outs["0"][0], 2e-4, what="encoder out")
     assert _rel_l2(outs["1"][0], outs["0"][0]) < tol
     e = _rel_l2(outs["1"][1], outs["0"][1])
