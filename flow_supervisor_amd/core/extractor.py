@@ -121,53 +121,62 @@ class _ToNCHW(torch.autograd.Function):
 
 
 class _InstNormReluCL(torch.autograd.Function):
-    """_InstNormRelu for channels_last tensors (storage [N][H*W][C]): csrc/norm_cl.hip."""
+    """_InstNormRelu for channels_last tensors (storage [N][H*W][C]): csrc/norm_cl.hip.  With `res` (the shortcut of a
+    residual unit, channels_last) the result is relu(res + relu?(norm(x))) in the same pass -- the unit's add and final ReLU
+    (and their backward) cost no extra trip over the tensor."""
 
     @staticmethod
-    def forward(ctx, x, eps, relu):
+    def forward(ctx, x, eps, relu, res=None):
         from .. import _lib as L
         ctx.in_cl = _is_cl(x)
         x = _as_cl(x)
         N, C, H, W = x.shape
+        if res is not None:
+            res = _as_cl(res)
         y = torch.empty_like(x)                                   # preserves channels_last
         acc = torch.zeros(2, N, C, device=x.device, dtype=torch.float32)
         stats = torch.empty(N, C, 2, device=x.device, dtype=torch.float32)
-        L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W, C,
-                                                  float(eps), int(relu), L.stream()), "inorm_relu_cl_fwd")
-        ctx.save_for_backward(x, stats)
+        L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W,
+                                                  C, float(eps), int(relu), L.stream()), "inorm_relu_cl_fwd")
+        ctx.fused = res is not None
+        ctx.save_for_backward(x, stats, y if ctx.fused else None)
         ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, g):
         from .. import _lib as L
-        x, stats = ctx.saved_tensors
+        x, stats, out = ctx.saved_tensors
         N, C, H, W = x.shape
         g = _as_cl(g)
         dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.fused else None
         acc = torch.zeros(2, N, C, device=x.device, dtype=torch.float32)
-        L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
-                                                  N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
-        return dx if ctx.in_cl else _as_nchw(dx), None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
+        L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
+                                                  L.ptr(dres), N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
+        return dx if ctx.in_cl else _as_nchw(dx), None, None, dres     # an NCHW producer (MIOpen) gets an NCHW gradient
 
 
 class _FrozenBNReluCL(torch.autograd.Function):
-    """_FrozenBNRelu for channels_last tensors."""
+    """_FrozenBNRelu for channels_last tensors; `res` as in _InstNormReluCL."""
 
     @staticmethod
-    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu):
+    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu, res=None):
         from .. import _lib as L
         ctx.in_cl = _is_cl(x)
         x = _as_cl(x)
         N, C, H, W = x.shape
+        if res is not None:
+            res = _as_cl(res)
         rs = torch.rsqrt(rv.float() + eps)
         scale = (weight.float() * rs).contiguous()
         rmc = rm.float() - cbias.float() if cbias is not None else rm.float()
         shift = (bias.float() - rmc * scale).contiguous()
         y = torch.empty_like(x)
-        L.check(L.load().fsraft_affine_relu_cl_fwd(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(y), N * H * W, C, int(relu),
+        L.check(L.load().fsraft_affine_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(scale), L.ptr(shift), L.ptr(y), N * H * W, C, int(relu),
                                                    L.stream()), "affine_relu_cl_fwd")
-        ctx.save_for_backward(x, scale, shift, rs, rmc)
+        ctx.fused = res is not None
+        ctx.save_for_backward(x, scale, shift, rs, rmc, y if ctx.fused else None)
         ctx.relu = relu
         ctx.has_cbias = cbias is not None
         return y
@@ -175,17 +184,19 @@ class _FrozenBNReluCL(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         from .. import _lib as L
-        x, scale, shift, rs, rm = ctx.saved_tensors
+        x, scale, shift, rs, rm, out = ctx.saved_tensors
         N, C, H, W = x.shape
         g = _as_cl(g)
         dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.fused else None
         part = torch.zeros(2, N * 8, C, device=x.device, dtype=torch.float32)      # partial rows (see norm_cl.hip)
-        L.check(L.load().fsraft_affine_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dx), L.ptr(part[0]),
-                                                   L.ptr(part[1]), N, H * W, C, int(ctx.relu), L.stream()), "affine_relu_cl_bwd")
+        L.check(L.load().fsraft_affine_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), L.ptr(dx), L.ptr(dres),
+                                                   L.ptr(part[0]), L.ptr(part[1]), N, H * W, C, int(ctx.relu), L.stream()),
+                "affine_relu_cl_bwd")
         sums = part.sum(dim=1)
         dweight = rs * (sums[1] - rm * sums[0])
         dcbias = scale * sums[0] if ctx.has_cbias else None
-        return dx if ctx.in_cl else _as_nchw(dx), dcbias, dweight, sums[0], None, None, None, None
+        return dx if ctx.in_cl else _as_nchw(dx), dcbias, dweight, sums[0], None, None, None, None, dres
 
 
 def _weight_packs(conv):
@@ -262,7 +273,7 @@ def _conv(conv, x, bias):
     return F.conv2d(_ToNCHW.apply(x) if _is_cl(x) else x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
-def _conv_norm(conv, norm, x, relu, to_cl=False):
+def _conv_norm(conv, norm, x, relu, to_cl=False, res=None):
     """relu?(norm(conv(x))) of pytorch/core/extractor.py.  The convolution stays a PyTorch-ROCm (MIOpen) call; for fp32
     CUDA tensors the normalisation + ReLU around it runs on the fused fsraft kernels:
       * non-affine InstanceNorm2d (feature encoder).  A per-channel constant added before it is removed again by its
@@ -278,17 +289,21 @@ def _conv_norm(conv, norm, x, relu, to_cl=False):
         if fused:
             y = _conv(conv, x, None)
             if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
-                return _InstNormReluCL.apply(y, norm.eps, relu)
-            return _InstNormRelu.apply(y, norm.eps, relu)
+                return _InstNormReluCL.apply(y, norm.eps, relu, res)
+            y = _InstNormRelu.apply(y, norm.eps, relu)
+            return y if res is None else F.relu(res + y)
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)
         y = norm(y)
     elif isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats and norm.affine and fused:
         y = _conv(conv, x, None)
-        fn = _FrozenBNReluCL if (to_cl or _is_cl(x)) and _cl_norm_ok(y) else _FrozenBNRelu
-        return fn.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
+        if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
+            return _FrozenBNReluCL.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu, res)
+        y = _FrozenBNRelu.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
+        return y if res is None else F.relu(res + y)
     else:
         y = norm(conv(x))
-    return F.relu(y, inplace=True) if relu else y
+    y = F.relu(y, inplace=True) if relu else y
+    return y if res is None else F.relu(res + y)
 
 
 def _make_norm(kind, ch, groups):
@@ -333,11 +348,12 @@ class _Block(nn.Module):
         if cl and self.downsample is not None:
             x = _ToNCHW.apply(x)        # the strided convolutions (first 3x3 / shortcut 1x1) are MIOpen NCHW calls: one copy for both
         y = x
-        for i in range(1, self.n + 1):
-            y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True, to_cl=cl)
         if self.downsample is not None:
             x = _conv_norm(self.downsample[0], self.downsample[1], x, False, to_cl=cl)
-        return self.relu(x + y)
+        for i in range(1, self.n):
+            y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True, to_cl=cl)
+        # last convolution of the unit: relu(x + relu(norm(conv(y)))), the add and outer ReLU fused into the norm kernel
+        return _conv_norm(getattr(self, f"conv{self.n}"), getattr(self, f"norm{self.n}"), y, True, to_cl=cl, res=x)
 
 
 class ResidualBlock(_Block):

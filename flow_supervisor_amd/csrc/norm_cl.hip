@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void cl_stats_kernel(const float* __restrict__
 // y = relu?((x - mean) * rstd) with mean / rstd from the accumulated sums; stats[b][c] = (mean, rstd) written by block (0, b)
 __global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ sums,
                                                              const float* __restrict__ sumsq, float* __restrict__ y,
-                                                             float* __restrict__ stats, int HW, int C, float eps, int relu, int PIX_PER_WG) {
+                                                             float* __restrict__ stats, int HW, int C, float eps, int relu, int PIX_PER_WG,
+                                                             const float* __restrict__ res) {
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int b = blockIdx.y;
@@ -70,6 +71,11 @@ __global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
       }
+      if (res) {                                            // residual unit: y = relu(res + relu?(norm(x)))
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(res + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + rv[i], 0.f);
+      }
       *reinterpret_cast<f32x4*>(y + o) = v;
     }
 }
@@ -80,7 +86,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ pa, const float* __restrict__ pb,
                                                           float* __restrict__ s1, float* __restrict__ s2,
-                                                          float* __restrict__ dx, int HW, int C, int relu, int PIX_PER_WG) {
+                                                          float* __restrict__ dx, int HW, int C, int relu, int PIX_PER_WG,
+                                                          const float* __restrict__ out, float* __restrict__ dres) {
   __shared__ f32x4 red[2][256];
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
@@ -98,7 +105,14 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
 #pragma unroll 4
     for (int p = p0 + pl; p < p1; p += lanes_p) {
       const int64_t o = ((int64_t)b * HW + p) * C + cl * 4;
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o), xv = *reinterpret_cast<const f32x4*>(x + o);
+      f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+      if (out) {                                            // fused residual: the gradient first passes relu(res + y)
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(out + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gv[i] = ov[i] > 0.f ? gv[i] : 0.f;
+        *reinterpret_cast<f32x4*>(dres + o) = gv;           // ... and this is what the shortcut receives
+      }
       f32x4 dv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
 __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                  const float* __restrict__ stats, const float* __restrict__ s1,
                                                                  const float* __restrict__ s2, float* __restrict__ dx, int HW,
-                                                                 int C, int relu, int PIX_PER_WG) {
+                                                                 int C, int relu, int PIX_PER_WG, const float* __restrict__ out) {
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int b = blockIdx.y;
@@ -143,7 +157,13 @@ __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __
 #pragma unroll 4
     for (int p = p0 + pl; p < p1; p += lanes_p) {
       const int64_t o = ((int64_t)b * HW + p) * C + cl * 4;
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o), xv = *reinterpret_cast<const f32x4*>(x + o);
+      f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+      if (out) {
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(out + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gv[i] = ov[i] > 0.f ? gv[i] : 0.f;
+      }
       f32x4 dv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __
 // y = relu?(x * scale[c] + shift[c])
 __global__ __launch_bounds__(256) void cl_affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ y,
-                                                            int64_t M, int C, int relu) {
+                                                            int64_t M, int C, int relu, const float* __restrict__ res) {
   const int c4n = C >> 2;
   const int64_t total = M * c4n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -166,6 +186,11 @@ __global__ __launch_bounds__(256) void cl_affine_fwd_kernel(const float* __restr
     f32x4 v = reinterpret_cast<const f32x4*>(x)[e];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = v[i] * scale[c + i] + shift[c + i]; if (relu) v[i] = fmaxf(v[i], 0.f); }
+    if (res) {
+      const f32x4 rv = reinterpret_cast<const f32x4*>(res)[e];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + rv[i], 0.f);
+    }
     reinterpret_cast<f32x4*>(y)[e] = v;
   }
 }
@@ -175,40 +200,44 @@ inline bool cl_ok(int C) { return C >= 4 && C <= 256 && C % 4 == 0; }      // (t
 }  // namespace
 
 // x, y: [B][HW][C].  sums / sumsq: [B][C] scratch that must be ZERO on entry; stats: [B][C][2] = (mean, rstd) out.
-extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, float* y, float* sums, float* sumsq, float* stats, int B, int HW, int C,
-                                        float eps, int relu, hipStream_t s) {
+// res (nullable, [B][HW][C]): fused residual unit, y = relu(res + relu?(norm(x))).
+extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B,
+                                        int HW, int C, float eps, int relu, hipStream_t s) {
   if (!x || !y || !sums || !sumsq || !stats || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
   hipLaunchKernelGGL(cl_stats_kernel, grid, dim3(256), 0, s, x, sums, sumsq, HW, C, ppw);
-  hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw);
+  hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw, res);
   return fs_launch_status();
 }
-// s1, s2: [B][C] scratch, ZERO on entry.
-extern "C" int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, float* s1, float* s2, float* dx,
-                                        int B, int HW, int C, int relu, hipStream_t s) {
-  if (!g || !x || !stats || !s1 || !s2 || !dx || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
+// s1, s2: [B][C] scratch, ZERO on entry.  Fused residual unit: out = the forward result y, dres receives the shortcut's
+// gradient g * (out > 0), and the norm branch continues from that; both NULL otherwise.
+extern "C" int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2,
+                                        float* dx, float* dres, int B, int HW, int C, int relu, hipStream_t s) {
+  if (!g || !x || !stats || !s1 || !s2 || !dx || B < 1 || HW < 1 || !cl_ok(C) || (out != nullptr) != (dres != nullptr)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
-  hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw);
-  hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw, out, dres);
+  hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw, out);
   return fs_launch_status();
 }
-extern "C" int fsraft_affine_relu_cl_fwd(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C,
-                                         int relu, hipStream_t s) {
+extern "C" int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M,
+                                         int C, int relu, hipStream_t s) {
   if (!x || !scale || !shift || !y || M < 1 || C < 4 || C % 4) return FS_ERR_ARG;
   int64_t blocks = (M * (C / 4) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(cl_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, y, M, C, relu);
+  hipLaunchKernelGGL(cl_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, y, M, C, relu, res);
   return fs_launch_status();
 }
 // dx = g' * scale[c]; partial sums of g' and g' * x over pixels, spread over B * 8 rows to keep the atomics apart:
-// dsum_g, dsum_gx: [B * 8][C], ZERO on entry; the caller adds the rows up.
-extern "C" int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, float* dx,
-                                         float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, hipStream_t s) {
-  if (!g || !x || !scale || !shift || !dx || !dsum_g || !dsum_gx || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
+// dsum_g, dsum_gx: [B * 8][C], ZERO on entry; the caller adds the rows up.  out / dres as in fsraft_inorm_relu_cl_bwd.
+extern "C" int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* out,
+                                         float* dx, float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu,
+                                         hipStream_t s) {
+  if (!g || !x || !scale || !shift || !dx || !dsum_g || !dsum_gx || B < 1 || HW < 1 || !cl_ok(C) ||
+      (out != nullptr) != (dres != nullptr)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
-  hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw, out, dres);
   return fs_launch_status();
 }

@@ -188,15 +188,18 @@ int fsraft_sequence_loss(const float* const* pred, float* const* dpred, const fl
 
 /* Channels-last ([B][HW][C], C % 4 == 0, C <= 256) variants, for the encoder stages whose convolutions run on
  * fsraft_conv_forward.  sums/sumsq/s1/s2: [B][C] scratch; dsum_g/dsum_gx: [B * 8][C] partial rows (the per-channel sums
- * are the column sums of these rows); all must be ZERO on entry.  stats: [B][C][2] = (mean, rstd). */
-int fsraft_inorm_relu_cl_fwd(const float* x, float* y, float* sums, float* sumsq, float* stats, int B, int HW, int C, float eps,
-                             int relu, hipStream_t stream);
-int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, float* s1, float* s2, float* dx, int B, int HW,
-                             int C, int relu, hipStream_t stream);
-int fsraft_affine_relu_cl_fwd(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C, int relu,
-                              hipStream_t stream);
-int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, float* dx, float* dsum_g,
-                              float* dsum_gx, int B, int HW, int C, int relu, hipStream_t stream);
+ * are the column sums of these rows); all must be ZERO on entry.  stats: [B][C][2] = (mean, rstd).
+ * Fused residual unit (pytorch/core/extractor.py:43-56, "return self.relu(x+y)"): res != NULL makes the forward write
+ * y = relu(res + relu?(norm(x))); the backward then takes out = that y and writes the shortcut's gradient g * (out > 0)
+ * to dres before continuing into the norm branch (out and dres both NULL: plain norm + ReLU). */
+int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B, int HW,
+                             int C, float eps, int relu, hipStream_t stream);
+int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2, float* dx,
+                             float* dres, int B, int HW, int C, int relu, hipStream_t stream);
+int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M, int C,
+                              int relu, hipStream_t stream);
+int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* out, float* dx,
+                              float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, hipStream_t stream);
 
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);

@@ -664,6 +664,25 @@ def test_channels_last_norm_relu_kernels_match_torch(shape):
         close(y, yr, 1e-5, what="frozen bn fwd"); close(x2.grad, x3.grad, 1e-5, what="frozen bn dx")
         close(w.grad, w3.grad, 1e-4, 1e-4, what="frozen bn dweight"); close(b.grad, b3.grad, 1e-4, 1e-4, what="frozen bn dbias")
         close(cb.grad, cb3.grad, 1e-4, 1e-4, what="folded conv bias grad")
+        # fused residual unit: relu(res + relu?(norm(x))), gradient to the shortcut included
+        r1 = cl(torch.randn(N, C, H, W, device=DEV)).requires_grad_(True); r2 = r1.detach().contiguous().requires_grad_(True)
+        x4 = x.detach().clone(memory_format=torch.preserve_format).requires_grad_(True); x5 = x.detach().contiguous().requires_grad_(True)
+        y = _InstNormReluCL.apply(x4, 1e-5, relu, r1)
+        y.backward(g)
+        yr = torch.nn.functional.instance_norm(x5, eps=1e-5)
+        yr = torch.relu(r2 + (torch.relu(yr) if relu else yr))
+        yr.backward(g.contiguous())
+        close(y, yr, 1e-5, what="residual instance norm fwd"); close(x4.grad, x5.grad, 2e-5, what="residual instance norm dx")
+        close(r1.grad, r2.grad, 1e-6, what="residual instance norm dres")
+        r1.grad = None; r2.grad = None
+        x6 = x.detach().clone(memory_format=torch.preserve_format).requires_grad_(True); x7 = x.detach().contiguous().requires_grad_(True)
+        y = _FrozenBNReluCL.apply(x6, None, w.detach(), b.detach(), rm, rv, 1e-5, relu, r1)
+        y.backward(g)
+        yr = torch.nn.functional.batch_norm(x7, rm, rv, w.detach(), b.detach(), False, 0.0, 1e-5)
+        yr = torch.relu(r2 + (torch.relu(yr) if relu else yr))
+        yr.backward(g.contiguous())
+        close(y, yr, 1e-5, what="residual frozen bn fwd"); close(x6.grad, x7.grad, 1e-5, what="residual frozen bn dx")
+        close(r1.grad, r2.grad, 1e-6, what="residual frozen bn dres")
 
 
 @pytest.mark.parametrize("B,C,N,H,W,k", [(2, 64, 64, 20, 32, 3), (1, 96, 96, 7, 9, 3), (2, 8, 24, 13, 5, 3), (3, 32, 32, 40, 24, 3),
