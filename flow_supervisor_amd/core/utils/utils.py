@@ -24,6 +24,25 @@ class InputPadder:
         return x[..., t:ht - b, l:wd - r]
 
 
+def forward_interpolate(flow):
+    """Warm start for the next frame (utils.py:26-54; evaluate.py:43 `forward_interpolate(flow_low[0])[None].cuda()`):
+    flow [2,H,W] -> [2,H,W], every vector carried to where it points and the grid filled from the nearest landed point.
+    The reference round-trips through the host (scipy griddata); this runs fsraft_forward_interpolate on the device and
+    returns a device tensor (the caller's `.cuda()` is then a no-op).  There is no host implementation here."""
+    from ... import _lib as L
+    if flow.dim() != 3 or flow.shape[0] != 2:
+        raise ValueError(f"forward_interpolate expects [2,H,W], got {tuple(flow.shape)}")
+    if not flow.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError("forward_interpolate runs on the HIP device only (no GPU visible)")
+        flow = flow.cuda()
+    flow = flow.detach().float().contiguous()
+    out = torch.empty_like(flow)
+    L.check(L.load().fsraft_forward_interpolate(L.ptr(flow), L.ptr(out), flow.shape[1], flow.shape[2], L.stream()),
+            "forward_interpolate")
+    return out
+
+
 def coords_grid(batch, ht, wd, device=None):
     """[B,2,ht,wd] float, channel 0 = x, channel 1 = y (utils.py:74-77)."""
     ys, xs = torch.meshgrid(torch.arange(ht, device=device, dtype=torch.float32),

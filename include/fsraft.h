@@ -186,6 +186,13 @@ int fsraft_sequence_loss(const float* const* pred, float* const* dpred, const fl
                          const float* gt, const float* valid, float max_flow, float eps, int B, int H, int W, float* out,
                          hipStream_t stream);
 
+/* ---- warm start (a step next to the path: pytorch/core/utils/utils.py:26-54 forward_interpolate, called between the
+ * frames of a sequence at pytorch/evaluate.py:43) -------------------------------------------------------------------
+ * flow [2][H][W] (dx plane, dy plane) at the resolution the flow lives on: every vector is carried to (x + dx, y + dy),
+ * landings outside the open rectangle (0, W) x (0, H) are dropped, and every grid node takes the vector of the nearest
+ * landed point (float64 distances, as scipy's griddata(method="nearest")); all zero when nothing lands.  out != flow. */
+int fsraft_forward_interpolate(const float* flow, float* out, int H, int W, hipStream_t stream);
+
 /* Channels-last ([B][HW][C], C % 4 == 0, C <= 256) variants, for the encoder stages whose convolutions run on
  * fsraft_conv_forward.  sums/sumsq/s1/s2: [B][C] scratch; dsum_g/dsum_gx: [B * 8][C] partial rows (the per-channel sums
  * are the column sums of these rows); all must be ZERO on entry.  stats: [B][C][2] = (mean, rstd).

@@ -327,8 +327,26 @@ def gen_train_step():
         save("train_step_" + ("small" if small else "basic"), **d)
 
 
+def gen_warm_start():
+    """forward_interpolate of the reference (core/utils/utils.py:26-54) on seeded flows: smooth + noise, a case where
+    many vectors leave the image, and a constant shift (whole columns of the grid inherit their nearest landed neighbour)."""
+    from core.utils.utils import forward_interpolate
+    d = {}
+    for name, h, w, scale, seed in (("a", 12, 16, 2.5, 801), ("b", 55, 128, 6.0, 802), ("c", 9, 7, 8.0, 803)):
+        flow = rand_tensor((2, h, w), seed, scale)
+        d["in_" + name] = flow
+        d["out_" + name] = forward_interpolate(flow)
+    shift = torch.zeros(2, 10, 12)
+    shift[0] += 3.25; shift[1] -= 1.5
+    d["in_shift"] = shift
+    d["out_shift"] = forward_interpolate(shift)
+    save("warm_start", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "kitti", "l2l", "gma", "train"]
+    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "kitti", "l2l", "gma", "train", "warm"]
+    if "warm" in which:
+        gen_warm_start()
     if "corr" in which:
         gen_corr()
     if "update" in which:

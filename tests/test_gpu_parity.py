@@ -892,3 +892,28 @@ def test_sequence_loss_matches_restatement():
         close(a.grad, b.grad, 1e-8, 1e-4, what="d loss / d prediction")
     z = raft_sequence_loss([p.detach() for p in preds_g])
     assert abs(z.item() - O.sequence_loss_zero_gt([p.detach() for p in preds_c]).item()) <= 1e-5 * abs(z.item())
+
+
+# ----------------------------------------------------------------------------- warm start (section 8f rank 4)
+def test_forward_interpolate_matches_reference_outputs_and_oracle():
+    """fsraft_forward_interpolate (csrc/warm_start.hip) against (a) outputs of the reference's forward_interpolate stored in
+    tests/golden/warm_start.npz and (b) the oracle restatement on fresh seeded flows, bit for bit: the result is a copy of
+    input vectors, so there is no rounding to allow for."""
+    from flow_supervisor_amd.core.utils.utils import forward_interpolate
+    g = load("warm_start")
+    for name in ("a", "b", "c", "shift"):
+        out = forward_interpolate(T(g["in_" + name]).to(DEV))
+        assert out.is_cuda and torch.equal(out.cpu(), T(g["out_" + name])), name
+    for h, w, scale, seed in ((55, 128, 10.0, 901), (33, 47, 3.0, 902), (1, 9, 2.0, 903), (8, 8, 100.0, 904)):
+        flow = rand_tensor((2, h, w), seed, scale)
+        ref = O.forward_interpolate(flow) if h * w > 1 and _lands(flow) else torch.zeros_like(flow)
+        assert torch.equal(forward_interpolate(flow.to(DEV)).cpu(), ref), (h, w)
+    with pytest.raises(ValueError):
+        forward_interpolate(torch.zeros(1, 2, 4, 4, device=DEV))
+
+
+def _lands(flow):
+    _, h, w = flow.shape
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    x1, y1 = xs + flow[0].double(), ys + flow[1].double()
+    return bool(((x1 > 0) & (x1 < w) & (y1 > 0) & (y1 < h)).any())

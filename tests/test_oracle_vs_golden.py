@@ -215,3 +215,11 @@ def test_gma_end_to_end_flow():
     s = int(g["stride"])
     assert O.epe(low, T(g["flow_low"])).item() < 1e-4
     assert O.epe(up[:, :, ::s, ::s], T(g["flow_up_strided"])).item() < 1e-4
+
+
+def test_warm_start_forward_interpolate():
+    """oracle.forward_interpolate against outputs of the reference's own function (core/utils/utils.py:26-54)."""
+    g = load("warm_start")
+    for name in ("a", "b", "c", "shift"):
+        out = O.forward_interpolate(T(g["in_" + name]))
+        assert torch.equal(out, T(g["out_" + name])), name
