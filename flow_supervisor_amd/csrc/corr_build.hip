@@ -299,7 +299,36 @@ __global__ __launch_bounds__(256) void corr_unpool_bwd_vec_kernel(Levels lv, int
   }
 }
 
+// dst[row][y][x] = 2x2 average of src[row][2y..][2x..] (floor sizes), the same expression the fused build uses
+__global__ __launch_bounds__(256) void corr_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows,
+                                                        int h, int w, int h2, int w2) {
+  const int64_t total = rows * h2 * w2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % w2), y = (int)((e / w2) % h2);
+    const int64_t r = e / ((int64_t)w2 * h2);
+    const float* s = src + (r * h + 2 * y) * w + 2 * x;
+    dst[e] = (((s[0] + s[1]) + s[w]) + s[w + 1]) * 0.25f;
+  }
+}
+
 }  // namespace
+
+// Pyramid of a level-0 volume that already exists: levels[0] is [rows][H2][W2] (rows = B*H1*W1), levels[l >= 1] receive the
+// 2x2 averages of levels[l-1].  raft/allfield.py:94-106 build_pyramid -- applied to the transposed volume for the backward
+// flow at raft/semi.py:250-251, 257-258.
+extern "C" int fsraft_corr_pool_pyramid(float* const* levels, int num_levels, int64_t rows, int H2, int W2, hipStream_t stream) {
+  if (!levels || num_levels < 1 || num_levels > 8 || rows < 1 || H2 < 1 || W2 < 1) return FS_ERR_ARG;
+  int h = H2, w = W2;
+  for (int l = 1; l < num_levels; ++l) {
+    const int h2 = h / 2, w2 = w / 2;
+    if (!levels[l - 1] || !levels[l] || h2 < 1 || w2 < 1) return FS_ERR_ARG;
+    int64_t blocks = (rows * h2 * w2 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(corr_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, levels[l - 1], levels[l], rows, h, w, h2, w2);
+    h = h2; w = w2;
+  }
+  return fs_launch_status();
+}
 
 extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* levels, int num_levels,
                                  int B, int C, int H, int W, hipStream_t stream) {

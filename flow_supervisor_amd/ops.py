@@ -85,6 +85,30 @@ def corr_build(fmap1, fmap2, num_levels=4):
     return levels
 
 
+def corr_pool_pyramid(level0, num_levels):
+    """level0 [rows, 1, h, w] (or [rows, h, w]) -> [level0, 2x2 averages, ...] with floor sizes (fsraft_corr_pool_pyramid)."""
+    L.require_cuda_f32(level0)
+    level0 = level0.contiguous()
+    rows, h, w = level0.shape[0], level0.shape[-2], level0.shape[-1]
+    sizes = pyramid_sizes(h, w, num_levels)
+    if sizes[-1][0] < 1 or sizes[-1][1] < 1:
+        raise RuntimeError(f"volume {h}x{w} too small for {num_levels} pyramid levels")
+    levels = [level0.view(rows, 1, h, w)] + [torch.empty(rows, 1, a, b, device=level0.device, dtype=torch.float32)
+                                              for a, b in sizes[1:]]
+    pp, keep = L.ptr_array(levels)
+    L.check(_lib().fsraft_corr_pool_pyramid(pp, num_levels, rows, h, w, L.stream()), "corr_pool_pyramid")
+    return levels
+
+
+def transpose_batched(x):
+    """x [B, M, N] contiguous -> [B, N, M] contiguous through the tiled layout kernel (4-6 TB/s)."""
+    L.require_cuda_f32(x)
+    B, M, N = x.shape
+    out = torch.empty(B, N, M, device=x.device, dtype=torch.float32)
+    L.check(_lib().fsraft_nhwc_to_nchw(L.ptr(x.contiguous()), L.ptr(out), B, N, M, N, 0, 0, L.stream()), "transpose_batched")
+    return out
+
+
 def corr_unpool_bwd_(dlevels, B, H, W):
     pp, keep = L.ptr_array(dlevels)
     L.check(_lib().fsraft_corr_unpool_bwd(pp, len(dlevels), B, H, W, L.stream()), "corr_unpool_bwd")

@@ -2,12 +2,17 @@
 
     raft.corr.CorrBlock(num_levels=4, radius=4, is_max_disp=False).__call__(corr_pyramid, coords)   raft/corr.py:5-22
     raft.allfield.calc_all_field(a, b, num_pool)                                                     raft/allfield.py:61-92
+    raft.allfield.build_pyramid(c_volume, num_pool)                                                  raft/allfield.py:94-106
+    transpose_volume(c_volume)  == tf.transpose(c_volume, [0, 3, 4, 1, 2])                           raft/semi.py:250, 257
     raft.upsample.UpsampleConvexWithMask(scale=8).call([x, mask, ref])                               raft/upsample.py:4-41
     raft.smurf_models.raft_update.BasicUpdateBlock(args, hidden_dim).call([net, inp, corr, flow])    raft_update.py:180-212
 
 TensorFlow is not installed here, so these take and return torch tensors laid out the way the TF code lays
 them out (channels last, coords as [B,H,W,2] with (x, y) in the last dim) and run the same HIP kernels as the
-PyTorch-shaped API.  PyTorch pooling semantics are normative (floor halving); TF's SAME/ceil pooling differs
-only when H/8 or W/8 is odd and is unpinned (no TF oracle in this environment).
+PyTorch-shaped API.  The pyramid kernels pool with PyTorch's floor halving; TF's padding='SAME' keeps partial edge
+windows when a pooled dimension is odd (e.g. 55 rows at 1/8 of Sintel), which they do not reproduce -- calc_all_field and
+build_pyramid raise NotImplementedError for such shapes instead of returning a differently-shaped pyramid (no TF oracle
+exists in this environment to pin that case against).
 """
-from .api import BasicUpdateBlock, CorrBlock, UpsampleConvexWithMask, calc_all_field  # noqa: F401
+from .api import (BasicUpdateBlock, CorrBlock, UpsampleConvexWithMask, build_pyramid, calc_all_field,  # noqa: F401
+                  transpose_volume)

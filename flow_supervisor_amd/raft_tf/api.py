@@ -8,9 +8,34 @@ from ..core.raft import convex_upsample
 def calc_all_field(a, b, num_pool=0):
     """a, b: [B,H,W,C] feature maps -> list of num_pool+1 volumes [B,H,W,h_l,w_l] (raft/allfield.py:61-92)."""
     B, H, W, C = a.shape
+    _check_pool_dims(H, W, num_pool)
     f1 = a.permute(0, 3, 1, 2).contiguous().float()
     f2 = b.permute(0, 3, 1, 2).contiguous().float()
     levels = ops.corr_build(f1, f2, num_pool + 1)
+    return [lv.view(B, H, W, lv.shape[-2], lv.shape[-1]) for lv in levels]
+
+
+def _check_pool_dims(h, w, num_pool):
+    # TF pools with padding='SAME' (ceil sizes, partial edge windows); the kernels follow the PyTorch reference
+    # (avg_pool2d floor sizes).  The two agree exactly when every pooled dimension stays even -- anything else fails loudly.
+    if num_pool and (h % (1 << num_pool) or w % (1 << num_pool)):
+        raise NotImplementedError(f"volume {h}x{w} is not divisible by 2^{num_pool}: TF 'SAME' pooling keeps partial edge "
+                                  "windows there, which the HIP pyramid (PyTorch floor semantics) does not reproduce")
+
+
+def transpose_volume(c_volume):
+    """tf.transpose(c_volume, [0, 3, 4, 1, 2]) of a [B,H,W,H2,W2] volume (raft/semi.py:250, 257: the backward-flow volume is
+    the forward one read the other way), materialised by the tiled transpose kernel instead of a strided copy."""
+    B, H, W, H2, W2 = c_volume.shape
+    return ops.transpose_batched(c_volume.reshape(B, H * W, H2 * W2).float()).view(B, H2, W2, H, W)
+
+
+def build_pyramid(c_volume, num_pool=0):
+    """[B,H,W,H2,W2] volume -> [c_volume, pooled x2, x4, ...] (raft/allfield.py:94-106), e.g. on transpose_volume(...) for
+    the backward flow (raft/semi.py:251, 258) without a second all-pairs GEMM."""
+    B, H, W, H2, W2 = c_volume.shape
+    _check_pool_dims(H2, W2, num_pool)
+    levels = ops.corr_pool_pyramid(c_volume.reshape(B * H * W, H2, W2).float(), num_pool + 1)
     return [lv.view(B, H, W, lv.shape[-2], lv.shape[-1]) for lv in levels]
 
 

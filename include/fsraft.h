@@ -36,6 +36,9 @@ int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* leve
 
 /* Backward of the pooling chain: dlevels[0] += unpool(dlevels[1..]) in place.
  * (autograd of F.avg_pool2d, pytorch/core/corr.py:25-27) */
+/* Pyramid of an existing level-0 volume (raft/allfield.py:94-106 build_pyramid; the backward-flow pyramid of the transposed
+ * volume at raft/semi.py:250-251): levels[0] = [rows][H2][W2] given, levels[l] = 2x2 averages of levels[l-1], floor sizes. */
+int fsraft_corr_pool_pyramid(float* const* levels, int num_levels, int64_t rows, int H2, int W2, hipStream_t stream);
 int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int B, int H, int W, hipStream_t stream);
 
 /* ---- radius-r pyramid lookup --------------------------------------------------------

@@ -917,3 +917,25 @@ def _lands(flow):
     ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
     x1, y1 = xs + flow[0].double(), ys + flow[1].double()
     return bool(((x1 > 0) & (x1 < w) & (y1 > 0) & (y1 < h)).any())
+
+
+def test_tf_backward_flow_pyramid_from_transposed_volume():
+    """raft/semi.py:250-251: the backward-flow pyramid is build_pyramid(transpose(forward volume)).  Against a fresh all-pairs
+    build with the feature maps swapped (same dot products) and against torch's own transpose + avg_pool2d."""
+    from flow_supervisor_amd import raft_tf
+    torch.manual_seed(31)
+    B, C, H, W = 2, 64, 16, 24
+    f1 = torch.randn(B, H, W, C, device=DEV); f2 = torch.randn(B, H, W, C, device=DEV)
+    fw = raft_tf.calc_all_field(f1, f2, num_pool=3)
+    vt = raft_tf.transpose_volume(fw[0])
+    assert torch.equal(vt, fw[0].permute(0, 3, 4, 1, 2).contiguous())
+    bw = raft_tf.build_pyramid(vt, num_pool=3)
+    swapped = raft_tf.calc_all_field(f2, f1, num_pool=3)
+    assert [tuple(p.shape) for p in bw] == [tuple(p.shape) for p in swapped]
+    lv = vt.reshape(B * H * W, 1, H, W)
+    for l in range(4):
+        close(bw[l], swapped[l], 2e-5, what=f"backward pyramid level {l} vs swapped build")
+        close(bw[l].reshape(lv.shape), lv, 1e-6, what=f"backward pyramid level {l} vs avg_pool2d")
+        lv = torch.nn.functional.avg_pool2d(lv, 2, 2)
+    with pytest.raises(NotImplementedError):
+        raft_tf.build_pyramid(torch.zeros(1, 4, 4, 5, 8, device=DEV), num_pool=1)
