@@ -7,7 +7,7 @@ import json
 import sys
 
 raw = json.load(open(sys.argv[1]))
-FAM = {"conv_igemm": ("conv_igemm", 2.0), "conv_wgrad": ("conv_wgrad", 2.0), "gemm_split": ("gemm_f32", 2.0),
+FAM = {"conv_igemm": ("conv_igemm", 2.0), "conv3x3_halo": ("conv_igemm", 2.0), "conv_wgrad": ("conv_wgrad", 2.0), "gemm_split": ("gemm_f32", 2.0),
        "gemm_kernel": ("gemm_f32", 2.0), "corr_build": ("corr_build", 1.0), "corr_lookup_fwd": ("corr_lookup_fwd", 1.0),
        "corr_lookup_bwd": ("corr_lookup_bwd", 1.0), "upsample_fwd": ("upsample_fwd", 2.0)}
 acc = {}
