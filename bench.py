@@ -201,7 +201,9 @@ def main():
                                f", {a.height}x{a.width} (Sintel 436x1024 padded), {a.iters} GRU iters, "
                                f"{B} pairs/GPU, train step = fwd + sequence loss + bwd + RCCL all-reduce + clip + AdamW",
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v,
-                   "launch": "hipGraph replay of the whole step" if graph is not None else "eager"},
+                   "launch": "hipGraph replay of the whole step" if graph is not None else "eager",
+                   "encoders": ("MIOpen NCHW convolutions (north_star configuration)" if os.environ.get("FSRAFT_ENCODER_CL", "1") == "0"
+                                else "channels_last; stride-1 convolutions on the fsraft kernels, stem / stride-2 pairs on MIOpen")},
     }
     if timer is not None:
         kern = {}

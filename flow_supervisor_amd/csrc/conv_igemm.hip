@@ -973,7 +973,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_split_kernel(const std::co
     const int span = 8 * a.xcd_xt, r = blockIdx.x / span, rem = blockIdx.x - r * span;
     const int g = r * 8 + (rem & 7);
     if (g >= a.xcd_groups) return;
-    bx = rem >> 3; by = g % a.xcd_yt; zblock = g / a.xcd_yt;
+    if (a.xcd_yt > 0) { bx = rem >> 3; by = g % a.xcd_yt; zblock = g / a.xcd_yt; }        // group = (Cout tile, pixel split)
+    else { const int tile = rem >> 3, x0 = -a.xcd_yt; bx = tile % x0; by = tile / x0; zblock = g; }   // group = pixel split
   }
   if constexpr (MULTI) { seg = zblock / args.zs; zblock -= seg * args.zs; seg = __builtin_amdgcn_readfirstlane(seg); }
   const int HW = a.H * a.W;
@@ -1758,7 +1759,10 @@ extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy
     m.zs = (int)((M + chunk - 1) / chunk);
     m.nseg = n;
     dim3 grid(xt128, ytiles, m.zs * n);
-    if (g_wgrad_xcd) {
+    if (g_wgrad_xcd == 3) {        // all tiles of one pixel split on one XCD (xcd_yt < 0 carries -x tiles)
+      m.a.xcd_xt = xt128 * ytiles; m.a.xcd_yt = -xt128; m.a.xcd_groups = m.zs * n;
+      grid = dim3((unsigned)(ceil_div(m.a.xcd_groups, 8) * 8 * xt128 * ytiles), 1, 1);
+    } else if (g_wgrad_xcd) {
       m.a.xcd_xt = xt128; m.a.xcd_yt = ytiles; m.a.xcd_groups = ytiles * m.zs * n;
       grid = dim3((unsigned)(ceil_div(m.a.xcd_groups, 8) * 8 * xt128), 1, 1);
     }
