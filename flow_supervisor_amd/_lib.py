@@ -32,7 +32,7 @@ class ConvDesc(Structure):
         ("aux1", c_void_p), ("ld1", c_int), ("aux2", c_void_p), ("ld2", c_int), ("hid", c_int),
         ("pre", c_void_p), ("ldpre", c_int),
         ("rmask", c_void_p * 3), ("ldmask", c_int * 3), ("maskc", c_int * 3),
-        ("wpk_frag", c_void_p),
+        ("wpk_frag", c_void_p), ("pad_h1", c_int), ("pad_w1", c_int),
     ]
 
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     "fsraft_affine_relu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, _S],
     "fsraft_sequence_loss": [_PP, _PP, POINTER(c_float), c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_corr_pool_pyramid": [_PP, c_int, c_int64, c_int, c_int, _S],
+    "fsraft_space_to_depth2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_forward_interpolate": [c_void_p, c_void_p, c_int, c_int, _S],
     "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, _S],
     "fsraft_inorm_relu_cl_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

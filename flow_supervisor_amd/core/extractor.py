@@ -273,6 +273,114 @@ def _conv(conv, x, bias):
     return F.conv2d(_ToNCHW.apply(x) if _is_cl(x) else x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+_S2D_TAP = ((0, 1), (1, 0), (1, 1))          # 3x3 tap index k -> (2x2 tap t, sub-pixel s): input row 2y - 1 + k = 2(y + t - 1) + s
+
+
+def _s2d_weight(w3):
+    """[N,C,3,3] stride-2 weights -> the equivalent stride-1 [N,4C,2,2] weights over the space-to-depth input (channel
+    (sy*2+sx)*C + c = pixel (2y+sy, 2x+sx)); 7 of the 16 (tap, sub-pixel) slots stay zero."""
+    N, C = w3.shape[:2]
+    w = w3.new_zeros(N, 2, 2, C, 2, 2)           # n, sy, sx, c, ty, tx
+    for ky, (ty, sy) in enumerate(_S2D_TAP):
+        for kx, (tx, sx) in enumerate(_S2D_TAP):
+            w[:, sy, sx, :, ty, tx] = w3[:, :, ky, kx]
+    return w.reshape(N, 4 * C, 2, 2)
+
+
+def _s2d_weight_grad(dw, C):
+    """Gradient of _s2d_weight: [N,4C,2,2] -> [N,C,3,3]."""
+    N = dw.shape[0]
+    d = dw.reshape(N, 2, 2, C, 2, 2)
+    out = dw.new_empty(N, C, 3, 3)
+    for ky, (ty, sy) in enumerate(_S2D_TAP):
+        for kx, (tx, sx) in enumerate(_S2D_TAP):
+            out[:, :, ky, kx] = d[:, sy, sx, :, ty, tx]
+    return out
+
+
+def _pair_packs(block):
+    """Packed matrices of a stride-2 residual unit's first convolution (as 2x2 over space-to-depth) and 1x1 shortcut."""
+    w3, wsc = block.conv1.weight, block.downsample[0].weight
+    key = (w3.data_ptr(), w3._version, wsc.data_ptr(), wsc._version)
+    c = block.__dict__.get("_fs_pair_packs")
+    if c is None or c[0] != key:
+        from .. import ops
+        w2 = _s2d_weight(w3.detach())
+        c4, c1, ws = [w2.shape[1]], [wsc.shape[1]], wsc.detach()
+        c = (key, tuple(ops.pack_weight(w2, c4, m) for m in (0, 10, 1, 11)), tuple(ops.pack_weight(ws, c1, m) for m in (0, 10, 1, 11)))
+        block.__dict__["_fs_pair_packs"] = c
+    return c
+
+
+class _StridedPairFn(torch.autograd.Function):
+    """First convolution (3x3, stride 2, pad 1) and shortcut (1x1, stride 2) of a stride-2 ResidualBlock
+    (pytorch/core/extractor.py:13, 39) on the stride-1 kernels: the channels_last input is permuted once to
+    space-to-depth order ([B,H/2,W/2,4C], fsraft_space_to_depth2); over that tensor the 3x3 becomes a 2x2 convolution
+    with 4C input channels (pad 1 forward, pad 0 in the data gradient) and the shortcut a 1x1 over its first C channels.
+    Both data gradients land in one [B,H/2,W/2,4C] buffer (the shortcut's accumulates into channels [0, C)) that is
+    permuted back once.  No MIOpen call, no NCHW hop.  Biases are the caller's business (dropped before InstanceNorm,
+    folded into a frozen BatchNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, wsc, packs):
+        from .. import ops
+        x = _as_cl(x)
+        B, C, H, W = x.shape
+        N, Ns = w3.shape[0], wsc.shape[0]
+        h, w = H // 2, W // 2
+        xs = ops.space_to_depth2(x.permute(0, 2, 3, 1))
+        y1 = torch.empty(B, h, w, N, device=x.device, dtype=torch.float32)
+        ys = torch.empty(B, h, w, Ns, device=x.device, dtype=torch.float32)
+        p, q = packs[1], packs[2]
+        ops.conv_forward([ops.V(xs, 4 * C)], p[0], None, B, h, w, 2, 2, N, [ops.Dst.nhwc(y1)], wpk_split=p[1])
+        ops.conv_forward([ops.V(xs, C, 0)], q[0], None, B, h, w, 1, 1, Ns, [ops.Dst.nhwc(ys)], wpk_split=q[1])
+        ctx.save_for_backward(xs, w3, wsc)
+        ctx.packs = packs
+        return y1.permute(0, 3, 1, 2), ys.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g1, gs):
+        from .. import ops
+        xs, w3, wsc = ctx.saved_tensors
+        B, h, w, C4 = xs.shape
+        C, N, Ns = C4 // 4, w3.shape[0], wsc.shape[0]
+        p, q = ctx.packs[1], ctx.packs[2]
+        g1v = ops.V(_as_cl(g1).permute(0, 2, 3, 1), N)
+        gsv = ops.V(_as_cl(gs).permute(0, 2, 3, 1), Ns)
+        dx = dw3 = dwsc = None
+        if ctx.needs_input_grad[0]:
+            dxs = torch.empty(B, h, w, C4, device=xs.device, dtype=torch.float32)
+            ops.conv_forward([g1v], p[2], None, B, h, w, 2, 2, C4, [ops.Dst.nhwc(dxs)], wpk_split=p[3], pad=(0, 0))
+            ops.conv_forward([gsv], q[2], None, B, h, w, 1, 1, C, [ops.Dst.nhwc(dxs, 0, 0, True)], wpk_split=q[3])
+            dx = ops.space_to_depth2(dxs, inverse=True).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dwpk = torch.zeros(N, ops.conv_ktot([C4], 2, 2), device=xs.device, dtype=torch.float32)
+            ops.conv_wgrad(g1v, [ops.V(xs, C4)], dwpk, B, h, w, 2, 2)
+            dw3 = _s2d_weight_grad(ops.unpack_weight_grad(dwpk, (N, C4, 2, 2), [C4]), C)
+        if ctx.needs_input_grad[2]:
+            dwpk = torch.zeros(Ns, ops.conv_ktot([C], 1, 1), device=xs.device, dtype=torch.float32)
+            ops.conv_wgrad(gsv, [ops.V(xs, C, 0)], dwpk, B, h, w, 1, 1)
+            dwsc = ops.unpack_weight_grad(dwpk, (Ns, C, 1, 1), [C])
+        return dx, dw3, dwsc, None
+
+
+def _norm_act(norm, y, cbias, relu, res=None):
+    """relu?(norm(y + cbias)) (+ fused residual) for a channels_last convolution output and one of the two norm kinds the
+    channels_last path covers; cbias is the bias the convolution ran without."""
+    if isinstance(norm, nn.InstanceNorm2d):
+        return _InstNormReluCL.apply(y, norm.eps, relu, res)
+    return _FrozenBNReluCL.apply(y, cbias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu, res)
+
+
+def _pair_ok(block, x):
+    import os
+    c1, ds = block.conv1, block.downsample[0]
+    return (os.environ.get("FSRAFT_ENCODER_S2D", "1") != "0" and block.n == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and x.shape[1] % 4 == 0 and c1.kernel_size == (3, 3) and c1.stride == (2, 2) and c1.padding == (1, 1)
+            and c1.dilation == (1, 1) and c1.groups == 1 and ds.kernel_size == (1, 1) and ds.stride == (2, 2)
+            and ds.padding == (0, 0) and ds.groups == 1 and _cl_norm_ok(torch.empty(0, c1.out_channels)))
+
+
 def _conv_norm(conv, norm, x, relu, to_cl=False, res=None):
     """relu?(norm(conv(x))) of pytorch/core/extractor.py.  The convolution stays a PyTorch-ROCm (MIOpen) call; for fp32
     CUDA tensors the normalisation + ReLU around it runs on the fused fsraft kernels:
@@ -345,6 +453,12 @@ class _Block(nn.Module):
 
     def forward(self, x):
         cl = _is_cl(x)
+        if cl and self.downsample is not None and _pair_ok(self, x):
+            # stride-2 unit, channels_last: both strided convolutions on the stride-1 kernels over the space-to-depth input
+            y1, ys = _StridedPairFn.apply(x, self.conv1.weight, self.downsample[0].weight, _pair_packs(self))
+            y = _norm_act(self.norm1, y1, self.conv1.bias, True)
+            xs = _norm_act(self.downsample[1], ys, self.downsample[0].bias, False)
+            return _conv_norm(self.conv2, self.norm2, y, True, to_cl=True, res=xs)
         if cl and self.downsample is not None:
             x = _ToNCHW.apply(x)        # the strided convolutions (first 3x3 / shortcut 1x1) are MIOpen NCHW calls: one copy for both
         y = x

@@ -33,6 +33,7 @@ struct ConvArgs {
   const float* wpk; int Ktot;
   const float* bias;
   int B, H, W, KH, KW, N;        // N = output channels of this GEMM
+  int PH, PW;                    // tap t reads pixel (y + t / KW - PH, x + t % KW - PW); KH / 2, KW / 2 unless overridden
   Dst dst[3]; int ndst;
   int relu; float alpha;
   // GRU epilogues
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + 31) / 32 * (32 / Cfg::BK) : 0;
   if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
   if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
-  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.KH / 2; la.PW = a.KW / 2; la.H = a.H; la.W = a.W;
+  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.PH; la.PW = a.PW; la.H = a.H; la.W = a.W;
 #pragma unroll
   for (int j = 0; j < ConvALoader<Cfg>::NF4; ++j) {
     const int row = (threadIdx.x + 256 * j) / ConvALoader<Cfg>::F4;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if constexpr (BUF != 0) {
-    const int PH = a.KH / 2, PW = a.KW / 2, taps = a.KH * a.KW;
+    const int PH = a.PH, PW = a.PW, taps = a.KH * a.KW;
     // Index the table where it lives, in the kernarg segment: going through the by-value struct would make the
     // compiler copy it to scratch (dynamic index), and a scratch load is per-lane, i.e. no longer provably uniform.
     const auto* ktab = (const unsigned __attribute__((address_space(4)))*)(
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
   la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + 31) / 32 : 0;
   if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
   if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
-  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.KH / 2; la.PW = a.KW / 2; la.H = a.H; la.W = a.W;
+  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.PH; la.PW = a.PW; la.H = a.H; la.W = a.W;
 #pragma unroll
   for (int j = 0; j < SplitConvALoader<Cfg>::NCH; ++j) {
     const int m = m0 + ((threadIdx.x + 256 * j) >> 3);
@@ -1402,7 +1403,7 @@ bool build_ktab(const ConvArgs& a, ConvArgsT& t) {
 // Uniform form of the table (see ConvArgsT): possible when every source has the same pitch and all of them, shifted
 // taps included, lie inside one 2 GiB window.
 bool build_ktab_uniform(const ConvArgs& a, ConvArgsT& t) {
-  const int taps = a.KH * a.KW, KT = a.Ktot / 32, PH = a.KH / 2, PW = a.KW / 2;
+  const int taps = a.KH * a.KW, KT = a.Ktot / 32, PH = a.PH, PW = a.PW;
   const int64_t M = (int64_t)a.B * a.H * a.W;
   if (!g_conv_uniform || 2 * KT > KTAB_MAX || taps > 15) return false;
   const int ld = a.src[0].ld;
@@ -1511,6 +1512,7 @@ struct fsraft_conv_desc {
   const float* pre; int ldpre;   // GRU epilogues: addend to the pre-activation (e.g. the context part of the conv), or NULL
   const float* rmask[3]; int ldmask[3]; int maskc[3];   // epi 0, per destination: zero column j < maskc where rmask[m*ldmask+j] <= 0
   const float* wpk_frag;         // wpk_split in fragment order (or NULL): enables the resident-patch 3x3 kernel
+  int pad_h1, pad_w1;            // 0: taps centred (KH / 2, KW / 2); else 1 + the top / left padding (even kernel sizes)
 };
 
 extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
@@ -1528,6 +1530,8 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   a.nsrc = d->nsrc;
   a.wpk = d->wpk; a.Ktot = conv_ktot(d->srcC, d->nsrc, d->KH * d->KW); a.bias = d->bias;
   a.B = d->B; a.H = d->H; a.W = d->W; a.KH = d->KH; a.KW = d->KW; a.N = d->N;
+  a.PH = d->pad_h1 ? d->pad_h1 - 1 : d->KH / 2; a.PW = d->pad_w1 ? d->pad_w1 - 1 : d->KW / 2;
+  if (a.PH < 0 || a.PH >= d->KH || a.PW < 0 || a.PW >= d->KW) return FS_ERR_ARG;
   for (int i = 0; i < 3; ++i) {
     const int j = i < d->ndst ? i : 0;
     a.dst[i] = Dst{d->dst[j], d->dst_bs[j], d->dst_ps[j], d->dst_cs[j], d->dst_n0[j], d->dst_acc[j]};
@@ -1548,6 +1552,7 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
   if (g_conv_halo && g_conv_split == 1 && d->wpk_frag && d->epi == EPI_PLAIN && d->nsrc == 1 && d->KH == 3 && d->KW == 3 &&
+      a.PH == 1 && a.PW == 1 &&
       d->srcC[0] % 4 == 0 && d->srcC[0] > 32 && d->srcC[0] <= 64 && d->N <= 128 && d->N > 32 && d->ndst == 1 &&
       d->dst_cs[0] == 1 && d->dst_n0[0] == 0 && !d->dst_acc[0] && !a.rmask[0] && d->alpha == 1.0f &&
       (int64_t)d->B * d->H * d->W >= g_conv_halo_min_m && (int64_t)d->H * d->W * d->srcld[0] * 4 < 0x7fffffff) {

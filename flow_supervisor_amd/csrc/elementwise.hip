@@ -53,6 +53,29 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
+// Space-to-depth by 2 of a channels-last tensor, as a pixel permutation: dst[b][y/2][x/2][(y%2)*2 + x%2][c] = src[b][y][x][c]
+// (INVERSE: the other way).  A stride-2 convolution over src is a stride-1 convolution with 2x2 taps over dst viewed as
+// [B][H/2][W/2][4C].  One 16-byte chunk per thread and step; both sides move whole pixels (C*4 contiguous bytes).
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int C) {
+  const int c4n = C >> 2;
+  const int64_t total = (int64_t)B * H * W * c4n;
+  const int h2 = H >> 1, w2 = W >> 1;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(e % c4n);
+    const int64_t q = e / c4n;                       // pixel index in the block-major (space-to-depth) order
+    const int sub = (int)(q & 3);
+    const int64_t blk = q >> 2;
+    const int x2 = (int)(blk % w2), y2 = (int)((blk / w2) % h2);
+    const int64_t b = blk / ((int64_t)w2 * h2);
+    const int64_t p = (b * H + 2 * y2 + (sub >> 1)) * W + 2 * x2 + (sub & 1);      // raster pixel index
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    if (INVERSE) d4[p * c4n + c4] = s4[q * c4n + c4];
+    else d4[q * c4n + c4] = s4[p * c4n + c4];
+  }
+}
+
 // cols[m][ci*49 + ky*7 + kx] = flow[b, ci, y+ky-3, x+kx-3] (zero outside); cols pitch = ld (>= 100), pad cols zeroed
 __global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ flow, int64_t bs, int64_t cs, int64_t ps,
                                                       float* __restrict__ cols, int ld, int B, int H, int W) {
@@ -189,6 +212,16 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
 inline int grid_for(int64_t work) { int64_t g = (work + 255) / 256; return (int)(g < 1 ? 1 : g > 16384 ? 16384 : g); }
 
 }  // namespace
+
+// src [B][H][W][C] -> dst [B][H/2][W/2][2][2][C] (inverse != 0: the other way; H, W are the full-resolution sizes).
+extern "C" int fsraft_space_to_depth2(const float* src, float* dst, int B, int H, int W, int C, int inverse, hipStream_t s) {
+  if (!src || !dst || src == dst || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || (C & 3)) return FS_ERR_ARG;
+  int64_t blocks = ((int64_t)B * H * W * (C / 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (inverse) hipLaunchKernelGGL((s2d_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, src, dst, B, H, W, C);
+  else hipLaunchKernelGGL((s2d_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, src, dst, B, H, W, C);
+  return fs_launch_status();
+}
 
 extern "C" int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate,
                                    hipStream_t s) {

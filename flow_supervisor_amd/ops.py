@@ -100,6 +100,21 @@ def corr_pool_pyramid(level0, num_levels):
     return levels
 
 
+def space_to_depth2(x, inverse=False):
+    """x [B,H,W,C] -> [B,H/2,W/2,4C] with channel (sy*2+sx)*C + c = pixel (2y+sy, 2x+sx) (inverse: [B,h,w,4C] -> [B,2h,2w,C])."""
+    L.require_cuda_f32(x)
+    x = x.contiguous()
+    if inverse:
+        B, h, w, C4 = x.shape
+        out = torch.empty(B, 2 * h, 2 * w, C4 // 4, device=x.device, dtype=torch.float32)
+        L.check(_lib().fsraft_space_to_depth2(L.ptr(x), L.ptr(out), B, 2 * h, 2 * w, C4 // 4, 1, L.stream()), "space_to_depth2")
+    else:
+        B, H, W, C = x.shape
+        out = torch.empty(B, H // 2, W // 2, 4 * C, device=x.device, dtype=torch.float32)
+        L.check(_lib().fsraft_space_to_depth2(L.ptr(x), L.ptr(out), B, H, W, C, 0, L.stream()), "space_to_depth2")
+    return out
+
+
 def transpose_batched(x):
     """x [B, M, N] contiguous -> [B, N, M] contiguous through the tiled layout kernel (4-6 TB/s)."""
     L.require_cuda_f32(x)
@@ -494,7 +509,7 @@ class Dst:
 
 
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
-                 aux1=None, aux2=None, hid=0, wpk_split=None, pre=None, wpk_frag=None):
+                 aux1=None, aux2=None, hid=0, wpk_split=None, pre=None, wpk_frag=None, pad=None):
     """srcs: list of V (concatenated along channels).  dsts: list of Dst.
     GRU epilogues (epi 2: z|r, epi 3: q) take h, z, aux buffers as [B,H,W,ld] tensors."""
     d = L.ConvDesc()
@@ -504,6 +519,8 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     d.wpk = wpk.data_ptr()
     d.wpk_split = wpk_split.data_ptr() if wpk_split is not None else None
     d.wpk_frag = wpk_frag.data_ptr() if wpk_frag is not None else None
+    if pad is not None:                       # (rows above, columns left of) the output pixel; default: centred taps
+        d.pad_h1, d.pad_w1 = pad[0] + 1, pad[1] + 1
     d.bias = bias.data_ptr() if bias is not None else None
     d.B, d.H, d.W, d.KH, d.KW, d.N = B, H, W, KH, KW, N
     for i, ds in enumerate(dsts):

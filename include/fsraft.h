@@ -104,6 +104,9 @@ typedef struct fsraft_conv_desc {
                                                                  [lane = 32 * (k half) + row][16 B], rows zero-padded to 32;
                                                                  enables the resident-patch 3x3 kernel (one source, 33..64
                                                                  channels in, N <= 64, large B*H*W).  NULL: never used */
+  int pad_h1, pad_w1;                                         /* 0: taps centred (KH/2, KW/2 rows / columns above / left of
+                                                                 the output pixel); else 1 + that count -- even kernel sizes:
+                                                                 a 2x2 kernel has pad 1 forward and pad 0 in its data gradient */
 } fsraft_conv_desc;
 
 int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);
@@ -213,6 +216,10 @@ int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale
 
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
+/* Space-to-depth by 2 of a channels-last tensor: dst[b][y/2][x/2][(y%2)*2 + x%2][c] = src[b][y][x][c] (inverse != 0: back).
+ * A stride-2 3x3 / 1x1 convolution over src (pytorch/core/extractor.py:13, 39: the first convolution and the shortcut of a
+ * stride-2 ResidualBlock) is a stride-1 2x2 / 1x1 convolution of fsraft_conv_forward over dst viewed as [B][H/2][W/2][4C]. */
+int fsraft_space_to_depth2(const float* src, float* dst, int B, int H, int W, int C, int inverse, hipStream_t s);
 int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 int fsraft_im2col7(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* cols, int ld, int B, int H, int W, hipStream_t s);
 int fsraft_col2im7(const float* dcols, int ld, float* dflow, int B, int H, int W, int accumulate, hipStream_t s);

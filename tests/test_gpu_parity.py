@@ -744,6 +744,34 @@ def test_conv3x3_resident_patch_kernel(B, C, N, H, W):
         lib.fsraft_set_tuning(21, 65536)
 
 
+@pytest.mark.parametrize("B,C,N,H,W", [(2, 64, 96, 20, 32), (1, 96, 128, 6, 10), (2, 8, 16, 14, 4)])
+def test_encoder_strided_pair_space_to_depth(B, C, N, H, W, precision):
+    """_StridedPairFn: the 3x3 stride-2 convolution and the 1x1 stride-2 shortcut of a stride-2 residual unit as 2x2 / 1x1
+    stride-1 convolutions over the space-to-depth input (fsraft_space_to_depth2, pad override of fsraft_conv_forward),
+    against F.conv2d: outputs, input gradient, both weight gradients."""
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core.extractor import ResidualBlock, _StridedPairFn, _pair_packs
+    f = 1.0 if precision == "exact" else 8.0
+    torch.manual_seed(13)
+    blk = ResidualBlock(C, N, "instance", stride=2).to(DEV)
+    x = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xs = ops.space_to_depth2(x.detach().permute(0, 2, 3, 1))
+    assert torch.equal(ops.space_to_depth2(xs, inverse=True), x.detach().permute(0, 2, 3, 1))
+    y1, ys = _StridedPairFn.apply(x, blk.conv1.weight, blk.downsample[0].weight, _pair_packs(blk))
+    g1, gs = torch.randn_like(y1), torch.randn_like(ys)
+    (y1 * g1).sum().add((ys * gs).sum()).backward()
+    got = (x.grad.clone(), blk.conv1.weight.grad.clone(), blk.downsample[0].weight.grad.clone())
+    blk.zero_grad(set_to_none=True)
+    xr = x.detach().contiguous().requires_grad_(True)
+    r1 = torch.nn.functional.conv2d(xr, blk.conv1.weight, None, 2, 1)
+    rs = torch.nn.functional.conv2d(xr, blk.downsample[0].weight, None, 2, 0)
+    (r1 * g1).sum().add((rs * gs).sum()).backward()
+    close(y1, r1, 2e-5 * f, what="3x3 stride 2 fwd"); close(ys, rs, 2e-5 * f, what="shortcut fwd")
+    close(got[0], xr.grad, 3e-5 * f, what="strided pair dx")
+    close(got[1], blk.conv1.weight.grad, 1e-4 * f, 1e-4, what="3x3 stride 2 dw")
+    close(got[2], blk.downsample[0].weight.grad, 1e-4 * f, 1e-4, what="shortcut dw")
+
+
 def _rel_l2(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
