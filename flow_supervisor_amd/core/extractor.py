@@ -134,7 +134,7 @@ class _InstNormReluCL(torch.autograd.Function):
         if res is not None:
             res = _as_cl(res)
         y = torch.empty_like(x)                                   # preserves channels_last
-        acc = torch.zeros(2, N, C, device=x.device, dtype=torch.float32)
+        acc = torch.zeros(2, N * 8, C, device=x.device, dtype=torch.float32)      # partial rows (norm_cl.hip)
         stats = torch.empty(N, C, 2, device=x.device, dtype=torch.float32)
         L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W,
                                                   C, float(eps), int(relu), L.stream()), "inorm_relu_cl_fwd")
@@ -151,7 +151,7 @@ class _InstNormReluCL(torch.autograd.Function):
         g = _as_cl(g)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.fused else None
-        acc = torch.zeros(2, N, C, device=x.device, dtype=torch.float32)
+        acc = torch.zeros(2, N * 8, C, device=x.device, dtype=torch.float32)      # partial rows (norm_cl.hip)
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
                                                   L.ptr(dres), N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
         return dx if ctx.in_cl else _as_nchw(dx), None, None, dres     # an NCHW producer (MIOpen) gets an NCHW gradient

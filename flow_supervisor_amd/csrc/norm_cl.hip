@@ -10,8 +10,9 @@ namespace {
 // pixels per workgroup: a few thousand workgroups per launch, so that every CU holds several and the strided walks
 // (one 16-byte load per lane and step, unrolled by four) hide each other's latency
 constexpr int CL_NSLOT = 8;
-__host__ __device__ inline int pix_per_wg(int B, int HW) {
-  int64_t p = ((int64_t)B * HW + 4095) / 4096;
+int g_cl_target_wgs = 4096;        // workgroups aimed at per launch (fsraft_set_norm_blocks)
+inline int pix_per_wg(int B, int HW) {
+  int64_t p = ((int64_t)B * HW + g_cl_target_wgs - 1) / g_cl_target_wgs;
   p = (p + 63) / 64 * 64;
   return p < 128 ? 128 : p > 1024 ? 1024 : (int)p;
 }
@@ -38,8 +39,9 @@ __global__ __launch_bounds__(256) void cl_stats_kernel(const float* __restrict__
     for (int k = 0; k < lanes_p; ++k) { ts += red[0][k * c4n + threadIdx.x]; tq += red[1][k * c4n + threadIdx.x]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      atomicAdd(sums + b * C + threadIdx.x * 4 + i, ts[i]);
-      atomicAdd(sumsq + b * C + threadIdx.x * 4 + i, tq[i]);
+      const int o = (b * CL_NSLOT + (int)(blockIdx.x % CL_NSLOT)) * C + threadIdx.x * 4 + i;     // partial rows: see CL_NSLOT
+      atomicAdd(sums + o, ts[i]);
+      atomicAdd(sumsq + o, tq[i]);
     }
   }
 }
@@ -56,8 +58,11 @@ __global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = cl * 4 + i;
-    const float m = sums[b * C + c] / (float)HW;
-    const float var = fmaxf(sumsq[b * C + c] / (float)HW - m * m, 0.f);
+    float su = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL_NSLOT; ++k) { su += sums[(b * CL_NSLOT + k) * C + c]; sq += sumsq[(b * CL_NSLOT + k) * C + c]; }
+    const float m = su / (float)HW;
+    const float var = fmaxf(sq / (float)HW - m * m, 0.f);
     mean[i] = m; rstd[i] = rsqrtf(var + eps);
     if (blockIdx.x == 0 && pl == 0) { stats[(b * C + c) * 2] = m; stats[(b * C + c) * 2 + 1] = rstd[i]; }
   }
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
     for (int k = 0; k < lanes_p; ++k) { t1 += red[0][k * c4n + threadIdx.x]; t2 += red[1][k * c4n + threadIdx.x]; }
     // MODE 1 sums over the whole batch: spread the workgroups over gridDim.y * NSLOT partial rows ([B * NSLOT][C],
     // summed by the caller) -- thousands of atomics on the same C addresses serialise in L2 otherwise
-    const int base = (MODE == 0 ? b * C : (b * CL_NSLOT + (int)(blockIdx.x % CL_NSLOT)) * C) + threadIdx.x * 4;
+    const int base = (b * CL_NSLOT + (int)(blockIdx.x % CL_NSLOT)) * C + threadIdx.x * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { atomicAdd(s1 + base + i, t1[i]); atomicAdd(s2 + base + i, t2[i]); }
   }
@@ -150,7 +155,10 @@ __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __
   for (int i = 0; i < 4; ++i) {
     const int c = cl * 4 + i;
     mean[i] = stats[(b * C + c) * 2]; rstd[i] = stats[(b * C + c) * 2 + 1];
-    m1[i] = s1[b * C + c] / (float)HW; m2[i] = s2[b * C + c] / (float)HW;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL_NSLOT; ++k) { a1 += s1[(b * CL_NSLOT + k) * C + c]; a2 += s2[(b * CL_NSLOT + k) * C + c]; }
+    m1[i] = a1 / (float)HW; m2[i] = a2 / (float)HW;
   }
   const int p0 = blockIdx.x * PIX_PER_WG, p1 = min(p0 + PIX_PER_WG, HW);
   if (pl < lanes_p)
@@ -199,7 +207,13 @@ inline bool cl_ok(int C) { return C >= 4 && C <= 256 && C % 4 == 0; }      // (t
 
 }  // namespace
 
-// x, y: [B][HW][C].  sums / sumsq: [B][C] scratch that must be ZERO on entry; stats: [B][C][2] = (mean, rstd) out.
+extern "C" int fsraft_set_norm_blocks(int target_workgroups) {     // tuning hook (scripts/norm_micro.py)
+  if (target_workgroups < 64) return FS_ERR_ARG;
+  g_cl_target_wgs = target_workgroups;
+  return FS_OK;
+}
+
+// x, y: [B][HW][C].  sums / sumsq: [B * 8][C] partial-row scratch that must be ZERO on entry; stats: [B][C][2] = (mean, rstd) out.
 // res (nullable, [B][HW][C]): fused residual unit, y = relu(res + relu?(norm(x))).
 extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B,
                                         int HW, int C, float eps, int relu, hipStream_t s) {
@@ -210,7 +224,7 @@ extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float*
   hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw, res);
   return fs_launch_status();
 }
-// s1, s2: [B][C] scratch, ZERO on entry.  Fused residual unit: out = the forward result y, dres receives the shortcut's
+// s1, s2: [B * 8][C] partial-row scratch, ZERO on entry.  Fused residual unit: out = the forward result y, dres receives the shortcut's
 // gradient g * (out > 0), and the norm branch continues from that; both NULL otherwise.
 extern "C" int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2,
                                         float* dx, float* dres, int B, int HW, int C, int relu, hipStream_t s) {

@@ -200,11 +200,13 @@ int fsraft_sequence_loss(const float* const* pred, float* const* dpred, const fl
 int fsraft_forward_interpolate(const float* flow, float* out, int H, int W, hipStream_t stream);
 
 /* Channels-last ([B][HW][C], C % 4 == 0, C <= 256) variants, for the encoder stages whose convolutions run on
- * fsraft_conv_forward.  sums/sumsq/s1/s2: [B][C] scratch; dsum_g/dsum_gx: [B * 8][C] partial rows (the per-channel sums
- * are the column sums of these rows); all must be ZERO on entry.  stats: [B][C][2] = (mean, rstd).
+ * fsraft_conv_forward.  sums/sumsq/s1/s2 and dsum_g/dsum_gx: [B * 8][C] partial rows (workgroups spread their atomics over
+ * eight rows per sample: thousands of adds on the same C addresses serialise in L2 otherwise; dsum_*: the per-channel sums
+ * are the column sums of the rows); all must be ZERO on entry.  stats: [B][C][2] = (mean, rstd).
  * Fused residual unit (pytorch/core/extractor.py:43-56, "return self.relu(x+y)"): res != NULL makes the forward write
  * y = relu(res + relu?(norm(x))); the backward then takes out = that y and writes the shortcut's gradient g * (out > 0)
  * to dres before continuing into the norm branch (out and dres both NULL: plain norm + ReLU). */
+int fsraft_set_norm_blocks(int target_workgroups);   /* tuning hook: workgroups per launch of the channels-last norm kernels (default 4096) */
 int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B, int HW,
                              int C, float eps, int relu, hipStream_t stream);
 int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2, float* dx,
