@@ -203,7 +203,7 @@ def main():
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v,
                    "launch": "hipGraph replay of the whole step" if graph is not None else "eager",
                    "encoders": ("MIOpen NCHW convolutions (north_star configuration)" if os.environ.get("FSRAFT_ENCODER_CL", "1") == "0"
-                                else "channels_last; stride-1 convolutions on the fsraft kernels, stem / stride-2 pairs on MIOpen")},
+                                else "channels_last on the fsraft kernels (stride-2 units via space-to-depth); 7x7 stem on MIOpen")},
     }
     if timer is not None:
         kern = {}

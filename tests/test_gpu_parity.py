@@ -777,14 +777,17 @@ def _rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("kind,norm", [("basic", "instance"), ("basic", "batch"), ("small", "instance"), ("small", "none")])
-def test_encoder_channels_last_path_matches_nchw_path(kind, norm, precision, monkeypatch):
+@pytest.mark.parametrize("kind,norm,s2d", [("basic", "instance", "1"), ("basic", "batch", "1"), ("small", "instance", "1"),
+                                           ("small", "none", "1"), ("basic", "instance", "0"), ("basic", "batch", "0")])
+def test_encoder_channels_last_path_matches_nchw_path(kind, norm, s2d, precision, monkeypatch):
     """The channels_last encoder (FSRAFT_ENCODER_CL=1, default: fsraft convolutions + norm kernels) against the all-MIOpen
     NCHW encoder (=0): outputs, input gradient and every parameter gradient.  Gradients are compared in relative L2:
     fifteen ReLU layers deep, a pre-activation that sits within rounding of zero flips its mask and moves a handful of
     gradient entries by O(1) in either implementation, which a max-abs bound cannot tell from a real error."""
     from flow_supervisor_amd.core.extractor import BasicEncoder, SmallEncoder
     torch.manual_seed(21)
+    # s2d "0": the stride-2 units fall back to MIOpen behind layout hops (the path odd-sized inputs take)
+    monkeypatch.setenv("FSRAFT_ENCODER_S2D", s2d)
     enc = (BasicEncoder if kind == "basic" else SmallEncoder)(output_dim=128, norm_fn=norm).to(DEV)
     if norm == "batch":
         enc.eval()
