@@ -84,6 +84,8 @@ SIGNATURES = {
     "fsraft_affine_relu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, _S],
     "fsraft_sequence_loss": [_PP, _PP, POINTER(c_float), c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_corr_pool_pyramid": [_PP, c_int, c_int64, c_int, c_int, _S],
+    "fsraft_corr_pool_pyramid_same": [_PP, c_int, c_int64, c_int, c_int, _S],
+    "fsraft_corr_lookup_fwd_same": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_set_norm_blocks": [c_int],
     "fsraft_space_to_depth2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_forward_interpolate": [c_void_p, c_void_p, c_int, c_int, _S],

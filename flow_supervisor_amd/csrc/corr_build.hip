@@ -311,6 +311,24 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const float* __restrict_
   }
 }
 
+// TensorFlow avg_pool2d(x, k, k, 'SAME') of the level-0 volume: out = ceil(size / k), total padding out * k - size split
+// floor / ceil between the leading and the trailing side, the average taken over the in-range elements only.
+__global__ __launch_bounds__(256) void corr_pool_same_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows,
+                                                             int h, int w, int k) {
+  const int h2 = (h + k - 1) / k, w2 = (w + k - 1) / k;
+  const int py = (h2 * k - h) / 2, px = (w2 * k - w) / 2;
+  const int64_t total = rows * h2 * w2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % w2), y = (int)((e / w2) % h2);
+    const int64_t r = e / ((int64_t)w2 * h2);
+    const int y0 = max(y * k - py, 0), y1 = min(y * k - py + k, h), x0 = max(x * k - px, 0), x1 = min(x * k - px + k, w);
+    float acc = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) acc += src[(r * h + yy) * w + xx];
+    dst[e] = acc / (float)((y1 - y0) * (x1 - x0));
+  }
+}
+
 }  // namespace
 
 // Pyramid of a level-0 volume that already exists: levels[0] is [rows][H2][W2] (rows = B*H1*W1), levels[l >= 1] receive the
@@ -378,5 +396,20 @@ extern "C" int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int
   }
   int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(corr_unpool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, lv, num_levels, nq);
+  return fs_launch_status();
+}
+
+// TensorFlow semantics of the same pyramid (raft/allfield.py:99-104: avg_pool2d(level 0, scale, scale, 'SAME') for scale =
+// 2, 4, ...): levels[l] is [rows][ceil(H2 / 2^l)][ceil(W2 / 2^l)], every level pooled from level 0 with partial edge windows
+// averaged over their in-range elements.  Equals fsraft_corr_pool_pyramid (to rounding) when H2 and W2 divide by 2^(L-1).
+extern "C" int fsraft_corr_pool_pyramid_same(float* const* levels, int num_levels, int64_t rows, int H2, int W2, hipStream_t stream) {
+  if (!levels || num_levels < 1 || num_levels > 8 || rows < 1 || H2 < 1 || W2 < 1 || !levels[0]) return FS_ERR_ARG;
+  for (int l = 1; l < num_levels; ++l) {
+    if (!levels[l]) return FS_ERR_ARG;
+    const int k = 1 << l, h2 = (H2 + k - 1) / k, w2 = (W2 + k - 1) / k;
+    int64_t blocks = (rows * h2 * w2 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(corr_pool_same_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, levels[0], levels[l], rows, H2, W2, k);
+  }
   return fs_launch_status();
 }

@@ -390,13 +390,13 @@ int dispatch_bwd(int qb, const Pyr& pyr, const Coords& co, const float* dout, in
 // several thousand of them be resident at once; planar (NCHW) output wants 32 queries per row segment
 inline int pick_qb(int nhwc) { return g_lookup_qb ? g_lookup_qb : (nhwc ? 8 : 32); }
 
-bool fill_pyr(Pyr& pyr, float* const* levels, int num_levels, int H, int W) {
+// ceil: level sizes of TensorFlow's padding='SAME' pooling (ceil halving) instead of avg_pool2d's floor halving
+bool fill_pyr(Pyr& pyr, float* const* levels, int num_levels, int H, int W, bool ceil = false) {
   if (!levels || num_levels != 4) return false;
-  int h = H, w = W;
   for (int l = 0; l < 4; ++l) {
+    const int h = ceil ? (H + (1 << l) - 1) >> l : H >> l, w = ceil ? (W + (1 << l) - 1) >> l : W >> l;
     if (!levels[l] || h < 1 || w < 1) return false;
     pyr.p[l] = levels[l]; pyr.h[l] = h; pyr.w[l] = w;
-    h /= 2; w /= 2;
   }
   return true;
 }
@@ -438,5 +438,19 @@ extern "C" int fsraft_corr_lookup_bwd(float* const* dlevels, int num_levels, con
   const int64_t nq = (int64_t)B * H * W;
   if (radius == 4) return dispatch_bwd<4>(pick_qb(nhwc_in), pyr, co, dout, nhwc_in, nq, H * W, stream);
   if (radius == 3) return dispatch_bwd<3>(pick_qb(nhwc_in), pyr, co, dout, nhwc_in, nq, H * W, stream);
+  return FS_ERR_ARG;
+}
+
+// Forward lookup on a pyramid whose levels have TensorFlow 'SAME' sizes (level l: ceil(H / 2^l) x ceil(W / 2^l)); everything
+// else as fsraft_corr_lookup_fwd.  (raft/allfield.py:109-135 on the pyramid of raft/allfield.py:94-106.)
+extern "C" int fsraft_corr_lookup_fwd_same(float* const* levels, int num_levels, const float* coords, int64_t coords_bs,
+                                           int64_t coords_cs, int64_t coords_ps, float* out, int nhwc_out, int B, int H,
+                                           int W, int radius, hipStream_t stream) {
+  Pyr pyr;
+  if (!coords || !out || B < 1 || !fill_pyr(pyr, levels, num_levels, H, W, true)) return FS_ERR_ARG;
+  Coords co{coords, coords_bs, coords_cs, coords_ps};
+  const int64_t nq = (int64_t)B * H * W;
+  if (radius == 4) return dispatch_fwd<4>(pick_qb(nhwc_out), pyr, co, out, nhwc_out, nq, H * W, stream);
+  if (radius == 3) return dispatch_fwd<3>(pick_qb(nhwc_out), pyr, co, out, nhwc_out, nq, H * W, stream);
   return FS_ERR_ARG;
 }

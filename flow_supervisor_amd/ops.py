@@ -85,11 +85,18 @@ def corr_build(fmap1, fmap2, num_levels=4):
     return levels
 
 
-def corr_pool_pyramid(level0, num_levels):
-    """level0 [rows, 1, h, w] (or [rows, h, w]) -> [level0, 2x2 averages, ...] with floor sizes (fsraft_corr_pool_pyramid)."""
+def corr_pool_pyramid(level0, num_levels, same=False):
+    """level0 [rows, 1, h, w] (or [rows, h, w]) -> [level0, 2x2 averages, ...] with floor sizes (fsraft_corr_pool_pyramid), or,
+    same=True, TensorFlow's avg_pool2d(level0, 2^l, 2^l, 'SAME') levels with ceil sizes (fsraft_corr_pool_pyramid_same)."""
     L.require_cuda_f32(level0)
     level0 = level0.contiguous()
     rows, h, w = level0.shape[0], level0.shape[-2], level0.shape[-1]
+    if same:
+        levels = [level0.view(rows, 1, h, w)] + [torch.empty(rows, 1, -(-h // (1 << l)), -(-w // (1 << l)), device=level0.device,
+                                                             dtype=torch.float32) for l in range(1, num_levels)]
+        pp, keep = L.ptr_array(levels)
+        L.check(_lib().fsraft_corr_pool_pyramid_same(pp, num_levels, rows, h, w, L.stream()), "corr_pool_pyramid_same")
+        return levels
     sizes = pyramid_sizes(h, w, num_levels)
     if sizes[-1][0] < 1 or sizes[-1][1] < 1:
         raise RuntimeError(f"volume {h}x{w} too small for {num_levels} pyramid levels")
@@ -129,7 +136,8 @@ def corr_unpool_bwd_(dlevels, B, H, W):
     L.check(_lib().fsraft_corr_unpool_bwd(pp, len(dlevels), B, H, W, L.stream()), "corr_unpool_bwd")
 
 
-def corr_lookup_fwd(levels, coords, radius, nhwc=False):
+def corr_lookup_fwd(levels, coords, radius, nhwc=False, same=False):
+    """same=True: the pyramid has TensorFlow 'SAME' (ceil) level sizes."""
     L.require_cuda_f32(coords, *levels)
     B, _, H, W = coords.shape
     bs, cs, ps = _planar2_strides(coords)
@@ -141,8 +149,8 @@ def corr_lookup_fwd(levels, coords, radius, nhwc=False):
     pp, keep = L.ptr_array(levels)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(_lib().fsraft_corr_lookup_fwd(pp, len(levels), L.ptr(coords), bs, cs, ps, L.ptr(out), int(nhwc), B, H, W,
-                                          radius, L.stream()), "corr_lookup_fwd")
+    fn = _lib().fsraft_corr_lookup_fwd_same if same else _lib().fsraft_corr_lookup_fwd
+    L.check(fn(pp, len(levels), L.ptr(coords), bs, cs, ps, L.ptr(out), int(nhwc), B, H, W, radius, L.stream()), "corr_lookup_fwd")
     if t:   # per query: L*(2r+2)^2 window floats + 2 coords in, L*(2r+1)^2 out  
         t.end("corr_lookup_fwd", e0, 0.0, 4.0 * B * H * W * (len(levels) * (2 * radius + 2) ** 2 + 2 + ch))
     return out

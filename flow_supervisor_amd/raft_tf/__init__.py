@@ -9,10 +9,11 @@
 
 TensorFlow is not installed here, so these take and return torch tensors laid out the way the TF code lays
 them out (channels last, coords as [B,H,W,2] with (x, y) in the last dim) and run the same HIP kernels as the
-PyTorch-shaped API.  The pyramid kernels pool with PyTorch's floor halving; TF's padding='SAME' keeps partial edge
-windows when a pooled dimension is odd (e.g. 55 rows at 1/8 of Sintel), which they do not reproduce -- calc_all_field and
-build_pyramid raise NotImplementedError for such shapes instead of returning a differently-shaped pyramid (no TF oracle
-exists in this environment to pin that case against).
+PyTorch-shaped API.  Pooling: the fused build pools with PyTorch's floor halving; TF pools level 0 with padding='SAME'
+(ceil sizes, partial edge windows averaged over their in-range elements: e.g. 55 rows at 1/8 of Sintel give 28 / 14 / 7 rows,
+not 27 / 13 / 6).  When a pooled dimension is odd, calc_all_field and build_pyramid therefore build the pyramid with
+fsraft_corr_pool_pyramid_same and CorrBlock looks it up with fsraft_corr_lookup_fwd_same.  No TF oracle exists in this
+environment: the SAME path is tested against a restatement of TF's documented semantics (parity unpinned).
 """
 from .api import (BasicUpdateBlock, CorrBlock, UpsampleConvexWithMask, build_pyramid, calc_all_field,  # noqa: F401
                   transpose_volume)

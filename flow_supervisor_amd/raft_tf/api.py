@@ -8,19 +8,20 @@ from ..core.raft import convex_upsample
 def calc_all_field(a, b, num_pool=0):
     """a, b: [B,H,W,C] feature maps -> list of num_pool+1 volumes [B,H,W,h_l,w_l] (raft/allfield.py:61-92)."""
     B, H, W, C = a.shape
-    _check_pool_dims(H, W, num_pool)
     f1 = a.permute(0, 3, 1, 2).contiguous().float()
     f2 = b.permute(0, 3, 1, 2).contiguous().float()
-    levels = ops.corr_build(f1, f2, num_pool + 1)
+    if _same_needed(H, W, num_pool):
+        levels = ops.corr_pool_pyramid(ops.corr_build(f1, f2, 1)[0], num_pool + 1, same=True)
+    else:
+        levels = ops.corr_build(f1, f2, num_pool + 1)
     return [lv.view(B, H, W, lv.shape[-2], lv.shape[-1]) for lv in levels]
 
 
-def _check_pool_dims(h, w, num_pool):
-    # TF pools with padding='SAME' (ceil sizes, partial edge windows); the kernels follow the PyTorch reference
-    # (avg_pool2d floor sizes).  The two agree exactly when every pooled dimension stays even -- anything else fails loudly.
-    if num_pool and (h % (1 << num_pool) or w % (1 << num_pool)):
-        raise NotImplementedError(f"volume {h}x{w} is not divisible by 2^{num_pool}: TF 'SAME' pooling keeps partial edge "
-                                  "windows there, which the HIP pyramid (PyTorch floor semantics) does not reproduce")
+def _same_needed(h, w, num_pool):
+    # TF pools level 0 with padding='SAME' (ceil sizes, partial edge windows averaged over their in-range elements); the
+    # fused build follows the PyTorch reference (avg_pool2d, floor sizes).  The two agree when every pooled dimension stays
+    # even; otherwise the pyramid comes from the SAME pooling kernel (fsraft_corr_pool_pyramid_same) and the lookup is told.
+    return bool(num_pool) and bool(h % (1 << num_pool) or w % (1 << num_pool))
 
 
 def transpose_volume(c_volume):
@@ -34,8 +35,7 @@ def build_pyramid(c_volume, num_pool=0):
     """[B,H,W,H2,W2] volume -> [c_volume, pooled x2, x4, ...] (raft/allfield.py:94-106), e.g. on transpose_volume(...) for
     the backward flow (raft/semi.py:251, 258) without a second all-pairs GEMM."""
     B, H, W, H2, W2 = c_volume.shape
-    _check_pool_dims(H2, W2, num_pool)
-    levels = ops.corr_pool_pyramid(c_volume.reshape(B * H * W, H2, W2).float(), num_pool + 1)
+    levels = ops.corr_pool_pyramid(c_volume.reshape(B * H * W, H2, W2).float(), num_pool + 1, same=_same_needed(H2, W2, num_pool))
     return [lv.view(B, H, W, lv.shape[-2], lv.shape[-1]) for lv in levels]
 
 
@@ -50,7 +50,9 @@ class CorrBlock:
         B, H, W, _ = coords.shape
         levels = [lv.reshape(B * H * W, 1, lv.shape[-2], lv.shape[-1]) for lv in corr_pyramid]
         c = coords.permute(0, 3, 1, 2)                       # NCHW view of the NHWC coords: strides, no copy
-        return ops.corr_lookup_fwd(levels, c.float(), self.radius, nhwc=True)
+        h2, w2 = corr_pyramid[0].shape[-2:]
+        same = any(tuple(lv.shape[-2:]) != (h2 >> l, w2 >> l) for l, lv in enumerate(corr_pyramid))    # TF 'SAME' (ceil) sizes
+        return ops.corr_lookup_fwd(levels, c.float(), self.radius, nhwc=True, same=same)
 
 
 class UpsampleConvexWithMask:

@@ -39,6 +39,13 @@ int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* leve
 /* Pyramid of an existing level-0 volume (raft/allfield.py:94-106 build_pyramid; the backward-flow pyramid of the transposed
  * volume at raft/semi.py:250-251): levels[0] = [rows][H2][W2] given, levels[l] = 2x2 averages of levels[l-1], floor sizes. */
 int fsraft_corr_pool_pyramid(float* const* levels, int num_levels, int64_t rows, int H2, int W2, hipStream_t stream);
+/* TensorFlow semantics of the same pyramid (raft/allfield.py:99-104, tf.nn.avg_pool2d(level 0, s, s, 'SAME'), s = 2, 4, ...):
+ * levels[l] = [rows][ceil(H2/2^l)][ceil(W2/2^l)], partial edge windows averaged over their in-range elements, and the
+ * forward lookup over a pyramid of those sizes (raft/allfield.py:109-135). */
+int fsraft_corr_pool_pyramid_same(float* const* levels, int num_levels, int64_t rows, int H2, int W2, hipStream_t stream);
+int fsraft_corr_lookup_fwd_same(float* const* levels, int num_levels, const float* coords, int64_t coords_bs,
+                                int64_t coords_cs, int64_t coords_ps, float* out, int nhwc_out, int B, int H, int W,
+                                int radius, hipStream_t stream);
 int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int B, int H, int W, hipStream_t stream);
 
 /* ---- radius-r pyramid lookup --------------------------------------------------------

@@ -968,5 +968,40 @@ def test_tf_backward_flow_pyramid_from_transposed_volume():
         close(bw[l], swapped[l], 2e-5, what=f"backward pyramid level {l} vs swapped build")
         close(bw[l].reshape(lv.shape), lv, 1e-6, what=f"backward pyramid level {l} vs avg_pool2d")
         lv = torch.nn.functional.avg_pool2d(lv, 2, 2)
-    with pytest.raises(NotImplementedError):
-        raft_tf.build_pyramid(torch.zeros(1, 4, 4, 5, 8, device=DEV), num_pool=1)
+
+
+def _tf_same_avg_pool(x, k):
+    """tf.nn.avg_pool2d(x, k, k, 'SAME') restated: out = ceil(n / k), padding out * k - n split floor / ceil (leading /
+    trailing), padded cells excluded from the average.  x: [R, H, W] on the CPU."""
+    R, H, W = x.shape
+    h2, w2 = -(-H // k), -(-W // k)
+    py, px = (h2 * k - H) // 2, (w2 * k - W) // 2
+    out = torch.empty(R, h2, w2, dtype=x.dtype)
+    for y in range(h2):
+        y0, y1 = max(y * k - py, 0), min(y * k - py + k, H)
+        for xx in range(w2):
+            x0, x1 = max(xx * k - px, 0), min(xx * k - px + k, W)
+            out[:, y, xx] = x[:, y0:y1, x0:x1].mean(dim=(1, 2))
+    return out
+
+
+@pytest.mark.parametrize("H,W", [(11, 16), (7, 13), (9, 10)])
+def test_tf_same_pooling_pyramid_and_lookup(H, W):
+    """Odd pooled sizes (55 rows at 1/8 of Sintel): the TF twins build the pyramid with TF's 'SAME' pooling (ceil sizes) and
+    look it up on those sizes.  PARITY UNPINNED (no TensorFlow here): checked against a restatement of the documented
+    tf.nn.avg_pool2d semantics and against an explicit bilinear gather (the oracle's lookup on the SAME pyramid)."""
+    from flow_supervisor_amd import raft_tf
+    torch.manual_seed(41)
+    B, C = 2, 32
+    f1 = torch.randn(B, H, W, C, device=DEV); f2 = torch.randn(B, H, W, C, device=DEV)
+    pyr = raft_tf.calc_all_field(f1, f2, num_pool=3)
+    assert [tuple(p.shape[-2:]) for p in pyr] == [(-(-H // (1 << l)), -(-W // (1 << l))) for l in range(4)]
+    v0 = pyr[0].reshape(B * H * W, H, W).cpu()
+    ref_levels = [v0] + [_tf_same_avg_pool(v0, 1 << l) for l in range(1, 4)]
+    for l in range(4):
+        close(pyr[l].reshape(ref_levels[l].shape), ref_levels[l], 2e-6, what=f"SAME level {l}")
+    assert [tuple(p.shape) for p in raft_tf.build_pyramid(pyr[0], 3)] == [tuple(p.shape) for p in pyr]
+    coords = (O.coords_grid(B, H, W) + (torch.rand(B, 2, H, W) - 0.5) * 5).to(DEV)
+    out = raft_tf.CorrBlock(4, 4)(pyr, coords.permute(0, 2, 3, 1))
+    ref = O.corr_lookup([lv.reshape(B * H * W, 1, lv.shape[-2], lv.shape[-1]) for lv in ref_levels], coords.cpu(), 4)
+    close(out.permute(0, 3, 1, 2), ref, 2e-5, what="lookup on the SAME pyramid")
