@@ -87,6 +87,7 @@ SIGNATURES = {
     "fsraft_corr_pool_pyramid_same": [_PP, c_int, c_int64, c_int, c_int, _S],
     "fsraft_corr_lookup_fwd_same": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_set_norm_blocks": [c_int],
+    "fsraft_get_tuning": [c_int],
     "fsraft_space_to_depth2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_forward_interpolate": [c_void_p, c_void_p, c_int, c_int, _S],
     "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, _S],

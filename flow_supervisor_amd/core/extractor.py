@@ -202,14 +202,14 @@ class _FrozenBNReluCL(torch.autograd.Function):
 def _weight_packs(conv):
     """Packed forward / data-gradient matrices of a 3x3 convolution for the split-bf16 implicit GEMM, cached on the module
     and rebuilt whenever the weight tensor changes (optimizer step, load_state_dict)."""
+    from .. import ops
     w = conv.weight
-    key = (w.data_ptr(), w._version)
+    key = (w.data_ptr(), w._version, ops.exact_mode())
     c = conv.__dict__.get("_fs_packs")
     if c is None or c[0] != key:
-        from .. import ops
         wd = w.detach()
         cin = [wd.shape[1]]
-        c = (key, ops.pack_weight(wd, cin, 0), ops.pack_weight(wd, cin, 10), ops.pack_weight(wd, cin, 1), ops.pack_weight(wd, cin, 11))
+        c = (key,) + ops.pack_pair(wd, cin) + ops.pack_pair(wd, cin, dgrad=True)
         if tuple(wd.shape[2:]) == (3, 3):     # the resident-patch kernel takes the 33..64-channel layers; the data gradient swaps the roles
             c = c + (ops.fragment_order(c[2]), ops.fragment_order(c[4]))
         else:
@@ -301,13 +301,13 @@ def _s2d_weight_grad(dw, C):
 def _pair_packs(block):
     """Packed matrices of a stride-2 residual unit's first convolution (as 2x2 over space-to-depth) and 1x1 shortcut."""
     w3, wsc = block.conv1.weight, block.downsample[0].weight
-    key = (w3.data_ptr(), w3._version, wsc.data_ptr(), wsc._version)
+    from .. import ops
+    key = (w3.data_ptr(), w3._version, wsc.data_ptr(), wsc._version, ops.exact_mode())
     c = block.__dict__.get("_fs_pair_packs")
     if c is None or c[0] != key:
-        from .. import ops
         w2 = _s2d_weight(w3.detach())
         c4, c1, ws = [w2.shape[1]], [wsc.shape[1]], wsc.detach()
-        c = (key, tuple(ops.pack_weight(w2, c4, m) for m in (0, 10, 1, 11)), tuple(ops.pack_weight(ws, c1, m) for m in (0, 10, 1, 11)))
+        c = (key, ops.pack_pair(w2, c4) + ops.pack_pair(w2, c4, dgrad=True), ops.pack_pair(ws, c1) + ops.pack_pair(ws, c1, dgrad=True))
         block.__dict__["_fs_pair_packs"] = c
     return c
 

@@ -257,7 +257,7 @@ class _Engine:
 
     def _packed(self, params):
         """{key: (wpk_fwd, wpk_dgrad, bias, out_channels, oihw_shape)}; repacked when any parameter changed."""
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (ops.exact_mode(),) + tuple((p.data_ptr(), p._version) for p in params)      # (the mode decides which packs exist)
         if key == self._cache_key:
             return self._cache
         byname = dict(zip(self.pnames, params))
@@ -281,9 +281,9 @@ class _Engine:
                 if l.cin_sel is not None:
                     w = torch.cat([w[:, a:b] for a, b in l.cin_sel], 1)
                 w = w.contiguous().float()
-                out[k] = (ops.pack_weight(w, l.src_c, 0), ops.pack_weight(w, l.src_c, 1), b,
-                          w.shape[0], tuple(w.shape),
-                          ops.pack_weight(w, l.src_c, 10), ops.pack_weight(w, l.src_c, 11))
+                fw, fws = ops.pack_pair(w, l.src_c)
+                dg, dgs = ops.pack_pair(w, l.src_c, dgrad=True)
+                out[k] = (fw, dg, b, w.shape[0], tuple(w.shape), fws, dgs)
         self._cache_key, self._cache = key, out
         return out
 

@@ -1612,6 +1612,14 @@ extern "C" int fsraft_set_ablate(int mask) {
 }
 #endif
 
+// Reads back the arithmetic-mode switches (key 3: forward / data-gradient convolutions, key 4: weight gradients); the
+// host side uses it to skip packing the exact-fp32 weight matrices while the split-bf16 kernels are the ones that run.
+extern "C" int fsraft_get_tuning(int key) {
+  if (key == 3) return g_conv_split;
+  if (key == 4) return g_wgrad_split;
+  return -1;
+}
+
 extern "C" int fsraft_set_tuning(int key, int value) {
   if (key == 0) g_conv_tile = value;
   else if (key == 1) g_wgrad_tile = value;

@@ -456,6 +456,21 @@ def pack_weight(w, srcC, mode):
     return wpk
 
 
+def exact_mode():
+    """True while the exact-fp32 convolution kernels are selected (fsraft_set_tuning key 3 = 0); in split-bf16 mode only
+    layers with <= 32 outputs still read the fp32 packs."""
+    return _lib().fsraft_get_tuning(3) == 0
+
+
+def pack_pair(w, srcC, dgrad=False):
+    """(fp32 pack, split pack) of a weight for the forward (modes 0 / 10) or data-gradient (1 / 11) GEMM.  The fp32 pack is
+    only built when a kernel will read it; otherwise the split pack stands in for it (same shape, never dereferenced as fp32)."""
+    m = 1 if dgrad else 0
+    split = pack_weight(w, srcC, 10 + m)
+    rows = w.shape[1] if dgrad else w.shape[0]
+    return (pack_weight(w, srcC, m) if (exact_mode() or rows <= 32) else split), split
+
+
 def fragment_order(wps):
     """Split pack [N, Ktot] (modes 10 / 11) -> fragment order for fsraft_conv_desc.wpk_frag: [k-tile][32-row block]
     [hi k0-15, hi k16-31, lo k0-15, lo k16-31][lane = 32 * (k half) + row][4 dwords], rows zero-padded to a multiple of 32."""

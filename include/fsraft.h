@@ -147,6 +147,7 @@ int fsraft_conv_small_wgrad(const float* const* dy, const float* const* x, int n
  * key 2: target workgroup count of the wgrad pixel split; key 3: 1 = split-bf16 (3 x bf16 MFMA,
  * fp32 accumulate, ~2^-17 relative error per product) core for forward / data-gradient GEMMs with N > 64. */
 int fsraft_set_tuning(int key, int value);
+int fsraft_get_tuning(int key);   /* keys 3 / 4: arithmetic mode of the forward+data-gradient / weight-gradient convolutions */
 /* volume build arithmetic: 1 (default) split-bf16, 0 exact fp32 MFMA */
 int fsraft_set_build_split(int on);
 /* queries per workgroup of the lookup kernels: 0 auto, 8, 16 or 32 */
