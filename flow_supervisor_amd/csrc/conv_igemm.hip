@@ -1436,15 +1436,20 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   const int M = a.B * a.H * a.W;
   dim3 grid(ceil_div(a.N, Cfg::BN), ceil_div(M, Cfg::BM));
   ConvArgsT t;
+  // XCD-aware tile order (tile_of_block) once several N tiles re-read each A tile and the grid is many rounds deep:
+  // 192 -> 256 at M = 225 K (encoder-sized data gradients): 776 -> 714 us; nothing at the update block's 220..880 tiles.
+  const int swz = g_xcd_swizzle || (grid.x >= 2 && (int64_t)grid.x * grid.y >= 2048);
   // buffer-addressed loaders + branch-free k-loop: measured faster on the 64-row tiles, slower on 128x128
   const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256 || Cfg::NT != 256;
   if (buf && build_ktab_uniform(a, t)) {
+    t.a.swz = swz;
     if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(Cfg::NT), 0, s, t);
     return fs_launch_status();
   }
   if (buf && build_ktab(a, t)) {
+    t.a.swz = swz;
     if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), grid, dim3(Cfg::NT), 0, s, t);
     else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 1>), grid, dim3(Cfg::NT), 0, s, t);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 1>), grid, dim3(Cfg::NT), 0, s, t);
