@@ -269,6 +269,19 @@ struct BufWeightLoader {                  // pre-split packed weights through on
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
     stage_copy<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
   }
+  // LDS-direct form (split_mainloop_bdma): chunk e lands at image + 16 e; dvoff[j] = the SOURCE offset of the 16 bytes
+  // that belong there under the row swizzle (row e >> 3, physical slot e & 7 <- logical slot (e & 7) ^ ((row >> 1) & 7))
+  unsigned dvoff[NCH];
+  __device__ __forceinline__ void dma_tile(int kt, char* image) const {
+    const int ku = __builtin_amdgcn_readfirstlane(kt);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ku < 0 ? 0u : nbytes);
+    const unsigned soff = ku < 0 ? 0u : (unsigned)ku * 128u;
+    const int w0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(image + (w0 * 64 + Cfg::NT * j) * 16), 16,
+                                               dvoff[j], soff, 0, 0);
+  }
 };
 
 template <class Cfg>
@@ -606,14 +619,16 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
     for (int j = 0; j < BufWeightLoader<Cfg>::NCH; ++j) {
       const int e = threadIdx.x + Cfg::NT * j;
       lb.voff[j] = (e >> 3) < a.N - n0 ? (unsigned)((e >> 3) * a.Ktot * 4 + (e & 7) * 16) : FS_OOB;
+      lb.dvoff[j] = (e >> 3) < a.N - n0 ? (unsigned)((e >> 3) * a.Ktot * 4 + (((e & 7) ^ ((e >> 4) & 7)) * 16)) : FS_OOB;
     }
-    if constexpr (BUF == 2) {
+    if constexpr (BUF >= 2) {
       BufConvALoaderU<Cfg> la;
       la.base = uni_ptr(args.ubase); la.ktab = ktab; la.kq16 = (threadIdx.x & 7) * 16;
       const unsigned ldb = uni((unsigned)args.uld * 4u);
 #pragma unroll
       for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.voff0[j] = pofs[j] * ldb + la.kq16; }
-      split_mainloop<Cfg, BufConvALoaderU<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
+      if constexpr (BUF == 3) split_mainloop_bdma<Cfg>(lds, a.Ktot / 32, la, lb, acc);
+      else split_mainloop<Cfg, BufConvALoaderU<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
     } else {
       BufConvALoader<Cfg> la;
       la.ld0x4 = uni(a.src[0].ld * 4); la.ld1x4 = uni(a.src[1].ld * 4); la.ld2x4 = uni(a.src[2].ld * 4);
@@ -1368,6 +1383,7 @@ int g_conv_halo = 1;           // resident-patch 3x3 kernel for few-channel laye
 int g_conv_halo_min_m = 65536;
 int g_wgrad_xcd = 1;           // XCD-aware workgroup order in the multi-segment weight gradient (key 22; 2: the few-channel kernel too).
                                // Measured: 10.73 -> 9.72 ms/step of weight-gradient time (15 K-tiles re-read each dY tile)
+int g_conv_bdma = 0;           // LDS-direct weight tiles in the wide implicit-GEMM kernels (key 24, experiment)
 int g_wgrad_pack = 1;          // few-channel single-source layers on conv_wgrad_pack_kernel (key 16)
 int g_wgrad_blocks_pack = 1024;   // its workgroup target (key 17)
 int g_wgrad_blocks = 512;   // target workgroup count of the pixel split (key 2); measured 256: 12.9, 512: 11.5, 1024: 12.9, 2048: 14.1 ms/step
@@ -1443,6 +1459,12 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256 || Cfg::NT != 256;
   if (buf && build_ktab_uniform(a, t)) {
     t.a.swz = swz;
+    if constexpr (Cfg::NT != 256 && Cfg::PITCH == 128 && Cfg::BN == 128) {
+      if (g_conv_bdma && epi == EPI_PLAIN) {      // experiment (key 24): weight tiles by LDS-direct loads
+        hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 3>), grid, dim3(Cfg::NT), 0, s, t);
+        return fs_launch_status();
+      }
+    }
     if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(Cfg::NT), 0, s, t);
@@ -1641,6 +1663,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 20) g_conv_halo = value;
   else if (key == 21) g_conv_halo_min_m = value;
   else if (key == 22) g_wgrad_xcd = value;
+  else if (key == 24) g_conv_bdma = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;

@@ -1005,3 +1005,27 @@ def test_tf_same_pooling_pyramid_and_lookup(H, W):
     out = raft_tf.CorrBlock(4, 4)(pyr, coords.permute(0, 2, 3, 1))
     ref = O.corr_lookup([lv.reshape(B * H * W, 1, lv.shape[-2], lv.shape[-1]) for lv in ref_levels], coords.cpu(), 4)
     close(out.permute(0, 3, 1, 2), ref, 2e-5, what="lookup on the SAME pyramid")
+
+
+def test_lds_direct_weight_tiles_variant_matches_default():
+    """Experiment kept in the library (fsraft_set_tuning key 24, off by default): the wide implicit-GEMM kernels with the weight
+    tile moved by `buffer_load ... lds` (split_mainloop_bdma; the swizzle is applied by permuting the source offsets).  Must
+    give bit-identical results to the register-staged path: same products, same accumulation order."""
+    from flow_supervisor_amd import _lib, ops
+    lib = _lib.load()
+    lib.fsraft_set_tuning(3, 1); lib.fsraft_set_tuning(4, 2)
+    torch.manual_seed(17)
+    outs = []
+    for B, H, W, cs, N, kh, kw in ((4, 55, 128, [128, 128], 256, 1, 5), (2, 40, 64, [256], 192, 3, 3), (1, 33, 47, [96], 128, 3, 3)):
+        srcs = [torch.randn(B, H, W, c, device=DEV) for c in cs]
+        w = torch.randn(N, sum(cs), kh, kw, device=DEV) * 0.05
+        bias = torch.randn(N, device=DEV)
+        res = []
+        for flag in (0, 1):
+            lib.fsraft_set_tuning(24, flag)
+            out = torch.full((B, H, W, N), float("nan"), device=DEV)
+            ops.conv_forward([ops.V(t, c) for t, c in zip(srcs, cs)], ops.pack_weight(w, cs, 0), bias, B, H, W, kh, kw, N,
+                             [ops.Dst.nhwc(out)], relu=True, wpk_split=ops.pack_weight(w, cs, 10))
+            res.append(out)
+        lib.fsraft_set_tuning(24, 0)
+        assert torch.equal(res[0], res[1]), (B, H, W, cs, N)
