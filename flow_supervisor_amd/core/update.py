@@ -755,7 +755,7 @@ class _UpdateBlockBase(nn.Module):
         if c is None or c[0]() is not attention or c[1] != attention._version:
             with torch.no_grad():
                 B, N = attention.shape[0], attention.shape[-1]
-                t = attention.detach().reshape(B, N, N).transpose(1, 2).contiguous()
+                t = ops.transpose_batched(attention.detach().reshape(B, N, N).contiguous().float())
             c = (weakref.ref(attention), attention._version, t)
             self.__dict__["_attn_t"] = c
         return c[2]
