@@ -1371,7 +1371,6 @@ int g_wgrad_blocks_multi = 2048;   // workgroup target of the multi-segment laun
 int g_wgrad_multi = 1;  // one weight-gradient launch per layer per step over all stashed iterations (key 10)
 int g_conv_n256 = 0;    // 64x256 tiles for layers whose N fills them (key 9); measured slower than 64x128 (zr 139 vs 119 us, hd 182 vs 125 us)
 int g_wgrad_buf = 1;    // buffer-addressed loaders + pixel mask in the split weight-gradient kernel (key 8)
-int g_ktab_order = 0;   // experiment switch (key 6)
 int g_xcd_swizzle = 0;  // experiment switch (key 7)
 int g_conv_buf = 1;     // buffer-addressed loaders in the split conv kernels (key 5): 0 never, 1 on 64-row tiles, 2 always
 int g_conv_split = 1;   // 0: exact fp32 MFMA; 1: split-bf16 (3-MFMA) core for forward / data-gradient convolutions (key 3)
@@ -1403,8 +1402,7 @@ bool build_ktab(const ConvArgs& a, ConvArgsT& t) {
     const int C = a.src[s].C, ld = a.src[s].ld, cpt = (C + 31) / 32;
     if (M * ld * 4 >= (int64_t)FS_OOB) return false;
     for (int i = 0; i < taps * cpt; ++i, ++kt) {
-        // g_ktab_order 1 (EXPERIMENT, results are wrong: the weight pack is tap-major): taps innermost
-        const int tap = g_ktab_order ? i % taps : i / cpt, c = g_ktab_order ? i / taps : i % cpt;
+        const int tap = i / cpt, c = i % cpt;
         const int64_t soff = ((int64_t)((tap / a.KW) * a.W + tap % a.KW) * ld + c * 32) * 4;
         if (soff % 16 != 0 || soff / 16 > 0xffff) return false;
         const int crem = C - c * 32 < 32 ? C - c * 32 : 32;
@@ -1653,7 +1651,6 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 2) g_wgrad_blocks = value;
   else if (key == 3) g_conv_split = value;
   else if (key == 5) g_conv_buf = value;
-  else if (key == 6) g_ktab_order = value;
   else if (key == 8) g_wgrad_buf = value;
   else if (key == 9) g_conv_n256 = value;
   else if (key == 10) g_wgrad_multi = value;

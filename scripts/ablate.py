@@ -17,7 +17,7 @@ from flow_supervisor_amd.ops import Dst, V  # noqa: E402
 lib = _lib.load()
 lib.fsraft_set_ablate.argtypes = [ctypes.c_int]
 lib.fsraft_set_tuning(5, int(sys.argv[1]) if len(sys.argv) > 1 else 0)     # buffer-addressed loaders
-lib.fsraft_set_tuning(6, int(sys.argv[2]) if len(sys.argv) > 2 else 0)     # tap-inner k order (experiment; wrong numbers)
+# (argv[2] used to select a tap-inner k order experiment; removed from the library)
 lib.fsraft_set_tuning(7, int(sys.argv[3]) if len(sys.argv) > 3 else 0)     # XCD-aware tile mapping
 MASKS = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else None
 B, H, W = 4, 55, 128
