@@ -327,6 +327,86 @@ def gen_train_step():
         save("train_step_" + ("small" if small else "basic"), **d)
 
 
+def _train_digest(model, preds, stride=4):
+    """loss of the benchmark objective (sum_i 0.8^(n-1-i) mean sqrt(p^2 + 1e-6), zero gt) + backward digests."""
+    n = len(preds)
+    loss = 0.0
+    for i, p in enumerate(preds):
+        loss = loss + (0.8 ** (n - i - 1)) * torch.sqrt(p * p + 1e-6).mean()
+    loss.backward()
+    d = dict(loss=loss.detach(), last=preds[-1].detach()[:, :, ::stride, ::stride].contiguous(),
+             first=preds[0].detach()[:, :, ::stride, ::stride].contiguous(), stride=stride)
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        d["gnorm." + k] = g.norm()
+        d["ghead." + k] = g.reshape(-1)[:32].clone()
+    return d
+
+
+def gen_bench_scale():
+    """The benchmark's own shapes, fwd + bwd, ONE pair, 12 iterations: exercises the 12-segment batched
+    weight gradient, the 12-deep stash, the once-per-step context backward; 376x1248 is the KITTI-padded shape of config 4
+    (the alt-corr path's oracle is CorrBlock itself); GMA at N = 7040 covers the K = 1536 dattn GEMM."""
+    for name, H, W, seed in (("train_step_basic_440x1024", 440, 1024, 611), ("train_step_basic_376x1248", 376, 1248, 612)):
+        model = RAFT(args_ns(False))
+        model.load_state_dict(procedural_state_dict(shapes_of(model), seed))
+        model.train()
+        model.freeze_bn()
+        im1, im2 = synthetic_pair(1, H, W, seed + 1)
+        preds = model(im1, im2, iters=12)
+        save(name, small=False, H=H, W=W, iters=12, seed=seed, B=1, **_train_digest(model, preds))
+        del model, preds
+
+    from core.gma_network import RAFTGMA
+    seed, H, W = 613, 440, 1024
+    model = RAFTGMA(gma_ns())
+    shapes = shapes_of(model)
+    model.load_state_dict(procedural_state_dict(shapes, seed), strict=False)
+    with torch.no_grad():
+        model.update_block.aggregator.gamma.fill_(0.1)     # zero gamma would leave the aggregate path (and dattn) unexercised
+    model.eval()
+    im1, im2 = synthetic_pair(1, H, W, seed + 1)
+    with torch.no_grad():
+        low, up = model(im1, im2, iters=12, test_mode=True)
+    save("e2e_gma_440x1024", B=1, H=H, W=W, iters=12, seed=seed, stride=4, gamma=0.1, flow_low=low,
+         flow_up_strided=up[:, :, ::4, ::4].contiguous(), flow_up_absmean=up.abs().mean())
+    model.train()
+    model.freeze_bn()
+    preds = model(im1, im2, iters=12)
+    save("train_step_gma_440x1024", H=H, W=W, iters=12, seed=seed, B=1, gamma=0.1, **_train_digest(model, preds))
+
+
+def gen_seq_loss():
+    """sequence_loss of pytorch/train.py:60-96.  train.py imports cv2 / tensorflow at module level and cannot be imported
+    here, but the function is pure torch: its FunctionDef is taken out of the module's syntax tree and executed with only
+    `torch` and MAX_FLOW in scope.  Stored: loss, metrics and d loss / d pred on seeded inputs that include invalid pixels,
+    |gt| >= max_flow, and the student / supervisor (gamma / gamma2) halves."""
+    import ast
+    src = open("/root/reference/pytorch/train.py").read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "sequence_loss"][0]
+    scope = {"torch": torch, "MAX_FLOW": 400}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "train.py:sequence_loss", "exec"), scope)
+    ref = scope["sequence_loss"]
+    d = {}
+    for name, B, H, W, n, gamma, gamma2, seed in (("a", 2, 24, 40, 12, 0.8, 1.0, 901), ("b", 1, 17, 23, 6, 0.85, 0.9, 902),
+                                                   ("c", 3, 8, 8, 2, 0.8, 1.0, 903)):
+        preds = [rand_tensor((B, 2, H, W), seed + 10 + i, 3.0).requires_grad_(True) for i in range(n)]
+        gt = rand_tensor((B, 2, H, W), seed + 1, 4.0)
+        gt[:, :, 0, :3] = 500.0                                   # |gt| >= max_flow -> excluded from the loss only
+        gt[:, 0, 1, 1] = 300.0; gt[:, 1, 1, 1] = 300.0            # each component < 400 but the magnitude is not
+        valid = (rand_uniform((B, H, W), seed + 2, 0.0, 1.0) > 0.2).float()
+        valid[:, 2, 2] = 0.5                                      # counts for the loss (>= 0.5), not for the metrics (> 0.5)
+        loss, metrics = ref(preds, gt, valid, gamma=gamma, gamma2=gamma2)
+        loss.backward()
+        d.update({f"{name}_cfg": np.array([B, H, W, n, seed], dtype=np.int64), f"{name}_gamma": np.array([gamma, gamma2]),
+                  f"{name}_loss": loss.detach(),
+                  f"{name}_metrics": np.array([metrics["epe"], metrics["1px"], metrics["3px"], metrics["5px"]])})
+        for i, p in enumerate(preds):
+            d[f"{name}_dpred{i}"] = p.grad
+    save("sequence_loss", **d)
+
+
 def gen_warm_start():
     """forward_interpolate of the reference (core/utils/utils.py:26-54) on seeded flows: smooth + noise, a case where
     many vectors leave the image, and a constant shift (whole columns of the grid inherit their nearest landed neighbour)."""
@@ -344,7 +424,7 @@ def gen_warm_start():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "kitti", "l2l", "gma", "train", "warm"]
+    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "kitti", "l2l", "gma", "train", "warm", "seqloss", "bench"]
     if "warm" in which:
         gen_warm_start()
     if "corr" in which:
@@ -363,3 +443,7 @@ if __name__ == "__main__":
         gen_gma()
     if "train" in which:
         gen_train_step()
+    if "seqloss" in which:
+        gen_seq_loss()
+    if "bench" in which:
+        gen_bench_scale()

@@ -223,3 +223,27 @@ def test_warm_start_forward_interpolate():
     for name in ("a", "b", "c", "shift"):
         out = O.forward_interpolate(T(g["in_" + name]))
         assert torch.equal(out, T(g["out_" + name])), name
+
+
+def test_sequence_loss_restatement_vs_reference_function():
+    """oracle.sequence_loss against outputs of the reference's sequence_loss (pytorch/train.py:60-96; the FunctionDef is
+    executed out of the module's syntax tree by tests/golden/make_golden.py::gen_seq_loss, train.py itself needs cv2)."""
+    from oracle.weights import rand_uniform
+    g = load("sequence_loss")
+    for name in ("a", "b", "c"):
+        B, H, W, n, seed = (int(v) for v in g[name + "_cfg"])
+        gamma, gamma2 = (float(v) for v in g[name + "_gamma"])
+        preds = [rand_tensor((B, 2, H, W), seed + 10 + i, 3.0).requires_grad_(True) for i in range(n)]
+        gt = rand_tensor((B, 2, H, W), seed + 1, 4.0)
+        gt[:, :, 0, :3] = 500.0
+        gt[:, 0, 1, 1] = 300.0; gt[:, 1, 1, 1] = 300.0
+        valid = (rand_uniform((B, H, W), seed + 2, 0.0, 1.0) > 0.2).float()
+        valid[:, 2, 2] = 0.5
+        loss, metrics = O.sequence_loss(preds, gt, valid, gamma, gamma2, 400.0)
+        loss.backward()
+        ref = float(g[name + "_loss"])
+        assert abs(loss.item() - ref) <= 1e-6 * abs(ref), (name, loss.item(), ref)
+        for k, r in zip(("epe", "1px", "3px", "5px"), g[name + "_metrics"]):
+            assert abs(metrics[k] - float(r)) <= 1e-6 + 1e-6 * abs(float(r)), (name, k)
+        for i, p in enumerate(preds):
+            close(p.grad, g[f"{name}_dpred{i}"], 1e-9, 1e-5)
