@@ -806,14 +806,16 @@ class _UpdateBlockBase(nn.Module):
         return h, (mask if eng.has_mask else None), delta
 
     def _forward_nchw(self, net, inp, corr, flow, attention=None):
-        cache = self.__dict__.setdefault("_inp_cache", [None, None])
-        key = (inp.data_ptr(), inp._version, tuple(inp.shape))
-        if cache[0] != key or (inp.requires_grad and torch.is_grad_enabled()):
+        # The channels-last copy of `inp` is reused while the caller passes the SAME tensor object at the same version
+        # (identity through a weak reference: a freed tensor's address is handed out again by the caching allocator, so
+        # an address-keyed cache would serve the previous pair's context features to the next pair).
+        cache = self.__dict__.get("_inp_cache")
+        if (cache is None or cache[0]() is not inp or cache[1] != inp._version
+                or (inp.requires_grad and torch.is_grad_enabled())):
             inp_cl = to_channels_last(inp)
-            if not inp.requires_grad:
-                cache[0], cache[1] = key, inp_cl
+            self.__dict__["_inp_cache"] = None if inp.requires_grad else (weakref.ref(inp), inp._version, inp_cl)
         else:
-            inp_cl = cache[1]
+            inp_cl = cache[2]
         h, mask, delta = self.forward_cl(to_channels_last(net), inp_cl, to_channels_last(corr), flow, attention)
         return from_channels_last(h), (from_channels_last(mask) if mask is not None else None), delta
 

@@ -17,9 +17,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(device_type=None):
+def init_distributed(device_type=None, backend=None):
     """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
-    backend: nccl (= RCCL on ROCm) for GPU tensors, gloo for CPU tests."""
+    backend: nccl (= RCCL on ROCm) for GPU tensors, gloo for CPU tests; backend="gloo" with GPU tensors (several ranks
+    sharing one device, which RCCL refuses -- the 2-process GPU test) stages the exchange through host memory."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,7 +29,10 @@ def init_distributed(device_type=None):
             device_type = "cuda" if torch.cuda.is_available() else "cpu"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if device_type == "cuda":
+        if device_type == "cuda" and backend == "gloo":
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif device_type == "cuda":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -59,11 +63,14 @@ class FlatGradients:
     def zero_(self):
         self.flat.zero_()
 
-    def all_reduce_mean_(self):
-        """sum over ranks then divide by world (what DataParallel's reduce + batch-mean loss give)."""
+    def all_reduce_mean_(self, local_batch=None, global_batch=None):
+        """Gradient of the GLOBAL-batch mean loss from per-rank gradients of local-batch mean losses: every rank's
+        gradient is weighted by local_batch / global_batch before the sum (equal shards: 1 / world, what DataParallel's
+        reduce + batch-mean loss give).  `shard_batch` hands out unequal shards when the global batch does not divide."""
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / dist.get_world_size())
+            w = 1.0 / dist.get_world_size() if local_batch is None else float(local_batch) / float(global_batch)
+            self.flat.mul_(w)
+            _all_reduce_sum_(self.flat)
 
     def clip_norm_(self, max_norm):
         """clip_grad_norm_(params, max_norm) on the flat buffer (pytorch/train.py:280)."""
@@ -73,16 +80,37 @@ class FlatGradients:
         return total
 
 
+def _host_staged(t):
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce_sum_(t):
+    if _host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def broadcast_parameters(module, src=0):
     """One-time parameter sync at start-up (instead of DataParallel's per-step replicate)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src)
+        # Received into a staging tensor and copied INTO the parameter under no_grad: `copy_` bumps the tensor's version
+        # counter, which the packed-weight caches of the update block / encoders key on (a c10d broadcast into the
+        # parameter, or any write through `.data`, leaves the counter alone and those caches stale).
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                h = t.cpu() if _host_staged(t) else t.detach().clone()
+                dist.broadcast(h, src)
+                t.copy_(h)
 
 
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     if dist.is_initialized() and dist.get_world_size() > 1:
+        if _host_staged(t):
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -77,12 +77,16 @@ class TrainStep:
         self.opt = torch.optim.AdamW(self.grads.params, lr=lr, weight_decay=wdecay, eps=eps, fused=fused,
                                      capturable=bool(capturable and fused))
 
-    def __call__(self, image1, image2, flow_gt=None):
+    def __call__(self, image1, image2, flow_gt=None, global_batch=None):
+        """image1/image2: this rank's shard.  global_batch: pairs over all ranks (default: equal shards)."""
         self.grads.zero_()
         preds = self.model(image1, image2, iters=self.iters)
         loss = raft_sequence_loss(preds, flow_gt)
         loss.backward()
-        self.grads.all_reduce_mean_()
+        if global_batch is None:
+            self.grads.all_reduce_mean_()
+        else:
+            self.grads.all_reduce_mean_(image1.shape[0], global_batch)
         self.grads.clip_norm_(self.clip)
         self.opt.step()
         return loss.detach()

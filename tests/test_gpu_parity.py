@@ -1130,3 +1130,64 @@ def test_lds_direct_weight_tiles_variant_matches_default():
             res.append(out)
         lib.fsraft_set_tuning(24, 0)
         assert torch.equal(res[0], res[1]), (B, H, W, cs, N)
+
+
+# ----------------------------------------------------------------------------- data parallelism on the real step (row e)
+@pytest.mark.parametrize("global_batch", [4, 3])
+def test_two_process_train_step_matches_single_process(global_batch, tmp_path):
+    """Two fresh processes (tests/_dp_worker.py), each running the real TrainStep on its shard of `global_batch` pairs at
+    128x192 x 3 iterations and exchanging the flat gradient (gloo staged through the host: both ranks sit on cuda:0),
+    against one process on the whole batch: reduced + clipped flat gradient and post-AdamW weights.  global_batch = 3
+    gives shards of 2 and 1 (gradients weighted by local / global batch)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from flow_supervisor_amd.train import TrainStep
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    out = str(tmp_path / "r0.pt")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(global_batch), out]) for r in range(2)]
+    rcs = [p.wait(timeout=900) for p in procs]
+    assert rcs == [0, 0], rcs
+    got = torch.load(out)
+    m = _model(False, 650).train()
+    m.freeze_bn()
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(global_batch, 128, 192, 651))
+    step = TrainStep(m, lr=1e-4, iters=3)
+    loss = step(im1, im2)
+    ref_g = step.grads.flat.cpu()
+    ref_p = torch.cat([p.detach().reshape(-1).cpu() for p in step.grads.params])
+    rel_g = float((got["flat"] - ref_g).norm() / ref_g.norm())
+    rel_p = float((got["params"] - ref_p).norm() / ref_p.norm())
+    print("dp2 vs single: grad rel", rel_g, "param rel", rel_p, "loss(rank 0 shard)", got["loss"], "loss(all)", float(loss))
+    assert rel_g <= 2e-3, rel_g          # split-bf16 products + a different summation order over the batch
+    assert rel_p <= 1e-5, rel_p
+
+
+def test_nchw_entry_does_not_reuse_context_of_a_freed_tensor():
+    """BasicUpdateBlock.forward (the NCHW drop-in entry INTEGRATION.md hands to the reference's raft.py)
+    caches the channels-last copy of `inp`.  Under no_grad every pair's `inp = relu(...)` is a fresh tensor that the caching
+    allocator places at the address of the previous pair's (freed) one: the cache must key on identity, not address."""
+    from flow_supervisor_amd.core.update import BasicUpdateBlock
+    sh = shapes("update_basic")
+    blk = BasicUpdateBlock(ns(False), hidden_dim=128)
+    blk.load_state_dict(procedural_state_dict(sh, 300))
+    blk = blk.to(DEV).eval()
+    sd = {"update_block." + k: v for k, v in blk.state_dict().items()}
+    B, H, W = 1, 12, 16
+    net = torch.tanh(rand_tensor((B, 128, H, W), 310)).to(DEV)
+    corr = rand_tensor((B, 324, H, W), 312, 2.0).to(DEV)
+    flow = rand_tensor((B, 2, H, W), 313, 3.0).to(DEV)
+    outs, ptrs = [], []
+    with torch.no_grad():
+        for seed in (311, 411):
+            inp = torch.relu(rand_tensor((B, 128, H, W), seed).to(DEV))      # fresh tensor, version 0, same shape
+            ptrs.append(inp.data_ptr())
+            n2, mask, delta = blk(net, inp, corr, flow)
+            outs.append((n2.cpu(), delta.cpu(), inp.cpu()))
+            del inp, n2, mask, delta
+    for n2, delta, inp in outs:
+        rn, _, rd = O.basic_update_block({k: v.cpu() for k, v in sd.items()}, "update_block.", net.cpu(), inp, corr.cpu(), flow.cpu())
+        close(n2, rn, 2e-4, what="net (pair %d)" % len(ptrs)); close(delta, rd, 2e-4, what="delta")
+    print("inp addresses of the two pairs:", ptrs, "(equal = the allocator reused the block)")

@@ -73,3 +73,42 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     assert abs(float(got["norm"]) - float(ref_norm)) < 1e-5
     assert got["t"] == 2.0                               # max over ranks of (1, 2)
     assert [shard_batch(7, r, 3) for r in range(3)] == [(0, 3), (3, 2), (5, 2)]
+
+
+def _worker_unequal(rank, world, port, out):
+    """global batch 5 on 2 ranks -> shards of 3 and 2; broadcast AFTER a first use of the weights (resume / re-sync)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from flow_supervisor_amd.parallel import FlatGradients, broadcast_parameters, init_distributed, shard_batch
+    init_distributed("cpu")
+    torch.manual_seed(200 + rank)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    versions = [p._version for p in model.parameters()]
+    broadcast_parameters(model)
+    # the packed-weight caches of the product key on (data_ptr, _version): a broadcast must be visible there
+    assert all(p._version > v for p, v in zip(model.parameters(), versions)), "broadcast did not bump the version counters"
+    grads = FlatGradients(model.parameters())
+    torch.manual_seed(8)
+    x = torch.randn(5, 3, 10, 12)
+    s, n = shard_batch(5, rank, world)
+    grads.zero_()
+    _toy_loss([model(x[s:s + n]), 0.5 * model(x[s:s + n])]).backward()
+    grads.all_reduce_mean_(n, 5)
+    if rank == 0:
+        torch.save({"flat": grads.flat.clone()}, out)
+
+
+def test_unequal_shards_are_weighted_by_local_batch(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_unequal, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    sys.path.insert(0, ROOT)
+    from flow_supervisor_amd.parallel import FlatGradients
+    torch.manual_seed(200)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    grads = FlatGradients(model.parameters())
+    torch.manual_seed(8)
+    x = torch.randn(5, 3, 10, 12)
+    _toy_loss([model(x), 0.5 * model(x)]).backward()
+    assert torch.allclose(got["flat"], grads.flat, atol=1e-6, rtol=1e-5)
