@@ -7,11 +7,14 @@ numbers without the N x N volume (corr.py:63-91 + alt_cuda_corr).
 
 Autograd design (differs from the reference on purpose): the reference lets autograd
 allocate a dense zero gradient for the whole volume on every one of the 4x12 grid_sample
-backward calls.  Here each CorrBlock owns ONE gradient pyramid that all lookups of a step
-accumulate into in place (each query owns its slice, so no atomics), and the volume
-backward (un-pool + two fp32-MFMA GEMMs) runs once, when autograd reaches the build node.
-A 1-element "anchor" tensor threads that dependency through the autograd graph.
-Coordinates get no gradient: every caller detaches them first (raft.py:123).
+backward calls.  Here a lookup's backward only keeps (coords, dOut) -- the window gradients
+are a pure function of them -- and when autograd reaches the build node the gradient volume
+is written ONCE (fsraft_corr_dvol_build: every query row accumulated in LDS over all
+lookups of the step, no zero fill, no read-modify-write) and two GEMMs that contract over
+whole rows produce dF1 / dF2; the pooling chain's backward runs on the 7 MB feature
+gradient, not on the 1 GB volume gradient.  A 1-element "anchor" tensor threads the
+dependency through the autograd graph.  Coordinates get no gradient: every caller
+detaches them first (raft.py:123).
 """
 import math
 
@@ -22,85 +25,96 @@ from .. import ops
 
 
 class _GradState:
-    """Accumulated dL/dV pyramid of one CorrBlock (allocated by the first lookup backward)."""
-    __slots__ = ("dlevels", "shapes", "zero")
+    """Backward state of one CorrBlock: the (coords, dOut) pairs of every lookup whose gradient has arrived.  The window
+    gradients are a pure function of those, so nothing else is done until autograd reaches the volume build."""
+    __slots__ = ("stash", "zero")
 
-    def __init__(self, levels):
-        self.dlevels = None
-        self.shapes = [tuple(l.shape) for l in levels]
-        self.zero = torch.zeros(1, device=levels[0].device)
+    def __init__(self, device):
+        self.stash = []
+        self.zero = torch.zeros(1, device=device)
 
 
 class _BuildFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fmap1, fmap2, num_levels, holder):
-        levels = ops.corr_build(fmap1, fmap2, num_levels)
-        state = _GradState(levels)
-        holder.append(state)
-        ctx.state = state
+    def forward(ctx, fmap1, fmap2, num_levels, radius, holder):
+        vol, lay = ops.corr_build_tiled(fmap1, fmap2, num_levels)
+        state = _GradState(fmap1.device)
+        holder.append((state, lay))
+        ctx.state, ctx.lay, ctx.radius = state, lay, radius
         ctx.save_for_backward(fmap1, fmap2)
         anchor = torch.zeros(1, device=fmap1.device)
-        ctx.mark_non_differentiable(*levels)
-        return (anchor, *levels)
+        ctx.mark_non_differentiable(vol)
+        return anchor, vol
 
     @staticmethod
-    def backward(ctx, ganchor, *glevels):
+    def backward(ctx, ganchor, gvol):
         fmap1, fmap2 = ctx.saved_tensors
         st = ctx.state
-        if st.dlevels is None:                      # no lookup contributed a gradient
-            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None
-        dl, st.dlevels = st.dlevels, None
-        d1, d2 = ops.corr_build_bwd(fmap1, fmap2, dl)
-        return d1, d2, None, None
+        if not st.stash:                            # no lookup contributed a gradient
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None, None
+        stash, st.stash = st.stash, []
+        dvol = ops.corr_dvol_build([d for _, d in stash], [c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius)
+        del stash
+        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay)
+        return d1, d2, None, None, None
 
 
 class _LookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, coords, block, channels_last):
-        out = ops.corr_lookup_fwd(block.corr_pyramid, coords, block.radius, nhwc=channels_last)
+        out = ops.corr_lookup_tiled_fwd(block._vol, block._lay, coords, block.radius)
         ctx.state = block._state
-        ctx.radius = block.radius
         ctx.cl = channels_last
         ctx.save_for_backward(coords)
-        return out
+        return out if channels_last else ops.nhwc_to_nchw(out)
 
     @staticmethod
     def backward(ctx, dout):
         (coords,) = ctx.saved_tensors
-        st = ctx.state
-        if st.dlevels is None:
-            st.dlevels = [torch.zeros(s, device=dout.device, dtype=torch.float32) for s in st.shapes]
-        ops.corr_lookup_bwd_(st.dlevels, coords, dout, ctx.radius, nhwc=ctx.cl)
-        return st.zero, None, None, None
+        dout = dout.contiguous() if ctx.cl else ops.nchw_to_nhwc(dout)
+        ctx.state.stash.append((coords, dout))
+        return ctx.state.zero, None, None, None
 
 
 class CorrBlock:
+    """All-pairs volume + pyramid + lookup (pytorch/core/corr.py:13-60).  The volume lives in the tiled-row layout of
+    csrc/corr_layout.hpp (one row per query, all levels, 4x4-cell tiles); `corr_pyramid` -- the reference's list of
+    [B*H*W, 1, h_l, w_l] tensors -- is materialised from it on first access (API edge; nothing on the path reads it)."""
+
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
-        if num_levels != 4:
-            raise NotImplementedError("the HIP lookup kernels are built for 4 pyramid levels (all RAFT variants use 4)")
+        if not 1 <= num_levels <= 4:
+            raise NotImplementedError("the HIP correlation kernels are built for 1..4 pyramid levels (all RAFT variants use 4)")
         if radius not in (3, 4):
             raise NotImplementedError("the HIP lookup kernels are built for radius 3 (raft-small) and 4 (RAFT)")
         self.num_levels = num_levels
         self.radius = radius
         fmap1 = fmap1.float()
         fmap2 = fmap2.float()
+        self._pyr = None
         self._tracks_grad = torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)
         if self._tracks_grad:
             holder = []
-            self._anchor, *levels = _BuildFn.apply(fmap1, fmap2, num_levels, holder)
-            self._state = holder[0]
+            self._anchor, self._vol = _BuildFn.apply(fmap1, fmap2, num_levels, radius, holder)
+            self._state, self._lay = holder[0]
         else:
-            levels = ops.corr_build(fmap1, fmap2, num_levels)
+            self._vol, self._lay = ops.corr_build_tiled(fmap1, fmap2, num_levels)
             self._anchor, self._state = None, None
-        self.corr_pyramid = list(levels)            # [B*H*W, 1, h_l, w_l], as in corr.py:19-27
+
+    @property
+    def corr_pyramid(self):
+        """[B*H*W, 1, h_l, w_l] per level, as in corr.py:19-27 (copies out of the tiled rows)."""
+        if self._pyr is None:
+            self._pyr = [self._lay.level_view(self._vol, l) for l in range(self.num_levels)]
+        return self._pyr
 
     def __call__(self, coords, channels_last=False):
-        """coords [B,2,H,W] (x,y).  Returns [B, 4*(2r+1)^2, H, W] contiguous (or [B,H,W,C] when
+        """coords [B,2,H,W] (x,y).  Returns [B, L*(2r+1)^2, H, W] contiguous (or [B,H,W,C] when
         channels_last=True, the layout our update block consumes directly)."""
         coords = coords.float()
         if self._tracks_grad and torch.is_grad_enabled():
             return _LookupFn.apply(self._anchor, coords.detach(), self, channels_last)
-        return ops.corr_lookup_fwd(self.corr_pyramid, coords, self.radius, nhwc=channels_last)
+        out = ops.corr_lookup_tiled_fwd(self._vol, self._lay, coords, self.radius)
+        return out if channels_last else ops.nhwc_to_nchw(out)
 
     @staticmethod
     def corr(fmap1, fmap2):

@@ -1,6 +1,6 @@
 """pytorch/core/gma_corr.py surface.  gma_corr.CorrBlock (:15-63) is the same all-pairs volume + pyramid + lookup as
-core/corr.py; the reference's CorrBlockSingleScale (:66-103) is never constructed anywhere in the reference and
-is the one-level special case of the same kernels."""
+core/corr.py; CorrBlockSingleScale (:66-103, never constructed anywhere in the reference) is the one-level case of the
+same kernels: one (2r+1)^2 lookup of the full-resolution volume."""
 from .corr import AlternateCorrBlock, CorrBlock  # noqa: F401
 
 

@@ -15,6 +15,7 @@
 // 55x128, C=256.  FLOPs 2*N*N*C = 25.4 G => fp32-MFMA bound.
 #include "gemm_core.hpp"
 #include "gemm_core_split.hpp"
+#include "corr_layout.hpp"
 
 namespace {
 
@@ -155,6 +156,102 @@ __device__ __forceinline__ void build_epilogue(f32x16 (&acc)[2][2], float* lds, 
   }
 }
 
+// Tiled-row variant of the epilogue (corr_layout.hpp): the same 64 x (8x32 patch) tile, written as whole 64-byte tiles
+// of the query's row.  The patch is aligned to 8 rows / 32 columns, so it holds 2x8 whole level-0 tiles (512 contiguous
+// bytes per tile row and query), 1x4 level-1 tiles, two rows of 2 level-2 tiles and one row of 1 level-3 tile.
+__device__ __forceinline__ void build_epilogue_tiled(f32x16 (&acc)[2][2], float* lds, float* __restrict__ vol, const VolLayout& L,
+                                                     int N, int b, int i0, int px0, int py0, float scale) {
+  float* S = lds;                 // [32][256]  scaled level-0 patch, patch-linear (row*32+col)
+  float* P1 = lds + 32 * 256;     // [32][4*16]
+  float* P2 = P1 + 32 * 64;       // [32][2*8]
+  const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nlev = L.nlev;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int pj = (4 * nt + (l31 >> 3)) * 32 + 8 * wn + (l31 & 7);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        S[i * S_LD + pj] = acc[mt][nt][r] * scale;
+      }
+    }
+    __syncthreads();
+    const int qbase = i0 + mt * 32;
+    float* rows = vol + ((int64_t)b * N + qbase) * L.P;
+    // level 0: chunk = (query i, tile row ty, tile t, row r of the tile), 16 bytes; 32 lanes cover one 512-byte run
+#pragma unroll 4
+    for (int jj = 0; jj < 8; ++jj) {
+      const int id = threadIdx.x + 256 * jj;
+      const int r = id & 3, t = (id >> 2) & 7, ty = (id >> 5) & 1, i = id >> 6;
+      const int gty = (py0 >> 2) + ty, gtx = (px0 >> 2) + t;
+      if (gty < L.th[0] && gtx < L.tw[0] && qbase + i < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(S + i * S_LD + (4 * ty + r) * 32 + 4 * t);
+        gstore4(rows + (int64_t)i * L.P + L.off[0] + (gty * L.tw[0] + gtx) * 16 + r * 4, v);
+      }
+    }
+    if (nlev > 1) {
+      const int h1 = L.h[1], w1 = L.w[1];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int e = threadIdx.x + 256 * jj;
+        const int i = e >> 6, c = e & 63, y = c >> 4, x = c & 15;
+        const float* s = S + i * S_LD + (2 * y) * 32 + 2 * x;
+        const float v = (((s[0] + s[1]) + s[32]) + s[33]) * 0.25f;
+        // cells beyond the floor-halved size do not exist in the reference pyramid: pad cells of the tile hold 0
+        P1[i * 64 + c] = ((py0 >> 1) + y < h1 && (px0 >> 1) + x < w1) ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    if (nlev > 1) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int id = threadIdx.x + 256 * jj;
+        const int r = id & 3, t = (id >> 2) & 3, i = id >> 4;
+        const int gty = py0 >> 3, gtx = (px0 >> 3) + t;
+        if (gty < L.th[1] && gtx < L.tw[1] && qbase + i < N) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(P1 + i * 64 + r * 16 + 4 * t);
+          gstore4(rows + (int64_t)i * L.P + L.off[1] + (gty * L.tw[1] + gtx) * 16 + r * 4, v);
+        }
+      }
+    }
+    if (nlev > 2) {
+      const int h2 = L.h[2], w2 = L.w[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int e = threadIdx.x + 256 * jj;
+        const int i = e >> 4, c = e & 15, y = c >> 3, x = c & 7;
+        const float* s = P1 + i * 64 + (2 * y) * 16 + 2 * x;
+        const float v = (((s[0] + s[1]) + s[16]) + s[17]) * 0.25f;
+        P2[i * 16 + c] = ((py0 >> 2) + y < h2 && (px0 >> 2) + x < w2) ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    if (nlev > 2 && threadIdx.x < 128) {
+      const int id = threadIdx.x;
+      const int y = id & 1, t = (id >> 1) & 1, i = id >> 2;
+      const int gy = (py0 >> 2) + y, gtx = (px0 >> 4) + t;
+      if ((gy >> 2) < L.th[2] && gtx < L.tw[2] && qbase + i < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(P2 + i * 16 + y * 8 + 4 * t);
+        gstore4(rows + (int64_t)i * L.P + L.off[2] + ((gy >> 2) * L.tw[2] + gtx) * 16 + (gy & 3) * 4, v);
+      }
+    }
+    if (nlev > 3 && threadIdx.x >= 128) {
+      const int h3 = L.h[3], w3 = L.w[3];
+      const int id = threadIdx.x - 128;
+      const int i = id >> 2, x = id & 3;
+      const float* s = P2 + i * 16 + 2 * x;
+      const float v = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
+      const int gy = (py0 >> 3), gx = (px0 >> 3) + x;
+      if ((gy >> 2) < L.th[3] && (gx >> 2) < L.tw[3] && qbase + i < N)
+        gstore1(rows + (int64_t)i * L.P + vol_cell(L, 3, gy, gx), (gy < h3 && gx < w3) ? v : 0.f);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void corr_build_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          Levels lv, int nlev, int C, int H, int W, float scale) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -240,6 +337,52 @@ __global__ __launch_bounds__(256) void corr_build_split_kernel(const float* __re
   split_mainloop_tn<BuildSplitCfg>(lds, ceil_div_dev(C, 32), la, lb, acc);
   __syncthreads();
   build_epilogue(acc, reinterpret_cast<float*>(lds), lv, nlev, H, W, N, b, i0, px0, py0, scale);
+}
+
+// ---- the same two kernels writing the tiled-row layout (corr_layout.hpp) ----
+__global__ __launch_bounds__(256) void corr_build_tiled_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                               float* __restrict__ vol, VolLayout L, int C, float scale) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int H = L.H, W = L.W, N = H * W;
+  const int npx = ceil_div_dev(W, 32);
+  const int px0 = (blockIdx.x % npx) * 32, py0 = (blockIdx.x / npx) * 8;
+  const int i0 = blockIdx.y * 64;
+  const int b = blockIdx.z;
+  F1Loader la{f1 + (int64_t)b * C * N, N, i0, C};
+  const int prow = threadIdx.x >> 5, pcol = threadIdx.x & 31;
+  const bool pok = (py0 + prow < H) && (px0 + pcol < W);
+  F2Loader lb{f2 + (int64_t)b * C * N, N, C, (py0 + prow) * W + px0 + pcol, pok};
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  gemm_mainloop<BuildCfg>(lds, ceil_div_dev(C, 16), la, lb, acc);
+  build_epilogue_tiled(acc, lds, vol, L, N, b, i0, px0, py0, scale);
+}
+
+__global__ __launch_bounds__(256) void corr_build_tiled_split_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                     float* __restrict__ vol, VolLayout L, int C, float scale) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_SPLIT_BYTES];
+  const int H = L.H, W = L.W, N = H * W;
+  const int npx = ceil_div_dev(W, 32);
+  const int px0 = (blockIdx.x % npx) * 32, py0 = (blockIdx.x / npx) * 8;
+  const int i0 = blockIdx.y * 64;
+  const int b = blockIdx.z;
+  F1SplitLoader la{f1 + (int64_t)b * C * N, N, i0, C};
+  F2SplitLoader lb{f2 + (int64_t)b * C * N, N, C, H, W, px0, py0};
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  split_mainloop_tn<BuildSplitCfg>(lds, ceil_div_dev(C, 32), la, lb, acc);
+  __syncthreads();
+  build_epilogue_tiled(acc, reinterpret_cast<float*>(lds), vol, L, N, b, i0, px0, py0, scale);
 }
 
 int g_build_split = 1;    // 0: exact fp32 MFMA build, 1: split-bf16 (fsraft_set_build_split)
@@ -368,6 +511,30 @@ extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* 
     hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, lv, num_levels, C, H, W,
                        1.0f / sqrtf((float)C));
   return fs_launch_status();
+}
+
+// Volume + pyramid of one batch in the tiled-row layout: vol [B*H*W][P] (fsraft_vol_layout gives P and the level offsets).
+extern "C" int fsraft_corr_build_tiled(const float* fmap1, const float* fmap2, float* vol, int num_levels, int B, int C, int H,
+                                       int W, hipStream_t stream) {
+  VolLayout L;
+  if (!fmap1 || !fmap2 || !vol || B < 1 || C < 2 || (C & 1) || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
+  if ((uintptr_t)vol % 16) return FS_ERR_ARG;
+  const int N = H * W;
+  dim3 grid(ceil_div(W, 32) * ceil_div(H, 8), ceil_div(N, 64), B);
+  if (g_build_split)
+    hipLaunchKernelGGL(corr_build_tiled_split_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, vol, L, C, 1.0f / sqrtf((float)C));
+  else
+    hipLaunchKernelGGL(corr_build_tiled_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, vol, L, C, 1.0f / sqrtf((float)C));
+  return fs_launch_status();
+}
+
+// out[0..19] = nlev, H, W, P, h[4], w[4], th[4], tw[4] ... see fsraft.h
+extern "C" int fsraft_vol_layout(int H, int W, int num_levels, int* out) {
+  VolLayout L;
+  if (!out || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
+  out[0] = L.nlev; out[1] = L.H; out[2] = L.W; out[3] = L.P;
+  for (int l = 0; l < 4; ++l) { out[4 + l] = L.h[l]; out[8 + l] = L.w[l]; out[12 + l] = L.th[l]; out[16 + l] = L.tw[l]; out[20 + l] = L.off[l]; }
+  return FS_OK;
 }
 
 extern "C" int fsraft_set_build_split(int on) {

@@ -1,0 +1,331 @@
+// Pyramid lookup and its backward on the tiled-row volume layout (corr_layout.hpp); rows a3 of SURVEY.md section 8,
+// reference: pytorch/core/corr.py:29-50 + core/utils/utils.py:57-71 (forward), grid_sampler_2d_backward w.r.t. the
+// volume (backward).
+//
+// Forward: ONE WAVE PER QUERY.  Per level a single wave instruction fetches the 4x4-tile superset of the (2r+2)^2 window
+// (lane = (tile, row of the tile): 16 bytes each, four lanes = one 64-byte tile), masked down to the tiles / rows the
+// window really touches; the 16x16-cell region goes to LDS and the (2r+1)^2 bilinear blends of the level are computed
+// from it with the channel on the lane, so every store instruction writes 256 contiguous bytes of the channels-last
+// output.  Algorithmic HBM bytes per query: L (2r+2)^2 4 read + 8 coords + L (2r+1)^2 4 written.
+//
+// Backward: the reference materialises a dense zero gradient of the whole volume on each of the 4 x 12 grid_sample
+// backward calls; round 1 of this library kept one dense gradient pyramid and read-modify-wrote the windows of every
+// lookup into it (12 passes + a zero fill over ~1 GB).  Here a lookup's backward does NOTHING but keep (coords, dOut):
+// the window gradients are a pure function of those 324 + 2 floats per query.  When autograd reaches the volume build,
+// fsraft_corr_dvol_build writes the gradient volume ONCE: per query, all lookups of the step are accumulated in LDS
+// (zero-initialised there) and the finished row -- pad cells zero -- leaves as 16-byte stores.  HBM traffic:
+// read n * 324 * 4 + write P * 4 bytes per query, no zero fill, no read-modify-write.
+//
+// The pooling chain has no backward pass of its own any more: with V_l[i, cell] = f1[i] . mean_{cell}(f2),
+//     dF1[c][i]  = s * sum_p F2cat[c][p] * dV[i][p]          F2cat = pooled f2 in the row layout (fsraft_corr_f2cat)
+//     dF2cat[p][c] = s * sum_i dV[i][p] * f1[i][c]            then dF2 = sum_l 4^-l unpool_l (fsraft_corr_dfmap2)
+// i.e. the un-pool runs on the 7 MB feature gradient instead of the 1 GB volume gradient.
+#include "corr_layout.hpp"
+
+namespace {
+
+struct Coords {
+  const float* p;
+  int64_t bs, cs, ps;
+};
+
+template <int R>
+struct TL {
+  static constexpr int N1 = 2 * R + 1, WIN = 2 * R + 2, N2 = N1 * N1;
+  static constexpr int RP = 20;             // region row pitch (floats): 16-byte aligned rows, <= 3-way bank conflicts in the blend
+  static constexpr int REGION = 16 * RP;    // one level's 16x16-cell region
+  static constexpr int ROUNDS = (N2 + 63) / 64;
+};
+
+struct LevelQ {      // one (query, level): integer window origin and bilinear weights
+  int wx0, wy0;
+  float fx, fy;
+};
+
+__device__ __forceinline__ LevelQ level_query(float cx, float cy, int l, int R) {
+  const float s = 1.0f / (float)(1 << l);
+  cx *= s; cy *= s;
+  // anything this far out has an all-zero window; the clamp keeps floor->int defined (also for NaN)
+  cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+  cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+  const float flx = floorf(cx), fly = floorf(cy);
+  return LevelQ{(int)flx - R, (int)fly - R, cx - flx, cy - fly};
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving them across
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int R, int QW>
+__global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __restrict__ vol, VolLayout L, Coords co,
+                                                               float* __restrict__ out, int64_t nq, int HW) {
+  using S = TL<R>;
+  __shared__ __attribute__((aligned(16))) float region[4][4][S::REGION];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nlev = L.nlev, CH = nlev * S::N2;
+  float* reg = &region[wave][0][0];
+  const int tsx = (lane >> 2) & 3, tsy = lane >> 4, r = lane & 3;
+  int choff[S::ROUNDS];            // channel (i, j) of a level handled by this lane in round k -> offset inside the region
+#pragma unroll
+  for (int k = 0; k < S::ROUNDS; ++k) {
+    const int kk = lane + 64 * k;
+    choff[k] = kk < S::N2 ? (kk % S::N1) * S::RP + kk / S::N1 : -1;      // i = kk / N1 (x offset, slow), j = kk % N1 (y offset)
+  }
+  for (int qq = 0; qq < QW; ++qq) {
+    const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * QW + qq;         // wave-uniform
+    if (q >= nq) break;
+    const int b = (int)(q / HW), pix = (int)(q % HW);
+    const float cx = gload1(co.p + b * co.bs + pix * co.ps), cy = gload1(co.p + b * co.bs + co.cs + pix * co.ps);
+    const float* row = vol + q * L.P;
+    LevelQ lq[4];
+    f32x4 v[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      v[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (l < nlev) {
+        lq[l] = level_query(cx, cy, l, R);
+        const int tx = (lq[l].wx0 >> 2) + tsx, ty = (lq[l].wy0 >> 2) + tsy;     // >> on negatives = floor division
+        const int y = 4 * ty + r, x = 4 * tx;
+        const bool need = tx >= 0 && tx < L.tw[l] && ty >= 0 && y < L.h[l] && y >= lq[l].wy0 && y < lq[l].wy0 + S::WIN &&
+                          x + 3 >= lq[l].wx0 && x < lq[l].wx0 + S::WIN;
+        if (need) {
+          v[l] = gload4(row + L.off[l] + (ty * L.tw[l] + tx) * 16 + r * 4);
+          const int xr = L.w[l] - x;                 // cells at or beyond the true width are pad: read as zero
+#pragma unroll
+          for (int c = 1; c < 4; ++c) v[l][c] = c < xr ? v[l][c] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (l < nlev) *reinterpret_cast<f32x4*>(reg + l * S::REGION + (4 * tsy + r) * S::RP + 4 * tsx) = v[l];
+    wave_lds_sync();
+    float* o = out + q * CH;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l >= nlev) continue;
+      const float* base = reg + l * S::REGION + (lq[l].wy0 & 3) * S::RP + (lq[l].wx0 & 3);
+      const float fx = lq[l].fx, fy = lq[l].fy;
+#pragma unroll
+      for (int k = 0; k < S::ROUNDS; ++k) {
+        if (choff[k] < 0) continue;
+        const float* p = base + choff[k];
+        const float top = p[0] + fx * (p[1] - p[0]);
+        const float bot = p[S::RP] + fx * (p[S::RP + 1] - p[S::RP]);
+        gstore1(o + l * S::N2 + lane + 64 * k, top + fy * (bot - top));
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gradient volume from the stashed lookups of a step.
+constexpr int DV_MAXN = 16;        // lookups per launch (more: further launches with accumulate = 1)
+constexpr int DV_SEG = 8192;       // floats of a row held in LDS at a time
+
+struct DvolArgs {
+  const float* dout[DV_MAXN];      // [B,H,W,CH] channels-last gradient of each lookup's output
+  Coords co[DV_MAXN];
+  int n;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate) {
+  using S = TL<R>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* seg = smem;                                   // [DV_SEG]
+  float* g = smem + DV_SEG;                            // [n][CH]
+  const int nlev = L.nlev, CH = nlev * S::N2, n = a.n;
+  LevelQ* qi = reinterpret_cast<LevelQ*>(g + n * CH);   // [n][4]
+  const int64_t q = blockIdx.x;
+  const int b = (int)(q / HW), pix = (int)(q % HW);
+  // dOut rows of the n lookups -> LDS.  The lookup index is wave-uniform (pointer from the kernarg table by a scalar load),
+  // a row is CH * 4 bytes: 16-byte loads when CH % 4 == 0 (324, 196), all of them in flight before the first LDS store.
+  if ((CH & 3) == 0) {
+    const int c4 = CH >> 2;
+    constexpr int UN = 4;
+    for (int t0 = 0; t0 < n; t0 += UN) {
+      f32x4 v[UN][2];
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int c = threadIdx.x + 256 * k;
+          if (t0 + u < n && c < c4) v[u][k] = gload4(a.dout[t0 + u] + q * CH + 4 * c);
+        }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int c = threadIdx.x + 256 * k;
+          if (t0 + u < n && c < c4) *reinterpret_cast<f32x4*>(g + (t0 + u) * CH + 4 * c) = v[u][k];
+        }
+    }
+  } else {
+    for (int t = 0; t < n; ++t)
+      for (int c = threadIdx.x; c < CH; c += 256) g[t * CH + c] = gload1(a.dout[t] + q * CH + c);
+  }
+  if (threadIdx.x < n * 4) {
+    const int t = threadIdx.x >> 2, l = threadIdx.x & 3;
+    const Coords& c = a.co[t];
+    qi[threadIdx.x] = level_query(gload1(c.p + b * c.bs + pix * c.ps), gload1(c.p + b * c.bs + c.cs + pix * c.ps), l, R);
+  }
+  float* row = dvol + q * L.P;
+  for (int s0 = 0; s0 < L.P; s0 += DV_SEG) {
+    const int len = min(DV_SEG, L.P - s0);
+    __syncthreads();
+    for (int e = threadIdx.x * 4; e < len; e += 1024)
+      *reinterpret_cast<f32x4*>(seg + e) = accumulate ? gload4(row + s0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    // one thread per window ROW (lookup t, level l, row wy): s[i] = lerp over y of the (2r+1)^2 gradient, then
+    // d[wx] = lerp over x, added to the row's cells of the tiled layout (LDS float adds: windows of different lookups overlap)
+    for (int e = threadIdx.x; e < n * nlev * S::WIN; e += 256) {
+      const int wy = e % S::WIN, tl = e / S::WIN;
+      const int l = tl % nlev, t = tl / nlev;
+      const int lbeg = L.off[l] - s0, lend = lbeg + L.th[l] * L.tw[l] * 16;
+      if (lend <= 0 || lbeg >= len) continue;                     // this level's section is outside the segment
+      const LevelQ v = qi[t * 4 + l];
+      const int gy = v.wy0 + wy;
+      if (gy < 0 || gy >= L.h[l]) continue;
+      const float* gp = g + t * CH + l * S::N2;
+      float sv[S::N1];
+#pragma unroll
+      for (int i = 0; i < S::N1; ++i) {
+        const float ga = wy < S::N1 ? gp[i * S::N1 + wy] : 0.f;
+        const float gb = wy >= 1 ? gp[i * S::N1 + wy - 1] : 0.f;
+        sv[i] = ga * (1.f - v.fy) + gb * v.fy;
+      }
+      const int rowbase = lbeg + (gy >> 2) * L.tw[l] * 16 + (gy & 3) * 4;
+      const int w = L.w[l];
+#pragma unroll
+      for (int wx = 0; wx < S::WIN; ++wx) {
+        const float d = (wx < S::N1 ? sv[wx] * (1.f - v.fx) : 0.f) + (wx >= 1 ? sv[wx - 1] * v.fx : 0.f);
+        const int gx = v.wx0 + wx;
+        const int o = rowbase + (gx >> 2) * 16 + (gx & 3);
+        if (gx >= 0 && gx < w && o >= 0 && o < len) atomicAdd(seg + o, d);
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x * 4; e < len; e += 1024) gstore4(row + s0 + e, *reinterpret_cast<const f32x4*>(seg + e));
+  }
+}
+
+// F2cat[b][c][p]: the target-side operand of dF1 = s * F2cat . dV^T in the row layout -- level-l cell = mean of f2 over its
+// 2^l x 2^l pixels where the cell exists in the floor pyramid, 0 in pad cells.
+__global__ __launch_bounds__(256) void corr_f2cat_kernel(const float* __restrict__ f2, float* __restrict__ f2cat, VolLayout L, int C,
+                                                         int64_t total) {
+  const int H = L.H, W = L.W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int p = (int)(e % L.P);
+    const int64_t bc = e / L.P;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) l = (k < L.nlev && p >= L.off[k]) ? k : l;
+    const int rel = p - L.off[l], t = rel >> 4, y = ((t / L.tw[l]) << 2) + ((rel >> 2) & 3), x = ((t % L.tw[l]) << 2) + (rel & 3);
+    float v = 0.f;
+    if (t < L.th[l] * L.tw[l] && y < L.h[l] && x < L.w[l]) {
+      const float* s = f2 + bc * H * W;
+      const int k = 1 << l;
+      float acc = 0.f;
+      for (int yy = 0; yy < k; ++yy)
+        for (int xx = 0; xx < k; ++xx) acc += gload1(s + (y * k + yy) * W + x * k + xx);
+      v = acc * (1.0f / (float)(k * k));
+    }
+    f2cat[e] = v;
+  }
+}
+
+// dF2 (channels-last [B][N][C]) = sum_l 4^-l * dF2cat[b][cell_l(y >> l, x >> l)][c] over the levels whose cell exists
+__global__ __launch_bounds__(256) void corr_dfmap2_kernel(const float* __restrict__ d2cat, float* __restrict__ d2, VolLayout L, int C,
+                                                          int64_t total) {
+  const int N = L.H * L.W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int64_t bp = e / C;
+    const int pix = (int)(bp % N), b = (int)(bp / N);
+    const int y = pix / L.W, x = pix % L.W;
+    const float* src = d2cat + (int64_t)b * L.P * C + c;
+    float acc = 0.f, wgt = 1.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l < L.nlev) {
+        const int yl = y >> l, xl = x >> l;
+        if (yl < L.h[l] && xl < L.w[l]) acc += wgt * gload1(src + (int64_t)vol_cell(L, l, yl, xl) * C);
+        wgt *= 0.25f;
+      }
+    }
+    d2[e] = acc;
+  }
+}
+
+template <int R>
+int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float* out, int64_t nq, int HW, hipStream_t s) {
+  constexpr int QW = 4;
+  hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW>), dim3((unsigned)((nq + 4 * QW - 1) / (4 * QW))), dim3(256), 0, s, vol, L, co,
+                     out, nq, HW);
+  return fs_launch_status();
+}
+
+}  // namespace
+
+// out: [B, H, W, L*(2r+1)^2] channels-last.  coords element (b, c, pix) at coords[b*bs + c*cs + pix*ps].
+extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* coords, int64_t coords_bs,
+                                            int64_t coords_cs, int64_t coords_ps, float* out, int B, int H, int W, int radius,
+                                            hipStream_t stream) {
+  VolLayout L;
+  if (!vol || !coords || !out || B < 1 || !vol_layout_make(H, W, num_levels, L) || ((uintptr_t)vol % 16)) return FS_ERR_ARG;
+  Coords co{coords, coords_bs, coords_cs, coords_ps};
+  const int64_t nq = (int64_t)B * H * W;
+  if (radius == 4) return launch_lookup<4>(vol, L, co, out, nq, H * W, stream);
+  if (radius == 3) return launch_lookup<3>(vol, L, co, out, nq, H * W, stream);
+  return FS_ERR_ARG;
+}
+
+// dvol [B*H*W][P] (=, or += when accumulate) sum over the n lookups of (d out_t / d V)^T dout_t; dout[t]: [B,H,W,CH]
+// channels-last; coords[t] with per-lookup strides coords_str[3*t + {0,1,2}] = (bs, cs, ps).  n <= 16 per call.
+extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
+                                      float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate,
+                                      hipStream_t stream) {
+  VolLayout L;
+  if (!dout || !coords || !coords_str || !dvol || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) ||
+      ((uintptr_t)dvol % 16))
+    return FS_ERR_ARG;
+  if (radius != 3 && radius != 4) return FS_ERR_ARG;
+  DvolArgs a;
+  a.n = n;
+  for (int t = 0; t < n; ++t) {
+    if (!dout[t] || !coords[t]) return FS_ERR_ARG;
+    a.dout[t] = dout[t];
+    a.co[t] = Coords{coords[t], coords_str[3 * t], coords_str[3 * t + 1], coords_str[3 * t + 2]};
+  }
+  for (int t = n; t < DV_MAXN; ++t) { a.dout[t] = nullptr; a.co[t] = Coords{nullptr, 0, 0, 0}; }
+  const int N1 = 2 * radius + 1, CH = num_levels * N1 * N1;
+  const size_t lds = (size_t)(DV_SEG + n * CH) * 4 + (size_t)n * 4 * sizeof(LevelQ);
+  const unsigned grid = (unsigned)((int64_t)B * H * W);
+  if (radius == 4) hipLaunchKernelGGL(corr_dvol_kernel<4>, dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
+  else hipLaunchKernelGGL(corr_dvol_kernel<3>, dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
+  return fs_launch_status();
+}
+
+extern "C" int fsraft_corr_f2cat(const float* fmap2, float* f2cat, int num_levels, int B, int C, int H, int W, hipStream_t stream) {
+  VolLayout L;
+  if (!fmap2 || !f2cat || B < 1 || C < 1 || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
+  const int64_t total = (int64_t)B * C * L.P;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(corr_f2cat_kernel, dim3(blocks), dim3(256), 0, stream, fmap2, f2cat, L, C, total);
+  return fs_launch_status();
+}
+
+// d2cat [B][P][C] -> d2 [B][H*W][C] (channels-last feature gradient)
+extern "C" int fsraft_corr_dfmap2(const float* d2cat, float* d2, int num_levels, int B, int C, int H, int W, hipStream_t stream) {
+  VolLayout L;
+  if (!d2cat || !d2 || B < 1 || C < 1 || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
+  const int64_t total = (int64_t)B * H * W * C;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(corr_dfmap2_kernel, dim3(blocks), dim3(256), 0, stream, d2cat, d2, L, C, total);
+  return fs_launch_status();
+}

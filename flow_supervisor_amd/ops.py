@@ -85,6 +85,112 @@ def corr_build(fmap1, fmap2, num_levels=4):
     return levels
 
 
+class VolLayout:
+    """Tiled-row layout of the volume pyramid (csrc/corr_layout.hpp, fsraft_vol_layout)."""
+    __slots__ = ("nlev", "H", "W", "P", "h", "w", "th", "tw", "off")
+    _cache = {}
+
+    def __init__(self, H, W, num_levels=4):
+        buf = (ctypes.c_int * 24)()
+        L.check(_lib().fsraft_vol_layout(H, W, num_levels, buf), "vol_layout")
+        v = list(buf)
+        self.nlev, self.H, self.W, self.P = v[:4]
+        self.h, self.w, self.th, self.tw, self.off = v[4:8], v[8:12], v[12:16], v[16:20], v[20:24]
+
+    @classmethod
+    def get(cls, H, W, num_levels=4):
+        k = (H, W, num_levels)
+        if k not in cls._cache:
+            cls._cache[k] = cls(H, W, num_levels)
+        return cls._cache[k]
+
+    def level_view(self, vol, l):
+        """Level l of a tiled volume [rows, P] as the reference's row-major [rows, 1, h_l, w_l] tensor (a copy: API edge)."""
+        rows = vol.shape[0]
+        n = self.th[l] * self.tw[l] * 16
+        t = vol[:, self.off[l]:self.off[l] + n].reshape(rows, self.th[l], self.tw[l], 4, 4).permute(0, 1, 3, 2, 4)
+        return t.reshape(rows, 1, self.th[l] * 4, self.tw[l] * 4)[:, :, :self.h[l], :self.w[l]].contiguous()
+
+
+def corr_build_tiled(fmap1, fmap2, num_levels=4):
+    """-> (vol [B*H*W, P], VolLayout): all-pairs volume + pyramid in the tiled-row layout."""
+    L.require_cuda_f32(fmap1, fmap2)
+    fmap1 = fmap1.contiguous()
+    fmap2 = fmap2.contiguous()
+    B, C, H, W = fmap1.shape
+    lay = VolLayout.get(H, W, num_levels)
+    vol = torch.empty(B * H * W, lay.P, device=fmap1.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_corr_build_tiled(L.ptr(fmap1), L.ptr(fmap2), L.ptr(vol), num_levels, B, C, H, W, L.stream()),
+            "corr_build_tiled")
+    if t:
+        N = H * W
+        t.end("corr_build", e0, 2.0 * B * N * N * C, 4.0 * B * (2 * N * C + N * sum(h * w for h, w in zip(lay.h, lay.w))))
+    return vol, lay
+
+
+def corr_lookup_tiled_fwd(vol, lay, coords, radius):
+    """-> [B,H,W,L*(2r+1)^2] channels-last."""
+    L.require_cuda_f32(vol, coords)
+    B, _, H, W = coords.shape
+    bs, cs, ps = _planar2_strides(coords)
+    ch = lay.nlev * (2 * radius + 1) ** 2
+    out = torch.empty(B, H, W, ch, device=coords.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_corr_lookup_tiled_fwd(L.ptr(vol), lay.nlev, L.ptr(coords), bs, cs, ps, L.ptr(out), B, H, W, radius,
+                                                L.stream()), "corr_lookup_tiled_fwd")
+    if t:
+        t.end("corr_lookup_fwd", e0, 0.0, 4.0 * B * H * W * (lay.nlev * (2 * radius + 2) ** 2 + 2 + ch))
+    return out
+
+
+def corr_dvol_build(douts, coords, lay, B, radius):
+    """Gradient volume [B*H*W, P] of all stashed lookups (douts[t]: [B,H,W,CH] channels-last, coords[t]: [B,2,H,W])."""
+    H, W = lay.H, lay.W
+    dvol = torch.empty(B * H * W, lay.P, device=douts[0].device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    for g0 in range(0, len(douts), 16):
+        ds, cs_ = douts[g0:g0 + 16], coords[g0:g0 + 16]
+        L.require_cuda_f32(*ds, *cs_)
+        n = len(ds)
+        a_d = (ctypes.c_void_p * n)(*[d.data_ptr() for d in ds])
+        a_c = (ctypes.c_void_p * n)(*[c.data_ptr() for c in cs_])
+        st = []
+        for c in cs_:
+            st += list(_planar2_strides(c))
+        a_s = (ctypes.c_int64 * (3 * n))(*st)
+        L.check(_lib().fsraft_corr_dvol_build(ctypes.cast(a_d, L._PP), ctypes.cast(a_c, L._PP), a_s, n, L.ptr(dvol), lay.nlev, B, H,
+                                              W, radius, int(g0 > 0), L.stream()), "corr_dvol_build")
+    if t:   # SURVEY.md 8d: per lookup read dOut + read-modify-write the window taps; plus the zero fill of the dense gradient
+        nl, nq = lay.nlev, B * H * W
+        t.end("corr_lookup_bwd", e0, 0.0, 4.0 * nq * (len(douts) * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2)
+                                                       + sum(h * w for h, w in zip(lay.h, lay.w))))
+    return dvol
+
+
+def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay):
+    """(dfmap1, dfmap2) NCHW from the gradient volume in the tiled-row layout: two GEMMs that contract over whole rows
+    (K = P resp. M = P), the pooling chain folded into the pooled operand f2cat and the un-pool of the feature gradient."""
+    B, C, H, W = fmap1.shape
+    N, P = H * W, lay.P
+    s = 1.0 / math.sqrt(C)
+    f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
+    L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
+    dV = dvol.view(B, N, P)
+    d1 = gemm(f2cat, dV, True, s)                                 # [B,C,N] = s * f2cat . dV^T
+    f1t = nchw_to_nhwc(fmap1).view(B, N, C)
+    if C % 4 == 0 and SPLIT_VOLUME_BWD:
+        d2cat = gemm_tn_split(dV, f1t, s)                         # [B,P,C] = s * dV^T . f1^T   (both operands k-major)
+    else:
+        d2cat = gemm(dV.transpose(1, 2).contiguous(), f1t.transpose(1, 2).contiguous(), True, s)
+    d2 = torch.empty(B, H, W, C, device=fmap1.device, dtype=torch.float32)
+    L.check(_lib().fsraft_corr_dfmap2(L.ptr(d2cat), L.ptr(d2), lay.nlev, B, C, H, W, L.stream()), "corr_dfmap2")
+    return d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
+
+
 def corr_pool_pyramid(level0, num_levels, same=False):
     """level0 [rows, 1, h, w] (or [rows, h, w]) -> [level0, 2x2 averages, ...] with floor sizes (fsraft_corr_pool_pyramid), or,
     same=True, TensorFlow's avg_pool2d(level0, 2^l, 2^l, 'SAME') levels with ceil sizes (fsraft_corr_pool_pyramid_same)."""

@@ -48,6 +48,35 @@ int fsraft_corr_lookup_fwd_same(float* const* levels, int num_levels, const floa
                                 int radius, hipStream_t stream);
 int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int B, int H, int W, hipStream_t stream);
 
+/* ---- the same volume in the tiled-row layout (what CorrBlock runs on) ------------------------------------------------
+ * Every query i = (b, y, x) owns ONE row of P floats: its pyramid levels back to back, each level cut into 4x4-cell
+ * tiles of 64 contiguous bytes (tiles x-fastest; ceil(h_l/4) x ceil(w_l/4) tiles, pad cells beyond the reference's
+ * floor-halved h_l x w_l):
+ *     cell (y, x) of level l  at  row[off[l] + ((y>>2) * tw[l] + (x>>2)) * 16 + (y&3) * 4 + (x&3)]
+ * fsraft_vol_layout fills out[24] = {nlev, H, W, P, h[4], w[4], th[4], tw[4], off[4]}; P % 32 == 0.
+ * A (2r+2)^2 lookup window touches ~0.8 KB of 128-byte lines here against ~1.7 KB in the reference's row-major
+ * [B*N,1,h_l,w_l] tensors (pytorch/core/corr.py:19-27), which fsraft_corr_build above still produces for API twins. */
+int fsraft_vol_layout(int H, int W, int num_levels, int* out);
+/* vol [B*H*W][P] <- all-pairs volume + pyramid (pad cells of V: unspecified, never read by the lookup) */
+int fsraft_corr_build_tiled(const float* fmap1, const float* fmap2, float* vol, int num_levels, int B, int C, int H, int W,
+                            hipStream_t stream);
+/* CorrBlock.__call__ (pytorch/core/corr.py:29-50) on that layout; out [B,H,W,L*(2r+1)^2] channels-last; one wave per query */
+int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs,
+                                 int64_t coords_ps, float* out, int B, int H, int W, int radius, hipStream_t stream);
+/* Gradient volume of n lookups at once (grid_sampler_2d_backward w.r.t. the volume, pytorch/core/utils/utils.py:57-71, for
+ * all iterations of a step): dvol [B*H*W][P] = (or +=, accumulate != 0) sum_t (d out_t / d V)^T dout_t, pad cells zero;
+ * dout[t] is [B,H,W,CH] channels-last, coords[t] element (b, c, pix) at coords[t][b*s0 + c*s1 + pix*s2] with
+ * (s0, s1, s2) = coords_str[3t .. 3t+2].  n <= 16 per call.  Each row is accumulated in LDS and written once. */
+int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
+                           int num_levels, int B, int H, int W, int radius, int accumulate, hipStream_t stream);
+/* Backward of matmul + avg_pool2d chain (pytorch/core/corr.py:21-27, 52-60) without un-pooling the volume gradient:
+ *   f2cat [B][C][P]: level-l cell = mean of fmap2 over its 2^l x 2^l pixels (0 in pad cells), so that
+ *   dF1[b][c][i] = s * sum_p f2cat[b][c][p] * dvol[b][i][p]   (one NT GEMM, K = P)  and
+ *   d2cat[b][p][c] = s * sum_i dvol[b][i][p] * f1[b][i][c]    (one TN GEMM, M = P);
+ *   fsraft_corr_dfmap2: d2 [B][H*W][C] = sum_l 4^-l * d2cat[b][cell_l(y>>l, x>>l)][c] over the levels whose cell exists. */
+int fsraft_corr_f2cat(const float* fmap2, float* f2cat, int num_levels, int B, int C, int H, int W, hipStream_t stream);
+int fsraft_corr_dfmap2(const float* d2cat, float* d2, int num_levels, int B, int C, int H, int W, hipStream_t stream);
+
 /* ---- radius-r pyramid lookup --------------------------------------------------------
  * Replaces CorrBlock.__call__, pytorch/core/corr.py:29-50 (+ bilinear_sampler,
  * core/utils/utils.py:57-71) and TF smurf_corr_block, raft/allfield.py:109-135.

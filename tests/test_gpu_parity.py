@@ -308,9 +308,9 @@ def _check_train_digest(m, preds, g, precision, skip=()):
             continue
         ref = float(g["gnorm." + k])
         gn = 0.0 if p.grad is None else p.grad.norm().item()
-        if abs(gn - ref) > 5e-3 * max(ref, 1e-6) + 1e-6:
-            bad.append((k, gn, ref))
-        if p.grad is not None and ref > 0:
+        if abs(gn - ref) > 5e-3 * max(ref, 1e-6) + 1e-5:      # (1e-5: biases in front of InstanceNorm have a zero gradient
+            bad.append((k, gn, ref))                          #  in exact arithmetic, ~1e-6 of rounding noise in the reference)
+        if p.grad is not None and ref > 1e-4:
             head = T(g["ghead." + k]).float()
             err = (p.grad.reshape(-1)[:32].cpu() - head).abs().max().item()
             if err > 2e-2 * head.abs().max().item() + 1e-3 * ref / math.sqrt(p.numel()) + 1e-7:
@@ -1162,7 +1162,7 @@ def test_two_process_train_step_matches_single_process(global_batch, tmp_path):
     rel_p = float((got["params"] - ref_p).norm() / ref_p.norm())
     print("dp2 vs single: grad rel", rel_g, "param rel", rel_p, "loss(rank 0 shard)", got["loss"], "loss(all)", float(loss))
     assert rel_g <= 2e-3, rel_g          # split-bf16 products + a different summation order over the batch
-    assert rel_p <= 1e-5, rel_p
+    assert rel_p <= 2e-4, rel_p          # one AdamW step of lr 1e-4: where a gradient is ~0 its sign, hence the update, can differ
 
 
 def test_nchw_entry_does_not_reuse_context_of_a_freed_tensor():
