@@ -32,7 +32,7 @@ class ConvDesc(Structure):
         ("aux1", c_void_p), ("ld1", c_int), ("aux2", c_void_p), ("ld2", c_int), ("hid", c_int),
         ("pre", c_void_p), ("ldpre", c_int),
         ("rmask", c_void_p * 3), ("ldmask", c_int * 3), ("maskc", c_int * 3),
-        ("wpk_frag", c_void_p), ("pad_h1", c_int), ("pad_w1", c_int),
+        ("wpk_frag", c_void_p), ("srcr", c_void_p * 3), ("srcrld", c_int * 3), ("pad_h1", c_int), ("pad_w1", c_int),
     ]
 
 
@@ -100,9 +100,14 @@ SIGNATURES = {
     "fsraft_vol_layout": [c_int, c_int, c_int, _IP],
     "fsraft_corr_build_tiled": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_lookup_tiled_fwd": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
-    "fsraft_corr_dvol_build": [_PP, _PP, POINTER(c_int64), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_dvol_build": [_PP, _PP, POINTER(c_int64), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_f2cat": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_dfmap2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_to_records": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, _S],
+    "fsraft_gemm_rec_tn": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                           c_float, c_int, c_int, _S],
+    "fsraft_gemm_rec_nt": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_int,
+                           c_int, _S],
 }
 
 
@@ -132,7 +137,7 @@ def load():
         lib.fsraft_set_build_split(int(bsplit))
     for key, env in ((0, "FSRAFT_CONV_TILE"), (2, "FSRAFT_WGRAD_BLOCKS"), (5, "FSRAFT_CONV_BUF"), (8, "FSRAFT_WGRAD_BUF"), (11, "FSRAFT_WGRAD_BLOCKS_MULTI"), (13, "FSRAFT_CONV_W8"), (14, "FSRAFT_CONV_W8_MIN"), (15, "FSRAFT_WGRAD_W8"),
                      (16, "FSRAFT_WGRAD_PACK"), (17, "FSRAFT_WGRAD_BLOCKS_PACK"), (18, "FSRAFT_CONV_N64"), (20, "FSRAFT_CONV_HALO"),
-                     (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA")):
+                     (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA"), (25, "FSRAFT_CONV_REC")):
         if os.environ.get(env) is not None:
             lib.fsraft_set_tuning(key, int(os.environ[env]))
     wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")

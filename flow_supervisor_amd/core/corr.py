@@ -53,9 +53,10 @@ class _BuildFn(torch.autograd.Function):
         if not st.stash:                            # no lookup contributed a gradient
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None, None
         stash, st.stash = st.stash, []
-        dvol = ops.corr_dvol_build([d for _, d in stash], [c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius)
+        rec = ops.SPLIT_VOLUME_BWD             # (off = the exact-fp32 test mode: fp32 gradient volume, exact GEMMs)
+        dvol = ops.corr_dvol_build([d for _, d in stash], [c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius, records=rec)
         del stash
-        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay)
+        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay, records=rec)
         return d1, d2, None, None, None
 
 

@@ -20,6 +20,7 @@
 // with the pixel dimension split across workgroups and fp32 atomics into the packed layout.
 #include "gemm_core.hpp"
 #include "gemm_core_split.hpp"
+#include "gemm_rec.hpp"
 #include <cstddef>
 #include <type_traits>
 
@@ -161,7 +162,6 @@ struct SplitConvALoader {                 // implicit-GEMM gather of fp32 activa
 // matrix" is expressed by pointing the lane offset past num_records, which makes the hardware return zeros.
 // That removes the 64-bit per-lane address arithmetic and the bounds compares (about 15 VALU per 16-byte chunk)
 // from the k-loop; what is left per chunk is one mask test and one select.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define FS_RSRC_FLAGS 0x00020000            // raw buffer, 32-bit data format (gfx9 family word 3)
 #define FS_OOB 0x80000000u                  // lane offset that always fails the num_records check
 
@@ -529,6 +529,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
 
 // rows of every destination are 16-byte aligned and channels-last (column stride 1)?
 __device__ __forceinline__ bool epilogue_rows_ok(const ConvArgs& a) {
+  bool ok = true;
+  for (int i = 0; i < a.ndst; ++i)
+    ok = ok && a.dst[i].cs == 1 && (a.dst[i].ps & 3) == 0 && (a.dst[i].n0 & 3) == 0 && ((uintptr_t)a.dst[i].p & 15) == 0 &&
+         a.dst[i].bs == a.dst[i].ps * (int64_t)(a.H * a.W);
+  return ok;
+}
+
+bool epilogue_rows_ok_host(const ConvArgs& a) {
   bool ok = true;
   for (int i = 0; i < a.ndst; ++i)
     ok = ok && a.dst[i].cs == 1 && (a.dst[i].ps & 3) == 0 && (a.dst[i].n0 & 3) == 0 && ((uintptr_t)a.dst[i].p & 15) == 0 &&
@@ -1512,6 +1520,9 @@ int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
   return fs_launch_status();
 }
 
+int g_conv_rec = 1;        // record-activation kernel (conv_rec.inc): 0 off, 1 layers with > 128 outputs, 2 every layer it can run
+#include "conv_rec.inc"
+
 int conv_ktot(const int* C, int nsrc, int taps) {
   int k = 0;
   for (int s = 0; s < nsrc; ++s) k += taps * (((C[s] + 31) / 32) * 32);
@@ -1537,6 +1548,7 @@ struct fsraft_conv_desc {
   const float* pre; int ldpre;   // GRU epilogues: addend to the pre-activation (e.g. the context part of the conv), or NULL
   const float* rmask[3]; int ldmask[3]; int maskc[3];   // epi 0, per destination: zero column j < maskc where rmask[m*ldmask+j] <= 0
   const float* wpk_frag;         // wpk_split in fragment order (or NULL): enables the resident-patch 3x3 kernel
+  const float* srcr[3]; int srcrld[3];   // the sources as record tensors (or NULL): enables the LDS-DMA kernel (conv_rec.inc)
   int pad_h1, pad_w1;            // 0: taps centred (KH / 2, KW / 2); else 1 + the top / left padding (even kernel sizes)
 };
 
@@ -1587,6 +1599,20 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
     // GEMM (96 -> 96 at 8x110x256: 249 vs 165 us; 128 -> 128 at 8x55x128: 93 vs 65 us), so only two-group layers come here.
     return d->N > 64 ? launch_halo<2, 2>(h, stream) : launch_halo<2, 1>(h, stream);
+  }
+  if (g_conv_rec && g_conv_split == 1 && d->wpk_split && d->srcr[0] && (d->N > 128 || g_conv_rec == 2) && d->N > 32 &&
+      (d->epi != EPI_PLAIN || epilogue_rows_ok_host(a))) {
+    ConvArgs r = a;
+    bool ok = true;
+    for (int s = 0; s < d->nsrc; ++s) {
+      ok = ok && d->srcr[s] != nullptr;
+      r.src[s].p = d->srcr[s]; r.src[s].ld = d->srcrld[s];
+    }
+    r.wpk = d->wpk_split;
+    if (ok) {
+      const int rc = launch_conv_rec(r, d->epi, stream);
+      if (rc >= 0) return rc;
+    }
   }
   if (d->N <= 32 && d->epi == EPI_PLAIN) return launch_conv<Cfg32>(a, d->epi, stream);
   // 33..64 outputs: half of a 64x128 split tile is padding, still ~2x faster than the exact 64-wide kernel
@@ -1661,6 +1687,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 21) g_conv_halo_min_m = value;
   else if (key == 22) g_wgrad_xcd = value;
   else if (key == 24) g_conv_bdma = value;
+  else if (key == 25) g_conv_rec = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;

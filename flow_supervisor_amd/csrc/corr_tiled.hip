@@ -21,6 +21,7 @@
 //     dF2cat[p][c] = s * sum_i dV[i][p] * f1[i][c]            then dF2 = sum_l 4^-l unpool_l (fsraft_corr_dfmap2)
 // i.e. the un-pool runs on the 7 MB feature gradient instead of the 1 GB volume gradient.
 #include "corr_layout.hpp"
+#include "gemm_rec.hpp"
 
 namespace {
 
@@ -133,7 +134,9 @@ struct DvolArgs {
   int n;
 };
 
-template <int R>
+// REC: the row leaves as records ([32 bf16 hi | 32 bf16 lo] per 32 cells, gemm_rec.hpp) -- the operand format of the two
+// volume-backward GEMMs, which then stage it by LDS-DMA without converting.
+template <int R, bool REC>
 __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate) {
   using S = TL<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -178,8 +181,20 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
   for (int s0 = 0; s0 < L.P; s0 += DV_SEG) {
     const int len = min(DV_SEG, L.P - s0);
     __syncthreads();
-    for (int e = threadIdx.x * 4; e < len; e += 1024)
-      *reinterpret_cast<f32x4*>(seg + e) = accumulate ? gload4(row + s0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (REC && accumulate) {
+      for (int e = threadIdx.x * 8; e < len; e += 2048) {        // hi + lo back to fp32 (exact to ~2^-17 relative)
+        const char* rp = reinterpret_cast<const char*>(row + s0) + (e >> 5) * 128 + (e & 31) * 2;
+        const u32x4 h = __builtin_bit_cast(u32x4, gload4(rp)), l = __builtin_bit_cast(u32x4, gload4(rp + 64));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          seg[e + 2 * i] = __builtin_bit_cast(float, h[i] << 16) + __builtin_bit_cast(float, l[i] << 16);
+          seg[e + 2 * i + 1] = __builtin_bit_cast(float, h[i] & 0xffff0000u) + __builtin_bit_cast(float, l[i] & 0xffff0000u);
+        }
+      }
+    } else {
+      for (int e = threadIdx.x * 4; e < len; e += 1024)
+        *reinterpret_cast<f32x4*>(seg + e) = accumulate ? gload4(row + s0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();
     // one thread per window ROW (lookup t, level l, row wy): s[i] = lerp over y of the (2r+1)^2 gradient, then
     // d[wx] = lerp over x, added to the row's cells of the tiled layout (LDS float adds: windows of different lookups overlap)
@@ -210,7 +225,18 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x * 4; e < len; e += 1024) gstore4(row + s0 + e, *reinterpret_cast<const f32x4*>(seg + e));
+    if (REC) {
+      for (int e = threadIdx.x * 8; e < len; e += 2048) {        // (segments and P are multiples of 32 cells)
+        uint2 h0, l0, h1, l1;
+        rec_split4(seg + e, h0, l0);
+        rec_split4(seg + e + 4, h1, l1);
+        char* rp = reinterpret_cast<char*>(row + s0) + (e >> 5) * 128 + (e & 31) * 2;
+        gstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}));
+        gstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0.x, l0.y, l1.x, l1.y}));
+      }
+    } else {
+      for (int e = threadIdx.x * 4; e < len; e += 1024) gstore4(row + s0 + e, *reinterpret_cast<const f32x4*>(seg + e));
+    }
   }
 }
 
@@ -287,8 +313,9 @@ extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, co
 
 // dvol [B*H*W][P] (=, or += when accumulate) sum over the n lookups of (d out_t / d V)^T dout_t; dout[t]: [B,H,W,CH]
 // channels-last; coords[t] with per-lookup strides coords_str[3*t + {0,1,2}] = (bs, cs, ps).  n <= 16 per call.
+// records != 0: rows are written as [32 bf16 hi | 32 bf16 lo] records (operands of fsraft_gemm_rec_nt / _tn).
 extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
-                                      float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate,
+                                      float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate, int records,
                                       hipStream_t stream) {
   VolLayout L;
   if (!dout || !coords || !coords_str || !dvol || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) ||
@@ -306,8 +333,10 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   const int N1 = 2 * radius + 1, CH = num_levels * N1 * N1;
   const size_t lds = (size_t)(DV_SEG + n * CH) * 4 + (size_t)n * 4 * sizeof(LevelQ);
   const unsigned grid = (unsigned)((int64_t)B * H * W);
-  if (radius == 4) hipLaunchKernelGGL(corr_dvol_kernel<4>, dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
-  else hipLaunchKernelGGL(corr_dvol_kernel<3>, dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
+  if (radius == 4 && records) hipLaunchKernelGGL((corr_dvol_kernel<4, true>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
+  else if (radius == 4) hipLaunchKernelGGL((corr_dvol_kernel<4, false>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
+  else if (records) hipLaunchKernelGGL((corr_dvol_kernel<3, true>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
+  else hipLaunchKernelGGL((corr_dvol_kernel<3, false>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
   return fs_launch_status();
 }
 

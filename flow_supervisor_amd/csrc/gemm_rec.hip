@@ -1,0 +1,198 @@
+// Batched GEMMs on pre-split operands (gemm_rec.hpp) and the kernels that produce records from fp32 data.
+//   NT:  C[b][m][n] (+)= alpha * sum_k A[b][m][k] * B[b][n][k]        A, B: rows of K / 32 records (128 bytes each)
+// Used by the volume backward (dF1 = s * F2cat . dV^T with K = P, pytorch/core/corr.py:52-60's autograd).
+#include "gemm_rec.hpp"
+
+namespace {
+
+using G = RecCfg<256, 128, 4, 2>;
+
+struct RecGemmArgs {
+  const char* A; int64_t sA; unsigned pitchA;      // bytes
+  const char* Bm; int64_t sB; unsigned pitchB;
+  float* C; int64_t ldc, sC;
+  int M, N, KT, ksplit;
+  float alpha; int atomic;
+};
+
+__global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) char lds[G::LDS_BYTES];
+  const int ntn = (g.N + G::BN - 1) / G::BN;
+  const int tile = blockIdx.x, ks = blockIdx.y, b = blockIdx.z;
+  const int n0 = (tile % ntn) * G::BN, m0 = (tile / ntn) * G::BM;
+  const int per = (g.KT + g.ksplit - 1) / g.ksplit;
+  const int kt0 = ks * per, kt = min(per, g.KT - kt0);
+  const char* A = g.A + b * g.sA + (int64_t)m0 * g.pitchA;
+  const char* Bm = g.Bm + b * g.sB + (int64_t)n0 * g.pitchB;
+  const int ar = min(G::BM, g.M - m0), br = min(G::BN, g.N - n0);
+  RecOperands<G> o;
+  rec_setup<G>(o, A, (unsigned)min((int64_t)ar * g.pitchA, (int64_t)0x7fffffff), g.pitchA, ar, Bm,
+               (unsigned)min((int64_t)br * g.pitchB, (int64_t)0x7fffffff), g.pitchB, br);
+  f32x16 acc[G::TM][G::TN];
+#pragma unroll
+  for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  RecPlainA<G> pa;
+#pragma unroll
+  for (int j = 0; j < G::NPA; ++j) pa.va[j] = o.va[j];
+  pa.kt0 = kt0; pa.step = 128u;
+  rec_mainloop<G>(lds, o, pa, kt0, kt, acc);
+  float* C = g.C + b * g.sC;
+#pragma unroll
+  for (int nt = 0; nt < G::TN; ++nt) {
+    const int n = n0 + rec_col<G>(nt);
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int mt = 0; mt < G::TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + rec_row<G>(mt, r);
+        if (m >= g.M) continue;
+        float* p = C + (int64_t)m * g.ldc + n;
+        const float v = g.alpha * acc[mt][nt][r];
+        if (g.atomic) atomicAdd(p, v);
+        else gstore1(p, v);
+      }
+  }
+}
+
+// C[b][m][n] (+)= alpha * sum_k A[b][k][m] * B[b][k][n], both operands k-major rows of records (along m resp. n)
+using GT = RecCfg<256, 128, 4, 2, 3, true>;
+
+__global__ __launch_bounds__(512) void gemm_rec_tn_kernel(RecGemmArgs g, int K) {
+  __shared__ __attribute__((aligned(1024))) char lds[GT::LDS_BYTES];
+  const int ntn = (g.N + GT::BN - 1) / GT::BN;
+  const int tile = blockIdx.x, ks = blockIdx.y, b = blockIdx.z;
+  const int n0 = (tile % ntn) * GT::BN, m0 = (tile / ntn) * GT::BM;
+  const int per = (g.KT + g.ksplit - 1) / g.ksplit;
+  const int kt0 = ks * per, kt = min(per, g.KT - kt0);
+  const char* A = g.A + b * g.sA + (int64_t)m0 * 4;
+  const char* Bm = g.Bm + b * g.sB + (int64_t)n0 * 4;
+  RecOperands<GT> o;
+  rec_setup_km<GT>(o, A, (unsigned)min((int64_t)K * g.pitchA - (int64_t)m0 * 4, (int64_t)0x7fffffff), g.pitchA, Bm,
+                   (unsigned)min((int64_t)K * g.pitchB - (int64_t)n0 * 4, (int64_t)0x7fffffff), g.pitchB);
+  f32x16 acc[GT::TM][GT::TN];
+#pragma unroll
+  for (int i = 0; i < GT::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < GT::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  RecPlainA<GT> pa;
+#pragma unroll
+  for (int j = 0; j < GT::NPA; ++j) pa.va[j] = o.va[j];
+  pa.kt0 = kt0; pa.step = 32u * g.pitchA;
+  rec_mainloop<GT>(lds, o, pa, kt0, kt, acc);
+  float* C = g.C + b * g.sC;
+#pragma unroll
+  for (int nt = 0; nt < GT::TN; ++nt) {
+    const int n = n0 + rec_col<GT>(nt);
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int mt = 0; mt < GT::TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + rec_row<GT>(mt, r);
+        if (m >= g.M) continue;
+        float* p = C + (int64_t)m * g.ldc + n;
+        const float v = g.alpha * acc[mt][nt][r];
+        if (g.atomic) atomicAdd(p, v);
+        else gstore1(p, v);
+      }
+  }
+}
+
+// fp32 rows -> records: dst row = ceil(K / 32) records, the tail of the last one zero
+__global__ __launch_bounds__(256) void to_records_kernel(const float* __restrict__ src, int64_t ld, char* __restrict__ dst, int64_t dpitch,
+                                                         int64_t rows, int K, int KR) {
+  const int64_t total = rows * KR * 4;                       // 8-float units
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int u = (int)(e % (KR * 4));
+    const int64_t row = e / (KR * 4);
+    const int k = u * 8;
+    float v[8];
+    const float* s = src + row * ld + k;
+    if (k + 8 <= K && ((ld & 3) == 0)) {
+      const f32x4 a = gload4(s), b = gload4(s + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = k + i < K ? gload1(s + i) : 0.f;
+    }
+    uint2 h0, l0, h1, l1;
+    rec_split4(v, h0, l0);
+    rec_split4(v + 4, h1, l1);
+    char* d = dst + row * dpitch + (u >> 2) * 128 + (u & 3) * 16;
+    gstore4(d, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}));
+    gstore4(d + 64, __builtin_bit_cast(f32x4, u32x4{l0.x, l0.y, l1.x, l1.y}));
+  }
+}
+
+}  // namespace
+
+// src [rows][K] fp32 (row pitch ld floats) -> dst [rows][ceil(K/32)] records of [32 hi | 32 lo] bf16 (128 bytes), row pitch
+// dst_ld floats (>= 32 * ceil(K/32), a multiple of 32; 0 = dense)
+extern "C" int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, hipStream_t stream) {
+  if (!src || !dst || rows < 1 || K < 1 || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16)) return FS_ERR_ARG;
+  const int KR = (K + 31) / 32;
+  if (dst_ld == 0) dst_ld = (int64_t)KR * 32;
+  if (dst_ld < (int64_t)KR * 32 || dst_ld % 32) return FS_ERR_ARG;
+  const int64_t total = rows * KR * 4;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(to_records_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, (char*)dst, dst_ld * 4, rows, K, KR);
+  return fs_launch_status();
+}
+
+// C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] on record operands: A [batch][M][K/32 records], B [batch][N][K/32 records]
+// (K % 32 == 0; sA / sB: batch strides in BYTES).  ksplit > 1 splits K over workgroups that add their partial tiles with
+// fp32 atomics (C is zeroed first unless accumulate != 0); ksplit == 1 and accumulate == 0: plain stores.
+extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t sA, const void* Bm, int64_t sB, float* C, int64_t ldc, int64_t sC,
+                                  int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream) {
+  if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 32 || (K % 32) || ksplit < 1 || ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16))
+    return FS_ERR_ARG;
+  const int KT = K / 32;
+  if (ksplit > KT) ksplit = KT;
+  const bool atomic = ksplit > 1 || accumulate;
+  if (atomic && !accumulate) {
+    if (ldc == N && sC == (int64_t)M * N) {
+      if (hipMemsetAsync(C, 0, (size_t)batch * M * N * 4, stream) != hipSuccess) return FS_ERR_LAUNCH;
+    } else {
+      for (int b = 0; b < batch; ++b)
+        if (hipMemset2DAsync(C + b * sC, ldc * 4, 0, (size_t)N * 4, M, stream) != hipSuccess) return FS_ERR_LAUNCH;
+    }
+  }
+  RecGemmArgs g{(const char*)A, sA, (unsigned)K * 4u, (const char*)Bm, sB, (unsigned)K * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
+  dim3 grid(ceil_div(N, G::BN) * ceil_div(M, G::BM), ksplit, batch);
+  hipLaunchKernelGGL(gemm_rec_nt_kernel, grid, dim3(512), 0, stream, g);
+  return fs_launch_status();
+}
+
+// C[b][m][n] = alpha * sum_k A[b][k][m] B[b][k][n]: A [batch][K][lda floats] with the records along m, B [batch][K][ldb
+// floats] with the records along n (lda, ldb multiples of 32 covering M resp. N; sA / sB batch strides in BYTES).  K need not
+// be a multiple of 32 (rows beyond K read as zeros).  ksplit / accumulate as fsraft_gemm_rec_nt.
+extern "C" int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
+                                  int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
+                                  hipStream_t stream) {
+  if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 1 || ksplit < 1 || (lda % 32) || (ldb % 32) || lda < M || ldb < N ||
+      ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16))
+    return FS_ERR_ARG;
+  const int KT = (K + 31) / 32;
+  if (ksplit > KT) ksplit = KT;
+  const bool atomic = ksplit > 1 || accumulate;
+  if (atomic && !accumulate) {
+    if (ldc == N && sC == (int64_t)M * N) {
+      if (hipMemsetAsync(C, 0, (size_t)batch * M * N * 4, stream) != hipSuccess) return FS_ERR_LAUNCH;
+    } else {
+      for (int b = 0; b < batch; ++b)
+        if (hipMemset2DAsync(C + b * sC, ldc * 4, 0, (size_t)N * 4, M, stream) != hipSuccess) return FS_ERR_LAUNCH;
+    }
+  }
+  RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
+  dim3 grid(ceil_div(N, GT::BN) * ceil_div(M, GT::BM), ksplit, batch);
+  hipLaunchKernelGGL(gemm_rec_tn_kernel, grid, dim3(512), 0, stream, g, K);
+  return fs_launch_status();
+}

@@ -15,10 +15,10 @@
 // Pipeline: a ring of NSLOT k-tile images, NSLOT - 1 tiles in flight.  The DMAs are issued from inline asm -- the
 // compiler would wait vmcnt(0) before every LDS read that follows an LDS-DMA it knows about -- and retired by a counted
 // s_waitcnt vmcnt(N) followed by ONE raw s_barrier per k-tile:
-//     wait(own pieces of tile t landed) ; barrier (=> tile t complete, slot of tile t-1 free) ; issue tile t+NSLOT-1 ;
-//     fragment reads + 3 x MFMA on tile t.
+// (schedule: see rec_mainloop).
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -40,8 +40,12 @@ __device__ __forceinline__ void rec_wait_vm() {
 }
 
 // 8 waves, WM x WN of them, each computing (BM / WM) x (BN / WN) of the BM x BN tile out of [row][128-byte record] images
-template <int BM_, int BN_, int WM_, int WN_, int NSLOT_ = 3>
+// KM_ = false: both operands are rows of records along k ("NT": C = A . B^T).  KM_ = true: both operands are k-major ("TN":
+// C[m][n] = sum_k A[k][m] B[k][n]; row k of A holds records along m) -- the LDS images are then [32 k][BM * 4 bytes] and
+// the MFMA fragments are gathered with ds_read_b64_tr_b16 (the hardware transpose read).
+template <int BM_, int BN_, int WM_, int WN_, int NSLOT_ = 3, bool KM_ = false>
 struct RecCfg {
+  static constexpr bool KM = KM_;
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSLOT = NSLOT_, NT = WM_ * WN_ * 64;
   static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
   static constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, SLOT = A_BYTES + B_BYTES;
@@ -64,6 +68,7 @@ template <class Cfg>
 struct RecOperands {
   u32x4 da, db;                          // descriptors of the A / B row blocks of this workgroup
   unsigned va[Cfg::NPA], vb[Cfg::NPB];   // per-lane source offsets of this wave's pieces
+  unsigned b_step;                       // bytes one k-tile advances in B (128 for rows of records, 32 * pitch for k-major)
 };
 
 template <class Cfg>
@@ -72,72 +77,200 @@ __device__ __forceinline__ void rec_setup(RecOperands<Cfg>& o, const void* A, un
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   o.da = rec_desc(A, a_bytes);
   o.db = rec_desc(Bm, b_bytes);
+  o.b_step = 128u;
 #pragma unroll
   for (int j = 0; j < Cfg::NPA; ++j) o.va[j] = rec_piece_voff(wave + Cfg::NWAVE * j, lane, a_rows, a_pitch);
 #pragma unroll
   for (int j = 0; j < Cfg::NPB; ++j) o.vb[j] = rec_piece_voff(wave + Cfg::NWAVE * j, lane, b_rows, b_pitch);
 }
 
-// acc += A[rows][kt0 .. kt0+KT) . B[rows][same]^T over KT k-tiles (records) of both operands.
+// k-major operand: the tile image is [32 k][ROWB bytes] (ROWB = 4 * tile width: the records of one k-row), piece p holds
+// 1024 / ROWB consecutive k-rows, 16-byte chunk c of k-row r lives at chunk c ^ ((r & 3) << 2) -- the four rows of a
+// transposed-read block then sit on four different 64-byte bank groups.  Rows at or beyond K fall outside the
+// descriptor (its size is K * pitch minus the column offset of the tile) and read as zeros.
+template <int ROWB>
+__device__ __forceinline__ unsigned rec_piece_voff_km(int piece, int lane, unsigned pitch) {
+  constexpr int RPP = 1024 / ROWB;
+  const int row = piece * RPP + (lane * 16) / ROWB, pc = (lane * 16 % ROWB) / 16;
+  return (unsigned)row * pitch + (unsigned)(pc ^ ((row & 3) << 2)) * 16u;
+}
 template <class Cfg>
-__device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOperands<Cfg>& o, int kt0, int KT,
+__device__ __forceinline__ void rec_setup_km(RecOperands<Cfg>& o, const void* A, unsigned a_bytes, unsigned a_pitch, const void* Bm,
+                                             unsigned b_bytes, unsigned b_pitch) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  o.da = rec_desc(A, a_bytes);
+  o.db = rec_desc(Bm, b_bytes);
+  o.b_step = 32u * b_pitch;
+#pragma unroll
+  for (int j = 0; j < Cfg::NPA; ++j) o.va[j] = rec_piece_voff_km<Cfg::BM * 4>(wave + Cfg::NWAVE * j, lane, a_pitch);
+#pragma unroll
+  for (int j = 0; j < Cfg::NPB; ++j) o.vb[j] = rec_piece_voff_km<Cfg::BN * 4>(wave + Cfg::NWAVE * j, lane, b_pitch);
+}
+
+typedef short rec_s16x4 __attribute__((ext_vector_type(4)));
+// 8 consecutive k of this lane's column out of a k-major image: two transposed 4 x 16 blocks, rows k .. k+3 and k+4 .. k+7
+__device__ __forceinline__ bf16x8r rec_tr_frag(const char* p, int pitch) {
+  const rec_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rec_s16x4 __attribute__((address_space(3)))*)(p));
+  const rec_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rec_s16x4 __attribute__((address_space(3)))*)(p + 4 * pitch));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8r, v);
+}
+
+// Where the A pieces of k-tile t come from.  Plain GEMM: a fixed per-lane offset and the k-tile in the scalar offset.
+// (The implicit-GEMM convolution supplies its own: per-tile (source, tap, chunk) from a table, per-lane tap validity.)
+template <class Cfg>
+struct RecPlainA {
+  unsigned va[Cfg::NPA];
+  int kt0;
+  unsigned step;                         // bytes per k-tile (128, or 32 * pitch for a k-major operand)
+  struct Tile { unsigned soff; };
+  __device__ __forceinline__ Tile tile(int t) const { return Tile{(unsigned)(kt0 + t) * step}; }
+  __device__ __forceinline__ unsigned voff(const Tile&, int j) const { return va[j]; }
+};
+
+// acc += A(k-tiles 0 .. KT-1 as described by asrc) . B[rows][kt0 .. kt0+KT)^T
+//
+// Schedule: three ring slots, two k-tiles in flight, ONE barrier per k-tile placed in the MIDDLE of a tile's MFMAs:
+//   read k-half 1 of tile t | 12 MFMAs on k-half 0 (the B pieces of tile t+2 issued in between) | own reads done, own
+//   pieces of tile t+1 landed | barrier (tile t+1 complete, nobody reads tile t any more) | read k-half 0 of tile t+1 |
+//   12 MFMAs on k-half 1 of tile t (the A pieces of tile t+3 issued in between, into tile t's slot).
+// Every group of eight fragment reads has twelve MFMAs (~400 cycles) to land behind, and the DMA pieces -- each costs its
+// wave 60-180 issue cycles -- are spread between MFMAs instead of piling up behind the barrier where both waves of a SIMD
+// would issue them at the same time.  The loop is unrolled three times so that ring slots, LDS offsets and wait counts
+// are compile-time constants: the two waves of a SIMD share its issue slots (~144 non-MFMA instructions per wave and
+// k-tile at full matrix-pipe rate), so every scalar modulo / address add taken out of the loop counts.
+template <class Cfg, class ASrc = RecPlainA<Cfg>>
+__device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOperands<Cfg>& o, const ASrc& asrc, int kt0, int KT,
                                              f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
-  constexpr int NP = Cfg::NPA + Cfg::NPB;
+  constexpr int NPA = Cfg::NPA, NPB = Cfg::NPB;
   static_assert(Cfg::NSLOT == 3, "the wait counts below are written for two tiles in flight");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  const unsigned wbase = (unsigned)(uintptr_t)lds + (unsigned)wave * 1024u;      // this wave's first piece of slot 0
 
-  auto issue = [&](int t) {                      // k-tile t (relative) -> ring slot t % 3; t >= KT: nothing to fetch (the
-    const unsigned slot = lds0 + (unsigned)(t % 3) * Cfg::SLOT;   // descriptor range check turns the pieces into zero fills)
-    const unsigned soff = t < KT ? (unsigned)(kt0 + t) * 128u : 0x80000000u;
+  // A pieces of k-tile t into ring slot SL (t >= KT: a scalar offset beyond the descriptor's range = zero fill)
+  auto issue_a = [&](int t, int SL, int j, const typename ASrc::Tile& ts) {
+    rec_dma16(asrc.voff(ts, j), o.da, t < KT ? ts.soff : 0x80000000u, wbase + (unsigned)(SL * Cfg::SLOT + Cfg::NWAVE * j * 1024));
+  };
+  auto issue_b = [&](int t, int SL, int j) {
+    rec_dma16(o.vb[j], o.db, t < KT ? (unsigned)(kt0 + t) * o.b_step : 0x80000000u,
+              wbase + (unsigned)(SL * Cfg::SLOT + Cfg::A_BYTES + Cfg::NWAVE * j * 1024));
+  };
+  auto issue_all = [&](int t, int SL) {
+    const typename ASrc::Tile ts = asrc.tile(t);
 #pragma unroll
-    for (int j = 0; j < Cfg::NPA; ++j) rec_dma16(o.va[j], o.da, soff, slot + (unsigned)(wave + Cfg::NWAVE * j) * 1024u);
+    for (int j = 0; j < NPA; ++j) issue_a(t, SL, j, ts);
 #pragma unroll
-    for (int j = 0; j < Cfg::NPB; ++j)
-      rec_dma16(o.vb[j], o.db, soff, slot + Cfg::A_BYTES + (unsigned)(wave + Cfg::NWAVE * j) * 1024u);
+    for (int j = 0; j < NPB; ++j) issue_b(t, SL, j);
   };
 
-  // fragment addressing: this lane's row of the wave's sub-tile; slot of (k-step s, hi / lo) = 2 s + lh (+ 4); rows 32 apart
-  // share (row >> 1) & 7, so the swizzled slot offsets are per-lane constants
+  struct Frag { bf16x8r ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN]; };
+  // fragment addressing.  Rows of records: this lane's row of the wave's sub-tile; slot of (k-step s, hi / lo) = 2 s + lh
+  // (+ 4); rows 32 apart share (row >> 1) & 7, so the swizzled slot offsets are per-lane constants.  k-major: lane 4 q + p
+  // of a 16-lane group supplies k-row q (+ 8 lh + 16 s), columns 16 gb + 4 p .. + 3 of the 32-column block; the chunk
+  // swizzle depends on q only, and the lo half of a record is the hi address ^ 64.
   const int ra = wm * (Cfg::TM * 32) + l31, rb = wn * (Cfg::TN * 32) + l31;
   const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
-
-  if (KT <= 0) return;
-  issue(0);
-  issue(1);
-  for (int t = 0; t < KT; ++t) {
-    rec_wait_vm<NP>();                           // all but the youngest tile's pieces of this wave have landed
-    __builtin_amdgcn_s_barrier();                // ... of every wave: tile t complete, and everyone is done reading tile t - 1
-    issue(t + 2);                                // into the slot tile t - 1 occupied
-    const char* cur = lds + (t % 3) * Cfg::SLOT;
-    const char* As = cur + ra * 128;
-    const char* Bs = cur + Cfg::A_BYTES + rb * 128;
+  const int gb = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
+  constexpr int PA = Cfg::BM * 4, PB = Cfg::BN * 4;
+  auto km_off = [&](int col) {             // byte offset of columns col .. col+3 (hi) inside k-row (8 lh + q) of an image
+    const int byte = (col >> 5) * 128 + (col & 31) * 2;
+    return (((byte >> 4) ^ (q << 2)) << 4) + (byte & 15);
+  };
+  const char* fa = Cfg::KM ? lds + (8 * lh + q) * PA : lds + ra * 128;
+  const char* fb = Cfg::KM ? lds + Cfg::A_BYTES + (8 * lh + q) * PB : lds + Cfg::A_BYTES + rb * 128;
+  int ka[Cfg::TM], kb[Cfg::TN];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8r ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN];
+  for (int mt = 0; mt < Cfg::TM; ++mt) ka[mt] = km_off(wm * (Cfg::TM * 32) + mt * 32 + 16 * gb + 4 * p4);
+#pragma unroll
+  for (int nt = 0; nt < Cfg::TN; ++nt) kb[nt] = km_off(wn * (Cfg::TN * 32) + nt * 32 + 16 * gb + 4 * p4);
+
+  auto read_frag = [&](int SL, int s, Frag& f) {
+    if constexpr (Cfg::KM) {
 #pragma unroll
       for (int mt = 0; mt < Cfg::TM; ++mt) {
-        ah[mt] = *reinterpret_cast<const bf16x8r*>(As + mt * 32 * 128 + (((2 * s + lh) ^ sa) << 4));
-        al[mt] = *reinterpret_cast<const bf16x8r*>(As + mt * 32 * 128 + (((4 + 2 * s + lh) ^ sa) << 4));
+        f.ah[mt] = rec_tr_frag(fa + SL * Cfg::SLOT + s * 16 * PA + ka[mt], PA);
+        f.al[mt] = rec_tr_frag(fa + SL * Cfg::SLOT + s * 16 * PA + (ka[mt] ^ 64), PA);
       }
 #pragma unroll
       for (int nt = 0; nt < Cfg::TN; ++nt) {
-        bh[nt] = *reinterpret_cast<const bf16x8r*>(Bs + nt * 32 * 128 + (((2 * s + lh) ^ sb) << 4));
-        bl[nt] = *reinterpret_cast<const bf16x8r*>(Bs + nt * 32 * 128 + (((4 + 2 * s + lh) ^ sb) << 4));
+        f.bh[nt] = rec_tr_frag(fb + SL * Cfg::SLOT + s * 16 * PB + kb[nt], PB);
+        f.bl[nt] = rec_tr_frag(fb + SL * Cfg::SLOT + s * 16 * PB + (kb[nt] ^ 64), PB);
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < Cfg::TM; ++mt) {
+        f.ah[mt] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((2 * s + lh) ^ sa) << 4));
+        f.al[mt] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((4 + 2 * s + lh) ^ sa) << 4));
       }
 #pragma unroll
-      for (int mt = 0; mt < Cfg::TM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < Cfg::TN; ++nt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-        }
+      for (int nt = 0; nt < Cfg::TN; ++nt) {
+        f.bh[nt] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((2 * s + lh) ^ sb) << 4));
+        f.bl[nt] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((4 + 2 * s + lh) ^ sb) << 4));
+      }
     }
+  };
+  // the 3 TM TN MFMAs of one k-half with NPIECE DMA pieces spaced evenly between the accumulator groups
+  auto mfmas = [&](const Frag& f, auto&& piece, int npiece) {
+    constexpr int NM = Cfg::TM * Cfg::TN;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::TM; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < Cfg::TN; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+        const int i = mt * Cfg::TN + nt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < npiece && (k * NM) / npiece == i) {
+            __builtin_amdgcn_sched_barrier(0);
+            piece(k);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+  };
+
+  if (KT <= 0) return;
+  issue_all(0, 0);
+  issue_all(1, 1);
+  {                                              // tile 2: A pieces now, B pieces inside the first MFMA group (as in steady state)
+    const typename ASrc::Tile ts = asrc.tile(2);
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) issue_a(2, 2, j, ts);
   }
-  rec_wait_vm<0>();                              // the two zero-fill tiles issued past the end
+  rec_wait_vm<NPA + NPA + NPB>();                // tile 0 landed (tile 1 and the A pieces of tile 2 may be in flight)
+  __builtin_amdgcn_s_barrier();
+  Frag f0, f1;
+  read_frag(0, 0, f0);
+
+  // one k-tile: tile t lives in slot SL, tile t+1 in slot (SL + 1) % 3
+  auto step = [&](int t, auto SLc) {
+    constexpr int SL = decltype(SLc)::value, SN = (SL + 1) % 3, SP = (SL + 2) % 3;
+    read_frag(SL, 1, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f0, [&](int k) { issue_b(t + 2, SP, k); }, NPB);            // B pieces of tile t+2 (its A pieces went last step)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    rec_wait_vm<NPA + NPB>();                    // outstanding: tile t+1, tile t+2 -> leave tile t+2 in flight
+    __builtin_amdgcn_s_barrier();
+    read_frag(SN, 0, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    const typename ASrc::Tile ts = asrc.tile(t + 3);
+    mfmas(f1, [&](int k) { issue_a(t + 3, SL, k, ts); }, NPA);        // A pieces of tile t+3 into the slot tile t leaves
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int t = 0; t < KT; t += 3) {
+    step(t, std::integral_constant<int, 0>{});
+    if (t + 1 >= KT) break;
+    step(t + 1, std::integral_constant<int, 1>{});
+    if (t + 2 >= KT) break;
+    step(t + 2, std::integral_constant<int, 2>{});
+  }
+  rec_wait_vm<0>();                              // zero-fill pieces issued past the end
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
 

@@ -146,8 +146,9 @@ def corr_lookup_tiled_fwd(vol, lay, coords, radius):
     return out
 
 
-def corr_dvol_build(douts, coords, lay, B, radius):
-    """Gradient volume [B*H*W, P] of all stashed lookups (douts[t]: [B,H,W,CH] channels-last, coords[t]: [B,2,H,W])."""
+def corr_dvol_build(douts, coords, lay, B, radius, records=False):
+    """Gradient volume [B*H*W, P] of all stashed lookups (douts[t]: [B,H,W,CH] channels-last, coords[t]: [B,2,H,W]);
+    records=True: rows of [32 hi | 32 lo] bf16 records (the operand format of gemm_rec_nt / gemm_rec_tn)."""
     H, W = lay.H, lay.W
     dvol = torch.empty(B * H * W, lay.P, device=douts[0].device, dtype=torch.float32)
     t = TIMER
@@ -163,7 +164,7 @@ def corr_dvol_build(douts, coords, lay, B, radius):
             st += list(_planar2_strides(c))
         a_s = (ctypes.c_int64 * (3 * n))(*st)
         L.check(_lib().fsraft_corr_dvol_build(ctypes.cast(a_d, L._PP), ctypes.cast(a_c, L._PP), a_s, n, L.ptr(dvol), lay.nlev, B, H,
-                                              W, radius, int(g0 > 0), L.stream()), "corr_dvol_build")
+                                              W, radius, int(g0 > 0), int(records), L.stream()), "corr_dvol_build")
     if t:   # per lookup read dOut + read-modify-write the window taps; plus the zero fill of the dense gradient
         nl, nq = lay.nlev, B * H * W
         t.end("corr_lookup_bwd", e0, 0.0, 4.0 * nq * (len(douts) * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2)
@@ -171,21 +172,26 @@ def corr_dvol_build(douts, coords, lay, B, radius):
     return dvol
 
 
-def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay):
+def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False):
     """(dfmap1, dfmap2) NCHW from the gradient volume in the tiled-row layout: two GEMMs that contract over whole rows
-    (K = P resp. M = P), the pooling chain folded into the pooled operand f2cat and the un-pool of the feature gradient."""
+    (K = P resp. M = P), the pooling chain folded into the pooled operand f2cat and the un-pool of the feature gradient.
+    records=True: dvol holds records; both GEMMs run on the LDS-DMA record core (gemm_rec.hpp)."""
     B, C, H, W = fmap1.shape
     N, P = H * W, lay.P
     s = 1.0 / math.sqrt(C)
     f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
     L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
     dV = dvol.view(B, N, P)
-    d1 = gemm(f2cat, dV, True, s)                                 # [B,C,N] = s * f2cat . dV^T
     f1t = nchw_to_nhwc(fmap1).view(B, N, C)
-    if C % 4 == 0 and SPLIT_VOLUME_BWD:
-        d2cat = gemm_tn_split(dV, f1t, s)                         # [B,P,C] = s * dV^T . f1^T   (both operands k-major)
+    if records:
+        d1 = gemm_rec_nt(to_records(f2cat), dV, s)                # [B,C,N] = s * f2cat . dV^T
+        d2cat = gemm_rec_tn(dV, to_records(f1t), P, C, s, ksplit=2)   # [B,P,C] = s * dV^T . f1^T
     else:
-        d2cat = gemm(dV.transpose(1, 2).contiguous(), f1t.transpose(1, 2).contiguous(), True, s)
+        d1 = gemm(f2cat, dV, True, s)
+        if C % 4 == 0 and SPLIT_VOLUME_BWD:
+            d2cat = gemm_tn_split(dV, f1t, s)                     # (both operands k-major)
+        else:
+            d2cat = gemm(dV.transpose(1, 2).contiguous(), f1t.transpose(1, 2).contiguous(), True, s)
     d2 = torch.empty(B, H, W, C, device=fmap1.device, dtype=torch.float32)
     L.check(_lib().fsraft_corr_dfmap2(L.ptr(d2cat), L.ptr(d2), lay.nlev, B, C, H, W, L.stream()), "corr_dfmap2")
     return d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
@@ -292,6 +298,57 @@ def gemm(A, Bm, trans_b, alpha=1.0, out=None, accumulate=False):
     L.check(_lib().fsraft_gemm_f32(L.ptr(A), K, M * K, L.ptr(Bm), Bm.shape[2], Bm.shape[1] * Bm.shape[2], L.ptr(out),
                                    N, M * N, b, M, N, K, int(trans_b), float(alpha), int(accumulate), L.stream()),
             "gemm_f32")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
+    return out
+
+
+def rec_pitch(C):
+    """Row pitch (floats) of an activation record tensor with C channels: whole records, and an odd number of 128-byte lines
+    per row -- with an even count (128 channels = 512 B, 256 = 1 KB) the 256 rows of a k-tile hit every 4th / 8th line,
+    i.e. a fraction of the L2 channels, and every workgroup does so at the same time."""
+    r = (C + 31) // 32
+    return 32 * (r | 1)
+
+
+def to_records(x, pad=False):
+    """x [..., K] fp32 contiguous -> [..., ceil32(K)] "records" (same dtype container: every 32 floats of a row are replaced
+    by [32 bf16 hi | 32 bf16 lo]; the padded tail of the last record is zero).  pad=True: row pitch rec_pitch(K)."""
+    L.require_cuda_f32(x)
+    x = x.contiguous()
+    K = x.shape[-1]
+    rows = x.numel() // K
+    ldr = rec_pitch(K) if pad else (K + 31) // 32 * 32
+    out = torch.empty(*x.shape[:-1], ldr, device=x.device, dtype=torch.float32)
+    L.check(_lib().fsraft_to_records(L.ptr(x), K, L.ptr(out), ldr, rows, K, L.stream()), "to_records")
+    return out
+
+
+def gemm_rec_nt(Ar, Br, alpha=1.0, ksplit=1, out=None, accumulate=False):
+    """C[b] = alpha * A[b] @ B[b]^T on record operands Ar [b,M,K], Br [b,N,K] (outputs of to_records / record producers)."""
+    b, M, K = Ar.shape
+    N = Br.shape[1]
+    if out is None:
+        out = torch.empty(b, M, N, device=Ar.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_gemm_rec_nt(L.ptr(Ar), M * K * 4, L.ptr(Br), N * K * 4, L.ptr(out), N, M * N, b, M, N, K, float(alpha),
+                                      int(ksplit), int(accumulate), L.stream()), "gemm_rec_nt")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
+    return out
+
+
+def gemm_rec_tn(Ar, Br, M, N, alpha=1.0, ksplit=1, out=None, accumulate=False):
+    """C[b] = alpha * A[b]^T @ B[b] on k-major record operands Ar [b,K,lda] (records along m), Br [b,K,ldb] (records along n)."""
+    b, K, lda = Ar.shape
+    ldb = Br.shape[2]
+    if out is None:
+        out = torch.empty(b, M, N, device=Ar.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_gemm_rec_tn(L.ptr(Ar), lda, K * lda * 4, L.ptr(Br), ldb, K * ldb * 4, L.ptr(out), N, M * N, b, M, N, K,
+                                      float(alpha), int(ksplit), int(accumulate), L.stream()), "gemm_rec_tn")
     if t:
         t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
     return out
@@ -600,12 +657,14 @@ def unpack_weight_grad(dwpk, shape, srcC, out=None, accumulate=False):
 
 
 class V:
-    """Channels [off, off+C) of a channels-last buffer [B,H,W,ld] (pitch = the buffer's ld)."""
-    __slots__ = ("t", "off", "C", "ld")
+    """Channels [off, off+C) of a channels-last buffer [B,H,W,ld] (pitch = the buffer's ld).  `rec`: optionally the same
+    buffer as records (to_records(t): [B,H,W,ceil32(ld)]) for the LDS-DMA convolution kernel; needs off % 32 == 0."""
+    __slots__ = ("t", "off", "C", "ld", "rec")
 
-    def __init__(self, t, C=None, off=0):
+    def __init__(self, t, C=None, off=0, rec=None):
         self.t, self.off, self.ld = t, off, t.shape[-1]
         self.C = (t.shape[-1] - off) if C is None else C
+        self.rec = rec if (rec is not None and off % 32 == 0) else None
         assert off % 4 == 0 and self.ld % 4 == 0, "channel slices must stay 16-byte aligned"
 
     @property
@@ -644,6 +703,8 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     d = L.ConvDesc()
     for i, v in enumerate(srcs):
         d.src[i] = v.ptr; d.srcC[i] = v.C; d.srcld[i] = v.ld
+        if v.rec is not None:
+            d.srcr[i] = v.rec.data_ptr() + 4 * v.off; d.srcrld[i] = v.rec.shape[-1]
     d.nsrc = len(srcs)
     d.wpk = wpk.data_ptr()
     d.wpk_split = wpk_split.data_ptr() if wpk_split is not None else None

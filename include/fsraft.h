@@ -66,9 +66,10 @@ int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* 
 /* Gradient volume of n lookups at once (grid_sampler_2d_backward w.r.t. the volume, pytorch/core/utils/utils.py:57-71, for
  * all iterations of a step): dvol [B*H*W][P] = (or +=, accumulate != 0) sum_t (d out_t / d V)^T dout_t, pad cells zero;
  * dout[t] is [B,H,W,CH] channels-last, coords[t] element (b, c, pix) at coords[t][b*s0 + c*s1 + pix*s2] with
- * (s0, s1, s2) = coords_str[3t .. 3t+2].  n <= 16 per call.  Each row is accumulated in LDS and written once. */
+ * (s0, s1, s2) = coords_str[3t .. 3t+2].  n <= 16 per call.  Each row is accumulated in LDS and written once; records != 0:
+ * as [32 bf16 hi | 32 bf16 lo] records, the operand format of fsraft_gemm_rec_nt / _tn below. */
 int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
-                           int num_levels, int B, int H, int W, int radius, int accumulate, hipStream_t stream);
+                           int num_levels, int B, int H, int W, int radius, int accumulate, int records, hipStream_t stream);
 /* Backward of matmul + avg_pool2d chain (pytorch/core/corr.py:21-27, 52-60) without un-pooling the volume gradient:
  *   f2cat [B][C][P]: level-l cell = mean of fmap2 over its 2^l x 2^l pixels (0 in pad cells), so that
  *   dF1[b][c][i] = s * sum_p f2cat[b][c][p] * dvol[b][i][p]   (one NT GEMM, K = P)  and
@@ -140,6 +141,10 @@ typedef struct fsraft_conv_desc {
                                                                  [lane = 32 * (k half) + row][16 B], rows zero-padded to 32;
                                                                  enables the resident-patch 3x3 kernel (one source, 33..64
                                                                  channels in, N <= 64, large B*H*W).  NULL: never used */
+  const float* srcr[3]; int srcrld[3];                        /* optional: the same sources as RECORD tensors (fsraft_to_records of
+                                                                 the whole channels-last buffer; pointer = its channel slice, which
+                                                                 must start at a multiple of 32 channels; pitch in floats): the
+                                                                 operand is then staged by LDS-DMA with no conversion.  NULL: unused */
   int pad_h1, pad_w1;                                         /* 0: taps centred (KH/2, KW/2 rows / columns above / left of
                                                                  the output pixel); else 1 + that count -- even kernel sizes:
                                                                  a 2x2 kernel has pad 1 forward and pad 0 in its data gradient */
@@ -193,6 +198,25 @@ int fsraft_gemm_tn_split(const float* A, int64_t lda, int64_t sA, const float* B
                          hipStream_t stream);
 /* 1 (default): fsraft_gemm_f32 with trans_b uses the split-bf16 core when its operands are 16-byte aligned */
 int fsraft_set_gemm_split(int on);
+
+/* ---- GEMM on pre-split ("record") operands -------------------------------------------------------------------------
+ * A record is 32 consecutive k of one row as [32 x bf16 hi | 32 x bf16 lo] (hi = bf16(x), lo = bf16(x - hi)): 128 bytes, the
+ * bytes the 32 floats took.  Producers split once; the GEMM stages by LDS-DMA (no conversion, no VGPR round trip) and
+ * evaluates a_hi b_hi + a_hi b_lo + a_lo b_hi on bf16 MFMA with fp32 accumulation (csrc/gemm_rec.hpp).
+ * fsraft_to_records: src [rows][K] fp32 (pitch ld floats) -> dst [rows][ceil(K/32)] records (tail of the last record zero),
+ * row pitch dst_ld floats (0 = dense; activation tensors use an ODD number of 128-byte lines per row so that the rows of a
+ * k-tile spread over all L2 channels instead of every 4th / 8th line).
+ * fsraft_gemm_rec_nt: C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k]; A [batch][M][K/32] records, B [batch][N][K/32]
+ * records, K % 32 == 0, sA / sB batch strides in BYTES.  ksplit > 1: K split over workgroups, partial tiles added with fp32
+ * atomics (C zeroed first unless accumulate != 0). */
+int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, hipStream_t stream);
+int fsraft_gemm_rec_nt(const void* A, int64_t sA, const void* Bm, int64_t sB, float* C, int64_t ldc, int64_t sC, int batch,
+                       int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream);
+/* C[b][m][n] = alpha * sum_k A[b][k][m] B[b][k][n]: both operands k-major, A [batch][K][lda floats] with the records along m,
+ * B [batch][K][ldb floats] with the records along n (lda, ldb multiples of 32; K arbitrary).  Fragments are gathered with the
+ * transposed LDS read (ds_read_b64_tr_b16). */
+int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
+                       int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream);
 
 /* ---- GMA variant (config 5) --------------------------------------------------------------
  * Attention.forward, pytorch/core/gma.py:54-76: sim = scale * q k^T runs on fsraft_gemm_f32 (trans_b), then this

@@ -80,7 +80,14 @@ t_new = timeit(lambda: ops.corr_dvol_build(douts, coords, lay, B, r), 5)
 lb = 4.0 * nq * (T * (324 + 2 + 800) + P)
 print(f"lookup bwd (x{T}) zero+RMW {t_old*1e6:8.1f} us   dvol_build {t_new*1e6:8.1f} us   ({lb/t_new/1e9:6.0f} GB/s algorithmic, {lb/t_new/8e12*100:4.1f} %)")
 
+dvol_r = ops.corr_dvol_build(douts, coords, lay, B, r, records=True)
+t_rec = timeit(lambda: ops.corr_dvol_build(douts, coords, lay, B, r, records=True), 5)
+print(f"                dvol_build as records {t_rec*1e6:8.1f} us")
 d1o, d2o = ops.corr_build_bwd(f1, f2, [d.clone() for d in dlv])
+d1r, d2r = ops.corr_build_bwd_tiled(f1, f2, dvol_r, lay, records=True)
+print("record path: dfmap1 rel err", ((d1o - d1r).norm() / d1o.norm()).item(), " dfmap2 rel err", ((d2o - d2r).norm() / d2o.norm()).item())
+t_r = timeit(lambda: ops.corr_build_bwd_tiled(f1, f2, dvol_r, lay, records=True), 3)
+print(f"                build bwd on the record GEMMs {t_r*1e6:8.1f} us")
 d1n, d2n = ops.corr_build_bwd_tiled(f1, f2, dvol, lay)
 print("dfmap1 rel err", ((d1o - d1n).norm() / d1o.norm()).item(), " dfmap2 rel err", ((d2o - d2n).norm() / d2o.norm()).item())
 t_old = timeit(lambda: ops.corr_build_bwd(f1, f2, [d.clone() for d in dlv]), 3) - timeit(lambda: [d.clone() for d in dlv], 3)
