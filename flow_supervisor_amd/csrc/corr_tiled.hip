@@ -134,43 +134,42 @@ struct DvolArgs {
   int n;
 };
 
-// REC: the row leaves as records ([32 bf16 hi | 32 bf16 lo] per 32 cells, gemm_rec.hpp) -- the operand format of the two
-// volume-backward GEMMs, which then stage it by LDS-DMA without converting.
-template <int R, bool REC>
-__global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate) {
+// One workgroup = one (query, job): a job is a run of whole pyramid levels [l0, l1] whose cells fit the LDS segment
+// (level 0 alone; levels 1..3 together), so two launches cover a row.  REC: the run leaves as records ([32 bf16 hi | 32
+// bf16 lo] per 32 cells, gemm_rec.hpp) -- the operand format of the two volume-backward GEMMs, which then stage it by
+// LDS-DMA without converting.  CLIP: the run is longer than the segment (very large images) and is processed in pieces.
+template <int R, bool REC, bool CLIP>
+__global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate, int l0,
+                                                        int l1) {
   using S = TL<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* seg = smem;                                   // [DV_SEG]
-  float* g = smem + DV_SEG;                            // [n][CH]
-  const int nlev = L.nlev, CH = nlev * S::N2, n = a.n;
-  LevelQ* qi = reinterpret_cast<LevelQ*>(g + n * CH);   // [n][4]
+  float* seg = smem;                                   // [min(run, DV_SEG)]
+  const int nlev = L.nlev, CH = nlev * S::N2, n = a.n, nl = l1 - l0 + 1;
+  const int rbeg = L.off[l0], rend = (l1 + 1 < nlev) ? L.off[l1 + 1] : L.P;       // the run, in floats of the row
+  const int seglen = CLIP ? DV_SEG : rend - rbeg;
+  const int GC = nl * S::N2;                           // channels of dOut this job needs: [l0 * N2, (l1 + 1) * N2)
+  float* g = smem + seglen;                            // [n][GC]
+  LevelQ* qi = reinterpret_cast<LevelQ*>(g + ((n * GC + 3) & ~3));   // [n][4]
   const int64_t q = blockIdx.x;
   const int b = (int)(q / HW), pix = (int)(q % HW);
-  // dOut rows of the n lookups -> LDS.  The lookup index is wave-uniform (pointer from the kernarg table by a scalar load),
-  // a row is CH * 4 bytes: 16-byte loads when CH % 4 == 0 (324, 196), all of them in flight before the first LDS store.
-  if ((CH & 3) == 0) {
-    const int c4 = CH >> 2;
-    constexpr int UN = 4;
-    for (int t0 = 0; t0 < n; t0 += UN) {
-      f32x4 v[UN][2];
+  // dOut slices of the n lookups -> LDS; the lookup index is wave-uniform (pointer from the kernarg table by scalar loads)
+  // and ALL loads are in flight before the first LDS store: one memory latency per workgroup, not one per lookup
+  {
+    float v[DV_MAXN][2];
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
+    for (int t = 0; t < DV_MAXN; ++t)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int c = threadIdx.x + 256 * k;
-          if (t0 + u < n && c < c4) v[u][k] = gload4(a.dout[t0 + u] + q * CH + 4 * c);
-        }
+      for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (t < n && c < GC) v[t][k] = gload1(a.dout[t] + q * CH + l0 * S::N2 + c);
+      }
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
+    for (int t = 0; t < DV_MAXN; ++t)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int c = threadIdx.x + 256 * k;
-          if (t0 + u < n && c < c4) *reinterpret_cast<f32x4*>(g + (t0 + u) * CH + 4 * c) = v[u][k];
-        }
-    }
-  } else {
-    for (int t = 0; t < n; ++t)
-      for (int c = threadIdx.x; c < CH; c += 256) g[t * CH + c] = gload1(a.dout[t] + q * CH + c);
+      for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (t < n && c < GC) g[t * GC + c] = v[t][k];
+      }
   }
   if (threadIdx.x < n * 4) {
     const int t = threadIdx.x >> 2, l = threadIdx.x & 3;
@@ -178,8 +177,8 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
     qi[threadIdx.x] = level_query(gload1(c.p + b * c.bs + pix * c.ps), gload1(c.p + b * c.bs + c.cs + pix * c.ps), l, R);
   }
   float* row = dvol + q * L.P;
-  for (int s0 = 0; s0 < L.P; s0 += DV_SEG) {
-    const int len = min(DV_SEG, L.P - s0);
+  for (int s0 = rbeg; s0 < rend; s0 += seglen) {
+    const int len = min(seglen, rend - s0);
     __syncthreads();
     if (REC && accumulate) {
       for (int e = threadIdx.x * 8; e < len; e += 2048) {        // hi + lo back to fp32 (exact to ~2^-17 relative)
@@ -196,43 +195,64 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
         *reinterpret_cast<f32x4*>(seg + e) = accumulate ? gload4(row + s0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    // one thread per window ROW (lookup t, level l, row wy): s[i] = lerp over y of the (2r+1)^2 gradient, then
-    // d[wx] = lerp over x, added to the row's cells of the tiled layout (LDS float adds: windows of different lookups overlap)
-    for (int e = threadIdx.x; e < n * nlev * S::WIN; e += 256) {
-      const int wy = e % S::WIN, tl = e / S::WIN;
-      const int l = tl % nlev, t = tl / nlev;
-      const int lbeg = L.off[l] - s0, lend = lbeg + L.th[l] * L.tw[l] * 16;
-      if (lend <= 0 || lbeg >= len) continue;                     // this level's section is outside the segment
-      const LevelQ v = qi[t * 4 + l];
-      const int gy = v.wy0 + wy;
-      if (gy < 0 || gy >= L.h[l]) continue;
-      const float* gp = g + t * CH + l * S::N2;
-      float sv[S::N1];
+    // The lookups are applied ONE AFTER THE OTHER, a barrier apart: inside one lookup the cells of its windows are
+    // distinct, so the accumulation is a plain LDS read-add-write.  (LDS float atomics were tried first -- all lookups in
+    // parallel, ds_add_f32 -- and ran at about one lane per clock: 540 of the kernel's 800 us.)  One thread per window
+    // cell (level, wy, wx): 4 taps of the (2r+1)^2 gradient, bilinear weights of the lookup.
+    // what does not depend on the lookup is decoded once per thread: its (at most two) window cells, their level's layout
+    // fields, the four gradient taps and which of them exist
+    constexpr int KC = (4 * S::WIN * S::WIN + 255) / 256;
+    const int ncell = nl * S::WIN * S::WIN;
+    int c_wy[KC], c_wx[KC], c_l[KC], c_base[KC], c_tw[KC], c_h[KC], c_w[KC], c_g[KC];
+    float c_m[KC][4];
 #pragma unroll
-      for (int i = 0; i < S::N1; ++i) {
-        const float ga = wy < S::N1 ? gp[i * S::N1 + wy] : 0.f;
-        const float gb = wy >= 1 ? gp[i * S::N1 + wy - 1] : 0.f;
-        sv[i] = ga * (1.f - v.fy) + gb * v.fy;
-      }
-      const int rowbase = lbeg + (gy >> 2) * L.tw[l] * 16 + (gy & 3) * 4;
-      const int w = L.w[l];
-#pragma unroll
-      for (int wx = 0; wx < S::WIN; ++wx) {
-        const float d = (wx < S::N1 ? sv[wx] * (1.f - v.fx) : 0.f) + (wx >= 1 ? sv[wx - 1] * v.fx : 0.f);
-        const int gx = v.wx0 + wx;
-        const int o = rowbase + (gx >> 2) * 16 + (gx & 3);
-        if (gx >= 0 && gx < w && o >= 0 && o < len) atomicAdd(seg + o, d);
-      }
+    for (int k = 0; k < KC; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      const int lr = c / (S::WIN * S::WIN), cell = c % (S::WIN * S::WIN), wy = cell / S::WIN, wx = cell % S::WIN;
+      const int l = l0 + lr;
+      // (the level is per-lane: a dynamic index into the by-value layout would be a dependent vector load from the
+      // kernarg segment per field -- select instead)
+      c_base[k] = (l == 0 ? L.off[0] : l == 1 ? L.off[1] : l == 2 ? L.off[2] : L.off[3]) - s0;
+      c_tw[k] = l == 0 ? L.tw[0] : l == 1 ? L.tw[1] : l == 2 ? L.tw[2] : L.tw[3];
+      c_h[k] = c < ncell ? (l == 0 ? L.h[0] : l == 1 ? L.h[1] : l == 2 ? L.h[2] : L.h[3]) : 0;      // 0 rows: never in range
+      c_w[k] = l == 0 ? L.w[0] : l == 1 ? L.w[1] : l == 2 ? L.w[2] : L.w[3];
+      c_wy[k] = wy; c_wx[k] = wx; c_l[k] = l;
+      // window cell (wy, wx) is tap (ay, ax) of output (j = wy - ay, i = wx - ax); taps outside the (2r+1)^2 gradient get weight 0
+      const int i0 = wx >= 1 ? wx - 1 : 0, j0 = wy >= 1 ? wy - 1 : 0;
+      c_g[k] = lr * S::N2 + i0 * S::N1 + j0;           // tap (i0, j0); tap i1 / j1 = + N1 / + 1 floats where both taps exist
+      c_m[k][0] = wx < S::N1 ? 1.f : 0.f; c_m[k][1] = wx >= 1 ? 1.f : 0.f;
+      c_m[k][2] = wy < S::N1 ? 1.f : 0.f; c_m[k][3] = wy >= 1 ? 1.f : 0.f;
     }
-    __syncthreads();
+    // The lookups are applied ONE AFTER THE OTHER, a barrier apart: inside one lookup the cells of its windows are
+    // distinct, so the accumulation is a plain LDS read-add-write.  (LDS float atomics -- all lookups in parallel,
+    // ds_add_f32 -- were tried first and were slower.)
+    for (int t = 0; t < n; ++t) {
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const LevelQ v = qi[t * 4 + c_l[k]];
+        const int gy = v.wy0 + c_wy[k], gx = v.wx0 + c_wx[k];
+        const int o = c_base[k] + ((gy >> 2) * c_tw[k] + (gx >> 2)) * 16 + (gy & 3) * 4 + (gx & 3);
+        bool ok = (unsigned)gy < (unsigned)c_h[k] && (unsigned)gx < (unsigned)c_w[k];
+        if (CLIP) ok = ok && o >= 0 && o < len;
+        if (ok) {
+          const float* gp = g + t * GC + c_g[k];
+          // (a tap that does not exist has weight 0 and re-reads the other one)
+          const int di = (c_m[k][0] != 0.f && c_m[k][1] != 0.f) ? S::N1 : 0, dj = (c_m[k][2] != 0.f && c_m[k][3] != 0.f) ? 1 : 0;
+          const float wx1 = c_m[k][0] * (1.f - v.fx), wx0 = c_m[k][1] * v.fx;
+          const float wy1 = c_m[k][2] * (1.f - v.fy), wy0 = c_m[k][3] * v.fy;
+          seg[o] += wy1 * (wx1 * gp[di + dj] + wx0 * gp[dj]) + wy0 * (wx1 * gp[di] + wx0 * gp[0]);
+        }
+      }
+      __syncthreads();
+    }
     if (REC) {
-      for (int e = threadIdx.x * 8; e < len; e += 2048) {        // (segments and P are multiples of 32 cells)
-        uint2 h0, l0, h1, l1;
-        rec_split4(seg + e, h0, l0);
-        rec_split4(seg + e + 4, h1, l1);
+      for (int e = threadIdx.x * 8; e < len; e += 2048) {        // (level sections are multiples of 16 cells; runs start on 32)
+        uint2 h0, l0s, h1, l1s;
+        rec_split4(seg + e, h0, l0s);
+        rec_split4(seg + e + 4, h1, l1s);
         char* rp = reinterpret_cast<char*>(row + s0) + (e >> 5) * 128 + (e & 31) * 2;
         gstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}));
-        gstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0.x, l0.y, l1.x, l1.y}));
+        gstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}));
       }
     } else {
       for (int e = threadIdx.x * 4; e < len; e += 1024) gstore4(row + s0 + e, *reinterpret_cast<const f32x4*>(seg + e));
@@ -330,13 +350,31 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
     a.co[t] = Coords{coords[t], coords_str[3 * t], coords_str[3 * t + 1], coords_str[3 * t + 2]};
   }
   for (int t = n; t < DV_MAXN; ++t) { a.dout[t] = nullptr; a.co[t] = Coords{nullptr, 0, 0, 0}; }
-  const int N1 = 2 * radius + 1, CH = num_levels * N1 * N1;
-  const size_t lds = (size_t)(DV_SEG + n * CH) * 4 + (size_t)n * 4 * sizeof(LevelQ);
+  const int N1 = 2 * radius + 1, N2 = N1 * N1;
   const unsigned grid = (unsigned)((int64_t)B * H * W);
-  if (radius == 4 && records) hipLaunchKernelGGL((corr_dvol_kernel<4, true>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
-  else if (radius == 4) hipLaunchKernelGGL((corr_dvol_kernel<4, false>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
-  else if (records) hipLaunchKernelGGL((corr_dvol_kernel<3, true>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
-  else hipLaunchKernelGGL((corr_dvol_kernel<3, false>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate);
+  // jobs: runs of whole levels that fit the LDS segment (records need a run to start and end on a multiple of 32 floats)
+  int l0 = 0;
+  while (l0 < L.nlev) {
+    int l1 = l0;
+    auto run_end = [&](int l) { return l + 1 < L.nlev ? L.off[l + 1] : L.P; };
+    while (l1 + 1 < L.nlev && run_end(l1 + 1) - L.off[l0] <= DV_SEG) ++l1;
+    while (l1 + 1 < L.nlev && (run_end(l1) % 32) != 0) ++l1;                      // (only the last level may end off a record)
+    const int run = run_end(l1) - L.off[l0];
+    const bool clip = run > DV_SEG;
+    const int GC = (l1 - l0 + 1) * N2;
+    const size_t lds = (size_t)((clip ? DV_SEG : run) + ((n * GC + 3) & ~3)) * 4 + (size_t)n * 4 * sizeof(LevelQ);
+#define DVOL_LAUNCH(RR, REC, CLIP) \
+  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1)
+    if (radius == 4) {
+      if (records) { if (clip) DVOL_LAUNCH(4, true, true); else DVOL_LAUNCH(4, true, false); }
+      else { if (clip) DVOL_LAUNCH(4, false, true); else DVOL_LAUNCH(4, false, false); }
+    } else {
+      if (records) { if (clip) DVOL_LAUNCH(3, true, true); else DVOL_LAUNCH(3, true, false); }
+      else { if (clip) DVOL_LAUNCH(3, false, true); else DVOL_LAUNCH(3, false, false); }
+    }
+#undef DVOL_LAUNCH
+    l0 = l1 + 1;
+  }
   return fs_launch_status();
 }
 
