@@ -22,27 +22,39 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from .utils.utils import coords_grid
 
 
 class _GradState:
     """Backward state of one CorrBlock: the (coords, dOut) pairs of every lookup whose gradient has arrived.  The window
     gradients are a pure function of those, so nothing else is done until autograd reaches the volume build."""
-    __slots__ = ("stash", "zero")
+    __slots__ = ("stash", "is_flow")
 
     def __init__(self, device):
         self.stash = []
-        self.zero = torch.zeros(1, device=device)
+        self.is_flow = False                    # stash entries hold flows (pixel grid added by the kernel), not coordinates
+
+
+def _build_records(fmap1, fmap2):
+    """(f1r, f2r) pixel-major records of the feature maps for the record-core build, or None when that build does not apply
+    (exact-fp32 test mode, C not a multiple of 32)."""
+    if not (ops.BUILD_REC and ops.SPLIT_VOLUME_BWD and fmap1.shape[1] % 32 == 0 and fmap1.is_cuda):
+        return None
+    return ops.fmap_records(fmap1), ops.fmap_records(fmap2)
 
 
 class _BuildFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fmap1, fmap2, num_levels, radius, holder):
-        vol, lay = ops.corr_build_tiled(fmap1, fmap2, num_levels)
+        recs = _build_records(fmap1, fmap2)
+        vol, lay = ops.corr_build_tiled(fmap1, fmap2, num_levels, recs=recs)
+        ctx.f1r = recs[0] if recs is not None else None
         state = _GradState(fmap1.device)
         holder.append((state, lay))
         ctx.state, ctx.lay, ctx.radius = state, lay, radius
         ctx.save_for_backward(fmap1, fmap2)
-        anchor = torch.zeros(1, device=fmap1.device)
+        anchor = ops.zeros(1, device=fmap1.device)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(vol)
         return anchor, vol
 
@@ -54,18 +66,20 @@ class _BuildFn(torch.autograd.Function):
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None, None
         stash, st.stash = st.stash, []
         rec = ops.SPLIT_VOLUME_BWD             # (off = the exact-fp32 test mode: fp32 gradient volume, exact GEMMs)
-        dvol = ops.corr_dvol_build([d for _, d in stash], [c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius, records=rec)
+        dvol = ops.corr_dvol_build([d for _, d in stash], [c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius, records=rec,
+                                   is_flow=st.is_flow)
         del stash
-        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay, records=rec)
+        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay, records=rec, f1r=ctx.f1r if rec else None)
+        ctx.f1r = None
         return d1, d2, None, None, None
 
 
 class _LookupFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, coords, block, channels_last):
-        out = ops.corr_lookup_tiled_fwd(block._vol, block._lay, coords, block.radius)
+    def forward(ctx, anchor, coords, block, channels_last, is_flow):
+        out = ops.corr_lookup_tiled_fwd(block._vol, block._lay, coords, block.radius, is_flow)
         ctx.state = block._state
-        ctx.cl = channels_last
+        ctx.cl, ctx.is_flow = channels_last, is_flow
         ctx.save_for_backward(coords)
         return out if channels_last else ops.nhwc_to_nchw(out)
 
@@ -73,8 +87,12 @@ class _LookupFn(torch.autograd.Function):
     def backward(ctx, dout):
         (coords,) = ctx.saved_tensors
         dout = dout.contiguous() if ctx.cl else ops.nchw_to_nhwc(dout)
+        if ctx.is_flow != ctx.state.is_flow:       # (a block looked up both ways: keep one convention in the stash)
+            B, _, H, W = coords.shape
+            g = coords_grid(B, H, W, device=coords.device)
+            coords = coords - g if ctx.state.is_flow else coords + g
         ctx.state.stash.append((coords, dout))
-        return ctx.state.zero, None, None, None
+        return None, None, None, None, None   # (no gradient tensor for the anchor: the build node still runs after every lookup)
 
 
 class CorrBlock:
@@ -98,7 +116,7 @@ class CorrBlock:
             self._anchor, self._vol = _BuildFn.apply(fmap1, fmap2, num_levels, radius, holder)
             self._state, self._lay = holder[0]
         else:
-            self._vol, self._lay = ops.corr_build_tiled(fmap1, fmap2, num_levels)
+            self._vol, self._lay = ops.corr_build_tiled(fmap1, fmap2, num_levels, recs=_build_records(fmap1, fmap2))
             self._anchor, self._state = None, None
 
     @property
@@ -108,13 +126,16 @@ class CorrBlock:
             self._pyr = [self._lay.level_view(self._vol, l) for l in range(self.num_levels)]
         return self._pyr
 
-    def __call__(self, coords, channels_last=False):
+    def __call__(self, coords, channels_last=False, is_flow=False):
         """coords [B,2,H,W] (x,y).  Returns [B, L*(2r+1)^2, H, W] contiguous (or [B,H,W,C] when
-        channels_last=True, the layout our update block consumes directly)."""
+        channels_last=True, the layout our update block consumes directly).  is_flow=True: the tensor holds the flow and
+        the lookup is centred on pixel grid + flow (what the RAFT loop passes: it never forms coords1)."""
         coords = coords.float()
         if self._tracks_grad and torch.is_grad_enabled():
-            return _LookupFn.apply(self._anchor, coords.detach(), self, channels_last)
-        out = ops.corr_lookup_tiled_fwd(self._vol, self._lay, coords, self.radius)
+            if not self._state.stash:
+                self._state.is_flow = is_flow
+            return _LookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow)
+        out = ops.corr_lookup_tiled_fwd(self._vol, self._lay, coords, self.radius, is_flow)
         return out if channels_last else ops.nhwc_to_nchw(out)
 
     @staticmethod

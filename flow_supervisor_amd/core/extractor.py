@@ -7,6 +7,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 
 class _InstNormRelu(torch.autograd.Function):
     """relu?(instance_norm(x)) for NCHW fp32 on the fsraft kernels (two passes over the data each way)."""
@@ -66,7 +68,7 @@ class _FrozenBNRelu(torch.autograd.Function):
         N, C, H, W = x.shape
         g = g.contiguous()
         dx = torch.empty_like(x)
-        sums = torch.zeros(2, C, device=x.device, dtype=torch.float32)
+        sums = ops.zeros(2, C, device=x.device)
         L.check(L.load().fsraft_affine_relu_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dx), L.ptr(sums[0]),
                                                 L.ptr(sums[1]), N * C, C, H * W, int(ctx.relu), L.stream()), "affine_relu_bwd")
         dweight = rs * (sums[1] - rm * sums[0])               # sum g' * (x + cbias - rm) * rs
@@ -134,7 +136,7 @@ class _InstNormReluCL(torch.autograd.Function):
         if res is not None:
             res = _as_cl(res)
         y = torch.empty_like(x)                                   # preserves channels_last
-        acc = torch.zeros(2, N * 8, C, device=x.device, dtype=torch.float32)      # partial rows (norm_cl.hip)
+        acc = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (norm_cl.hip)
         stats = torch.empty(N, C, 2, device=x.device, dtype=torch.float32)
         L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W,
                                                   C, float(eps), int(relu), L.stream()), "inorm_relu_cl_fwd")
@@ -151,7 +153,7 @@ class _InstNormReluCL(torch.autograd.Function):
         g = _as_cl(g)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.fused else None
-        acc = torch.zeros(2, N * 8, C, device=x.device, dtype=torch.float32)      # partial rows (norm_cl.hip)
+        acc = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (norm_cl.hip)
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
                                                   L.ptr(dres), N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
         return dx if ctx.in_cl else _as_nchw(dx), None, None, dres     # an NCHW producer (MIOpen) gets an NCHW gradient
@@ -189,7 +191,7 @@ class _FrozenBNReluCL(torch.autograd.Function):
         g = _as_cl(g)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.fused else None
-        part = torch.zeros(2, N * 8, C, device=x.device, dtype=torch.float32)      # partial rows (see norm_cl.hip)
+        part = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (see norm_cl.hip)
         L.check(L.load().fsraft_affine_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), L.ptr(dx), L.ptr(dres),
                                                    L.ptr(part[0]), L.ptr(part[1]), N, H * W, C, int(ctx.relu), L.stream()),
                 "affine_relu_cl_bwd")
@@ -254,8 +256,8 @@ class _ConvCL(torch.autograd.Function):
             dx = dxb.permute(0, 3, 1, 2)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
-            dwpk = torch.zeros(N, ops.conv_ktot([C], KH, KW), device=x.device, dtype=torch.float32)
-            db = torch.zeros(N, device=x.device, dtype=torch.float32) if want_b else None
+            dwpk = ops.zeros(N, ops.conv_ktot([C], KH, KW), device=x.device)
+            db = ops.zeros(N, device=x.device) if want_b else None
             ops.conv_wgrad(gv, [ops.V(x.permute(0, 2, 3, 1), C)], dwpk, B, H, W, KH, KW, dbias=db)
             dw = ops.unpack_weight_grad(dwpk, tuple(weight.shape), [C])
         return dx, dw, db, None
@@ -354,11 +356,11 @@ class _StridedPairFn(torch.autograd.Function):
             ops.conv_forward([gsv], q[2], None, B, h, w, 1, 1, C, [ops.Dst.nhwc(dxs, 0, 0, True)], wpk_split=q[3])
             dx = ops.space_to_depth2(dxs, inverse=True).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dwpk = torch.zeros(N, ops.conv_ktot([C4], 2, 2), device=xs.device, dtype=torch.float32)
+            dwpk = ops.zeros(N, ops.conv_ktot([C4], 2, 2), device=xs.device)
             ops.conv_wgrad(g1v, [ops.V(xs, C4)], dwpk, B, h, w, 2, 2)
             dw3 = _s2d_weight_grad(ops.unpack_weight_grad(dwpk, (N, C4, 2, 2), [C4]), C)
         if ctx.needs_input_grad[2]:
-            dwpk = torch.zeros(Ns, ops.conv_ktot([C], 1, 1), device=xs.device, dtype=torch.float32)
+            dwpk = ops.zeros(Ns, ops.conv_ktot([C], 1, 1), device=xs.device)
             ops.conv_wgrad(gsv, [ops.V(xs, C, 0)], dwpk, B, h, w, 1, 1)
             dwsc = ops.unpack_weight_grad(dwpk, (Ns, C, 1, 1), [C])
         return dx, dw3, dwsc, None

@@ -101,27 +101,33 @@ class RAFT(nn.Module):
         net = to_channels_last(torch.tanh(net))          # hidden state stays channels-last in the loop
         inp = to_channels_last(torch.relu(inp))
 
-        coords0, coords1 = self.initialize_flow(image1)
+        # The loop carries the FLOW, not coords1 = coords0 + flow (raft.py:121-131): the lookup adds the pixel grid itself,
+        # the update block and the upsampler want the flow anyway, so an iteration has one framework op (flow + delta)
+        # instead of three.  Same gradient structure: the flow entering an iteration is detached, delta_flow reaches the
+        # loss through the upsampled prediction.
+        B, _, Hi, Wi = image1.shape
         if flow_init is not None:
-            coords1 = coords1 + flow_init
+            flow = flow_init.float()
+        else:
+            flow = torch.zeros(B, 2, Hi // 8, Wi // 8, device=image1.device)
+        coords0 = coords_grid(B, Hi // 8, Wi // 8, device=image1.device) if self.args.alternate_corr else None
 
         flow_predictions = []
         flow_up = None
         for _ in range(iters):
-            coords1 = coords1.detach()
+            flow = flow.detach()
             if self.args.alternate_corr:
-                corr = to_channels_last(corr_fn(coords1))
+                corr = to_channels_last(corr_fn(coords0 + flow))
             else:
-                corr = corr_fn(coords1, channels_last=True)
-            flow = coords1 - coords0
+                corr = corr_fn(flow, channels_last=True, is_flow=True)
             net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow)
-            coords1 = coords1 + delta_flow
+            flow = flow + delta_flow
             if up_mask is None:
-                flow_up = upflow8(coords1 - coords0)
+                flow_up = upflow8(flow)
             else:
-                flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+                flow_up = convex_upsample(flow, up_mask, channels_last=True)
             flow_predictions.append(flow_up)
 
         if test_mode:
-            return coords1 - coords0, flow_up
+            return flow, flow_up
         return flow_predictions

@@ -307,7 +307,7 @@ class _Engine:
         inp = cst.inp
         B, H, W, _ = inp.shape
         dW, dB = self._grad_arena(st, P, inp.device)
-        dinp = torch.zeros(B, H, W, _pad4(self.inp_c), device=inp.device, dtype=torch.float32)
+        dinp = ops.zeros(B, H, W, _pad4(self.inp_c), device=inp.device)
         for k in self.ctx_keys:
             g = cst.dsum.get(k)
             if g is None:
@@ -331,8 +331,9 @@ class _Engine:
 
         def buf(c, zero=False):
             ld = _pad4(c)
-            f = torch.zeros if (zero or ld != c) else torch.empty
-            return f(B, H, W, ld, device=dev, dtype=torch.float32)
+            if zero or ld != c:
+                return ops.zeros(B, H, W, ld, device=dev)
+            return torch.empty(B, H, W, ld, device=dev, dtype=torch.float32)
 
         def conv(k, srcs, dsts, relu=False, alpha=1.0, **kw):
             l = self.layers[k]
@@ -415,8 +416,9 @@ class _Engine:
 
         def buf(c, zero=False):
             ld = _pad4(c)
-            f = torch.zeros if (zero or ld != c) else torch.empty
-            return f(B, H, W, ld, device=dev, dtype=torch.float32)
+            if zero or ld != c:
+                return ops.zeros(B, H, W, ld, device=dev)
+            return torch.empty(B, H, W, ld, device=dev, dtype=torch.float32)
 
         dW, dB = self._grad_arena(st, P, dev)
         if st.keep is None:
@@ -467,7 +469,7 @@ class _Engine:
                 dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))], alpha=0.25)
             else:
                 dhead[..., self.head_c:].zero_()
-        dd = torch.zeros(B, H, W, 4, device=dev, dtype=torch.float32)
+        dd = ops.zeros(B, H, W, 4, device=dev)
         if ddelta is not None:
             ops.flow_to_nhwc(ddelta, dd, 0)
             wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
@@ -486,14 +488,21 @@ class _Engine:
 
         # ---- GRU passes, last to first
         motion = S["motion"]
-        dmotion = buf(self.x_c, zero=True)
+        # every GRU data gradient adds its motion part; the first one (the q convolution of the last pass covers all x_c
+        # channels) overwrites instead, so the buffer needs no zero fill -- only its padding channels, if any, do
+        dmotion = buf(self.x_c)
+        dm_first = [True]
+
+        def dm_acc():
+            first, dm_first[0] = dm_first[0], False
+            return not first
 
         def ctx_sum(k, like):
             """Running sum of the gate gradients over the iterations of the step (filled by the gru_bwd kernels)."""
             if cst is None:
                 return None
             if k not in cst.dsum:
-                cst.dsum[k] = torch.zeros_like(like)
+                cst.dsum[k] = ops.zeros(tuple(like.shape), device=like.device)
             return cst.dsum[k]
 
         first_pass = self.passes[0][0]
@@ -506,7 +515,7 @@ class _Engine:
             xs = [V(motion, self.x_c)]
             wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
             drh = buf(hid)
-            dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dmotion, 0, hid, True)])
+            dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dmotion, 0, hid, dm_acc())])
             ops.gru_bwd2(drh, r, h, dzr, dhp, hid, zsum)
             wgrad("zr" + sfx, V(dzr, 2 * hid), [V(h, hid)] + xs)
             dm = Dst.nhwc(dmotion, 0, hid, True)
@@ -550,7 +559,7 @@ class _Engine:
         dgrad("f2", V(dcorflo, self.f2, cor_out), [Dst.nhwc(dflo1).masked(V(flo1, self.f1))])
         cols = S["cols"]
         wgrad("f1", V(dflo1, self.f1), [V(cols, 98)])
-        dcols = buf(98)
+        dcols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)     # (col2im7 reads the 98 channels only)
         dgrad("f1", V(dflo1, self.f1), [Dst.nhwc(dcols)])
         ops.col2im7(dcols, dflow, True)
         corr = S["corr"]
@@ -586,8 +595,8 @@ class _CtxFn(torch.autograd.Function):
     def forward(ctx, engine, st, cst, params, anchor, inp):
         ctx.engine, ctx.st, ctx.cst = engine, st, cst
         ctx.P = engine._packed(params)
-        cst.zero = torch.zeros(1, device=inp.device)
-        return torch.zeros(1, device=inp.device)
+        ctx.set_materialize_grads(False)
+        return ops.zeros(1, device=inp.device)
 
     @staticmethod
     def backward(ctx, g):
@@ -595,7 +604,7 @@ class _CtxFn(torch.autograd.Function):
         cst.consumed = True
         dinp = ctx.engine.context_backward(cst, ctx.P, ctx.st)
         cst.bufs = None
-        return None, None, None, None, ctx.st.zero, dinp
+        return None, None, None, None, None, dinp
 
 
 class _ParamState:
@@ -614,8 +623,8 @@ class _ParamFn(torch.autograd.Function):
     def forward(ctx, engine, st, *params):
         ctx.engine, ctx.st, ctx.params = engine, st, params
         ctx.P = engine._packed(params)
-        st.zero = torch.zeros(1, device=params[0].device)
-        return torch.zeros(1, device=params[0].device)
+        ctx.set_materialize_grads(False)
+        return ops.zeros(1, device=params[0].device)
 
     @staticmethod
     def backward(ctx, g):
@@ -642,8 +651,8 @@ class _AttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ast, attn):
         ctx.ast, ctx.shape = ast, attn.shape
-        ast.zero = torch.zeros(1, device=attn.device)
-        return torch.zeros(1, device=attn.device)
+        ctx.set_materialize_grads(False)
+        return ops.zeros(1, device=attn.device)
 
     @staticmethod
     def backward(ctx, g):
@@ -687,8 +696,9 @@ class _UpdateFn(torch.autograd.Function):
         cst = ctx.cst
         dnet, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta, ast=ctx.ast,
                                           cst=cst if cst.anchor is not None else None)
-        return (None, None, None, ctx.st.zero, dnet, None, cst.zero if cst.anchor is not None else None, dcorr, dflow,
-                None, None, ctx.ast.zero if ctx.ast is not None else None, None)
+        # the three anchors get no gradient tensor: autograd still runs their producers (_ParamFn, _CtxFn, _AttnFn) once
+        # every consumer is done -- that ordering is all they are for -- and skips 3 x 12 one-element accumulation kernels
+        return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None)
 
 
 class _ToCL(torch.autograd.Function):
@@ -790,7 +800,7 @@ class _UpdateBlockBase(nn.Module):
                 st = self.__dict__.get("_frozen_st")       # inputs need grads, params frozen: one state per step
                 if st is None or st.consumed:
                     st = _ParamState(None)
-                    st.zero = torch.zeros(1, device=net.device)
+                    st.zero = ops.zeros(1, device=net.device)
                     self.__dict__["_frozen_st"] = st
                 anchor = st.zero
             else:

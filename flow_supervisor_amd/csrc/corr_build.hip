@@ -16,6 +16,7 @@
 #include "gemm_core.hpp"
 #include "gemm_core_split.hpp"
 #include "corr_layout.hpp"
+#include "gemm_rec.hpp"
 
 namespace {
 
@@ -385,6 +386,143 @@ __global__ __launch_bounds__(256) void corr_build_tiled_split_kernel(const float
   build_epilogue_tiled(acc, reinterpret_cast<float*>(lds), vol, L, N, b, i0, px0, py0, scale);
 }
 
+// ---- build on the record core (gemm_rec.hpp): feature maps arrive PRE-SPLIT, pixel-major ([B][N][C / 32 records]) ----
+// 256 queries x one 8x16 patch of targets per workgroup, K = C.  Both operands are staged by LDS-DMA (the target rows of
+// a patch are gathered through the per-lane source offsets; pixels outside the image read as zeros), eight waves, the
+// three-slot ring of rec_mainloop.  Epilogue as above, in two halves of 128 queries: parked in LDS, level 0 written as
+// whole 64-byte tiles, levels 1-3 pooled out of LDS.
+using BR = RecCfg<256, 128, 4, 2>;
+constexpr int BR_PH = 8, BR_PW = 16;                       // the target patch
+constexpr int BR_EPI_FLOATS = 128 * 128 + 128 * 32 + 128 * 8;
+
+__global__ __launch_bounds__(512) void corr_build_rec_kernel(const char* __restrict__ f1r, const char* __restrict__ f2r,
+                                                             float* __restrict__ vol, VolLayout L, int C, float scale) {
+  __shared__ __attribute__((aligned(1024))) char lds[BR::LDS_BYTES > BR_EPI_FLOATS * 4 ? BR::LDS_BYTES : BR_EPI_FLOATS * 4];
+  const int H = L.H, W = L.W, N = H * W;
+  const int npx = ceil_div_dev(W, BR_PW);
+  const int px0 = (blockIdx.x % npx) * BR_PW, py0 = (blockIdx.x / npx) * BR_PH;
+  const int i0 = blockIdx.y * BR::BM;
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned pitch = (unsigned)C * 4u;
+  RecOperands<BR> o;
+  const char* A = f1r + ((int64_t)b * N + i0) * pitch;
+  const int ar = min(BR::BM, N - i0);
+  o.da = rec_desc(A, (unsigned)ar * pitch);
+  o.db = rec_desc(f2r + (int64_t)b * N * pitch, (unsigned)min((int64_t)N * pitch, (int64_t)0x7fffffff));
+  o.b_step = 128u;
+  RecPlainA<BR> pa;
+#pragma unroll
+  for (int j = 0; j < BR::NPA; ++j) pa.va[j] = rec_piece_voff(wave + BR::NWAVE * j, lane, ar, pitch);
+  pa.kt0 = 0; pa.step = 128u;
+#pragma unroll
+  for (int j = 0; j < BR::NPB; ++j) {                      // tile row n = patch position (n / 16, n % 16)
+    const int n = (wave + BR::NWAVE * j) * 8 + (lane >> 3);
+    const int y = py0 + n / BR_PW, x = px0 + n % BR_PW;
+    const int ls = (lane & 7) ^ ((n >> 1) & 7);
+    o.vb[j] = (y < H && x < W) ? (unsigned)(y * W + x) * pitch + (unsigned)ls * 16u : 0x80000000u;
+  }
+  f32x16 acc[BR::TM][BR::TN];
+#pragma unroll
+  for (int a = 0; a < BR::TM; ++a)
+#pragma unroll
+    for (int c = 0; c < BR::TN; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  rec_mainloop<BR>(lds, o, pa, 0, C / 32, acc);
+
+  float* S = reinterpret_cast<float*>(lds);   // [128 queries][128 = 8 x 16 patch]
+  float* P1 = S + 128 * 128;                  // [128][4 x 8]
+  float* P2 = P1 + 128 * 32;                  // [128][2 x 4]
+  const int wm = wave / BR::WN, wn = wave % BR::WN, l31 = lane & 31, lh = lane >> 5;
+  const int nlev = L.nlev;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if ((wm >> 1) == half) {
+#pragma unroll
+      for (int mt = 0; mt < BR::TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < BR::TN; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = (wm & 1) * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            S[i * 128 + wn * 64 + nt * 32 + l31] = acc[mt][nt][r] * scale;
+          }
+    }
+    __syncthreads();
+    const int qbase = i0 + half * 128;
+    float* rows = vol + ((int64_t)b * N + qbase) * L.P;
+    // level 0: chunk = (query i, tile row ty, tile t, row r of the tile) = 16 bytes; 16 lanes cover one 256-byte run
+#pragma unroll 4
+    for (int jj = 0; jj < 8; ++jj) {
+      const int id = threadIdx.x + 512 * jj;
+      const int r = id & 3, t = (id >> 2) & 3, ty = (id >> 4) & 1, i = id >> 5;
+      const int gty = (py0 >> 2) + ty, gtx = (px0 >> 2) + t;
+      if (gty < L.th[0] && gtx < L.tw[0] && qbase + i < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(S + i * 128 + (4 * ty + r) * BR_PW + 4 * t);
+        gstore4(rows + (int64_t)i * L.P + L.off[0] + (gty * L.tw[0] + gtx) * 16 + r * 4, v);
+      }
+    }
+    if (nlev > 1) {
+      const int h1 = L.h[1], w1 = L.w[1];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int e = threadIdx.x + 512 * jj;
+        const int i = e >> 5, c = e & 31, y = c >> 3, x = c & 7;
+        const float* s = S + i * 128 + (2 * y) * BR_PW + 2 * x;
+        const float v = (((s[0] + s[1]) + s[BR_PW]) + s[BR_PW + 1]) * 0.25f;
+        // cells beyond the floor-halved size do not exist in the reference pyramid: pad cells of the tile hold 0
+        P1[i * 32 + c] = ((py0 >> 1) + y < h1 && (px0 >> 1) + x < w1) ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    if (nlev > 1) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int id = threadIdx.x + 512 * jj;
+        const int r = id & 3, t = (id >> 2) & 1, i = id >> 3;
+        const int gty = py0 >> 3, gtx = (px0 >> 3) + t;
+        if (gty < L.th[1] && gtx < L.tw[1] && qbase + i < N) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(P1 + i * 32 + r * 8 + 4 * t);
+          gstore4(rows + (int64_t)i * L.P + L.off[1] + (gty * L.tw[1] + gtx) * 16 + r * 4, v);
+        }
+      }
+    }
+    if (nlev > 2) {
+      const int h2 = L.h[2], w2 = L.w[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int e = threadIdx.x + 512 * jj;
+        const int i = e >> 3, c = e & 7, y = c >> 2, x = c & 3;
+        const float* s = P1 + i * 32 + (2 * y) * 8 + 2 * x;
+        const float v = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
+        P2[i * 8 + c] = ((py0 >> 2) + y < h2 && (px0 >> 2) + x < w2) ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    if (nlev > 2 && threadIdx.x < 256) {
+      const int id = threadIdx.x;
+      const int y = id & 1, i = id >> 1;
+      const int gy = (py0 >> 2) + y, gtx = px0 >> 4;
+      if ((gy >> 2) < L.th[2] && gtx < L.tw[2] && qbase + i < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(P2 + i * 8 + y * 4);
+        gstore4(rows + (int64_t)i * L.P + L.off[2] + ((gy >> 2) * L.tw[2] + gtx) * 16 + (gy & 3) * 4, v);
+      }
+    }
+    if (nlev > 3 && threadIdx.x >= 256) {
+      const int h3 = L.h[3], w3 = L.w[3];
+      const int id = threadIdx.x - 256;
+      const int i = id >> 1, x = id & 1;
+      const float* s = P2 + i * 8 + 2 * x;
+      const float v = (((s[0] + s[1]) + s[4]) + s[5]) * 0.25f;
+      const int gy = (py0 >> 3), gx = (px0 >> 3) + x;
+      if ((gy >> 2) < L.th[3] && (gx >> 2) < L.tw[3] && qbase + i < N)
+        gstore1(rows + (int64_t)i * L.P + vol_cell(L, 3, gy, gx), (gy < h3 && gx < w3) ? v : 0.f);
+    }
+    __syncthreads();
+  }
+}
+
 int g_build_split = 1;    // 0: exact fp32 MFMA build, 1: split-bf16 (fsraft_set_build_split)
 
 // Backward of the pooling chain, folded into level 0 in place:
@@ -535,6 +673,20 @@ extern "C" int fsraft_vol_layout(int H, int W, int num_levels, int* out) {
   out[0] = L.nlev; out[1] = L.H; out[2] = L.W; out[3] = L.P;
   for (int l = 0; l < 4; ++l) { out[4 + l] = L.h[l]; out[8 + l] = L.w[l]; out[12 + l] = L.th[l]; out[16 + l] = L.tw[l]; out[20 + l] = L.off[l]; }
   return FS_OK;
+}
+
+// The same build from PRE-SPLIT feature maps: f1r, f2r = [B][H*W][C / 32] records (fsraft_to_records of the channels-last
+// maps), C % 32 == 0.  Always bf16x3 arithmetic (the exact-fp32 build is fsraft_corr_build_tiled with the split switched off).
+extern "C" int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vol, int num_levels, int B, int C, int H, int W,
+                                     hipStream_t stream) {
+  VolLayout L;
+  if (!f1r || !f2r || !vol || B < 1 || C < 32 || (C % 32) || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
+  if (((uintptr_t)vol % 16) || ((uintptr_t)f1r % 16) || ((uintptr_t)f2r % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff) return FS_ERR_ARG;
+  const int N = H * W;
+  dim3 grid(ceil_div(W, BR_PW) * ceil_div(H, BR_PH), ceil_div(N, BR::BM), B);
+  hipLaunchKernelGGL(corr_build_rec_kernel, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
+                     1.0f / sqrtf((float)C));
+  return fs_launch_status();
 }
 
 extern "C" int fsraft_set_build_split(int on) {

@@ -29,6 +29,13 @@ struct Coords {
   const float* p;
   int64_t bs, cs, ps;
 };
+// The query position is either given (coords) or coords = pixel grid + flow: grid_w > 0 names the image width and the
+// tensor holds the FLOW, so that the RAFT loop never materialises coords1 = coords0 + flow (raft.py:121-131).
+__device__ __forceinline__ void query_xy(const Coords& c, int b, int pix, int grid_w, float& cx, float& cy) {
+  cx = gload1(c.p + b * c.bs + pix * c.ps);
+  cy = gload1(c.p + b * c.bs + c.cs + pix * c.ps);
+  if (grid_w > 0) { cx += (float)(pix % grid_w); cy += (float)(pix / grid_w); }
+}
 
 template <int R>
 struct TL {
@@ -62,7 +69,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 template <int R, int QW>
 __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __restrict__ vol, VolLayout L, Coords co,
-                                                               float* __restrict__ out, int64_t nq, int HW) {
+                                                               float* __restrict__ out, int64_t nq, int HW, int grid_w) {
   using S = TL<R>;
   __shared__ __attribute__((aligned(16))) float region[4][4][S::REGION];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,7 +86,8 @@ __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __re
     const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * QW + qq;         // wave-uniform
     if (q >= nq) break;
     const int b = (int)(q / HW), pix = (int)(q % HW);
-    const float cx = gload1(co.p + b * co.bs + pix * co.ps), cy = gload1(co.p + b * co.bs + co.cs + pix * co.ps);
+    float cx, cy;
+    query_xy(co, b, pix, grid_w, cx, cy);
     const float* row = vol + q * L.P;
     LevelQ lq[4];
     f32x4 v[4];
@@ -140,7 +148,7 @@ struct DvolArgs {
 // LDS-DMA without converting.  CLIP: the run is longer than the segment (very large images) and is processed in pieces.
 template <int R, bool REC, bool CLIP>
 __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate, int l0,
-                                                        int l1) {
+                                                        int l1, int grid_w) {
   using S = TL<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* seg = smem;                                   // [min(run, DV_SEG)]
@@ -173,8 +181,9 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
   }
   if (threadIdx.x < n * 4) {
     const int t = threadIdx.x >> 2, l = threadIdx.x & 3;
-    const Coords& c = a.co[t];
-    qi[threadIdx.x] = level_query(gload1(c.p + b * c.bs + pix * c.ps), gload1(c.p + b * c.bs + c.cs + pix * c.ps), l, R);
+    float cx, cy;
+    query_xy(a.co[t], b, pix, grid_w, cx, cy);
+    qi[threadIdx.x] = level_query(cx, cy, l, R);
   }
   float* row = dvol + q * L.P;
   for (int s0 = rbeg; s0 < rend; s0 += seglen) {
@@ -309,10 +318,10 @@ __global__ __launch_bounds__(256) void corr_dfmap2_kernel(const float* __restric
 }
 
 template <int R>
-int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float* out, int64_t nq, int HW, hipStream_t s) {
+int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float* out, int64_t nq, int HW, int grid_w, hipStream_t s) {
   constexpr int QW = 4;
   hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW>), dim3((unsigned)((nq + 4 * QW - 1) / (4 * QW))), dim3(256), 0, s, vol, L, co,
-                     out, nq, HW);
+                     out, nq, HW, grid_w);
   return fs_launch_status();
 }
 
@@ -321,13 +330,13 @@ int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float*
 // out: [B, H, W, L*(2r+1)^2] channels-last.  coords element (b, c, pix) at coords[b*bs + c*cs + pix*ps].
 extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* coords, int64_t coords_bs,
                                             int64_t coords_cs, int64_t coords_ps, float* out, int B, int H, int W, int radius,
-                                            hipStream_t stream) {
+                                            int add_grid, hipStream_t stream) {
   VolLayout L;
   if (!vol || !coords || !out || B < 1 || !vol_layout_make(H, W, num_levels, L) || ((uintptr_t)vol % 16)) return FS_ERR_ARG;
   Coords co{coords, coords_bs, coords_cs, coords_ps};
   const int64_t nq = (int64_t)B * H * W;
-  if (radius == 4) return launch_lookup<4>(vol, L, co, out, nq, H * W, stream);
-  if (radius == 3) return launch_lookup<3>(vol, L, co, out, nq, H * W, stream);
+  if (radius == 4) return launch_lookup<4>(vol, L, co, out, nq, H * W, add_grid ? W : 0, stream);
+  if (radius == 3) return launch_lookup<3>(vol, L, co, out, nq, H * W, add_grid ? W : 0, stream);
   return FS_ERR_ARG;
 }
 
@@ -336,7 +345,7 @@ extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, co
 // records != 0: rows are written as [32 bf16 hi | 32 bf16 lo] records (operands of fsraft_gemm_rec_nt / _tn).
 extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
                                       float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate, int records,
-                                      hipStream_t stream) {
+                                      int add_grid, hipStream_t stream) {
   VolLayout L;
   if (!dout || !coords || !coords_str || !dvol || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) ||
       ((uintptr_t)dvol % 16))
@@ -364,7 +373,7 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
     const int GC = (l1 - l0 + 1) * N2;
     const size_t lds = (size_t)((clip ? DV_SEG : run) + ((n * GC + 3) & ~3)) * 4 + (size_t)n * 4 * sizeof(LevelQ);
 #define DVOL_LAUNCH(RR, REC, CLIP) \
-  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1)
+  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1, add_grid ? W : 0)
     if (radius == 4) {
       if (records) { if (clip) DVOL_LAUNCH(4, true, true); else DVOL_LAUNCH(4, true, false); }
       else { if (clip) DVOL_LAUNCH(4, false, true); else DVOL_LAUNCH(4, false, false); }

@@ -47,6 +47,42 @@ class KernelTimer:
 TIMER = None
 
 
+class _ZeroPool:
+    """Small zero-initialised buffers (atomic-accumulation targets, padded channels) carved out of 32 MB chunks that are
+    zero-filled ONCE: a training step used to issue ~285 separate fill kernels of a few KB each.  A chunk lives as long
+    as any buffer carved from it; the pool itself only holds the chunk it is currently carving."""
+    CHUNK = 32 << 20
+
+    def __init__(self):
+        self.cur = {}
+
+    def take(self, shape, device):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        nb = (n * 4 + 255) // 256 * 256
+        if nb > self.CHUNK // 4 or n == 0 or torch.device(device).type != "cuda":
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+        ent = self.cur.get(key)
+        if ent is None or ent[1] + nb > self.CHUNK:
+            ent = [torch.zeros(self.CHUNK // 4, device=device, dtype=torch.float32), 0]
+            self.cur[key] = ent
+        o = ent[1] // 4
+        ent[1] += nb
+        return ent[0][o:o + n].view(shape)
+
+
+_ZEROS = _ZeroPool()
+
+
+def zeros(*shape, device):
+    """torch.zeros(shape, fp32) from the zero pool (see _ZeroPool)."""
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    return _ZEROS.take(shape, device)
+
+
 def pyramid_sizes(H, W, num_levels=4):
     out = []
     for _ in range(num_levels):
@@ -112,8 +148,21 @@ class VolLayout:
         return t.reshape(rows, 1, self.th[l] * 4, self.tw[l] * 4)[:, :, :self.h[l], :self.w[l]].contiguous()
 
 
-def corr_build_tiled(fmap1, fmap2, num_levels=4):
-    """-> (vol [B*H*W, P], VolLayout): all-pairs volume + pyramid in the tiled-row layout."""
+BUILD_REC = True       # volume build on the record GEMM core when the arithmetic mode is split-bf16 and C % 32 == 0
+
+
+def fmap_records(fmap):
+    """[B,C,H,W] fp32 -> [B,H*W,C] records (pixel-major, the operand format of the record GEMM core).  A channels_last
+    feature map (what the channels-last encoders hand over) already is pixel-major: no transpose."""
+    B, C, H, W = fmap.shape
+    if fmap.is_contiguous(memory_format=torch.channels_last) and not fmap.is_contiguous():
+        return to_records(fmap.permute(0, 2, 3, 1).reshape(B, H * W, C))
+    return to_records(nchw_to_nhwc(fmap).view(B, H * W, C))
+
+
+def corr_build_tiled(fmap1, fmap2, num_levels=4, recs=None):
+    """-> (vol [B*H*W, P], VolLayout): all-pairs volume + pyramid in the tiled-row layout.  recs: optional (f1r, f2r) from
+    fmap_records (reused by the backward pass)."""
     L.require_cuda_f32(fmap1, fmap2)
     fmap1 = fmap1.contiguous()
     fmap2 = fmap2.contiguous()
@@ -122,16 +171,20 @@ def corr_build_tiled(fmap1, fmap2, num_levels=4):
     vol = torch.empty(B * H * W, lay.P, device=fmap1.device, dtype=torch.float32)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(_lib().fsraft_corr_build_tiled(L.ptr(fmap1), L.ptr(fmap2), L.ptr(vol), num_levels, B, C, H, W, L.stream()),
-            "corr_build_tiled")
+    if recs is not None:
+        L.check(_lib().fsraft_corr_build_rec(L.ptr(recs[0]), L.ptr(recs[1]), L.ptr(vol), num_levels, B, C, H, W, L.stream()),
+                "corr_build_rec")
+    else:
+        L.check(_lib().fsraft_corr_build_tiled(L.ptr(fmap1), L.ptr(fmap2), L.ptr(vol), num_levels, B, C, H, W, L.stream()),
+                "corr_build_tiled")
     if t:
         N = H * W
         t.end("corr_build", e0, 2.0 * B * N * N * C, 4.0 * B * (2 * N * C + N * sum(h * w for h, w in zip(lay.h, lay.w))))
     return vol, lay
 
 
-def corr_lookup_tiled_fwd(vol, lay, coords, radius):
-    """-> [B,H,W,L*(2r+1)^2] channels-last."""
+def corr_lookup_tiled_fwd(vol, lay, coords, radius, is_flow=False):
+    """-> [B,H,W,L*(2r+1)^2] channels-last.  is_flow: `coords` holds the flow, the query position is pixel grid + flow."""
     L.require_cuda_f32(vol, coords)
     B, _, H, W = coords.shape
     bs, cs, ps = _planar2_strides(coords)
@@ -140,13 +193,13 @@ def corr_lookup_tiled_fwd(vol, lay, coords, radius):
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_corr_lookup_tiled_fwd(L.ptr(vol), lay.nlev, L.ptr(coords), bs, cs, ps, L.ptr(out), B, H, W, radius,
-                                                L.stream()), "corr_lookup_tiled_fwd")
+                                                int(is_flow), L.stream()), "corr_lookup_tiled_fwd")
     if t:
         t.end("corr_lookup_fwd", e0, 0.0, 4.0 * B * H * W * (lay.nlev * (2 * radius + 2) ** 2 + 2 + ch))
     return out
 
 
-def corr_dvol_build(douts, coords, lay, B, radius, records=False):
+def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False):
     """Gradient volume [B*H*W, P] of all stashed lookups (douts[t]: [B,H,W,CH] channels-last, coords[t]: [B,2,H,W]);
     records=True: rows of [32 hi | 32 lo] bf16 records (the operand format of gemm_rec_nt / gemm_rec_tn)."""
     H, W = lay.H, lay.W
@@ -164,7 +217,7 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False):
             st += list(_planar2_strides(c))
         a_s = (ctypes.c_int64 * (3 * n))(*st)
         L.check(_lib().fsraft_corr_dvol_build(ctypes.cast(a_d, L._PP), ctypes.cast(a_c, L._PP), a_s, n, L.ptr(dvol), lay.nlev, B, H,
-                                              W, radius, int(g0 > 0), int(records), L.stream()), "corr_dvol_build")
+                                              W, radius, int(g0 > 0), int(records), int(is_flow), L.stream()), "corr_dvol_build")
     if t:   # per lookup read dOut + read-modify-write the window taps; plus the zero fill of the dense gradient
         nl, nq = lay.nlev, B * H * W
         t.end("corr_lookup_bwd", e0, 0.0, 4.0 * nq * (len(douts) * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2)
@@ -172,7 +225,7 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False):
     return dvol
 
 
-def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False):
+def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None):
     """(dfmap1, dfmap2) NCHW from the gradient volume in the tiled-row layout: two GEMMs that contract over whole rows
     (K = P resp. M = P), the pooling chain folded into the pooled operand f2cat and the un-pool of the feature gradient.
     records=True: dvol holds records; both GEMMs run on the LDS-DMA record core (gemm_rec.hpp)."""
@@ -182,11 +235,13 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False):
     f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
     L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
     dV = dvol.view(B, N, P)
-    f1t = nchw_to_nhwc(fmap1).view(B, N, C)
     if records:
+        if f1r is None:
+            f1r = fmap_records(fmap1)
         d1 = gemm_rec_nt(to_records(f2cat), dV, s)                # [B,C,N] = s * f2cat . dV^T
-        d2cat = gemm_rec_tn(dV, to_records(f1t), P, C, s, ksplit=2)   # [B,P,C] = s * dV^T . f1^T
+        d2cat = gemm_rec_tn(dV, f1r, P, C, s, ksplit=2)           # [B,P,C] = s * dV^T . f1^T
     else:
+        f1t = nchw_to_nhwc(fmap1).view(B, N, C)
         d1 = gemm(f2cat, dV, True, s)
         if C % 4 == 0 and SPLIT_VOLUME_BWD:
             d2cat = gemm_tn_split(dV, f1t, s)                     # (both operands k-major)

@@ -37,7 +37,9 @@ class _SeqLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gstats):
         dps, ctx.dps = ctx.dps, None
-        return (None,) * 6 + tuple(d * g if d is not None else None for d in dps)
+        live = [d for d in dps if d is not None]
+        torch._foreach_mul_(live, g)              # one multi-tensor kernel instead of one multiply per prediction
+        return (None,) * 6 + tuple(dps)
 
 
 def weighted_sequence_loss(flow_preds, weights, flow_gt=None, valid=None, max_flow=MAX_FLOW, eps=1e-3, metric_idx=None):

@@ -60,16 +60,23 @@ int fsraft_vol_layout(int H, int W, int num_levels, int* out);
 /* vol [B*H*W][P] <- all-pairs volume + pyramid (pad cells of V: unspecified, never read by the lookup) */
 int fsraft_corr_build_tiled(const float* fmap1, const float* fmap2, float* vol, int num_levels, int B, int C, int H, int W,
                             hipStream_t stream);
-/* CorrBlock.__call__ (pytorch/core/corr.py:29-50) on that layout; out [B,H,W,L*(2r+1)^2] channels-last; one wave per query */
+/* the same from pre-split feature maps f1r, f2r = [B][H*W][C/32] records (fsraft_to_records of the channels-last maps,
+ * C % 32 == 0): both operands staged by LDS-DMA on the record GEMM core, 256 queries x an 8x16 target patch per workgroup */
+int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vol, int num_levels, int B, int C, int H, int W,
+                          hipStream_t stream);
+/* CorrBlock.__call__ (pytorch/core/corr.py:29-50) on that layout; out [B,H,W,L*(2r+1)^2] channels-last; one wave per query.
+ * add_grid != 0: `coords` holds the FLOW and the query position is pixel grid + flow (the caller's coords0 + flow,
+ * pytorch/core/raft.py:121-131, never materialised) */
 int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs,
-                                 int64_t coords_ps, float* out, int B, int H, int W, int radius, hipStream_t stream);
+                                 int64_t coords_ps, float* out, int B, int H, int W, int radius, int add_grid, hipStream_t stream);
 /* Gradient volume of n lookups at once (grid_sampler_2d_backward w.r.t. the volume, pytorch/core/utils/utils.py:57-71, for
  * all iterations of a step): dvol [B*H*W][P] = (or +=, accumulate != 0) sum_t (d out_t / d V)^T dout_t, pad cells zero;
  * dout[t] is [B,H,W,CH] channels-last, coords[t] element (b, c, pix) at coords[t][b*s0 + c*s1 + pix*s2] with
  * (s0, s1, s2) = coords_str[3t .. 3t+2].  n <= 16 per call.  Each row is accumulated in LDS and written once; records != 0:
  * as [32 bf16 hi | 32 bf16 lo] records, the operand format of fsraft_gemm_rec_nt / _tn below. */
 int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
-                           int num_levels, int B, int H, int W, int radius, int accumulate, int records, hipStream_t stream);
+                           int num_levels, int B, int H, int W, int radius, int accumulate, int records, int add_grid,
+                           hipStream_t stream);
 /* Backward of matmul + avg_pool2d chain (pytorch/core/corr.py:21-27, 52-60) without un-pooling the volume gradient:
  *   f2cat [B][C][P]: level-l cell = mean of fmap2 over its 2^l x 2^l pixels (0 in pad cells), so that
  *   dF1[b][c][i] = s * sum_p f2cat[b][c][p] * dvol[b][i][p]   (one NT GEMM, K = P)  and

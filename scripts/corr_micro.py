@@ -39,6 +39,14 @@ P = sum(h * w for h, w in zip(lay.h, lay.w))
 for l in range(4):
     err = (lay.level_view(vol, l) - levels[l]).abs().max().item()
     assert err < 1e-5, (l, err)
+recs = (ops.fmap_records(f1), ops.fmap_records(f2))
+vol_r, _ = ops.corr_build_tiled(f1, f2, 4, recs=recs)
+for l in range(4):
+    err = (lay.level_view(vol_r, l) - levels[l]).abs().max().item()
+    assert err < 1e-5, ("record build", l, err)
+t_rec = timeit(lambda: ops.corr_build_tiled(f1, f2, 4, recs=recs))
+t_cvt = timeit(lambda: (ops.fmap_records(f1), ops.fmap_records(f2)))
+print(f"build on the record core {t_rec*1e6:8.1f} us (+ {t_cvt*1e6:.1f} us for the two feature-map conversions)")
 t_old = timeit(lambda: ops.corr_build(f1, f2, 4))
 t_new = timeit(lambda: ops.corr_build_tiled(f1, f2, 4))
 bb = 4.0 * B * (2 * H * W * C + H * W * P)
