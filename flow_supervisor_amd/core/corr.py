@@ -146,44 +146,87 @@ class CorrBlock:
         return lvl0.view(B, H, W, 1, H, W)
 
 
-class _AltCorrFn(torch.autograd.Function):
-    """alt_cuda_corr.forward with the backward the reference compiled but never wired (corr.py:74-91)."""
+class _AltBuildFn(torch.autograd.Function):
+    """(fmap1, fmap2) -> anchor.  Forward does nothing; backward -- reached once every lookup of the step has handed in its
+    (coords, dOut) -- runs the volume backward a chunk of queries at a time (ops.corr_bwd_chunked): the gradient volume of
+    `chunk` queries, two record GEMMs, no O(N^2) buffer and no atomics on the feature gradients."""
 
     @staticmethod
-    def forward(ctx, fmap1, fmap2, coords, radius):
-        ctx.save_for_backward(fmap1, fmap2, coords)
-        ctx.radius = radius
-        return ops.altcorr_fwd(fmap1, fmap2, coords, radius)
+    def forward(ctx, fmap1, fmap2, block):
+        ctx.block = block
+        ctx.save_for_backward(fmap1, fmap2)
+        ctx.set_materialize_grads(False)
+        return ops.zeros(1, device=fmap1.device)
 
     @staticmethod
-    def backward(ctx, g):
-        fmap1, fmap2, coords = ctx.saved_tensors
-        g1, g2, _ = ops.altcorr_bwd(fmap1, fmap2, coords, g.contiguous(), ctx.radius)
-        return g1, g2, None, None
+    def backward(ctx, ganchor):
+        fmap1, fmap2 = ctx.saved_tensors
+        blk = ctx.block
+        stash, blk._stash = blk._stash, []
+        if not stash:
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
+        lay = ops.VolLayout.get(fmap1.shape[2], fmap1.shape[3], blk.num_levels)
+        d1, d2 = ops.corr_bwd_chunked(fmap1, fmap2, [d for _, d in stash], [c for c, _ in stash], lay, blk.radius,
+                                      is_flow=blk._stash_is_flow)
+        return d1, d2, None
+
+
+class _AltLookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, coords, block, channels_last, is_flow):
+        out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow)
+        ctx.block, ctx.cl, ctx.is_flow = block, channels_last, is_flow
+        ctx.save_for_backward(coords)
+        return out if channels_last else ops.nhwc_to_nchw(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coords,) = ctx.saved_tensors
+        blk = ctx.block
+        dout = dout.contiguous() if ctx.cl else ops.nchw_to_nhwc(dout)
+        if ctx.is_flow != blk._stash_is_flow:
+            B, _, H, W = coords.shape
+            g = coords_grid(B, H, W, device=coords.device)
+            coords = coords - g if blk._stash_is_flow else coords + g
+        blk._stash.append((coords, dout))
+        return None, None, None, None, None
 
 
 class AlternateCorrBlock:
+    """Memory-efficient correlation (pytorch/core/corr.py:63-91 + alt_cuda_corr): the same numbers as CorrBlock without the
+    N x N volume.  One fused launch per lookup (all levels, channels-last, scaled); the backward the reference compiled but
+    never wired is live here: lookups only stash (coords, dOut), the feature gradients are formed once per step from
+    chunks of the gradient volume (no O(N^2) buffer, no atomics).  alt_cuda_corr.forward / .backward themselves (one
+    level per call, the extension's signature) are in flow_supervisor_amd/alt_cuda_corr.py."""
+
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        if not 1 <= num_levels <= 4:
+            raise NotImplementedError("the HIP correlation kernels are built for 1..4 pyramid levels")
+        if fmap1.shape[1] % 4 != 0:
+            raise NotImplementedError("the HIP alt-corr kernels need a channel count that is a multiple of 4")
         self.num_levels = num_levels
         self.radius = radius
         fmap1 = fmap1.float()
         fmap2 = fmap2.float()
-        self.pyramid = [(fmap1, fmap2)]
-        for _ in range(self.num_levels):
-            fmap1 = F.avg_pool2d(fmap1, 2, stride=2)
-            fmap2 = F.avg_pool2d(fmap2, 2, stride=2)
-            self.pyramid.append((fmap1, fmap2))
-        # channels-last copies once per pair instead of once per level per iteration (corr.py:82-83)
-        self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
-        self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(self.num_levels)]
+        self._stash, self._stash_is_flow = [], False
+        self._tracks_grad = torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)
+        self._anchor = _AltBuildFn.apply(fmap1, fmap2, self) if self._tracks_grad else None
+        with torch.no_grad():
+            self.pyramid = [(fmap1, fmap2)]
+            f1, f2 = fmap1, fmap2
+            for _ in range(self.num_levels):
+                f1 = F.avg_pool2d(f1, 2, stride=2)
+                f2 = F.avg_pool2d(f2, 2, stride=2)
+                self.pyramid.append((f1, f2))
+            # channels-last copies once per pair instead of once per level per iteration (corr.py:82-83)
+            self._f1 = ops.nchw_to_nhwc(fmap1.detach())
+            self._f2 = [ops.nchw_to_nhwc(self.pyramid[i][1].detach()) for i in range(self.num_levels)]
 
-    def __call__(self, coords):
-        coords = coords.permute(0, 2, 3, 1)
-        B, H, W, _ = coords.shape
-        dim = self._f1.shape[-1]
-        outs = []
-        for i in range(self.num_levels):
-            ci = (coords / 2 ** i).reshape(B, 1, H, W, 2).contiguous()
-            outs.append(_AltCorrFn.apply(self._f1, self._f2[i], ci, self.radius).squeeze(1))
-        corr = torch.stack(outs, dim=1).reshape(B, -1, H, W)
-        return corr / math.sqrt(float(dim))
+    def __call__(self, coords, channels_last=False, is_flow=False):
+        coords = coords.float()
+        if self._tracks_grad and torch.is_grad_enabled():
+            if not self._stash:
+                self._stash_is_flow = is_flow
+            return _AltLookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow)
+        out = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow)
+        return out if channels_last else ops.nhwc_to_nchw(out)

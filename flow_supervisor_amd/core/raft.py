@@ -110,16 +110,12 @@ class RAFT(nn.Module):
             flow = flow_init.float()
         else:
             flow = torch.zeros(B, 2, Hi // 8, Wi // 8, device=image1.device)
-        coords0 = coords_grid(B, Hi // 8, Wi // 8, device=image1.device) if self.args.alternate_corr else None
 
         flow_predictions = []
         flow_up = None
         for _ in range(iters):
             flow = flow.detach()
-            if self.args.alternate_corr:
-                corr = to_channels_last(corr_fn(coords0 + flow))
-            else:
-                corr = corr_fn(flow, channels_last=True, is_flow=True)
+            corr = corr_fn(flow, channels_last=True, is_flow=True)
             net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow)
             flow = flow + delta_flow
             if up_mask is None:

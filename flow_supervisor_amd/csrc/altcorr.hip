@@ -169,6 +169,82 @@ __global__ __launch_bounds__(256) void altcorr_bwd_kernel(const float* __restric
     if (lane + 64 * k < C) g1[qq * C + lane + 64 * k] = acc[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// All pyramid levels in ONE launch, written straight into the channels-last [B,H,W,L*(2r+1)^2] tensor the update block
+// consumes, scaled by 1/sqrt(C): what AlternateCorrBlock.__call__ (pytorch/core/corr.py:74-91) assembles from four
+// extension calls, a stack, a reshape and a division per iteration.  Same wave-per-query dot-product scheme as above;
+// level l reads the l-times average-pooled target map f2[l] ([B,h_l,w_l,C] channels-last) at coords / 2^l.
+struct AltLevels {
+  const float* f2[4];
+  int h[4], w[4];
+};
+struct AltCoords {
+  const float* p;
+  int64_t bs, cs, ps;
+  int grid_w;          // > 0: p holds the flow, the query position is pixel grid + flow
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void altcorr_fused_fwd_kernel(const float* __restrict__ f1, AltLevels lv, AltCoords co,
+                                                                float* __restrict__ out, int nlev, int B, int HW, int C, float scale) {
+  constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN;
+  __shared__ float dots[4][NPOS + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nq = (int64_t)B * HW;
+  if (q >= nq) return;                                  // (wave-uniform; no workgroup barrier below)
+  const int b = (int)(q / HW), pix = (int)(q % HW);
+  float cx0 = co.p[b * co.bs + pix * co.ps], cy0 = co.p[b * co.bs + co.cs + pix * co.ps];
+  if (co.grid_w > 0) { cx0 += (float)(pix % co.grid_w); cy0 += (float)(pix / co.grid_w); }
+  float a[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) a[k] = (lane + 64 * k < C) ? f1[q * C + lane + 64 * k] : 0.f;
+  const int CH = nlev * RD * RD;
+  for (int l = 0; l < nlev; ++l) {
+    const float s = 1.0f / (float)(1 << l);
+    float cx = cx0 * s, cy = cy0 * s;
+    cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+    cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+    const float flx = floorf(cx), fly = floorf(cy);
+    const int x0 = (int)flx, y0 = (int)fly;
+    const float dx = cx - flx, dy = cy - fly;
+    const int H2 = lv.h[l], W2 = lv.w[l];
+    const float* f2b = lv.f2[l] + (int64_t)b * H2 * W2 * C;
+#pragma unroll 1
+    for (int base = 0; base < NPOS; base += 64) {
+      float part[64];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int p = base + i;
+        const int iy = p / WIN, ix = p % WIN;
+        const int h2 = y0 - R + iy, w2 = x0 - R + ix;
+        float sum = 0.f;
+        if (p < NPOS && h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+          const float* row = f2b + ((int64_t)h2 * W2 + w2) * C + lane;
+#pragma unroll
+          for (int k = 0; k < MAXK; ++k)
+            if (lane + 64 * k < C) sum += a[k] * row[64 * k];
+        }
+        part[i] = sum;
+      }
+      const float tot = butterfly64(part);
+      if (base + lane < NPOS) dots[wave][base + lane] = tot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float* o = out + q * CH + l * RD * RD;
+    for (int oc = lane; oc < RD * RD; oc += 64) {
+      const int iyo = oc % RD, ixo = oc / RD;          // channel = iy + RD * ix (x offset slow, as the reference)
+      const float* d = dots[wave] + iyo * WIN + ixo;
+      o[oc] = scale * ((1.f - dy) * (1.f - dx) * d[0] + (1.f - dy) * dx * d[1] + dy * (1.f - dx) * d[WIN] + dy * dx * d[WIN + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
 }  // namespace
 
 extern "C" int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
@@ -192,6 +268,33 @@ extern "C" int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const 
   dim3 grid((unsigned)((nq + 3) / 4));
   if (radius == 4) hipLaunchKernelGGL(altcorr_bwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, H1, W1, H2, W2, C);
   else if (radius == 3) hipLaunchKernelGGL(altcorr_bwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, H1, W1, H2, W2, C);
+  else return FS_ERR_ARG;
+  return fs_launch_status();
+}
+
+// f1 [B,H,W,C] channels-last, f2[l] [B, H >> l, W >> l, C] channels-last (l < num_levels <= 4), coords element (b, c, pix) at
+// coords[b*bs + c*cs + pix*ps] (add_grid != 0: the tensor holds the flow); out [B,H,W,num_levels*(2r+1)^2] = the lookup of
+// CorrBlock on the same maps (scaled by 1/sqrt(C)), without the volume.
+extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_levels, int num_levels, const float* coords,
+                                        int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B,
+                                        int H, int W, int C, int radius, hipStream_t stream) {
+  if (!fmap1 || !fmap2_levels || !coords || !out || num_levels < 1 || num_levels > 4 || B < 1 || H < 1 || W < 1 || C < 1 ||
+      C > 64 * MAXK)
+    return FS_ERR_ARG;
+  AltLevels lv;
+  int h = H, w = W;
+  for (int l = 0; l < 4; ++l) {
+    lv.f2[l] = l < num_levels ? fmap2_levels[l] : nullptr;
+    lv.h[l] = h; lv.w[l] = w;
+    if (l < num_levels && (!fmap2_levels[l] || h < 1 || w < 1)) return FS_ERR_ARG;
+    h /= 2; w /= 2;
+  }
+  AltCoords co{coords, coords_bs, coords_cs, coords_ps, add_grid ? W : 0};
+  const int64_t nq = (int64_t)B * H * W;
+  dim3 grid((unsigned)((nq + 3) / 4));
+  const float scale = 1.0f / sqrtf((float)C);
+  if (radius == 4) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
   else return FS_ERR_ARG;
   return fs_launch_status();
 }

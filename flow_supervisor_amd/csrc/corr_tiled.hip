@@ -148,7 +148,7 @@ struct DvolArgs {
 // LDS-DMA without converting.  CLIP: the run is longer than the segment (very large images) and is processed in pieces.
 template <int R, bool REC, bool CLIP>
 __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate, int l0,
-                                                        int l1, int grid_w) {
+                                                        int l1, int grid_w, int64_t q0) {
   using S = TL<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* seg = smem;                                   // [min(run, DV_SEG)]
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
   const int GC = nl * S::N2;                           // channels of dOut this job needs: [l0 * N2, (l1 + 1) * N2)
   float* g = smem + seglen;                            // [n][GC]
   LevelQ* qi = reinterpret_cast<LevelQ*>(g + ((n * GC + 3) & ~3));   // [n][4]
-  const int64_t q = blockIdx.x;
+  const int64_t q = q0 + blockIdx.x;                   // rows of dvol are numbered from q0 (a chunk of queries per call)
   const int b = (int)(q / HW), pix = (int)(q % HW);
   // dOut slices of the n lookups -> LDS; the lookup index is wave-uniform (pointer from the kernarg table by scalar loads)
   // and ALL loads are in flight before the first LDS store: one memory latency per workgroup, not one per lookup
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
     query_xy(a.co[t], b, pix, grid_w, cx, cy);
     qi[threadIdx.x] = level_query(cx, cy, l, R);
   }
-  float* row = dvol + q * L.P;
+  float* row = dvol + (int64_t)blockIdx.x * L.P;
   for (int s0 = rbeg; s0 < rend; s0 += seglen) {
     const int len = min(seglen, rend - s0);
     __syncthreads();
@@ -343,9 +343,11 @@ extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, co
 // dvol [B*H*W][P] (=, or += when accumulate) sum over the n lookups of (d out_t / d V)^T dout_t; dout[t]: [B,H,W,CH]
 // channels-last; coords[t] with per-lookup strides coords_str[3*t + {0,1,2}] = (bs, cs, ps).  n <= 16 per call.
 // records != 0: rows are written as [32 bf16 hi | 32 bf16 lo] records (operands of fsraft_gemm_rec_nt / _tn).
+// Queries [q0, q0 + nq) only (nq == 0: all from q0), written to dvol rows 0 .. nq-1: the memory-efficient path builds the
+// gradient volume a chunk of queries at a time.
 extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
                                       float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate, int records,
-                                      int add_grid, hipStream_t stream) {
+                                      int add_grid, int64_t q0, int64_t nq, hipStream_t stream) {
   VolLayout L;
   if (!dout || !coords || !coords_str || !dvol || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) ||
       ((uintptr_t)dvol % 16))
@@ -360,7 +362,8 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   }
   for (int t = n; t < DV_MAXN; ++t) { a.dout[t] = nullptr; a.co[t] = Coords{nullptr, 0, 0, 0}; }
   const int N1 = 2 * radius + 1, N2 = N1 * N1;
-  const unsigned grid = (unsigned)((int64_t)B * H * W);
+  if (q0 < 0 || nq < 0 || q0 + nq > (int64_t)B * H * W) return FS_ERR_ARG;
+  const unsigned grid = (unsigned)(nq > 0 ? nq : (int64_t)B * H * W - q0);
   // jobs: runs of whole levels that fit the LDS segment (records need a run to start and end on a multiple of 32 floats)
   int l0 = 0;
   while (l0 < L.nlev) {
@@ -373,7 +376,7 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
     const int GC = (l1 - l0 + 1) * N2;
     const size_t lds = (size_t)((clip ? DV_SEG : run) + ((n * GC + 3) & ~3)) * 4 + (size_t)n * 4 * sizeof(LevelQ);
 #define DVOL_LAUNCH(RR, REC, CLIP) \
-  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1, add_grid ? W : 0)
+  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1, add_grid ? W : 0, q0)
     if (radius == 4) {
       if (records) { if (clip) DVOL_LAUNCH(4, true, true); else DVOL_LAUNCH(4, true, false); }
       else { if (clip) DVOL_LAUNCH(4, false, true); else DVOL_LAUNCH(4, false, false); }

@@ -199,11 +199,13 @@ def corr_lookup_tiled_fwd(vol, lay, coords, radius, is_flow=False):
     return out
 
 
-def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False):
+def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False, q0=0, nq=0):
     """Gradient volume [B*H*W, P] of all stashed lookups (douts[t]: [B,H,W,CH] channels-last, coords[t]: [B,2,H,W]);
-    records=True: rows of [32 hi | 32 lo] bf16 records (the operand format of gemm_rec_nt / gemm_rec_tn)."""
+    records=True: rows of [32 hi | 32 lo] bf16 records (the operand format of gemm_rec_nt / gemm_rec_tn).
+    q0 / nq: build only queries [q0, q0 + nq) (into rows 0 .. nq-1)."""
     H, W = lay.H, lay.W
-    dvol = torch.empty(B * H * W, lay.P, device=douts[0].device, dtype=torch.float32)
+    rows = nq if nq else B * H * W - q0
+    dvol = torch.empty(rows, lay.P, device=douts[0].device, dtype=torch.float32)
     t = TIMER
     e0 = t.begin() if t else None
     for g0 in range(0, len(douts), 16):
@@ -217,12 +219,63 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False)
             st += list(_planar2_strides(c))
         a_s = (ctypes.c_int64 * (3 * n))(*st)
         L.check(_lib().fsraft_corr_dvol_build(ctypes.cast(a_d, L._PP), ctypes.cast(a_c, L._PP), a_s, n, L.ptr(dvol), lay.nlev, B, H,
-                                              W, radius, int(g0 > 0), int(records), int(is_flow), L.stream()), "corr_dvol_build")
+                                              W, radius, int(g0 > 0), int(records), int(is_flow), q0, rows, L.stream()), "corr_dvol_build")
     if t:   # per lookup read dOut + read-modify-write the window taps; plus the zero fill of the dense gradient
-        nl, nq = lay.nlev, B * H * W
-        t.end("corr_lookup_bwd", e0, 0.0, 4.0 * nq * (len(douts) * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2)
-                                                       + sum(h * w for h, w in zip(lay.h, lay.w))))
+        nl = lay.nlev
+        t.end("corr_lookup_bwd", e0, 0.0, 4.0 * rows * (len(douts) * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2)
+                                                         + sum(h * w for h, w in zip(lay.h, lay.w))))
     return dvol
+
+
+def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, chunk=2048, f1r=None):
+    """Backward of volume + lookups WITHOUT an O(N^2) buffer (AlternateCorrBlock's contract, pytorch/core/corr.py:63-91): the
+    gradient volume exists for `chunk` queries at a time (chunk x P floats, records), and every chunk feeds the same two
+    record GEMMs as the dense path: dF1[:, chunk] = s * f2cat . dV^T and d2cat += s * dV^T . f1[chunk].  (dfmap1, dfmap2) NCHW."""
+    B, C, H, W = fmap1.shape
+    N, P = H * W, lay.P
+    s = 1.0 / math.sqrt(C)
+    f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
+    L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
+    f2r = to_records(f2cat)
+    if f1r is None:
+        f1r = fmap_records(fmap1)                                   # [B, N, C] records
+    Cr = f1r.shape[-1]                                              # record pitch of a pixel's channel vector (ceil32(C) floats)
+    d1 = torch.empty(B, C, N, device=fmap1.device, dtype=torch.float32)
+    d2cat = torch.zeros(B, P, C, device=fmap1.device, dtype=torch.float32)
+    lib = _lib()
+    for b in range(B):
+        for i0 in range(0, N, chunk):
+            n = min(chunk, N - i0)
+            dV = corr_dvol_build(douts, coords, lay, B, radius, records=True, is_flow=is_flow, q0=b * N + i0, nq=n)
+            # d1[b][:, i0:i0+n] = s * f2cat[b] [C x P] . dV [n x P]^T
+            L.check(lib.fsraft_gemm_rec_nt(ctypes.c_void_p(f2r.data_ptr() + b * C * P * 4), 0, L.ptr(dV), 0,
+                                           ctypes.c_void_p(d1.data_ptr() + (b * C * N + i0) * 4), N, 0, 1, C, n, P, s, 8, 0, L.stream()),
+                    "gemm_rec_nt")
+            # d2cat[b] [P x C] += s * dV [n x P]^T . f1[b][i0:i0+n] [n x C]
+            L.check(lib.fsraft_gemm_rec_tn(L.ptr(dV), P, 0, ctypes.c_void_p(f1r.data_ptr() + (b * N + i0) * Cr * 4), Cr, 0,
+                                           ctypes.c_void_p(d2cat.data_ptr() + b * P * C * 4), C, 0, 1, P, C, n, s, 3, 1, L.stream()),
+                    "gemm_rec_tn")
+    d2 = torch.empty(B, H, W, C, device=fmap1.device, dtype=torch.float32)
+    L.check(lib.fsraft_corr_dfmap2(L.ptr(d2cat), L.ptr(d2), lay.nlev, B, C, H, W, L.stream()), "corr_dfmap2")
+    return d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
+
+
+def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False):
+    """f1_cl [B,H,W,C], f2_levels[l] [B,H>>l,W>>l,C] channels-last -> [B,H,W,L*(2r+1)^2] (scaled by 1/sqrt(C))."""
+    L.require_cuda_f32(f1_cl, coords, *f2_levels)
+    B, H, W, C = f1_cl.shape
+    bs, cs, ps = _planar2_strides(coords)
+    nl = len(f2_levels)
+    out = torch.empty(B, H, W, nl * (2 * radius + 1) ** 2, device=f1_cl.device, dtype=torch.float32)
+    pp, keep = L.ptr_array(f2_levels)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_altcorr_fused_fwd(L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out), B, H, W, C,
+                                            radius, L.stream()), "altcorr_fused_fwd")
+    if t:   # SURVEY.md 8d: compulsory bytes of the alt path per iteration = fmap1 + the pooled fmap2 pyramid + coords + out
+        t.end("altcorr_fwd", e0, 2.0 * B * H * W * nl * (2 * radius + 2) ** 2 * C,
+              4.0 * B * (H * W * C + sum(f.shape[1] * f.shape[2] for f in f2_levels) * C + H * W * (2 + out.shape[-1])))
+    return out
 
 
 def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None):
@@ -582,7 +635,8 @@ def nchw_to_nhwc(src, dst=None, coff=0, accumulate=False):
     src = src.contiguous()
     B, C, H, W = src.shape
     if dst is None:
-        dst = torch.zeros(B, H, W, (C + 3) // 4 * 4, device=src.device, dtype=torch.float32)
+        # (padding channels must read as zero; a multiple-of-4 channel count has none and needs no fill)
+        dst = (torch.empty if C % 4 == 0 else torch.zeros)(B, H, W, (C + 3) // 4 * 4, device=src.device, dtype=torch.float32)
     ld = dst.shape[-1]
     L.check(_lib().fsraft_nchw_to_nhwc(L.ptr(src), L.ptr(dst), B, C, H * W, ld, coff, int(accumulate), L.stream()),
             "nchw_to_nhwc")

@@ -73,10 +73,12 @@ int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* 
  * all iterations of a step): dvol [B*H*W][P] = (or +=, accumulate != 0) sum_t (d out_t / d V)^T dout_t, pad cells zero;
  * dout[t] is [B,H,W,CH] channels-last, coords[t] element (b, c, pix) at coords[t][b*s0 + c*s1 + pix*s2] with
  * (s0, s1, s2) = coords_str[3t .. 3t+2].  n <= 16 per call.  Each row is accumulated in LDS and written once; records != 0:
- * as [32 bf16 hi | 32 bf16 lo] records, the operand format of fsraft_gemm_rec_nt / _tn below. */
+ * as [32 bf16 hi | 32 bf16 lo] records, the operand format of fsraft_gemm_rec_nt / _tn below.  Only queries [q0, q0 + nq)
+ * (nq == 0: all from q0) are built, into dvol rows 0 .. nq-1 -- AlternateCorrBlock's backward walks the queries in chunks so
+ * that no O(N^2) buffer exists. */
 int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
                            int num_levels, int B, int H, int W, int radius, int accumulate, int records, int add_grid,
-                           hipStream_t stream);
+                           int64_t q0, int64_t nq, hipStream_t stream);
 /* Backward of matmul + avg_pool2d chain (pytorch/core/corr.py:21-27, 52-60) without un-pooling the volume gradient:
  *   f2cat [B][C][P]: level-l cell = mean of fmap2 over its 2^l x 2^l pixels (0 in pad cells), so that
  *   dF1[b][c][i] = s * sum_p f2cat[b][c][p] * dvol[b][i][p]   (one NT GEMM, K = P)  and
@@ -110,6 +112,13 @@ int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coor
 int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
                        float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C,
                        int radius, hipStream_t stream);
+
+/* AlternateCorrBlock.__call__ (pytorch/core/corr.py:74-91: four alt_cuda_corr.forward calls, stack, reshape, / sqrt(C)) as ONE
+ * launch that writes the channels-last [B,H,W,L*(2r+1)^2] lookup: fmap1 [B,H,W,C], fmap2_levels[l] [B,H>>l,W>>l,C] (the
+ * average-pooled maps), coords as in fsraft_corr_lookup_tiled_fwd. */
+int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_levels, int num_levels, const float* coords,
+                             int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B, int H, int W,
+                             int C, int radius, hipStream_t stream);
 
 /* ---- convex 8x upsampler -------------------------------------------------------------
  * Replaces RAFT.upsample_flow, pytorch/core/raft.py:72-83 and UpsampleConvexWithMask,
