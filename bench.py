@@ -52,13 +52,14 @@ def parse():
                          "alt: config 4 (AlternateCorrBlock, use --height 376 --width 1248 --batch-per-gpu 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the exact-fp32 / north_star-encoder short runs and the loss check")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: capture the whole train step in a hipGraph and time replays; 0: eager; -1: auto")
     return ap.parse_args()
 
 
-def cpu_baseline(height, width, iters):
-    """Oracle fwd+bwd on the host cores, one pair, one step (bounded: ~10-30 s of CPU work)."""
+def cpu_baseline(height, width, iters, batch):
+    """Oracle fwd+bwd on the host cores (bounded: ~30 s of CPU work): three steps at one pair, one step at the per-GPU batch."""
     from oracle import raft_torch as O
     from oracle.weights import synthetic_pair
     from flow_supervisor_amd.core.raft import RAFT
@@ -72,18 +73,61 @@ def cpu_baseline(height, width, iters):
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running" not in k:
             v.requires_grad_(True)
-    im1, im2 = synthetic_pair(1, height, width, 1234)
+    im1, im2 = synthetic_pair(batch, height, width, 1234)
     # page-in at a small size so the sample measures compute, not first-touch
-    O.sequence_loss_zero_gt(O.raft_forward(sd, im1[:, :, :64, :128], im2[:, :, :64, :128], iters=1)).backward()
+    O.sequence_loss_zero_gt(O.raft_forward(sd, im1[:1, :, :64, :128], im2[:1, :, :64, :128], iters=1)).backward()
     nstep = 3
     t0 = time.perf_counter()
     for _ in range(nstep):
-        loss = O.sequence_loss_zero_gt(O.raft_forward(sd, im1, im2, iters=iters))
-        loss.backward()
+        O.sequence_loss_zero_gt(O.raft_forward(sd, im1[:1], im2[:1], iters=iters)).backward()
     dt = (time.perf_counter() - t0) / nstep
-    return {"value": 1.0 / dt, "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 pair {height}x{width}, {iters} iters, fwd+bwd, {nstep} steps of oracle/raft_torch.py "
-                      f"(torch CPU fp32, {cores} threads), {dt:.1f} s per step"}
+    out = {"value": 1.0 / dt, "unit": "image-pairs/s", "cores": cores, "kind": "port",
+           "sample": f"1 pair {height}x{width}, {iters} iters, fwd+bwd, {nstep} steps of oracle/raft_torch.py "
+                     f"(torch CPU fp32, {cores} threads), {dt:.1f} s per step"}
+    if batch > 1:
+        t0 = time.perf_counter()
+        O.sequence_loss_zero_gt(O.raft_forward(sd, im1, im2, iters=iters)).backward()
+        dtb = time.perf_counter() - t0
+        out["value_at_gpu_batch"] = batch / dtb
+        out["sample"] += f"; {batch} pairs (the per-GPU batch), 1 step: {dtb:.1f} s"
+    return out
+
+
+def loss_check(dev):
+    """The first-step loss of the benchmark's own configuration against the reference: one pair at 440x1024, 12 iterations,
+    procedural weights and inputs of tests/golden/train_step_basic_440x1024.npz (generated by running the reference)."""
+    import numpy as np
+    from oracle.weights import procedural_state_dict, synthetic_pair
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.train import raft_sequence_loss
+    f = os.path.join(ROOT, "tests", "golden", "train_step_basic_440x1024.npz")
+    if not os.path.exists(f):
+        return None
+    g = np.load(f)
+    seed = int(g["seed"])
+    m = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False))
+    m.load_state_dict(procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed))
+    m = m.to(dev).train()
+    m.freeze_bn()
+    im1, im2 = synthetic_pair(1, int(g["H"]), int(g["W"]), seed + 1)
+    with torch.no_grad():
+        loss = float(raft_sequence_loss(m(im1.to(dev), im2.to(dev), iters=int(g["iters"]))))
+    ref = float(g["loss"])
+    rel = abs(loss - ref) / abs(ref)
+    if rel > 1e-3:
+        raise SystemExit(f"bench: first-step loss {loss} differs from the reference's {ref} (rel {rel:.2e})")
+    return {"loss": loss, "reference": ref, "rel_err": rel, "fixture": "tests/golden/train_step_basic_440x1024.npz"}
+
+
+def set_arithmetic(split):
+    """Switch every GEMM of the path between the bf16x3 cores (the default) and the exact-fp32 MFMA cores."""
+    from flow_supervisor_amd import _lib, ops
+    lib = _lib.load()
+    lib.fsraft_set_tuning(3, 1 if split else 0)
+    lib.fsraft_set_tuning(4, 2 if split else 0)
+    lib.fsraft_set_build_split(1 if split else 0)
+    lib.fsraft_set_gemm_split(1 if split else 0)
+    ops.SPLIT_VOLUME_BWD = bool(split)
 
 
 def main():
@@ -185,33 +229,62 @@ def main():
         torch.cuda.synchronize()
     loss_v = float(loss if loss is not None else loss_e)
 
+    split_mode = os.environ.get("FSRAFT_CONV_SPLIT", "1") != "0"
+    extra = {}
+    if world == 1 and a.variant == "raft" and not a.no_extra:
+        # the same step with every GEMM on the exact-fp32 MFMA cores, and with the encoders as BASELINE.json's north_star has
+        # them (PyTorch-ROCm / MIOpen convolutions): short runs, reported next to `value`
+        def short_run(n=3):
+            step(im1, im2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step(im1, im2)
+            torch.cuda.synchronize()
+            return B * n / (time.perf_counter() - t1)
+        if split_mode:
+            set_arithmetic(False)
+            extra["value_exact_f32"] = short_run()
+            set_arithmetic(True)
+        if os.environ.get("FSRAFT_ENCODER_CL", "1") != "0":
+            os.environ["FSRAFT_ENCODER_CL"] = "0"
+            extra["value_north_star_encoders"] = short_run()
+            os.environ["FSRAFT_ENCODER_CL"] = "1"
+        if a.height == 440 and a.width == 1024 and a.iters == 12:
+            lc = loss_check(dev)
+            if lc:
+                extra["loss_check"] = lc
+
     if rank != 0:
         return
     pairs = B * world * a.steps
+    shape_note = " (Sintel 436x1024 padded)" if (a.height, a.width) == (440, 1024) else (" (KITTI 375x1242 padded)" if (a.height, a.width) == (376, 1248) else "")
     out = {
-        "metric": "image-pairs/s fwd+bwd, 12 GRU iters, 436x1024", "value": pairs / dt, "unit": "image-pairs/s",
+        "metric": f"image-pairs/s fwd+bwd, {a.iters} GRU iters, " + ("436x1024" if (a.height, a.width) == (440, 1024) else f"{a.height}x{a.width}"),
+        "value": pairs / dt, "unit": "image-pairs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32 (bf16x3 products)" if split_mode else "f32",
         "dtype_note": ("f32 storage and accumulation; GEMM products evaluated as 3 bf16 MFMA products per fp32 product "
-                       "(split-bf16, ~2^-17 relative error per product; EPE vs the fp32 reference <= 3e-4)")
-                      if os.environ.get("FSRAFT_CONV_SPLIT", "1") != "0" else "exact fp32 MFMA",
+                       "(split-bf16, ~2^-17 relative error per product; EPE vs the fp32 reference <= 3e-4); "
+                       "value_exact_f32 = the same step on the exact-fp32 MFMA cores")
+                      if split_mode else "exact fp32 MFMA",
         "data": "synthetic",
         "config": {"workload": {"raft": "RAFT full", "gma": "RAFT-GMA (config 5)", "alt": "RAFT full, AlternateCorrBlock (config 4)"}[a.variant] +
-                               f", {a.height}x{a.width} (Sintel 436x1024 padded), {a.iters} GRU iters, "
+                               f", {a.height}x{a.width}{shape_note}, {a.iters} GRU iters, "
                                f"{B} pairs/GPU, train step = fwd + sequence loss + bwd + RCCL all-reduce + clip + AdamW",
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v,
                    "launch": "hipGraph replay of the whole step" if graph is not None else "eager",
                    "encoders": ("MIOpen NCHW convolutions (north_star configuration)" if os.environ.get("FSRAFT_ENCODER_CL", "1") == "0"
-                                else "channels_last on the fsraft kernels (stride-2 units via space-to-depth); 7x7 stem on MIOpen")},
+                                else "channels_last on the fsraft kernels (stride-2 units via space-to-depth); 7x7 stem on MIOpen; "
+                                     "value_north_star_encoders = the same step with the encoders on MIOpen")},
     }
+    out.update(extra)
     if timer is not None:
         kern = {}
-        split = {"conv_igemm": os.environ.get("FSRAFT_CONV_SPLIT", "1") != "0",
-                 "conv_wgrad": os.environ.get("FSRAFT_WGRAD_SPLIT", "2") != "0",
-                 "gemm_f32": True}
+        split = {"conv_igemm": split_mode, "conv_wgrad": os.environ.get("FSRAFT_WGRAD_SPLIT", "2") != "0", "gemm_f32": True}
         for fam, s in timer.summary().items():
-            mfma = fam in ("conv_igemm", "conv_wgrad", "gemm_f32")
+            mfma = fam in ("conv_igemm", "conv_wgrad", "gemm_f32", "altcorr_fwd", "altcorr_bwd")
             sec = s["ms_total"] * 1e-3
             basis = None
             if mfma and split.get(fam):
@@ -221,7 +294,10 @@ def main():
                 basis = "algorithmic fp32 FLOPs vs dense bf16 MFMA peak (2500 TFLOP/s) / 3 MFMA products per fp32 product"
             elif mfma:
                 ach, peak, unit = s["flops"] / sec / 1e12, PEAK_F32_MFMA_TF, "TFLOP/s"
-                basis = "algorithmic fp32 FLOPs vs dense fp32 MFMA peak"
+                basis = ("algorithmic fp32 FLOPs vs the fp32 vector / MFMA peak (157.3 TFLOP/s); the kernel is a vector-ALU dot-product "
+                         "kernel fed from L2" if fam == "altcorr_fwd" else
+                         "FLOPs of alt_cuda_corr.backward's window products vs the fp32 peak; computed here as chunks of the gradient "
+                         "volume + bf16x3 GEMMs" if fam == "altcorr_bwd" else "algorithmic fp32 FLOPs vs dense fp32 MFMA peak")
             else:
                 ach, peak, unit = s["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
             kern[fam] = {"bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": unit,
@@ -235,6 +311,18 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
         out["roofline"] = dict(kern[dom], kernel=dom)
         out["kernels"] = kern
+        # the north-star quantity: algorithmic bytes of the whole correlation path (build, lookups, their
+        # backward incl. the zero fill of the gradient volume, build backward) over the time of every kernel that serves it
+        fams = [f for f in ("corr_build", "corr_lookup_fwd", "corr_lookup_bwd", "corr_build_bwd") if f in kern]
+        if len(fams) == 4:
+            summ = timer.summary()
+            byt = sum(summ[f]["bytes"] for f in fams) / timer.steps
+            ms = sum(kern[f]["ms_per_step"] for f in fams)
+            out["roofline_corr"] = {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": byt / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_step": byt, "ms_per_step": ms,
+                                    "kernels": fams, "traffic": None,
+                                    "note": "algorithmic bytes of SURVEY.md 8d (1.452 GB per pair at 55x128, 12 lookups) / summed "
+                                            "kernel time of build + lookups + gradient volume + build backward"}
         tr = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
         if os.path.exists(tr):
             t = json.load(open(tr))
@@ -243,7 +331,7 @@ def main():
                     kern[fam]["traffic"] = v
             out["roofline"]["traffic"] = kern[dom]["traffic"]
     if world == 1 and not a.no_cpu_baseline and a.variant == "raft":
-        out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters)
+        out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, B)
     print(json.dumps(out))
 
 

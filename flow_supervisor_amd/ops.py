@@ -234,6 +234,8 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
     B, C, H, W = fmap1.shape
     N, P = H * W, lay.P
     s = 1.0 / math.sqrt(C)
+    tm = TIMER
+    e0 = tm.begin() if tm else None
     f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
     L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
     f2r = to_records(f2cat)
@@ -257,7 +259,13 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
                     "gemm_rec_tn")
     d2 = torch.empty(B, H, W, C, device=fmap1.device, dtype=torch.float32)
     L.check(lib.fsraft_corr_dfmap2(L.ptr(d2cat), L.ptr(d2), lay.nlev, B, C, H, W, L.stream()), "corr_dfmap2")
-    return d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
+    out = d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
+    if tm:   # alt-corr backward of all lookups of the step: compulsory bytes = per lookup dOut + coords, the feature maps and
+        #      their gradients; FLOPs = the window dot products of alt_cuda_corr.backward (correlation_kernel.cu:122-256)
+        T = len(douts)
+        K = lay.nlev * (2 * radius + 1) ** 2
+        tm.end("altcorr_bwd", e0, 4.0 * T * B * N * lay.nlev * (2 * radius + 2) ** 2 * C, 4.0 * B * N * (T * (K + 2) + 4 * C))
+    return out
 
 
 def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False):
@@ -285,6 +293,8 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None):
     B, C, H, W = fmap1.shape
     N, P = H * W, lay.P
     s = 1.0 / math.sqrt(C)
+    tm = TIMER
+    e0 = tm.begin() if tm else None
     f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
     L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
     dV = dvol.view(B, N, P)
@@ -302,7 +312,11 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None):
             d2cat = gemm(dV.transpose(1, 2).contiguous(), f1t.transpose(1, 2).contiguous(), True, s)
     d2 = torch.empty(B, H, W, C, device=fmap1.device, dtype=torch.float32)
     L.check(_lib().fsraft_corr_dfmap2(L.ptr(d2cat), L.ptr(d2), lay.nlev, B, C, H, W, L.stream()), "corr_dfmap2")
-    return d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
+    out = d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
+    if tm:   # SURVEY.md 8d, build backward: read dV + read the feature maps + write their gradients (the zero fill of dV is
+        #      counted with the lookups' backward); FLOPs of the two contractions over the level-0 volume
+        tm.end("corr_build_bwd", e0, 4.0 * B * N * N * C, 4.0 * B * (N * sum(h * w for h, w in zip(lay.h, lay.w)) + 4 * N * C))
+    return out
 
 
 def corr_pool_pyramid(level0, num_levels, same=False):
