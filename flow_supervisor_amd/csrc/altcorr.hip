@@ -245,6 +245,116 @@ __global__ __launch_bounds__(256) void altcorr_fused_fwd_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile variant of the fused lookup: the wave-per-query kernel above reads (2r+2)^2 target rows of C floats per query and
+// level straight from L2 (400 KB per query, 2.9 GB per lookup at 47x156: L2-bandwidth bound), although the windows of
+// neighbouring queries overlap almost completely when the flow is smooth.  Here a workgroup of SIXTEEN waves owns a 4x4
+// tile of queries: per level it stages ONE 16x16 region of target rows (anchored at the first query's window) in LDS, 64
+// channels at a time, and every wave (= query) takes its (2r+2)^2 dot products out of that region -- lane = window
+// position, running over the channels -- falling back to global reads only for positions the region does not cover
+// (flow discontinuities).  L2 traffic per tile and level: 256 rows instead of 16 x 100.
+constexpr int AT_TQ = 4, AT_RS = 16, AT_CS = 64, AT_PITCH = AT_CS + 1;   // odd pitch: lane = position reads hit 32 distinct banks
+
+template <int R>
+__global__ __launch_bounds__(1024) void altcorr_tile_fwd_kernel(const float* __restrict__ f1, AltLevels lv, AltCoords co,
+                                                                float* __restrict__ out, int nlev, int H, int W, int C, float scale) {
+  constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN, NRND = (NPOS + 63) / 64;
+  __shared__ float region[AT_RS * AT_RS * AT_PITCH];      // 65 KB
+  __shared__ __attribute__((aligned(16))) float f1s[16][256];
+  __shared__ float dots[16][NPOS + 4];
+  __shared__ int org[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_x = (W + AT_TQ - 1) / AT_TQ;
+  const int b = blockIdx.y, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int qx = tx * AT_TQ + (wave & 3), qy = ty * AT_TQ + (wave >> 2);
+  const bool active = qx < W && qy < H;                   // (wave-uniform)
+  const int pix = active ? qy * W + qx : 0;
+  const int64_t q = (int64_t)b * H * W + pix;
+  float cx0 = 0.f, cy0 = 0.f;
+  if (active) {
+    cx0 = co.p[b * co.bs + pix * co.ps]; cy0 = co.p[b * co.bs + co.cs + pix * co.ps];
+    if (co.grid_w > 0) { cx0 += (float)qx; cy0 += (float)qy; }
+    for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(&f1s[wave][c]) = *reinterpret_cast<const f32x4*>(f1 + q * C + c);
+  }
+  const int CH = nlev * RD * RD;
+  for (int l = 0; l < nlev; ++l) {
+    const float s = 1.0f / (float)(1 << l);
+    float cx = cx0 * s, cy = cy0 * s;
+    cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+    cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+    const float flx = floorf(cx), fly = floorf(cy);
+    const int wx0 = (int)flx - R, wy0 = (int)fly - R;
+    const float dx = cx - flx, dy = cy - fly;
+    const int H2 = lv.h[l], W2 = lv.w[l];
+    const float* f2b = lv.f2[l] + (int64_t)b * H2 * W2 * C;
+    if (threadIdx.x == 0) { org[0] = wx0 - 1; org[1] = wy0 - 1; }     // (query 0 of a tile is always inside the image)
+    __syncthreads();
+    const int rx0 = org[0], ry0 = org[1];
+    // this lane's window positions (one per round) and where they sit in the region / in the level
+    int rpos[NRND], gpos[NRND];
+#pragma unroll
+    for (int k = 0; k < NRND; ++k) {
+      const int p = lane + 64 * k, iy = p / WIN, ix = p % WIN;
+      const int gx = wx0 + ix, gy = wy0 + iy, ux = gx - rx0, uy = gy - ry0;
+      const bool inimg = active && p < NPOS && gx >= 0 && gx < W2 && gy >= 0 && gy < H2;
+      gpos[k] = inimg ? gy * W2 + gx : -1;
+      rpos[k] = (inimg && ux >= 0 && ux < AT_RS && uy >= 0 && uy < AT_RS) ? uy * AT_RS + ux : -1;
+    }
+    float acc[NRND];
+#pragma unroll
+    for (int k = 0; k < NRND; ++k) acc[k] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += AT_CS) {
+      // stage the region's rows, channels [c0, c0 + 64): 16 lanes x 16 bytes per row, 64 rows per pass
+      for (int rp = threadIdx.x >> 4; rp < AT_RS * AT_RS; rp += 64) {
+        const int gx = rx0 + (rp & (AT_RS - 1)), gy = ry0 + rp / AT_RS, cc = (threadIdx.x & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gx >= 0 && gx < W2 && gy >= 0 && gy < H2 && c0 + cc < C) v = *reinterpret_cast<const f32x4*>(f2b + ((int64_t)gy * W2 + gx) * C + c0 + cc);
+        float* d = region + rp * AT_PITCH + cc;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NRND; ++k) {
+        if (gpos[k] < 0) continue;
+        float sum = 0.f;
+        if (rpos[k] >= 0) {
+          const float* rr = region + rpos[k] * AT_PITCH;
+#pragma unroll 16
+          for (int c = 0; c < AT_CS; c += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&f1s[wave][c0 + c]);     // (same address in every lane: broadcast)
+            sum += a[0] * rr[c] + a[1] * rr[c + 1] + a[2] * rr[c + 2] + a[3] * rr[c + 3];
+          }
+        } else {                                            // outside the staged region: the row comes from L2
+          const float* row = f2b + (int64_t)gpos[k] * C + c0;
+          for (int c = 0; c < AT_CS && c0 + c < C; c += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&f1s[wave][c0 + c]);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            sum += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
+          }
+        }
+        acc[k] += sum;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NRND; ++k)
+      if (lane + 64 * k < NPOS) dots[wave][lane + 64 * k] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (active) {
+      float* o = out + q * CH + l * RD * RD;
+      for (int oc = lane; oc < RD * RD; oc += 64) {
+        const int iyo = oc % RD, ixo = oc / RD;          // channel = iy + RD * ix (x offset slow, as the reference)
+        const float* d = dots[wave] + iyo * WIN + ixo;
+        o[oc] = scale * ((1.f - dy) * (1.f - dx) * d[0] + (1.f - dy) * dx * d[1] + dy * (1.f - dx) * d[WIN] + dy * dx * d[WIN + 1]);
+      }
+    }
+  }
+}
+
+int g_alt_tile = 1;       // 1: tile kernel where it applies (C a multiple of 64), 0: wave-per-query kernel
+
 }  // namespace
 
 extern "C" int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
@@ -293,8 +403,20 @@ extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* 
   const int64_t nq = (int64_t)B * H * W;
   dim3 grid((unsigned)((nq + 3) / 4));
   const float scale = 1.0f / sqrtf((float)C);
+  if (g_alt_tile && C % 64 == 0 && C <= 256 && ((uintptr_t)fmap1 % 16) == 0) {
+    dim3 tg((unsigned)(((W + AT_TQ - 1) / AT_TQ) * ((H + AT_TQ - 1) / AT_TQ)), (unsigned)B);
+    if (radius == 4) hipLaunchKernelGGL(altcorr_tile_fwd_kernel<4>, tg, dim3(1024), 0, stream, fmap1, lv, co, out, num_levels, H, W, C, scale);
+    else if (radius == 3) hipLaunchKernelGGL(altcorr_tile_fwd_kernel<3>, tg, dim3(1024), 0, stream, fmap1, lv, co, out, num_levels, H, W, C, scale);
+    else return FS_ERR_ARG;
+    return fs_launch_status();
+  }
   if (radius == 4) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
   else if (radius == 3) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
   else return FS_ERR_ARG;
   return fs_launch_status();
+}
+
+extern "C" int fsraft_set_alt_tile(int on) {
+  g_alt_tile = on;
+  return FS_OK;
 }

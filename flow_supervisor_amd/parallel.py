@@ -5,11 +5,13 @@ single-process nn.DataParallel (pytorch/train.py:192: per step broadcast of all 
 scatter, gather of 12-24 full-resolution outputs to GPU 0, reduce of gradients to GPU 0) and
 tf.distribute.MirroredStrategy (train.py:75-78).
 
-Gradients live in one flat fp32 buffer (every ``p.grad`` is a view into it), so the exchange is
-a single 21 MB collective with no packing copies: on 8 fully connected MI355X (7 xGMI links of
-~153 GB/s each) that is ~0.1-0.3 ms against a >100 ms step, which is why there is no bucketing
-or overlap machinery here -- it would be hiding 0.2 % of the step.  Gradient clipping and AdamW
-then run identically on every rank on identical tensors, so no second collective is needed.
+Gradients live in one flat fp32 buffer (after the exchange every ``p.grad`` is a view into it), laid out in
+three buckets -- update block, context encoder, feature encoder, the order in which backward finishes them --
+and each bucket's all-reduce is issued asynchronously from a post-accumulate hook as soon as its last gradient
+exists, so that the exchange of the update block's 4.7 M parameters runs under the encoders' backward
+(SURVEY.md 5 / 8e).  21 MB over 7 xGMI links of ~153 GB/s is ~0.1-0.3 ms, so what the overlap buys is the
+latency of three collectives, not bandwidth.  Gradient clipping and AdamW then run identically on every rank
+on identical tensors, so no second collective is needed.
 """
 import os
 
@@ -48,29 +50,119 @@ def shard_batch(global_batch, rank, world):
 
 
 class FlatGradients:
-    """All gradients of `params` as views into one contiguous fp32 buffer."""
+    """All gradients of `params` in one contiguous fp32 buffer, exchanged in BUCKETS that overlap the rest of backward.
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    Backward of RAFT reaches the update block's parameters first (one packed-arena unpack after the last of the 12
+    iterations), then the context encoder, then -- behind the volume backward -- the feature encoder.  Parameters are
+    grouped into buckets by the top-level module they belong to, laid out bucket by bucket in the flat buffer, and a
+    bucket's all-reduce (RCCL, asynchronous, on the collective's own stream) starts from a post-accumulate hook the moment
+    its last gradient has arrived, while autograd continues with the encoders.  `finish()` -- called
+    by all_reduce_mean_ -- launches whatever is left and waits.
+
+    Gradients are not accumulated INTO the buffer by autograd: `begin()` sets every .grad to None, so autograd hands each
+    parameter its gradient tensor as is, and one multi-tensor copy per bucket moves them in (instead of one zero fill plus
+    ~150 separate accumulation kernels per step).  After finish(), p.grad are views into the buffer again."""
+
+    def __init__(self, params, names=None):
+        params = list(params)
+        names = list(names) if names is not None else [str(i) for i in range(len(params))]
+        keep = [(n, p) for n, p in zip(names, params) if p.requires_grad]
+        order = {}
+        for n, _ in keep:                                    # buckets in first-appearance order of the top-level module ...
+            order.setdefault(n.split(".", 1)[0], len(order))
+        # ... laid out so that the module whose gradients arrive first (update block) comes first when it exists
+        rank = lambda k: (0 if "update" in k else 1 if k.startswith("cnet") else 2, order[k])
+        keys = sorted(order, key=rank)
+        self.buckets = [[p for n, p in keep if n.split(".", 1)[0] == k] for k in keys]
+        self.params = [p for b in self.buckets for p in b]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        o = 0
+        self.views, self.slices, o = {}, [], 0
+        for b in self.buckets:
+            o0 = o
+            for p in b:
+                self.views[p] = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.slices.append((o0, o))
+        self._bucket_of = {p: i for i, b in enumerate(self.buckets) for p in b}
+        self._pending = None
+        self._handles = []
+        self._weight = 1.0
+        self._active = False
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
+            p.grad = self.views[p]
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    # ---- per step -------------------------------------------------------------------------------------------------
+    def begin(self, local_batch=None, global_batch=None):
+        """Call before backward: arms the bucket hooks for this step."""
+        for p in self.params:
+            p.grad = None
+        self._pending = [len(b) for b in self.buckets]
+        self._done = [False] * len(self.buckets)
+        self._handles = []
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        self._weight = (1.0 / world) if local_batch is None else float(local_batch) / float(global_batch)
+        self._active = True
 
     def zero_(self):
-        self.flat.zero_()
+        """(kept for callers of the round-1 interface) equivalent to begin()."""
+        self.begin()
+
+    def _hook(self, p):
+        if not self._active:
+            return
+        i = self._bucket_of[p]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._launch(i)
+
+    def _launch(self, i):
+        """Move bucket i's gradients into the flat buffer (one multi-tensor copy) and start its exchange."""
+        if self._done[i]:
+            return
+        self._done[i] = True
+        have = [p for p in self.buckets[i] if p.grad is not None and p.grad is not self.views[p]]
+        missing = [p for p in self.buckets[i] if p.grad is None]
+        if have:
+            torch._foreach_copy_([self.views[p] for p in have], [p.grad for p in have])
+        for p in missing:
+            self.views[p].zero_()
+        for p in self.buckets[i]:
+            p.grad = self.views[p]
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            a, b = self.slices[i]
+            seg = self.flat[a:b]
+            seg.mul_(self._weight)
+            if _host_staged(seg):
+                _all_reduce_sum_(seg)
+            else:
+                self._handles.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """Launch the buckets whose hooks did not complete (unused parameters) and wait for every exchange."""
+        if not self._active:
+            return
+        for i in range(len(self.buckets)):
+            self._launch(i)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._active = False
 
     def all_reduce_mean_(self, local_batch=None, global_batch=None):
         """Gradient of the GLOBAL-batch mean loss from per-rank gradients of local-batch mean losses: every rank's
         gradient is weighted by local_batch / global_batch before the sum (equal shards: 1 / world, what DataParallel's
-        reduce + batch-mean loss give).  `shard_batch` hands out unequal shards when the global batch does not divide."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            w = 1.0 / dist.get_world_size() if local_batch is None else float(local_batch) / float(global_batch)
-            self.flat.mul_(w)
-            _all_reduce_sum_(self.flat)
+        reduce + batch-mean loss give).  With begin() called before backward the buckets are already in flight and this
+        only waits; without it (plain use) it performs the whole exchange here."""
+        if not self._active:                      # begin() was not called: gradients were accumulated into the views by autograd
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                w = 1.0 / dist.get_world_size() if local_batch is None else float(local_batch) / float(global_batch)
+                self.flat.mul_(w)
+                _all_reduce_sum_(self.flat)
+            return
+        self.finish()
 
     def clip_norm_(self, max_norm):
         """clip_grad_norm_(params, max_norm) on the flat buffer (pytorch/train.py:280)."""

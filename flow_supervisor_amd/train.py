@@ -74,21 +74,22 @@ class TrainStep:
         self.model = model
         self.iters = iters
         self.clip = clip
-        self.grads = FlatGradients(model.parameters())
+        named = list(model.named_parameters())
+        self.grads = FlatGradients([p for _, p in named], [n for n, _ in named])
         fused = self.grads.flat.is_cuda
         self.opt = torch.optim.AdamW(self.grads.params, lr=lr, weight_decay=wdecay, eps=eps, fused=fused,
                                      capturable=bool(capturable and fused))
 
     def __call__(self, image1, image2, flow_gt=None, global_batch=None):
         """image1/image2: this rank's shard.  global_batch: pairs over all ranks (default: equal shards)."""
-        self.grads.zero_()
+        if global_batch is None:
+            self.grads.begin()
+        else:
+            self.grads.begin(image1.shape[0], global_batch)
         preds = self.model(image1, image2, iters=self.iters)
         loss = raft_sequence_loss(preds, flow_gt)
-        loss.backward()
-        if global_batch is None:
-            self.grads.all_reduce_mean_()
-        else:
-            self.grads.all_reduce_mean_(image1.shape[0], global_batch)
+        loss.backward()                           # bucket hooks start each all-reduce as its gradients complete
+        self.grads.all_reduce_mean_()
         self.grads.clip_norm_(self.clip)
         self.opt.step()
         return loss.detach()

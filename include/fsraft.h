@@ -120,6 +120,8 @@ int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_level
                              int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B, int H, int W,
                              int C, int radius, hipStream_t stream);
 
+int fsraft_set_alt_tile(int on);   /* 1 (default): 4x4-query tile kernel with an LDS-staged target region; 0: wave per query */
+
 /* ---- convex 8x upsampler -------------------------------------------------------------
  * Replaces RAFT.upsample_flow, pytorch/core/raft.py:72-83 and UpsampleConvexWithMask,
  * raft/upsample.py:11-41.  flow element (n,c,pix) at flow[n*bs + c*cs + pix*ps];

@@ -36,11 +36,12 @@ def _worker(rank, world, port, out):
     torch.manual_seed(100 + rank)                      # deliberately different init per rank
     model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
     broadcast_parameters(model)
-    grads = FlatGradients(model.parameters())
+    grads = FlatGradients([p for _, p in model.named_parameters()], [n for n, _ in model.named_parameters()])
+    assert len(grads.buckets) == 2                     # one bucket per top-level module ("0", "2")
     torch.manual_seed(7)
     x = torch.randn(6, 3, 10, 12)                      # the GLOBAL batch, identical on every rank
     s, n = shard_batch(6, rank, world)
-    grads.zero_()
+    grads.begin()                                      # arms the per-bucket hooks: exchanges start during backward
     # per-rank mean loss over its shard; mean over ranks of per-rank means == global mean (equal shards)
     loss = _toy_loss([model(x[s:s + n]), 0.5 * model(x[s:s + n])])
     loss.backward()
@@ -92,9 +93,9 @@ def _worker_unequal(rank, world, port, out):
     torch.manual_seed(8)
     x = torch.randn(5, 3, 10, 12)
     s, n = shard_batch(5, rank, world)
-    grads.zero_()
+    grads.begin(n, 5)
     _toy_loss([model(x[s:s + n]), 0.5 * model(x[s:s + n])]).backward()
-    grads.all_reduce_mean_(n, 5)
+    grads.all_reduce_mean_()
     if rank == 0:
         torch.save({"flat": grads.flat.clone()}, out)
 
