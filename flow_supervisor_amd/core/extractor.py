@@ -122,15 +122,27 @@ class _ToNCHW(torch.autograd.Function):
         return _as_cl(g)
 
 
+class _ResLink:
+    """Ties the two consumers of a residual unit's input x together in backward: the unit's last norm kernel writes the
+    shortcut gradient dres (and hands it to autograd as x's gradient), the first convolution's data gradient -- which runs
+    later -- ACCUMULATES into that same tensor through its epilogue and reports no gradient of its own.  Autograd would
+    otherwise add the two x-sized tensors in a separate pass (12 of them per step, up to 230 MB each)."""
+    __slots__ = ("dres",)
+
+    def __init__(self):
+        self.dres = None
+
+
 class _InstNormReluCL(torch.autograd.Function):
     """_InstNormRelu for channels_last tensors (storage [N][H*W][C]): csrc/norm_cl.hip.  With `res` (the shortcut of a
     residual unit, channels_last) the result is relu(res + relu?(norm(x))) in the same pass -- the unit's add and final ReLU
     (and their backward) cost no extra trip over the tensor."""
 
     @staticmethod
-    def forward(ctx, x, eps, relu, res=None):
+    def forward(ctx, x, eps, relu, res=None, link=None):
         from .. import _lib as L
         ctx.in_cl = _is_cl(x)
+        ctx.link = link
         x = _as_cl(x)
         N, C, H, W = x.shape
         if res is not None:
@@ -156,24 +168,29 @@ class _InstNormReluCL(torch.autograd.Function):
         acc = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (norm_cl.hip)
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
                                                   L.ptr(dres), N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
-        return dx if ctx.in_cl else _as_nchw(dx), None, None, dres     # an NCHW producer (MIOpen) gets an NCHW gradient
+        if ctx.link is not None:
+            ctx.link.dres = dres
+        return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None     # an NCHW producer (MIOpen) gets an NCHW gradient
 
 
 class _FrozenBNReluCL(torch.autograd.Function):
     """_FrozenBNRelu for channels_last tensors; `res` as in _InstNormReluCL."""
 
     @staticmethod
-    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu, res=None):
+    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu, res=None, link=None):
         from .. import _lib as L
         ctx.in_cl = _is_cl(x)
+        ctx.link = link
         x = _as_cl(x)
         N, C, H, W = x.shape
         if res is not None:
             res = _as_cl(res)
-        rs = torch.rsqrt(rv.float() + eps)
-        scale = (weight.float() * rs).contiguous()
-        rmc = rm.float() - cbias.float() if cbias is not None else rm.float()
-        shift = (bias.float() - rmc * scale).contiguous()
+        fold = torch.empty(4, C, device=x.device, dtype=torch.float32)       # scale, shift, rs, rmc: one launch (csrc/norm_cl.hip)
+        scale, shift, rs, rmc = fold[0], fold[1], fold[2], fold[3]
+        L.check(L.load().fsraft_bn_fold(L.ptr(weight.detach().float().contiguous()), L.ptr(bias.detach().float().contiguous()),
+                                        L.ptr(rm.float().contiguous()), L.ptr(rv.float().contiguous()),
+                                        L.ptr(cbias.detach().float().contiguous()) if cbias is not None else None, float(eps), C,
+                                        L.ptr(scale), L.ptr(shift), L.ptr(rs), L.ptr(rmc), L.stream()), "bn_fold")
         y = torch.empty_like(x)
         L.check(L.load().fsraft_affine_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(scale), L.ptr(shift), L.ptr(y), N * H * W, C, int(relu),
                                                    L.stream()), "affine_relu_cl_fwd")
@@ -195,10 +212,13 @@ class _FrozenBNReluCL(torch.autograd.Function):
         L.check(L.load().fsraft_affine_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), L.ptr(dx), L.ptr(dres),
                                                    L.ptr(part[0]), L.ptr(part[1]), N, H * W, C, int(ctx.relu), L.stream()),
                 "affine_relu_cl_bwd")
-        sums = part.sum(dim=1)
-        dweight = rs * (sums[1] - rm * sums[0])
-        dcbias = scale * sums[0] if ctx.has_cbias else None
-        return dx if ctx.in_cl else _as_nchw(dx), dcbias, dweight, sums[0], None, None, None, None, dres
+        dpar = torch.empty(3, C, device=x.device, dtype=torch.float32)       # dweight, dbias, dcbias: one launch
+        L.check(L.load().fsraft_bn_fold_bwd(L.ptr(part), N * 8, C, L.ptr(rs), L.ptr(rm), L.ptr(scale), L.ptr(dpar[0]), L.ptr(dpar[1]),
+                                            L.ptr(dpar[2]) if ctx.has_cbias else None, L.stream()), "bn_fold_bwd")
+        if ctx.link is not None:
+            ctx.link.dres = dres
+        return (dx if ctx.in_cl else _as_nchw(dx), dpar[2] if ctx.has_cbias else None, dpar[0], dpar[1], None, None, None, None, dres,
+                None)
 
 
 def _weight_packs(conv):
@@ -227,8 +247,9 @@ class _ConvCL(torch.autograd.Function):
     The storage of a channels_last [B,C,H,W] tensor IS the kernels' [B,H,W,C] layout, so nothing is transposed."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packs):
+    def forward(ctx, x, weight, bias, packs, link=None):
         from .. import ops
+        ctx.link = link if _is_cl(x) else None       # (a converted copy of x is not the tensor the shortcut gradient belongs to)
         x = _as_cl(x)
         B, C, H, W = x.shape
         N, _, KH, KW = weight.shape
@@ -250,20 +271,27 @@ class _ConvCL(torch.autograd.Function):
         gv = ops.V(g.permute(0, 2, 3, 1), N)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dxb = torch.empty(B, H, W, C, device=x.device, dtype=torch.float32)
-            ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dxb)], wpk_split=ctx.packs[4],
-                             wpk_frag=ctx.packs[6])
-            dx = dxb.permute(0, 3, 1, 2)
+            dres = ctx.link.dres if ctx.link is not None else None
+            if dres is not None and dres.shape == x.shape and _is_cl(dres) and dres.dtype == torch.float32:
+                # residual unit: add this data gradient into the shortcut gradient autograd already holds for x (see _ResLink)
+                ctx.link.dres = None
+                ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dres.permute(0, 2, 3, 1), acc=True)],
+                                 wpk_split=ctx.packs[4], wpk_frag=ctx.packs[6])
+            else:
+                dxb = torch.empty(B, H, W, C, device=x.device, dtype=torch.float32)
+                ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dxb)], wpk_split=ctx.packs[4],
+                                 wpk_frag=ctx.packs[6])
+                dx = dxb.permute(0, 3, 1, 2)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
             dwpk = ops.zeros(N, ops.conv_ktot([C], KH, KW), device=x.device)
             db = ops.zeros(N, device=x.device) if want_b else None
             ops.conv_wgrad(gv, [ops.V(x.permute(0, 2, 3, 1), C)], dwpk, B, H, W, KH, KW, dbias=db)
             dw = ops.unpack_weight_grad(dwpk, tuple(weight.shape), [C])
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def _conv(conv, x, bias):
+def _conv(conv, x, bias, link=None):
     """conv(x) with the given bias (None: without).  A channels_last fp32 input of a stride-1 1x1 / 3x3 convolution takes
     the fsraft kernels; anything else is MIOpen on an NCHW tensor (its NHWC fp32 kernels are far slower than its NCHW
     ones on gfx950 -- the backward-weights one by two orders of magnitude -- so a channels_last input is converted)."""
@@ -271,7 +299,7 @@ def _conv(conv, x, bias):
     if (_is_cl(x) and x.is_cuda and x.dtype == torch.float32 and k in ((3, 3), (1, 1)) and conv.stride == (1, 1)
             and conv.padding == (k[0] // 2, k[1] // 2) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.padding_mode == "zeros" and x.shape[1] % 4 == 0 and not torch.is_autocast_enabled()):
-        return _ConvCL.apply(x, conv.weight, bias, _weight_packs(conv))
+        return _ConvCL.apply(x, conv.weight, bias, _weight_packs(conv), link)
     return F.conv2d(_ToNCHW.apply(x) if _is_cl(x) else x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
@@ -383,7 +411,7 @@ def _pair_ok(block, x):
             and ds.padding == (0, 0) and ds.groups == 1 and _cl_norm_ok(torch.empty(0, c1.out_channels)))
 
 
-def _conv_norm(conv, norm, x, relu, to_cl=False, res=None):
+def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=None):
     """relu?(norm(conv(x))) of pytorch/core/extractor.py.  The convolution stays a PyTorch-ROCm (MIOpen) call; for fp32
     CUDA tensors the normalisation + ReLU around it runs on the fused fsraft kernels:
       * non-affine InstanceNorm2d (feature encoder).  A per-channel constant added before it is removed again by its
@@ -397,17 +425,18 @@ def _conv_norm(conv, norm, x, relu, to_cl=False, res=None):
     fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
     if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
         if fused:
-            y = _conv(conv, x, None)
+            y = _conv(conv, x, None, link)
             if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
-                return _InstNormReluCL.apply(y, norm.eps, relu, res)
+                return _InstNormReluCL.apply(y, norm.eps, relu, res, res_link)
             y = _InstNormRelu.apply(y, norm.eps, relu)
             return y if res is None else F.relu(res + y)
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)
         y = norm(y)
     elif isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats and norm.affine and fused:
-        y = _conv(conv, x, None)
+        y = _conv(conv, x, None, link)
         if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
-            return _FrozenBNReluCL.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu, res)
+            return _FrozenBNReluCL.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu, res,
+                                         res_link)
         y = _FrozenBNRelu.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
         return y if res is None else F.relu(res + y)
     else:
@@ -464,12 +493,15 @@ class _Block(nn.Module):
         if cl and self.downsample is not None:
             x = _ToNCHW.apply(x)        # the strided convolutions (first 3x3 / shortcut 1x1) are MIOpen NCHW calls: one copy for both
         y = x
+        # stride-1 unit on the channels_last path: x feeds the first convolution AND the shortcut -- their two gradients are
+        # merged inside the convolution's data-gradient epilogue instead of by an autograd add (_ResLink)
+        link = _ResLink() if (cl and self.downsample is None and self.n >= 2 and torch.is_grad_enabled() and x.requires_grad) else None
         if self.downsample is not None:
             x = _conv_norm(self.downsample[0], self.downsample[1], x, False, to_cl=cl)
         for i in range(1, self.n):
-            y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True, to_cl=cl)
+            y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True, to_cl=cl, link=link if i == 1 else None)
         # last convolution of the unit: relu(x + relu(norm(conv(y)))), the add and outer ReLU fused into the norm kernel
-        return _conv_norm(getattr(self, f"conv{self.n}"), getattr(self, f"norm{self.n}"), y, True, to_cl=cl, res=x)
+        return _conv_norm(getattr(self, f"conv{self.n}"), getattr(self, f"norm{self.n}"), y, True, to_cl=cl, res=x, res_link=link)
 
 
 class ResidualBlock(_Block):

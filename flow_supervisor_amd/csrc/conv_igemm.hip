@@ -695,6 +695,7 @@ struct HaloArgs {
   const float* bias;
   float* out; int64_t obs, ops;       // batch / pixel strides of the destination (floats), channels contiguous
   int N, B, H, W, relu;
+  int acc;                            // out += result (the data gradient of a residual unit's first convolution adds to the shortcut gradient)
 };
 
 template <int CG, int TN>
@@ -817,7 +818,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
         if (px >= a.W) continue;
         float v = acc[mt][nt][r] + bv;
         if (a.relu) v = fmaxf(v, 0.f);
-        outb[(int64_t)(py * a.W + px) * a.ops + n] = v;
+        float* o = outb + (int64_t)(py * a.W + px) * a.ops + n;
+        *o = a.acc ? *o + v : v;
       }
     }
   }
@@ -1591,10 +1593,10 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (g_conv_halo && g_conv_split == 1 && d->wpk_frag && d->epi == EPI_PLAIN && d->nsrc == 1 && d->KH == 3 && d->KW == 3 &&
       a.PH == 1 && a.PW == 1 &&
       d->srcC[0] % 4 == 0 && d->srcC[0] > 32 && d->srcC[0] <= 64 && d->N <= 128 && d->N > 32 && d->ndst == 1 &&
-      d->dst_cs[0] == 1 && d->dst_n0[0] == 0 && !d->dst_acc[0] && !a.rmask[0] && d->alpha == 1.0f &&
+      d->dst_cs[0] == 1 && d->dst_n0[0] == 0 && !(d->dst_acc[0] && d->relu) && !a.rmask[0] && d->alpha == 1.0f &&
       (int64_t)d->B * d->H * d->W >= g_conv_halo_min_m && (int64_t)d->H * d->W * d->srcld[0] * 4 < 0x7fffffff) {
     HaloArgs h{d->src[0], d->srcld[0], d->srcC[0], reinterpret_cast<const char*>(d->wpk_frag), d->bias,
-               d->dst[0], d->dst_bs[0], d->dst_ps[0], d->N, d->B, d->H, d->W, d->relu};
+               d->dst[0], d->dst_bs[0], d->dst_ps[0], d->N, d->B, d->H, d->W, d->relu, d->dst_acc[0]};
     // Measured (scripts/conv_micro.py, halo on / off): 64 -> 64 at 8x220x512 238 vs 442 us.  With three or four channel
     // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
     // GEMM (96 -> 96 at 8x110x256: 249 vs 165 us; 128 -> 128 at 8x55x128: 93 vs 65 us), so only two-group layers come here.

@@ -255,3 +255,43 @@ extern "C" int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const f
   hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw, out, dres);
   return fs_launch_status();
 }
+
+// ---- frozen-BatchNorm parameter folding (pytorch/core/extractor.py's BatchNorm2d layers after freeze_bn) ---------------
+// y = relu?(x * scale + shift) with scale = weight * rsqrt(var + eps), shift = bias - (mean - cbias) * scale, where cbias is
+// the bias the preceding convolution ran without.  The framework needs five elementwise launches on [C] tensors for this
+// per layer and step, and six more for the parameter gradients; here each direction is one launch.
+namespace {
+__global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __restrict__ bias, const float* __restrict__ rm,
+                               const float* __restrict__ rv, const float* __restrict__ cbias, float eps, int C, float* __restrict__ scale,
+                               float* __restrict__ shift, float* __restrict__ rs, float* __restrict__ rmc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float r = rsqrtf(rv[c] + eps), sc = weight[c] * r, m = rm[c] - (cbias ? cbias[c] : 0.f);
+  rs[c] = r; scale[c] = sc; rmc[c] = m; shift[c] = bias[c] - m * sc;
+}
+// part: [2][R][C] partial column sums of g' (part 0) and g' * x (part 1) from fsraft_affine_relu_cl_bwd
+__global__ void bn_fold_bwd_kernel(const float* __restrict__ part, int R, int C, const float* __restrict__ rs, const float* __restrict__ rmc,
+                                   const float* __restrict__ scale, float* __restrict__ dweight, float* __restrict__ dbias,
+                                   float* __restrict__ dcbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int r = 0; r < R; ++r) { s0 += part[(int64_t)r * C + c]; s1 += part[((int64_t)R + r) * C + c]; }
+  dweight[c] = rs[c] * (s1 - rmc[c] * s0);
+  dbias[c] = s0;
+  if (dcbias) dcbias[c] = scale[c] * s0;
+}
+}  // namespace
+
+extern "C" int fsraft_bn_fold(const float* weight, const float* bias, const float* rm, const float* rv, const float* cbias, float eps,
+                              int C, float* scale, float* shift, float* rs, float* rmc, hipStream_t stream) {
+  if (!weight || !bias || !rm || !rv || !scale || !shift || !rs || !rmc || C < 1) return FS_ERR_ARG;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, weight, bias, rm, rv, cbias, eps, C, scale, shift, rs, rmc);
+  return fs_launch_status();
+}
+extern "C" int fsraft_bn_fold_bwd(const float* part, int R, int C, const float* rs, const float* rmc, const float* scale,
+                                  float* dweight, float* dbias, float* dcbias, hipStream_t stream) {
+  if (!part || !rs || !rmc || !scale || !dweight || !dbias || R < 1 || C < 1) return FS_ERR_ARG;
+  hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, R, C, rs, rmc, scale, dweight, dbias, dcbias);
+  return fs_launch_status();
+}

@@ -295,6 +295,15 @@ int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* sca
 int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* out, float* dx,
                               float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, hipStream_t stream);
 
+/* Frozen-BatchNorm parameter folding in one launch per direction (instead of ~11 framework launches on [C] tensors per layer
+ * and step): scale = weight * rsqrt(var + eps), shift = bias - (mean - cbias) * scale, rs = rsqrt(var + eps), rmc = mean - cbias
+ * (cbias: bias of the preceding convolution, folded in; nullable).  Backward from the partial sums [2][R][C] that
+ * fsraft_affine_relu_cl_bwd leaves: dweight = rs * (S1 - rmc * S0), dbias = S0, dcbias = scale * S0 (nullable). */
+int fsraft_bn_fold(const float* weight, const float* bias, const float* rm, const float* rv, const float* cbias, float eps, int C,
+                   float* scale, float* shift, float* rs, float* rmc, hipStream_t stream);
+int fsraft_bn_fold_bwd(const float* part, int R, int C, const float* rs, const float* rmc, const float* scale, float* dweight,
+                       float* dbias, float* dcbias, hipStream_t stream);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 /* Space-to-depth by 2 of a channels-last tensor: dst[b][y/2][x/2][(y%2)*2 + x%2][c] = src[b][y][x][c] (inverse != 0: back).

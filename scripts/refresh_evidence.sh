@@ -1,9 +1,13 @@
 # refresh of the judged evidence: bench line via the driver's launch line, kernel stats, PMC traffic, variants
+# usage (on the GPU box, repo root): bash scripts/refresh_evidence.sh <tag>      -> gpurun_out/*_<tag>*, copied to profiles/ by hand
+tag=${1:-r2}
 export MIOPEN_FIND_MODE=2
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 2>&1 | tail -1 > gpurun_out/bench_final.json
-cut -c1-400 gpurun_out/bench_final.json
-bash scripts/prof.sh r1n
-bash scripts/pmc_traffic.sh r1n | head -12
-python bench.py --variant gma --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_gma.json; cut -c1-200 gpurun_out/bench_gma.json
-python bench.py --variant alt --height 376 --width 1248 --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_alt.json; cut -c1-200 gpurun_out/bench_alt.json
-python bench.py --height 368 --width 496 --batch-per-gpu 8 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_chairs.json; cut -c1-200 gpurun_out/bench_chairs.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench_${tag}_1gpu.json
+cut -c1-300 gpurun_out/bench_${tag}_1gpu.json
+bash scripts/prof.sh ${tag}
+bash scripts/pmc_traffic.sh ${tag} | head -14
+python bench.py --variant gma --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_gma.json; cut -c1-200 gpurun_out/bench_${tag}_gma.json
+bash scripts/prof.sh ${tag}_gma --variant gma
+python bench.py --variant alt --height 376 --width 1248 --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_alt.json; cut -c1-200 gpurun_out/bench_${tag}_alt.json
+bash scripts/prof.sh ${tag}_alt --variant alt --height 376 --width 1248 --batch-per-gpu 1
+python bench.py --height 368 --width 496 --batch-per-gpu 8 --no-cpu-baseline --no-extra 2>&1 | tail -1 > gpurun_out/bench_${tag}_chairs.json; cut -c1-200 gpurun_out/bench_${tag}_chairs.json
