@@ -112,8 +112,8 @@ SIGNATURES = {
     "fsraft_to_records": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, _S],
     "fsraft_gemm_rec_tn": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                            c_float, c_int, c_int, _S],
-    "fsraft_gemm_rec_nt": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_int,
-                           c_int, _S],
+    "fsraft_gemm_rec_nt": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                           c_float, c_int, c_int, _S],
 }
 
 

@@ -74,8 +74,13 @@ class _AttentionFn(torch.autograd.Function):
         w = w.detach().contiguous().float()
         qk = _conv1x1(x_cl, w, C, 2 * D, B, H, W, 0)
         attn = torch.empty(B, 1, N, N, device=x_cl.device, dtype=torch.float32)
-        ops.gemm_raw(qk.data_ptr(), 2 * D, N * 2 * D, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, attn.data_ptr(), N, N * N,
-                     B, N, N, D, True, scale)
+        if ops.SPLIT_VOLUME_BWD and D % 32 == 0:          # record GEMM core: q and k are record slices of one [N][2D] tensor
+            qkr = ops.to_records(qk.view(B, N, 2 * D))
+            ops.gemm_rec_nt_raw(qkr.data_ptr(), 2 * D, N * 2 * D, qkr.data_ptr() + 4 * D, 2 * D, N * 2 * D, attn.data_ptr(), N, N * N,
+                                B, N, N, D, scale)
+        else:
+            ops.gemm_raw(qk.data_ptr(), 2 * D, N * 2 * D, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, attn.data_ptr(), N, N * N,
+                         B, N, N, D, True, scale)
         ops.softmax_rows_(attn)
         ctx.save_for_backward(x_cl, w, qk, attn)
         ctx.scale = scale
@@ -89,6 +94,21 @@ class _AttentionFn(torch.autograd.Function):
         dS = ops.softmax_rows_bwd_(attn, dA.contiguous().clone())
         dqk = torch.empty_like(qk)
         # dq = scale dS k ; dk = scale dS^T q
+        if ops.SPLIT_VOLUME_BWD and D % 32 == 0:
+            # record GEMM core: dS split to records once; dq = dS . (k^T)^T with k^T [D][N] (rows of records along j),
+            # dk = dS^T . q with both operands read k-major (records along the output index)
+            dSr = ops.to_records(dS.view(B, N, N))
+            del dS
+            Nr = dSr.shape[-1]
+            qkr = ops.to_records(qk.view(B, N, 2 * D))                                   # q = records 0..D/32-1 of a row, k the rest
+            kt = ops.to_records(ops.transpose_batched(qk.view(B, N, 2 * D)[:, :, D:].contiguous()))    # [B, D, Nr]
+            ops.gemm_rec_nt_raw(dSr.data_ptr(), Nr, N * Nr, kt.data_ptr(), Nr, D * Nr, dqk.data_ptr(), 2 * D, N * 2 * D, B, N, D, Nr,
+                                scale, ksplit=2)
+            ops.gemm_rec_tn_raw(dSr.data_ptr(), Nr, N * Nr, qkr.data_ptr(), 2 * D, N * 2 * D, dqk.data_ptr() + 4 * D, 2 * D, N * 2 * D,
+                                B, N, D, N, scale, ksplit=2)
+            dw = _conv1x1_wgrad(dqk, x_cl, C, 2 * D, B, H, W) if ctx.needs_input_grad[1] else None
+            dx = _conv1x1(dqk, w, C, 2 * D, B, H, W, 1) if ctx.needs_input_grad[0] else None
+            return dx, dw, None
         dSt = ops.transpose_batched(dS.view(B, N, N))        # tiled transpose: 4-6 TB/s, the strided copy reaches 1.5-2
         if N % 4 == 0 and D % 4 == 0:      # k-major operands on the transposed-read split-bf16 GEMM
             ops.gemm_tn_raw(dSt.data_ptr(), N, N * N, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, dqk.data_ptr(), 2 * D,

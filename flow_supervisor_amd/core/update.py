@@ -369,10 +369,13 @@ class _Engine:
             attn = attn.contiguous()
             v, agg = buf(mc), buf(mc)
             conv("av", [V(motion, mc, 0)], [Dst.nhwc(v)])
-            if attn_t is not None and N % 4 == 0:
-                # attn @ v with attn^T resident (transposed once per pair): both operands k-major ->
-                # transposed-read split-bf16 GEMM instead of the exact-fp32 NN kernel
-                ops.gemm_tn_raw(attn_t.data_ptr(), N, N * N, v.data_ptr(), mc, N * mc, agg.data_ptr(), mc, N * mc, B, N, mc, N)
+            if attn_t is not None:
+                # attn @ v on the record GEMM core: the attention map was split to records once per pair (attn_t), v is
+                # transposed ([mc][N], 3.6 MB) so that both operands are rows of records along the contraction index
+                Nr = attn_t.shape[-1]
+                vt = ops.to_records(ops.transpose_batched(v.view(B, N, mc)))          # [B, mc, Nr]
+                ops.gemm_rec_nt_raw(attn_t.data_ptr(), Nr, N * Nr, vt.data_ptr(), Nr, mc * Nr, agg.data_ptr(), mc, N * mc, B, N, mc, Nr,
+                                    ksplit=2)
             else:
                 ops.gemm_raw(attn.data_ptr(), N, N * N, v.data_ptr(), mc, N * mc, agg.data_ptr(), mc, N * mc, B, N, mc, N, False)
             ops.gma_mix_fwd(V(motion, mc, 0), V(agg), P["aggregator.gamma"], V(motion, mc, mc))
@@ -401,7 +404,7 @@ class _Engine:
         saved = None
         if save:
             saved = dict(B=B, H=H, W=W, corr=corr, cor1=cor1, corflo=corflo, cols=cols, flo1=flo1,
-                         motion=motion, gates=gates, hlast=h, head=head, attn=attn, v=v, agg=agg)
+                         motion=motion, gates=gates, hlast=h, head=head, attn=attn, v=v, agg=agg, attn_r=attn_t)
         return h, mask, delta, saved
 
     # ---- backward -----------------------------------------------------------------
@@ -533,7 +536,13 @@ class _Engine:
             dagg, dv = buf(mc), buf(mc)
             ops.gma_mix_bwd(V(dmotion, mc, mc), V(agg), P["aggregator.gamma"], V(dmotion, mc, 0), V(dagg),
                             dB["aggregator.gamma"])
-            if N % 4 == 0:       # dv = attn^T dagg: both operands k-major -> transposed-read split GEMM
+            attn_r = S.get("attn_r")
+            if attn_r is not None:   # dv = attn^T dagg: both operands k-major records -> transposed-read record GEMM
+                Nr = attn_r.shape[-1]
+                dr = ops.to_records(dagg.view(B, N, mc))
+                ops.gemm_rec_tn_raw(attn_r.data_ptr(), Nr, N * Nr, dr.data_ptr(), dr.shape[-1], N * dr.shape[-1], dv.data_ptr(), mc,
+                                    N * mc, B, N, mc, N, ksplit=2)
+            elif N % 4 == 0:     # (exact-fp32 test mode) both operands k-major -> transposed-read split GEMM
                 ops.gemm_tn_raw(attn.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N)
             else:
                 at = attn.view(B, N, N).transpose(1, 2).contiguous()
@@ -665,7 +674,12 @@ class _AttnFn(torch.autograd.Function):
         Vc = torch.cat([v for _, v in stash], 2) if len(stash) > 1 else stash[0][1].contiguous()
         B, N, K = D.shape
         dattn = torch.empty(ctx.shape, device=D.device, dtype=torch.float32)
-        ops.gemm_raw(D.data_ptr(), K, N * K, Vc.data_ptr(), K, N * K, dattn.data_ptr(), N, N * N, B, N, N, K, True)
+        if ops.SPLIT_VOLUME_BWD:         # record GEMM core (K = T * 128 is a multiple of 32)
+            Dr, Vr = ops.to_records(D), ops.to_records(Vc)
+            ops.gemm_rec_nt_raw(Dr.data_ptr(), Dr.shape[-1], N * Dr.shape[-1], Vr.data_ptr(), Vr.shape[-1], N * Vr.shape[-1],
+                                dattn.data_ptr(), N, N * N, B, N, N, Dr.shape[-1])
+        else:
+            ops.gemm_raw(D.data_ptr(), K, N * K, Vc.data_ptr(), K, N * K, dattn.data_ptr(), N, N * N, B, N, N, K, True)
         return None, dattn
 
 
@@ -757,15 +771,16 @@ class _UpdateBlockBase(nn.Module):
         return ast, ast.anchor
 
     def _attn_transposed(self, attention):
-        """attention^T [B,N,N], computed once per attention tensor (one pair / one step) and reused by every
-        iteration's `attn @ v`."""
-        if attention is None or not self._engine().gma or attention.shape[-1] % 4 or not ops.SPLIT_VOLUME_BWD:
+        """The attention map as records ([B, N, ceil32(N)], gemm_rec.hpp), split once per attention tensor (one pair / one
+        step) and reused by every iteration's `attn @ v` (rows of records along the contraction index) and, in backward, by
+        `attn^T @ dagg` (the same tensor read k-major).  (Round 1 kept a transposed fp32 copy here instead.)"""
+        if attention is None or not self._engine().gma or not ops.SPLIT_VOLUME_BWD:
             return None         # (SPLIT_VOLUME_BWD off = exact-fp32 test mode: keep the exact NN GEMM)
         c = self.__dict__.get("_attn_t")
         if c is None or c[0]() is not attention or c[1] != attention._version:
             with torch.no_grad():
                 B, N = attention.shape[0], attention.shape[-1]
-                t = ops.transpose_batched(attention.detach().reshape(B, N, N).contiguous().float())
+                t = ops.to_records(attention.detach().reshape(B, N, N).contiguous().float())
             c = (weakref.ref(attention), attention._version, t)
             self.__dict__["_attn_t"] = c
         return c[2]

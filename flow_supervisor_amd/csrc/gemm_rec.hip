@@ -147,13 +147,18 @@ extern "C" int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_
   return fs_launch_status();
 }
 
-// C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] on record operands: A [batch][M][K/32 records], B [batch][N][K/32 records]
-// (K % 32 == 0; sA / sB: batch strides in BYTES).  ksplit > 1 splits K over workgroups that add their partial tiles with
-// fp32 atomics (C is zeroed first unless accumulate != 0); ksplit == 1 and accumulate == 0: plain stores.
-extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t sA, const void* Bm, int64_t sB, float* C, int64_t ldc, int64_t sC,
-                                  int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream) {
+// C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k] on record operands: A [batch][M] rows of K / 32 records with row pitch lda
+// floats, B [batch][N] rows with pitch ldb (lda, ldb multiples of 32, >= K; 0 = K: dense), K % 32 == 0; sA / sB: batch
+// strides in BYTES.  ksplit > 1 splits K over workgroups that add their partial tiles with fp32 atomics (C is zeroed first
+// unless accumulate != 0); ksplit == 1 and accumulate == 0: plain stores.
+extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
+                                  int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
+                                  hipStream_t stream) {
   if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 32 || (K % 32) || ksplit < 1 || ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16))
     return FS_ERR_ARG;
+  if (lda == 0) lda = K;
+  if (ldb == 0) ldb = K;
+  if (lda < K || ldb < K || (lda % 32) || (ldb % 32)) return FS_ERR_ARG;
   const int KT = K / 32;
   if (ksplit > KT) ksplit = KT;
   const bool atomic = ksplit > 1 || accumulate;
@@ -165,7 +170,7 @@ extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t sA, const void* Bm, int
         if (hipMemset2DAsync(C + b * sC, ldc * 4, 0, (size_t)N * 4, M, stream) != hipSuccess) return FS_ERR_LAUNCH;
     }
   }
-  RecGemmArgs g{(const char*)A, sA, (unsigned)K * 4u, (const char*)Bm, sB, (unsigned)K * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
+  RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
   dim3 grid(ceil_div(N, G::BN) * ceil_div(M, G::BM), ksplit, batch);
   hipLaunchKernelGGL(gemm_rec_nt_kernel, grid, dim3(512), 0, stream, g);
   return fs_launch_status();

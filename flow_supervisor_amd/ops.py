@@ -250,7 +250,7 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
             n = min(chunk, N - i0)
             dV = corr_dvol_build(douts, coords, lay, B, radius, records=True, is_flow=is_flow, q0=b * N + i0, nq=n)
             # d1[b][:, i0:i0+n] = s * f2cat[b] [C x P] . dV [n x P]^T
-            L.check(lib.fsraft_gemm_rec_nt(ctypes.c_void_p(f2r.data_ptr() + b * C * P * 4), 0, L.ptr(dV), 0,
+            L.check(lib.fsraft_gemm_rec_nt(ctypes.c_void_p(f2r.data_ptr() + b * C * P * 4), P, 0, L.ptr(dV), P, 0,
                                            ctypes.c_void_p(d1.data_ptr() + (b * C * N + i0) * 4), N, 0, 1, C, n, P, s, 8, 0, L.stream()),
                     "gemm_rec_nt")
             # d2cat[b] [P x C] += s * dV [n x P]^T . f1[b][i0:i0+n] [n x C]
@@ -454,11 +454,31 @@ def gemm_rec_nt(Ar, Br, alpha=1.0, ksplit=1, out=None, accumulate=False):
         out = torch.empty(b, M, N, device=Ar.device, dtype=torch.float32)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(_lib().fsraft_gemm_rec_nt(L.ptr(Ar), M * K * 4, L.ptr(Br), N * K * 4, L.ptr(out), N, M * N, b, M, N, K, float(alpha),
+    L.check(_lib().fsraft_gemm_rec_nt(L.ptr(Ar), K, M * K * 4, L.ptr(Br), K, N * K * 4, L.ptr(out), N, M * N, b, M, N, K, float(alpha),
                                       int(ksplit), int(accumulate), L.stream()), "gemm_rec_nt")
     if t:
         t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
     return out
+
+
+def gemm_rec_nt_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, ksplit=1, accumulate=False):
+    """fsraft_gemm_rec_nt on explicit (device address, pitch in floats, batch stride in floats) triples."""
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_gemm_rec_nt(ctypes.c_void_p(A), lda, sA * 4, ctypes.c_void_p(Bm), ldb, sB * 4, ctypes.c_void_p(C), ldc, sC,
+                                      batch, M, N, K, float(alpha), int(ksplit), int(accumulate), L.stream()), "gemm_rec_nt")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
+
+
+def gemm_rec_tn_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, ksplit=1, accumulate=False):
+    """fsraft_gemm_rec_tn on explicit (device address, pitch in floats, batch stride in floats) triples."""
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_gemm_rec_tn(ctypes.c_void_p(A), lda, sA * 4, ctypes.c_void_p(Bm), ldb, sB * 4, ctypes.c_void_p(C), ldc, sC,
+                                      batch, M, N, K, float(alpha), int(ksplit), int(accumulate), L.stream()), "gemm_rec_tn")
+    if t:
+        t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
 
 
 def gemm_rec_tn(Ar, Br, M, N, alpha=1.0, ksplit=1, out=None, accumulate=False):

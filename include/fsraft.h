@@ -224,12 +224,12 @@ int fsraft_set_gemm_split(int on);
  * fsraft_to_records: src [rows][K] fp32 (pitch ld floats) -> dst [rows][ceil(K/32)] records (tail of the last record zero),
  * row pitch dst_ld floats (0 = dense; activation tensors use an ODD number of 128-byte lines per row so that the rows of a
  * k-tile spread over all L2 channels instead of every 4th / 8th line).
- * fsraft_gemm_rec_nt: C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k]; A [batch][M][K/32] records, B [batch][N][K/32]
- * records, K % 32 == 0, sA / sB batch strides in BYTES.  ksplit > 1: K split over workgroups, partial tiles added with fp32
+ * fsraft_gemm_rec_nt: C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k]; A [batch][M] rows of K/32 records (row pitch lda
+ * floats), B [batch][N] rows (pitch ldb; 0 = K), K % 32 == 0, sA / sB batch strides in BYTES.  ksplit > 1: K split over workgroups, partial tiles added with fp32
  * atomics (C zeroed first unless accumulate != 0). */
 int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, hipStream_t stream);
-int fsraft_gemm_rec_nt(const void* A, int64_t sA, const void* Bm, int64_t sB, float* C, int64_t ldc, int64_t sC, int batch,
-                       int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream);
+int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
+                       int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream);
 /* C[b][m][n] = alpha * sum_k A[b][k][m] B[b][k][n]: both operands k-major, A [batch][K][lda floats] with the records along m,
  * B [batch][K][ldb floats] with the records along n (lda, ldb multiples of 32; K arbitrary).  Fragments are gathered with the
  * transposed LDS read (ds_read_b64_tr_b16). */
