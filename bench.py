@@ -213,9 +213,7 @@ def main():
         if graph is not None:
             # graph replays update the parameters without touching their Python-side version counters;
             # bump them so the eager pass repacks the GEMM weights from the current values
-            with torch.no_grad():
-                for p in model.parameters():
-                    p.add_(0.0)
+            ops.parameters_updated(list(model.parameters()))
         timer = ops.KernelTimer()
         ops.TIMER = timer
         tsteps = min(a.steps, 3)

@@ -36,6 +36,18 @@ class ConvDesc(Structure):
     ]
 
 
+class PackJob(Structure):
+    """Mirror of fsraft_pack_job (include/fsraft.h)."""
+    _fields_ = [
+        ("w", c_void_p * 3), ("rows", c_int * 3), ("npiece", c_int),
+        ("wpk", c_void_p),
+        ("cin_full", c_int), ("kh", c_int), ("kw", c_int),
+        ("srcC", c_int * 3), ("srcOff", c_int * 3), ("nsrc", c_int),
+        ("mode", c_int), ("flags", c_int),
+        ("scale", c_float), ("accumulate", c_int),
+    ]
+
+
 _PP = POINTER(c_void_p)
 _IP = POINTER(c_int)
 _S = c_void_p   # hipStream_t
@@ -57,6 +69,7 @@ SIGNATURES = {
     "fsraft_conv_wgrad_multi": [_PP, c_int, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_wgrad": [_PP, _PP, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_pack_conv_weights": [POINTER(PackJob), c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_tuning": [c_int, c_int],
     "fsraft_set_lookup_qb": [c_int],

@@ -221,22 +221,87 @@ class _FrozenBNReluCL(torch.autograd.Function):
                 None)
 
 
-def _weight_packs(conv):
-    """Packed forward / data-gradient matrices of a 3x3 convolution for the split-bf16 implicit GEMM, cached on the module
-    and rebuilt whenever the weight tensor changes (optimizer step, load_state_dict)."""
+def _conv_key(conv):
     from .. import ops
     w = conv.weight
-    key = (w.data_ptr(), w._version, ops.exact_mode())
+    return (w.data_ptr(), w._version, ops.exact_mode())
+
+
+def _queue_conv_packs(plan, conv):
+    """Queue the packed forward / data-gradient matrices of a stride-1 1x1 / 3x3 convolution; returns the handle tuple that
+    _finish_conv_packs turns into the cached `(key, fwd fp32, fwd split, dgrad fp32, dgrad split, fwd fragment order, dgrad
+    fragment order)`.  The fragment-order packs are the resident-patch kernel's (33..64 input channels, 3x3)."""
+    from .. import ops
+    wd = conv.weight.detach()
+    N, C, KH, KW = wd.shape
+    exact = ops.exact_mode()
+    fs = plan.pack([wd], [C], 10)
+    f = plan.pack([wd], [C], 0) if (exact or N <= 32) else fs
+    ds = plan.pack([wd], [C], 11)
+    d = plan.pack([wd], [C], 1) if (exact or C <= 32) else ds
+    ff = plan.pack([wd], [C], 10, frag=True) if (KH, KW) == (3, 3) and 32 < C <= 64 else None
+    df = plan.pack([wd], [C], 11, frag=True) if (KH, KW) == (3, 3) and 32 < N <= 64 else None
+    return (f, fs, d, ds, ff, df)
+
+
+def _prepare_packs(root):
+    """Every packed weight image of an encoder (or of one convolution) whose parameter changed since it was packed, built by
+    ONE batched launch per 16 matrices (fsraft_pack_conv_weights) instead of two to four launches per layer plus the torch
+    ops of the space-to-depth rewrite and of the fragment-order permutation."""
+    from .. import ops
+    todo = []
+    for m in root.modules():
+        if isinstance(m, _Block) and _pair_shape_ok(m):
+            w3, wsc = m.conv1.weight, m.downsample[0].weight
+            key = (w3.data_ptr(), w3._version, wsc.data_ptr(), wsc._version, ops.exact_mode())
+            c = m.__dict__.get("_fs_pair_packs")
+            if (c is None or c[0] != key) and w3.is_cuda and w3.dtype == torch.float32:
+                todo.append(("pair", m, key))
+        if (isinstance(m, nn.Conv2d) and m.stride == (1, 1) and m.kernel_size in ((1, 1), (3, 3)) and m.groups == 1
+                and m.weight.is_cuda and m.weight.dtype == torch.float32):
+            c = m.__dict__.get("_fs_packs")
+            key = _conv_key(m)
+            if c is None or c[0] != key:
+                todo.append(("conv", m, key))
+    if not todo:
+        return
+    with torch.no_grad():
+        plan = ops.PackPlan(todo[0][1].conv1.weight.device if todo[0][0] == "pair" else todo[0][1].weight.device)
+        hs = []
+        exact = ops.exact_mode()
+        for kind, m, key in todo:
+            if kind == "conv":
+                hs.append(_queue_conv_packs(plan, m))
+                continue
+            w3, ws = m.conv1.weight.detach(), m.downsample[0].weight.detach()
+            N, C = w3.shape[:2]
+            # the 3x3 stride-2 weight seen as its 2x2 stride-1 equivalent over the space-to-depth input (flag s2d): [N][4C][2][2]
+            a = plan.pack([w3], [4 * C], 10, cin_full=C, s2d=True)
+            b = plan.pack([w3], [4 * C], 11, cin_full=C, s2d=True)
+            a0 = plan.pack([w3], [4 * C], 0, cin_full=C, s2d=True) if (exact or N <= 32) else a
+            b0 = plan.pack([w3], [4 * C], 1, cin_full=C, s2d=True) if (exact or 4 * C <= 32) else b
+            Ns, Cs = ws.shape[:2]
+            c_ = plan.pack([ws], [Cs], 10)
+            d_ = plan.pack([ws], [Cs], 11)
+            c0 = plan.pack([ws], [Cs], 0) if (exact or Ns <= 32) else c_
+            d0 = plan.pack([ws], [Cs], 1) if (exact or Cs <= 32) else d_
+            hs.append(((a0, a, b0, b), (c0, c_, d0, d_)))
+        out = plan.run()
+        for (kind, m, key), h in zip(todo, hs):
+            if kind == "conv":
+                m.__dict__["_fs_packs"] = (key,) + tuple(None if i is None else out[i] for i in h)
+            else:
+                m.__dict__["_fs_pair_packs"] = (key, tuple(out[i] for i in h[0]), tuple(out[i] for i in h[1]))
+
+
+def _weight_packs(conv):
+    """Packed forward / data-gradient matrices of a convolution for the split-bf16 implicit GEMM, cached on the module and
+    rebuilt whenever the weight tensor changes (optimizer step, load_state_dict).  The encoders build all of theirs at once
+    (_prepare_packs at the top of forward); a convolution used on its own gets here with a stale cache and packs itself."""
     c = conv.__dict__.get("_fs_packs")
-    if c is None or c[0] != key:
-        wd = w.detach()
-        cin = [wd.shape[1]]
-        c = (key,) + ops.pack_pair(wd, cin) + ops.pack_pair(wd, cin, dgrad=True)
-        if tuple(wd.shape[2:]) == (3, 3):     # the resident-patch kernel takes the 33..64-channel layers; the data gradient swaps the roles
-            c = c + (ops.fragment_order(c[2]), ops.fragment_order(c[4]))
-        else:
-            c = c + (None, None)
-        conv.__dict__["_fs_packs"] = c
+    if c is None or c[0] != _conv_key(conv):
+        _prepare_packs(conv)
+        c = conv.__dict__["_fs_packs"]
     return c
 
 
@@ -308,7 +373,8 @@ _S2D_TAP = ((0, 1), (1, 0), (1, 1))          # 3x3 tap index k -> (2x2 tap t, su
 
 def _s2d_weight(w3):
     """[N,C,3,3] stride-2 weights -> the equivalent stride-1 [N,4C,2,2] weights over the space-to-depth input (channel
-    (sy*2+sx)*C + c = pixel (2y+sy, 2x+sx)); 7 of the 16 (tap, sub-pixel) slots stay zero."""
+    (sy*2+sx)*C + c = pixel (2y+sy, 2x+sx)); 7 of the 16 (tap, sub-pixel) slots stay zero.  Host statement of the rewrite that
+    fsraft_pack_conv_weights performs in its address arithmetic (flag bit 1); the tests hold the kernel to it."""
     N, C = w3.shape[:2]
     w = w3.new_zeros(N, 2, 2, C, 2, 2)           # n, sy, sx, c, ty, tx
     for ky, (ty, sy) in enumerate(_S2D_TAP):
@@ -328,17 +394,27 @@ def _s2d_weight_grad(dw, C):
     return out
 
 
+def _pair_shape_ok(block):
+    """A unit whose first convolution is 3x3 / stride 2 / pad 1 with a 1x1 / stride 2 shortcut: the pair that runs on the
+    stride-1 kernels over a space-to-depth copy of the input."""
+    c1 = getattr(block, "conv1", None)
+    ds = block.downsample[0] if getattr(block, "downsample", None) is not None else None
+    return (block.n == 2 and c1 is not None and ds is not None and c1.kernel_size == (3, 3) and c1.stride == (2, 2)
+            and c1.padding == (1, 1) and c1.dilation == (1, 1) and c1.groups == 1 and ds.kernel_size == (1, 1)
+            and ds.stride == (2, 2) and ds.padding == (0, 0) and ds.groups == 1)
+
+
 def _pair_packs(block):
-    """Packed matrices of a stride-2 residual unit's first convolution (as 2x2 over space-to-depth) and 1x1 shortcut."""
-    w3, wsc = block.conv1.weight, block.downsample[0].weight
+    """Packed matrices of a stride-2 residual unit's first convolution (as 2x2 over space-to-depth: the rewrite
+    `input row 2y - 1 + k = 2(y + t - 1) + s` maps 3x3 tap k to (2x2 tap t, sub-pixel s), 7 of the 16 (tap, sub-pixel) slots
+    are structural zeros) and of its 1x1 shortcut: `(key, (fwd fp32, fwd split, dgrad fp32, dgrad split) x 2)`."""
     from .. import ops
+    w3, wsc = block.conv1.weight, block.downsample[0].weight
     key = (w3.data_ptr(), w3._version, wsc.data_ptr(), wsc._version, ops.exact_mode())
     c = block.__dict__.get("_fs_pair_packs")
     if c is None or c[0] != key:
-        w2 = _s2d_weight(w3.detach())
-        c4, c1, ws = [w2.shape[1]], [wsc.shape[1]], wsc.detach()
-        c = (key, ops.pack_pair(w2, c4) + ops.pack_pair(w2, c4, dgrad=True), ops.pack_pair(ws, c1) + ops.pack_pair(ws, c1, dgrad=True))
-        block.__dict__["_fs_pair_packs"] = c
+        _prepare_packs(block)
+        c = block.__dict__["_fs_pair_packs"]
     return c
 
 
@@ -383,14 +459,18 @@ class _StridedPairFn(torch.autograd.Function):
             ops.conv_forward([g1v], p[2], None, B, h, w, 2, 2, C4, [ops.Dst.nhwc(dxs)], wpk_split=p[3], pad=(0, 0))
             ops.conv_forward([gsv], q[2], None, B, h, w, 1, 1, C, [ops.Dst.nhwc(dxs, 0, 0, True)], wpk_split=q[3])
             dx = ops.space_to_depth2(dxs, inverse=True).permute(0, 3, 1, 2)
+        items = []
         if ctx.needs_input_grad[1]:
             dwpk = ops.zeros(N, ops.conv_ktot([C4], 2, 2), device=xs.device)
             ops.conv_wgrad(g1v, [ops.V(xs, C4)], dwpk, B, h, w, 2, 2)
-            dw3 = _s2d_weight_grad(ops.unpack_weight_grad(dwpk, (N, C4, 2, 2), [C4]), C)
+            dw3 = torch.empty(N, C, 3, 3, device=xs.device, dtype=torch.float32)
+            items.append((dwpk, [dw3], [C4], [0], C, 2, 2, 1.0, True))       # gradient of the space-to-depth rewrite: a gather
         if ctx.needs_input_grad[2]:
             dwpk = ops.zeros(Ns, ops.conv_ktot([C], 1, 1), device=xs.device)
             ops.conv_wgrad(gsv, [ops.V(xs, C, 0)], dwpk, B, h, w, 1, 1)
-            dwsc = ops.unpack_weight_grad(dwpk, (Ns, C, 1, 1), [C])
+            dwsc = torch.empty(Ns, C, 1, 1, device=xs.device, dtype=torch.float32)
+            items.append((dwpk, [dwsc], [C], [0], C, 1, 1, 1.0, False))
+        ops.unpack_weight_grads(items, xs.device)
         return dx, dw3, dwsc, None
 
 
@@ -404,11 +484,8 @@ def _norm_act(norm, y, cbias, relu, res=None):
 
 def _pair_ok(block, x):
     import os
-    c1, ds = block.conv1, block.downsample[0]
-    return (os.environ.get("FSRAFT_ENCODER_S2D", "1") != "0" and block.n == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-            and x.shape[1] % 4 == 0 and c1.kernel_size == (3, 3) and c1.stride == (2, 2) and c1.padding == (1, 1)
-            and c1.dilation == (1, 1) and c1.groups == 1 and ds.kernel_size == (1, 1) and ds.stride == (2, 2)
-            and ds.padding == (0, 0) and ds.groups == 1 and _cl_norm_ok(torch.empty(0, c1.out_channels)))
+    return (os.environ.get("FSRAFT_ENCODER_S2D", "1") != "0" and _pair_shape_ok(block) and x.shape[2] % 2 == 0
+            and x.shape[3] % 2 == 0 and x.shape[1] % 4 == 0 and _cl_norm_ok(torch.empty(0, block.conv1.out_channels)))
 
 
 def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=None):
@@ -561,6 +638,8 @@ class _Encoder(nn.Module):
         # channels_last after the stem (an NCHW MIOpen call: 3 input channels): the stride-1 convolutions then run on the
         # fsraft implicit-GEMM kernels and the norm + ReLU kernels read and write [N][HW][C] directly
         cl = _channels_last_ok(self, x)
+        if cl:
+            _prepare_packs(self)         # all packed weight images of this encoder that are stale: one batched launch
         x = _conv_norm(self.conv1, self.norm1, x, True, to_cl=bool(cl))
         x = self.layer3(self.layer2(self.layer1(x)))
         x = _ToNCHW.apply(_conv(self.conv2, x, self.conv2.bias)) if cl else self.conv2(x)

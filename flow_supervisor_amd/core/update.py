@@ -221,32 +221,33 @@ class _Engine:
                                      dbias=dB[k])
             st.pending = {}
         if self.has_mask and st.dW is not None:
-            st.dW["m2"].mul_(0.25)
-            st.dB["m2"].mul_(0.25)
+            st.dB["m2"].mul_(0.25)          # (the weight gradient's 0.25 is the scale of its unpack job)
         byname = dict(zip(self.pnames, params))
-        grads = {}
+        # parameter-shaped gradients carved out of one buffer and filled by ONE batched un-pack launch: fused layers split
+        # back, and the two GEMMs of a GRU convolution ((h, motion) part, context part) write their channel ranges of the same
+        # tensor -- together they cover it, so nothing is zero-filled
+        wn = [n for n in self.pnames if n.endswith(".weight")]
+        flat = torch.empty(sum((byname[n].numel() + 3) // 4 * 4 for n in wn), device=params[0].device, dtype=torch.float32)
+        grads, o = {}, 0
+        for n in wn:
+            grads[n] = flat[o:o + byname[n].numel()].view(byname[n].shape)
+            o += (byname[n].numel() + 3) // 4 * 4
+        items = []
         for k in self.order:
             l = self.layers[k]
-            gw = ops.unpack_weight_grad(st.dW[k], P[k][4], l.src_c)
-            o = 0
-            for wname in l.wnames:
-                p = byname[wname + ".weight"]
-                n = p.shape[0]
-                if l.cin_sel is None:
-                    grads[wname + ".weight"] = gw[o:o + n].reshape(p.shape)
-                else:                       # this GEMM saw only some input channels of the parameter
-                    full = grads.get(wname + ".weight")
-                    if full is None:
-                        full = grads[wname + ".weight"] = torch.zeros_like(p, dtype=torch.float32)
-                    c = 0
-                    for a, b in l.cin_sel:
-                        full[:, a:b] = gw[o:o + n, c:c + b - a]
-                        c += b - a
-                if l.bias:
-                    grads[wname + ".bias"] = st.dB[k][o:o + n].clone()
-                o += n
+            gs = [grads[w + ".weight"] for w in l.wnames]
+            cin_full, kh, kw = l.view_as if l.view_as is not None else tuple(gs[0].shape[1:])
+            off = [a for a, _ in l.cin_sel] if l.cin_sel is not None else [sum(l.src_c[:i]) for i in range(len(l.src_c))]
+            items.append((st.dW[k], gs, l.src_c, off, cin_full, kh, kw, 0.25 if k == "m2" else 1.0, False))
+            if l.bias:
+                o = 0
+                for wname in l.wnames:
+                    n = byname[wname + ".weight"].shape[0]
+                    grads[wname + ".bias"] = st.dB[k][o:o + n]
+                    o += n
+        ops.unpack_weight_grads(items, params[0].device)
         for n in self.extra:
-            grads[n] = st.dB[n].clone().reshape(byname[n].shape)
+            grads[n] = st.dB[n].reshape(byname[n].shape)
         st.arena = st.dW = st.dB = None
         return [grads[n] for n in self.pnames]
 
@@ -262,28 +263,36 @@ class _Engine:
             return self._cache
         byname = dict(zip(self.pnames, params))
         out = {}
+        exact = ops.exact_mode()
         with torch.no_grad():
             for n in self.extra:
                 out[n] = byname[n].detach().float().reshape(-1)
             # the 2-output flow-head convolution runs on the dot-product kernels straight from the OIHW weight
             out["fh2.raw"] = (byname["flow_head.conv2.weight"].detach().contiguous().float(),
                               byname["flow_head.conv2.bias"].detach().contiguous().float())
+            # every packed matrix of the block in one batched launch, read in place from the parameters (fused layers and the
+            # (h, motion) / context split of the GRU weights are address arithmetic of fsraft_pack_conv_weights)
+            plan = ops.PackPlan(params[0].device)
+            handles = {}
             for k in self.order:
                 l = self.layers[k]
-                ws = [byname[w + ".weight"].detach() for w in l.wnames]
-                w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
+                ws = [byname[w + ".weight"].detach().contiguous().float() for w in l.wnames]
+                cin_full, kh, kw = l.view_as if l.view_as is not None else tuple(ws[0].shape[1:])
+                off = [a for a, _ in l.cin_sel] if l.cin_sel is not None else None
+                cout, cin = sum(w.shape[0] for w in ws), sum(l.src_c)
+                kw_ = dict(srcOff=off, kh=kh, kw=kw, cin_full=cin_full)
+                fws = plan.pack(ws, l.src_c, 10, **kw_)
+                fw = plan.pack(ws, l.src_c, 0, **kw_) if (exact or cout <= 32) else fws
+                dgs = plan.pack(ws, l.src_c, 11, **kw_)
+                dg = plan.pack(ws, l.src_c, 1, **kw_) if (exact or cin <= 32) else dgs
                 b = None
                 if l.bias:
-                    bs = [byname[w_ + ".bias"].detach() for w_ in l.wnames]
-                    b = (bs[0] if len(bs) == 1 else torch.cat(bs, 0)).contiguous().float()
-                if l.view_as is not None:
-                    w = w.reshape(w.shape[0], *l.view_as)
-                if l.cin_sel is not None:
-                    w = torch.cat([w[:, a:b] for a, b in l.cin_sel], 1)
-                w = w.contiguous().float()
-                fw, fws = ops.pack_pair(w, l.src_c)
-                dg, dgs = ops.pack_pair(w, l.src_c, dgrad=True)
-                out[k] = (fw, dg, b, w.shape[0], tuple(w.shape), fws, dgs)
+                    bs = [byname[w_ + ".bias"].detach().contiguous().float() for w_ in l.wnames]
+                    b = bs[0] if len(bs) == 1 else plan.bias(bs)
+                handles[k] = (fw, dg, b, cout, (cout, cin, kh, kw), fws, dgs)
+            packed = plan.run()
+            for k, (fw, dg, b, cout, shape, fws, dgs) in handles.items():
+                out[k] = (packed[fw], packed[dg], packed[b] if isinstance(b, int) else b, cout, shape, packed[fws], packed[dgs])
         self._cache_key, self._cache = key, out
         return out
 

@@ -1358,6 +1358,116 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
   }
 }
 
+// ---- batched packing: every GEMM-ready weight image of a module (and, in reverse, every weight gradient) in one launch ----
+// One job = one packed matrix.  Its logical OIHW weight is read in place from the parameter tensors: up to three tensors
+// stacked along the output channels (fused layers: z|r gates, flow-head|mask-head), GEMM sources = channel ranges of the
+// parameters' input channels (a GRU convolution split into its (h, motion) part and its context part), optionally seen
+// through the space-to-depth rewrite of a stride-2 3x3 weight.  (Mirror of fsraft_pack_job in include/fsraft.h.)
+struct PackJob {
+  float* w[3]; int rows[3]; int npiece;
+  float* wpk;
+  int cin_full, kh, kw;
+  int srcC[3], srcOff[3], nsrc;
+  int mode, flags;
+  float scale; int accumulate;
+};
+constexpr int PACK_JOBS = 16;
+struct PackJobs { PackJob j[PACK_JOBS]; };
+
+// logical element (output channel n, concatenated-source channel given as (source s, channel c), tap t of kh x kw) -> address
+// in the parameter tensors, or nullptr where the logical weight is structurally zero (space-to-depth slots)
+__device__ __forceinline__ float* pack_elem(const PackJob& j, int n, int s, int c, int t) {
+  int p = 0;
+  while (p + 1 < j.npiece && n >= j.rows[p]) { n -= j.rows[p]; ++p; }
+  float* w = j.w[p];
+  if (j.flags & 2) {
+    // parameter [N][C][3][3] (stride 2, pad 1); logical [N][4C][2][2]: channel (sy*2+sx)*C + c0, tap (ty, tx);
+    // input row 2y - 1 + ky = 2(y + ty - 1) + sy  ->  ky = 2*ty + sy - 1
+    const int C = j.cin_full;
+    const int sp = c / C, c0 = c % C;
+    const int ky = 2 * (t >> 1) + (sp >> 1) - 1, kx = 2 * (t & 1) + (sp & 1) - 1;
+    if (ky < 0 || kx < 0) return nullptr;
+    return w + ((int64_t)n * C + c0) * 9 + ky * 3 + kx;
+  }
+  return w + ((int64_t)n * j.cin_full + j.srcOff[s] + c) * (j.kh * j.kw) + t;
+}
+
+__device__ __forceinline__ void pack_store(const PackJob& j, int Ktot, int rows, int n, int k, float v) {
+  const int64_t e = (int64_t)n * Ktot + k;
+  if (j.mode < 10) { j.wpk[e] = v; return; }
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  __bf16* out = reinterpret_cast<__bf16*>(j.wpk);
+  if (!(j.flags & 1)) {
+    __bf16* rec = out + (e >> 5) * 64;
+    rec[e & 31] = h;
+    rec[32 + (e & 31)] = l;
+    return;
+  }
+  // fragment order (resident-patch kernel): [k-tile][32-row block][hi/lo][k quarter pair s][k half][row][4 dwords];
+  // bf16 q of a record's 32-k run sits in dword q / 2: s = q / 16, k half = (q / 8) % 2, dword = (q / 2) % 4
+  const int nb = (rows + 31) / 32, kt = k >> 5, q = k & 31;
+  const int64_t base = (((int64_t)kt * nb + (n >> 5)) * 2) ;
+  const int sidx = (q >> 4) & 1, kh2 = (q >> 3) & 1, dw = (q >> 1) & 3, half = q & 1;
+  const int64_t dh = ((((base + 0) * 2 + sidx) * 2 + kh2) * 32 + (n & 31)) * 4 + dw;
+  const int64_t dl = ((((base + 1) * 2 + sidx) * 2 + kh2) * 32 + (n & 31)) * 4 + dw;
+  out[dh * 2 + half] = h;
+  out[dl * 2 + half] = l;
+}
+
+__global__ __launch_bounds__(256) void pack_jobs_kernel(PackJobs tab) {
+  const PackJob& j = tab.j[blockIdx.y];
+  const int taps = j.kh * j.kw;
+  int cout = 0;
+  for (int p = 0; p < j.npiece; ++p) cout += j.rows[p];
+  if (j.mode == 3) {                         // concatenated bias vectors
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < cout; e += gridDim.x * 256) {
+      int n = e, p = 0;
+      while (p + 1 < j.npiece && n >= j.rows[p]) { n -= j.rows[p]; ++p; }
+      j.wpk[e] = j.w[p][n];
+    }
+    return;
+  }
+  int cin = 0;
+  for (int s = 0; s < j.nsrc; ++s) cin += j.srcC[s];
+  const int m = j.mode % 10;
+  int Ktot, rows;
+  if (m == 1) { Ktot = taps * ((cout + 31) / 32 * 32); rows = cin; }
+  else { Ktot = 0; for (int s = 0; s < j.nsrc; ++s) Ktot += taps * ((j.srcC[s] + 31) / 32 * 32); rows = cout; }
+  const int rows_out = (j.flags & 1) ? (rows + 31) / 32 * 32 : rows;     // fragment order pads the rows with zeros
+  const int64_t total = (int64_t)rows_out * Ktot;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int n = (int)(e / Ktot);
+    int k = (int)(e % Ktot);
+    if (m == 1) {
+      const int cpad = (cout + 31) / 32 * 32;
+      const int tp = k / cpad, c = k % cpad;
+      float v = 0.f;
+      if (c < cout && n < rows) {
+        int s = 0, cs = n;
+        while (s + 1 < j.nsrc && cs >= j.srcC[s]) { cs -= j.srcC[s]; ++s; }
+        const float* q = pack_elem(j, c, s, cs, taps - 1 - tp);
+        if (q) v = *q;
+      }
+      pack_store(j, Ktot, rows, n, k, v);
+    } else {
+      const int k0 = k;
+      int s = 0;
+      for (; s < j.nsrc; ++s) {
+        const int span = taps * ((j.srcC[s] + 31) / 32 * 32);
+        if (k < span) break;
+        k -= span;
+      }
+      const int cpad = (j.srcC[s] + 31) / 32 * 32;
+      const int t = k / cpad, c = k % cpad;
+      const bool ok = c < j.srcC[s] && n < rows;
+      float* q = ok ? pack_elem(j, n, s, c, t) : nullptr;
+      if (m == 0) pack_store(j, Ktot, rows, n, k0, q ? *q : 0.f);
+      else if (q) *q = j.accumulate ? *q + j.scale * j.wpk[e] : j.scale * j.wpk[e];
+    }
+  }
+}
+
 using Cfg128 = GemmCfg<128, 128, 32, 2, 2, 2, 2>;
 using Cfg64 = GemmCfg<128, 64, 32, 4, 1, 2, 2>;
 using CfgM64 = GemmCfg<64, 128, 32, 1, 4, 2, 2>;     // half-height tile: doubles the workgroup count for narrow N
@@ -1848,6 +1958,39 @@ extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy
 
 // mode 0: OIHW -> forward packed; mode 1: OIHW -> data-gradient packed (rows = Cin);
 // mode 2: packed (forward layout) -> OIHW, optionally accumulating.  srcC splits Cin for modes 0/2.
+extern "C" int fsraft_pack_conv_weights(const PackJob* jobs, int njobs, hipStream_t stream) {
+  if (njobs < 0 || (njobs && !jobs)) return FS_ERR_ARG;
+  for (int i = 0; i < njobs; ++i) {
+    const PackJob& j = jobs[i];
+    const int m = j.mode;
+    if (!(m == 0 || m == 1 || m == 2 || m == 3 || m == 10 || m == 11) || !j.wpk || j.npiece < 1 || j.npiece > 3) return FS_ERR_ARG;
+    for (int p = 0; p < j.npiece; ++p) if (!j.w[p] || j.rows[p] < 1) return FS_ERR_ARG;
+    if (m == 3) continue;
+    if (j.nsrc < 1 || j.nsrc > 3 || j.kh < 1 || j.kw < 1 || j.cin_full < 1) return FS_ERR_ARG;
+    if ((j.flags & 1) && m < 10) return FS_ERR_ARG;
+    if ((j.flags & 2) && (j.kh != 2 || j.kw != 2 || j.nsrc != 1 || j.srcC[0] != 4 * j.cin_full || j.srcOff[0] != 0)) return FS_ERR_ARG;
+    if (!(j.flags & 2)) for (int s = 0; s < j.nsrc; ++s) if (j.srcC[s] < 1 || j.srcOff[s] < 0 || j.srcOff[s] + j.srcC[s] > j.cin_full) return FS_ERR_ARG;
+  }
+  for (int i0 = 0; i0 < njobs; i0 += PACK_JOBS) {
+    PackJobs tab{};
+    const int n = njobs - i0 < PACK_JOBS ? njobs - i0 : PACK_JOBS;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+      tab.j[i] = jobs[i0 + i];
+      const PackJob& j = tab.j[i];
+      int64_t cout = 0, cin = 0;
+      for (int p = 0; p < j.npiece; ++p) cout += j.rows[p];
+      for (int s = 0; s < j.nsrc; ++s) cin += (j.srcC[s] + 31) / 32 * 32;
+      const int64_t tot = j.mode == 3 ? cout : ((cout + 31) / 32 * 32) * ((cin + 31) / 32 * 32) * j.kh * j.kw;
+      most = tot > most ? tot : most;
+    }
+    int blocks = (int)((most + 1023) / 1024);
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(blocks, n), dim3(256), 0, stream, tab);
+  }
+  return fs_launch_status();
+}
+
 extern "C" int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
                                        int nsrc, int mode, int accumulate, hipStream_t stream) {
   if (!w_oihw || !wpk || mode < 0 || (mode > 2 && mode != 10 && mode != 11)) return FS_ERR_ARG;

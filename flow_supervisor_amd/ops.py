@@ -8,12 +8,30 @@ import ctypes
 import math
 
 import torch
+import torch.optim.optimizer as _optimizer_module
 
 from . import _lib as L
 
 
 def _lib():
     return L.load()
+
+
+def parameters_updated(params):
+    """Tell the weight-pack caches (keyed on `Parameter._version`) that `params` changed by a route that does not bump
+    the version counter.  `torch.optim.*(fused=True)` is such a route: `_fused_adamw_` updates the parameters in place and
+    leaves `_version` where it was (checked on torch 2.10), so a GEMM-ready pack made before the step would be reused
+    after it.  The post-step hook below calls this for every fused optimizer; hipGraph replays need it by hand."""
+    ps = [p for p in params if isinstance(p, torch.Tensor)]
+    if ps:
+        torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
+
+
+def _after_optimizer_step(opt, args, kwargs):
+    parameters_updated([p for g in opt.param_groups if g.get("fused") for p in g["params"]])
+
+
+_optimizer_module.register_optimizer_step_post_hook(_after_optimizer_step)
 
 
 class KernelTimer:
@@ -760,6 +778,93 @@ def pack_weight(w, srcC, mode):
     L.check(_lib().fsraft_pack_conv_weight(L.ptr(w), L.ptr(wpk), Cout, Cin, KH, KW, L.int_array(srcC), len(srcC), mode,
                                            0, L.stream()), "pack_conv_weight")
     return wpk
+
+
+class PackPlan:
+    """Jobs for fsraft_pack_conv_weights: every packed matrix of a module in ceil(n / 16) launches, carved out of one
+    allocation, read in place from the parameters (fused layers, channel selections and the space-to-depth rewrite of a
+    stride-2 weight are address arithmetic of the kernel, not torch.cat / slicing / scatter launches)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []          # (PackJob, offset in floats, shape)
+        self.total = 0
+        self.keep = []
+
+    def _job(self, ws, cin_full, kh, kw, srcC, srcOff, mode, flags=0, scale=1.0, accumulate=False):
+        j = L.PackJob()
+        for i, w in enumerate(ws):
+            L.require_cuda_f32(w)
+            assert w.is_contiguous()
+            j.w[i] = w.data_ptr()
+            j.rows[i] = w.shape[0]
+        j.npiece = len(ws)
+        j.cin_full, j.kh, j.kw = cin_full, kh, kw
+        for i, (c, o) in enumerate(zip(srcC, srcOff)):
+            j.srcC[i], j.srcOff[i] = c, o
+        j.nsrc = len(srcC)
+        j.mode, j.flags, j.scale, j.accumulate = mode, flags, scale, int(accumulate)
+        self.keep.append(ws)
+        return j
+
+    def pack(self, ws, srcC, mode, srcOff=None, kh=None, kw=None, cin_full=None, frag=False, s2d=False):
+        """Queue one packed matrix (modes 0 / 1 / 10 / 11); returns a handle for result()."""
+        w0 = ws[0]
+        cin_full = w0.shape[1] if cin_full is None else cin_full
+        kh = (2 if s2d else w0.shape[2]) if kh is None else kh
+        kw = (2 if s2d else w0.shape[3]) if kw is None else kw
+        srcOff = [sum(srcC[:i]) for i in range(len(srcC))] if srcOff is None else srcOff
+        cout = sum(w.shape[0] for w in ws)
+        if mode % 10 == 0:
+            rows, kt = cout, conv_ktot(srcC, kh, kw)
+        else:
+            rows, kt = sum(srcC), conv_ktot([cout], kh, kw)
+        if frag:
+            rows = (rows + 31) // 32 * 32
+        j = self._job(ws, cin_full, kh, kw, srcC, srcOff, mode, (1 if frag else 0) | (2 if s2d else 0))
+        self.jobs.append((j, self.total, (rows, kt)))
+        self.total += (rows * kt + 63) // 64 * 64
+        return len(self.jobs) - 1
+
+    def bias(self, bs):
+        j = self._job(bs, 1, 1, 1, [1], [0], 3)
+        n = sum(b.shape[0] for b in bs)
+        self.jobs.append((j, self.total, (n,)))
+        self.total += (n + 63) // 64 * 64
+        return len(self.jobs) - 1
+
+    def run(self):
+        """Launch; returns the list of packed tensors in queue order (views of one buffer)."""
+        buf = torch.empty(max(self.total, 1), device=self.device, dtype=torch.float32)
+        arr = (L.PackJob * max(len(self.jobs), 1))()
+        outs = []
+        for i, (j, off, shape) in enumerate(self.jobs):
+            n = 1
+            for v in shape:
+                n *= v
+            t = buf[off:off + n].view(shape)
+            j.wpk = t.data_ptr()
+            arr[i] = j
+            outs.append(t)
+        if self.jobs:
+            L.check(_lib().fsraft_pack_conv_weights(arr, len(self.jobs), L.stream()), "pack_conv_weights")
+        self.keep = []
+        return outs
+
+
+def unpack_weight_grads(items, device):
+    """items: (dwpk, grad_tensors, srcC, srcOff, cin_full, kh, kw, scale, s2d) per packed gradient; grad_tensors are the
+    parameter-shaped pieces (stacked along the output channels) the gradient is written into, in place, by one launch per 16
+    items -- the reverse of PackPlan."""
+    if not items:
+        return
+    arr = (L.PackJob * len(items))()
+    plan = PackPlan(device)
+    for i, (dwpk, gs, srcC, srcOff, cin_full, kh, kw, scale, s2d) in enumerate(items):
+        j = plan._job(gs, cin_full, kh, kw, srcC, srcOff, 2, 2 if s2d else 0, scale)
+        j.wpk = dwpk.data_ptr()
+        arr[i] = j
+    L.check(_lib().fsraft_pack_conv_weights(arr, len(items), L.stream()), "unpack_conv_weights")
 
 
 def exact_mode():

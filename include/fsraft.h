@@ -184,6 +184,27 @@ int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy, int Cout,
 int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
                             int nsrc, int mode, int accumulate, hipStream_t stream);
 
+/* Batched form: every packed matrix of a module (or, mode 2, every weight gradient) in one launch per 16 jobs, read in place
+ * from / written in place to the parameter-shaped tensors -- no torch.cat of fused layers, no channel gather.
+ *   w[p], rows[p]   up to three OIHW tensors stacked along the output channels (z|r gates, flow-head|mask-head), all with
+ *                   cin_full input channels and kh x kw taps
+ *   srcC, srcOff    GEMM source s = input channels [srcOff[s], srcOff[s] + srcC[s]) of those tensors
+ *   mode            0 / 1 / 10 / 11 as above; 2: wpk -> w (w = scale * wpk, or += when accumulate); 3: wpk = the rows[p]-long
+ *                   vectors w[p] concatenated (fused biases)
+ *   flags           bit 0: split pack in fragment order (resident-patch 3x3 kernel, rows zero-padded to a multiple of 32);
+ *                   bit 1: w is the [N][C][3][3] weight of a stride-2, pad-1 convolution and the packed matrix is its
+ *                   stride-1 2x2 equivalent over the space-to-depth input ([N][4C][2][2], fsraft_space_to_depth2):
+ *                   cin_full = C, kh = kw = 2, one source of 4C channels */
+typedef struct {
+  float* w[3]; int rows[3]; int npiece;
+  float* wpk;
+  int cin_full, kh, kw;
+  int srcC[3], srcOff[3], nsrc;
+  int mode, flags;
+  float scale; int accumulate;
+} fsraft_pack_job;
+int fsraft_pack_conv_weights(const fsraft_pack_job* jobs, int njobs, hipStream_t stream);
+
 /* Convolutions with 2 output channels (FlowHead.conv2, pytorch/core/update.py:10: 3x3, hidden -> 2) as per-pixel dot
  * products instead of a padded GEMM tile.  x channels-last [M][ld]; w_oihw [2][C][3][3]; out element (b,o,pix) at
  * out[b*obs + o*ocs + pix*ops].  C % 4 == 0, C <= 512. */

@@ -1132,6 +1132,88 @@ def test_lds_direct_weight_tiles_variant_matches_default():
         assert torch.equal(res[0], res[1]), (B, H, W, cs, N)
 
 
+def test_batched_pack_jobs_match_the_single_matrix_packer():
+    """fsraft_pack_conv_weights (one launch per 16 matrices, parameters read in place) against fsraft_pack_conv_weight on
+    torch-assembled weights: fused layers (cat along Cout), channel selections (cat of slices along Cin), the space-to-depth
+    rewrite of a stride-2 weight (core/extractor.py::_s2d_weight), the fragment-order permutation (ops.fragment_order), fused
+    biases, and the reverse direction (packed gradient -> parameter-shaped gradients, scaled)."""
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core.extractor import _s2d_weight, _s2d_weight_grad
+    torch.manual_seed(23)
+    wz, wr = torch.randn(40, 100, 1, 5, device=DEV), torch.randn(24, 100, 1, 5, device=DEV)
+    sel, src_c = [(0, 36), (60, 100)], [36, 40]
+    wcat = torch.cat([torch.cat([wz, wr], 0)[:, a:b] for a, b in sel], 1).contiguous()
+    w64 = torch.randn(48, 64, 3, 3, device=DEV)
+    w3 = torch.randn(20, 12, 3, 3, device=DEV)
+    b1, b2 = torch.randn(40, device=DEV), torch.randn(24, device=DEV)
+    plan = ops.PackPlan(DEV)
+    hs = {}
+    for mode in (0, 1, 10, 11):
+        hs["cat", mode] = plan.pack([wz, wr], src_c, mode, srcOff=[a for a, _ in sel])
+        hs["s2d", mode] = plan.pack([w3], [48], mode, cin_full=12, s2d=True)
+        hs["plain", mode] = plan.pack([w64], [64], mode)
+    hs["frag", 10] = plan.pack([w64], [64], 10, frag=True)
+    hs["frag", 11] = plan.pack([w64], [64], 11, frag=True)
+    hb = plan.bias([b1, b2])
+    out = plan.run()
+    for mode in (0, 1, 10, 11):
+        assert torch.equal(out[hs["cat", mode]], ops.pack_weight(wcat, src_c, mode)), ("cat", mode)
+        assert torch.equal(out[hs["s2d", mode]], ops.pack_weight(_s2d_weight(w3).contiguous(), [48], mode)), ("s2d", mode)
+        assert torch.equal(out[hs["plain", mode]], ops.pack_weight(w64, [64], mode)), ("plain", mode)
+    for mode in (10, 11):
+        ref = ops.fragment_order(ops.pack_weight(w64, [64], mode))
+        assert torch.equal(out[hs["frag", mode]].view(torch.int32).flatten(), ref.view(torch.int32).flatten()), ("frag", mode)
+    assert torch.equal(out[hb], torch.cat([b1, b2]))
+    # reverse: packed gradients -> parameter-shaped gradients
+    gcat = torch.randn_like(out[hs["cat", 0]])
+    gz, gr = torch.full_like(wz, float("nan")), torch.full_like(wr, float("nan"))
+    g3p = torch.randn_like(out[hs["s2d", 0]])
+    g3 = torch.full_like(w3, float("nan"))
+    ops.unpack_weight_grads([(gcat, [gz, gr], src_c, [a for a, _ in sel], 100, 1, 5, 0.25, False),
+                             (g3p, [g3], [48], [0], 12, 2, 2, 1.0, True)], DEV)
+    ref = ops.unpack_weight_grad(gcat, tuple(wcat.shape), src_c) * 0.25
+    full = torch.cat([gz, gr], 0)
+    c = 0
+    for a, b in sel:
+        assert torch.equal(full[:, a:b], ref[:, c:c + b - a])
+        c += b - a
+    assert torch.isnan(full[:, 36:60]).all()             # channels no source covers are not touched
+    assert torch.equal(g3, _s2d_weight_grad(ops.unpack_weight_grad(g3p, (20, 48, 2, 2), [48]), 12))
+
+
+def test_weight_packs_follow_a_fused_optimizer_step():
+    """`torch.optim.AdamW(fused=True)` updates parameters without bumping `Parameter._version`, which the GEMM-ready weight
+    packs are keyed on (ops.parameters_updated): after two TrainStep steps the stepped model must predict exactly what a fresh
+    model loaded from its state_dict predicts -- stale packs would still hold the initial weights."""
+    import argparse
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.train import TrainStep
+    torch.manual_seed(5)
+    args = argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)
+    model = RAFT(args).to(DEV).train()
+    model.freeze_bn()
+    step = TrainStep(model, lr=1e-3, iters=3)
+    im1 = torch.rand(1, 3, 128, 192, device=DEV) * 255
+    im2 = torch.rand(1, 3, 128, 192, device=DEV) * 255
+    v0 = model.update_block.gru.convz1.weight._version
+    w0 = model.update_block.gru.convz1.weight.detach().clone()
+    for _ in range(2):
+        step(im1, im2)
+    assert model.update_block.gru.convz1.weight._version > v0
+    assert not torch.equal(w0, model.update_block.gru.convz1.weight)
+    fresh = RAFT(args).to(DEV).train()
+    fresh.load_state_dict(model.state_dict())
+    fresh.freeze_bn()
+    with torch.no_grad():
+        a = model(im1, im2, iters=3)[-1]
+        b = fresh(im1, im2, iters=3)[-1]
+    # (not bit-equal: the InstanceNorm statistics are summed with float atomics; stale packs give differences of order 1)
+    assert (a - b).abs().max().item() < 1e-3, (a - b).abs().max().item()
+    fresh.load_state_dict(RAFT(args).state_dict())
+    with torch.no_grad():
+        assert (fresh(im1, im2, iters=3)[-1] - b).abs().max().item() > 1e-2
+
+
 # ----------------------------------------------------------------------------- data parallelism on the real step (row e)
 @pytest.mark.parametrize("global_batch", [4, 3])
 def test_two_process_train_step_matches_single_process(global_batch, tmp_path):
