@@ -67,67 +67,109 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// A wave walks through QW consecutive queries.  The chain of one query is coords -> window origin -> region loads -> LDS ->
+// blends -> stores, every link waiting for the one before, and 32 resident waves per CU do not hide it (measured: 2.5 TB/s
+// algorithmic with the queries handled one after the other).  So the chain is software-pipelined over the queries of a wave:
+// all QW coordinate pairs are fetched first (wave-uniform addresses), and the region loads of query k + 1 are issued before
+// the blends of query k, i.e. two queries' regions (up to 8 KB per wave) are in flight while one is being consumed.
+// The loads are buffer loads (base = the query's row, wave-uniform): a lane whose 16 bytes the window does not touch gets bit
+// 31 in its offset, fails the range check and reads zeros -- no branch around the load, so the loop body is straight-line
+// code and the compiler can count the loads in flight (`s_waitcnt vmcnt(N)`, not 0).
+struct LevelGeo { int off, tw, h, w; };        // per-level constants of the layout, in SGPRs
+
+template <int R>
+struct LookupLoad {
+  LevelQ lq[4];
+  f32x4 v[4];
+  int xr[4];       // true width minus the x of this lane's first cell: cells at or beyond it are pad and read as zero
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* row, unsigned bytes) {
+  const uint64_t u = reinterpret_cast<uint64_t>(row);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uint64_t)hi << 32 | lo), 0, bytes, 0x00020000);
+}
+
+template <int R>
+__device__ __forceinline__ void lookup_issue(LookupLoad<R>& ld, const float* __restrict__ row, unsigned row_bytes, const LevelGeo (&g)[4],
+                                             int nlev, float cx, float cy, int tsx, int tsy, int r) {
+  using S = TL<R>;
+  const __amdgpu_buffer_rsrc_t rs = row_rsrc(row, row_bytes);
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    ld.lq[l] = level_query(cx, cy, l, R);
+    const int tx = (ld.lq[l].wx0 >> 2) + tsx, ty = (ld.lq[l].wy0 >> 2) + tsy;     // >> on negatives = floor division
+    const int y = 4 * ty + r, x = 4 * tx;
+    const bool need = l < nlev && tx >= 0 && tx < g[l].tw && ty >= 0 && y < g[l].h && y >= ld.lq[l].wy0 && y < ld.lq[l].wy0 + S::WIN &&
+                      x + 3 >= ld.lq[l].wx0 && x < ld.lq[l].wx0 + S::WIN;
+    const unsigned voff = need ? (unsigned)(g[l].off + (ty * g[l].tw + tx) * 16 + r * 4) * 4u : 0x80000000u;
+    ld.v[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    ld.xr[l] = g[l].w - x;
+  }
+}
+
 template <int R, int QW>
 __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __restrict__ vol, VolLayout L, Coords co,
                                                                float* __restrict__ out, int64_t nq, int HW, int grid_w) {
   using S = TL<R>;
   __shared__ __attribute__((aligned(16))) float region[4][4][S::REGION];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nlev = L.nlev, CH = nlev * S::N2;
+  LevelGeo g[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) g[l] = LevelGeo{L.off[l], L.tw[l], L.h[l], L.w[l]};
+  const unsigned row_bytes = (unsigned)L.P * 4u;
   float* reg = &region[wave][0][0];
   const int tsx = (lane >> 2) & 3, tsy = lane >> 4, r = lane & 3;
   int choff[S::ROUNDS];            // channel (i, j) of a level handled by this lane in round k -> offset inside the region
 #pragma unroll
   for (int k = 0; k < S::ROUNDS; ++k) {
     const int kk = lane + 64 * k;
-    choff[k] = kk < S::N2 ? (kk % S::N1) * S::RP + kk / S::N1 : -1;      // i = kk / N1 (x offset, slow), j = kk % N1 (y offset)
+    choff[k] = kk < S::N2 ? (kk % S::N1) * S::RP + kk / S::N1 : 0;      // i = kk / N1 (x offset, slow), j = kk % N1 (y offset)
   }
+  const unsigned q0 = (blockIdx.x * 4u + (unsigned)wave) * QW;          // wave-uniform; nq < 2^31 (checked by the host)
+  if (q0 >= (unsigned)nq) return;
+  const int nqw = (int)((unsigned)nq - q0 < (unsigned)QW ? (unsigned)nq - q0 : (unsigned)QW);
+  float cxs[QW], cys[QW];
+#pragma unroll
   for (int qq = 0; qq < QW; ++qq) {
-    const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * QW + qq;         // wave-uniform
-    if (q >= nq) break;
-    const int b = (int)(q / HW), pix = (int)(q % HW);
-    float cx, cy;
-    query_xy(co, b, pix, grid_w, cx, cy);
-    const float* row = vol + q * L.P;
-    LevelQ lq[4];
-    f32x4 v[4];
+    const unsigned q = q0 + (qq < nqw ? qq : 0);
+    query_xy(co, (int)(q / (unsigned)HW), (int)(q % (unsigned)HW), grid_w, cxs[qq], cys[qq]);
+  }
+  LookupLoad<R> cur, nxt;
+  lookup_issue<R>(cur, vol + (int64_t)q0 * L.P, row_bytes, g, nlev, cxs[0], cys[0], tsx, tsy, r);
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      v[l] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (l < nlev) {
-        lq[l] = level_query(cx, cy, l, R);
-        const int tx = (lq[l].wx0 >> 2) + tsx, ty = (lq[l].wy0 >> 2) + tsy;     // >> on negatives = floor division
-        const int y = 4 * ty + r, x = 4 * tx;
-        const bool need = tx >= 0 && tx < L.tw[l] && ty >= 0 && y < L.h[l] && y >= lq[l].wy0 && y < lq[l].wy0 + S::WIN &&
-                          x + 3 >= lq[l].wx0 && x < lq[l].wx0 + S::WIN;
-        if (need) {
-          v[l] = gload4(row + L.off[l] + (ty * L.tw[l] + tx) * 16 + r * 4);
-          const int xr = L.w[l] - x;                 // cells at or beyond the true width are pad: read as zero
-#pragma unroll
-          for (int c = 1; c < 4; ++c) v[l][c] = c < xr ? v[l][c] : 0.f;
-        }
-      }
-    }
+  for (int qq = 0; qq < QW; ++qq) {
+    if (qq >= nqw) break;
+    const unsigned q = q0 + qq;
+    // the next query's regions are requested before this one's are consumed (the last valid query is simply requested again)
+    const int qn = qq + 1 < nqw ? qq + 1 : qq;
+    if (qq + 1 < QW) lookup_issue<R>(nxt, vol + (int64_t)(q0 + qn) * L.P, row_bytes, g, nlev, cxs[qn], cys[qn], tsx, tsy, r);
 #pragma unroll
     for (int l = 0; l < 4; ++l)
-      if (l < nlev) *reinterpret_cast<f32x4*>(reg + l * S::REGION + (4 * tsy + r) * S::RP + 4 * tsx) = v[l];
+      if (l < nlev) {
+        f32x4 v = cur.v[l];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) v[c] = c < cur.xr[l] ? v[c] : 0.f;
+        *reinterpret_cast<f32x4*>(reg + l * S::REGION + (4 * tsy + r) * S::RP + 4 * tsx) = v;
+      }
     wave_lds_sync();
-    float* o = out + q * CH;
+    float* o = out + (int64_t)q * CH;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       if (l >= nlev) continue;
-      const float* base = reg + l * S::REGION + (lq[l].wy0 & 3) * S::RP + (lq[l].wx0 & 3);
-      const float fx = lq[l].fx, fy = lq[l].fy;
+      const float* base = reg + l * S::REGION + (cur.lq[l].wy0 & 3) * S::RP + (cur.lq[l].wx0 & 3);
+      const float fx = cur.lq[l].fx, fy = cur.lq[l].fy;
 #pragma unroll
       for (int k = 0; k < S::ROUNDS; ++k) {
-        if (choff[k] < 0) continue;
         const float* p = base + choff[k];
         const float top = p[0] + fx * (p[1] - p[0]);
         const float bot = p[S::RP] + fx * (p[S::RP + 1] - p[S::RP]);
-        gstore1(o + l * S::N2 + lane + 64 * k, top + fy * (bot - top));
+        if (lane + 64 * k < S::N2) gstore1(o + l * S::N2 + lane + 64 * k, top + fy * (bot - top));
       }
     }
     wave_lds_sync();
+    if (qq + 1 < QW) cur = nxt;
   }
 }
 
@@ -335,6 +377,7 @@ extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, co
   if (!vol || !coords || !out || B < 1 || !vol_layout_make(H, W, num_levels, L) || ((uintptr_t)vol % 16)) return FS_ERR_ARG;
   Coords co{coords, coords_bs, coords_cs, coords_ps};
   const int64_t nq = (int64_t)B * H * W;
+  if (nq >= (int64_t)1 << 31 || (int64_t)L.P * 4 >= (int64_t)1 << 31) return FS_ERR_ARG;
   if (radius == 4) return launch_lookup<4>(vol, L, co, out, nq, H * W, add_grid ? W : 0, stream);
   if (radius == 3) return launch_lookup<3>(vol, L, co, out, nq, H * W, add_grid ? W : 0, stream);
   return FS_ERR_ARG;
