@@ -316,7 +316,11 @@ class _Engine:
         inp = cst.inp
         B, H, W, _ = inp.shape
         dW, dB = self._grad_arena(st, P, inp.device)
-        dinp = ops.zeros(B, H, W, _pad4(self.inp_c), device=inp.device)
+        # the first data gradient overwrites, the others accumulate: only padding channels (if any) need a zero fill
+        pad = _pad4(self.inp_c) != self.inp_c
+        dinp = (ops.zeros if pad else (lambda *sh, device: torch.empty(*sh, device=device, dtype=torch.float32)))(
+            B, H, W, _pad4(self.inp_c), device=inp.device)
+        acc = pad
         for k in self.ctx_keys:
             g = cst.dsum.get(k)
             if g is None:
@@ -324,8 +328,11 @@ class _Engine:
             l = self.layers[k]
             n = P[k][3]
             ops.conv_wgrad(V(g, n), [V(inp, self.inp_c)], dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
-            ops.conv_forward([V(g, n)], P[k][1], None, B, H, W, l.kh, l.kw, self.inp_c, [Dst.nhwc(dinp, 0, 0, True)],
+            ops.conv_forward([V(g, n)], P[k][1], None, B, H, W, l.kh, l.kw, self.inp_c, [Dst.nhwc(dinp, 0, 0, acc)],
                              wpk_split=P[k][6])
+            acc = True
+        if not acc:
+            dinp.zero_()
         cst.dsum = {}
         return dinp
 
@@ -353,7 +360,7 @@ class _Engine:
         hid = self.hid
         cor1 = buf(self.c1) if self.c2 else None
         corflo = buf(self.cf_c)
-        cols = buf(98)
+        cols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)      # (im2col7 writes the two pad columns itself)
         flo1 = buf(self.f1)
         motion = buf(self.x_c)           # GMA: channels [mot_c, 2 mot_c) hold motion_global
         if self.c2:

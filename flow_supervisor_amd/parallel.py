@@ -127,8 +127,8 @@ class FlatGradients:
         missing = [p for p in self.buckets[i] if p.grad is None]
         if have:
             torch._foreach_copy_([self.views[p] for p in have], [p.grad for p in have])
-        for p in missing:
-            self.views[p].zero_()
+        if missing:                                   # (parameters that took no part in this step, e.g. biases in front of InstanceNorm)
+            torch._foreach_zero_([self.views[p] for p in missing])
         for p in self.buckets[i]:
             p.grad = self.views[p]
         if dist.is_initialized() and dist.get_world_size() > 1:

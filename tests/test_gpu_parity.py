@@ -1132,6 +1132,154 @@ def test_lds_direct_weight_tiles_variant_matches_default():
         assert torch.equal(res[0], res[1]), (B, H, W, cs, N)
 
 
+def test_record_gemms_against_fp64():
+    """fsraft_to_records / fsraft_gemm_rec_nt / fsraft_gemm_rec_tn (csrc/gemm_rec.hip, the LDS-DMA record core): ragged shapes,
+    split-K with atomics, explicit pitches, accumulate.  Split-bf16 products: relative error ~2^-17 per product."""
+    from flow_supervisor_amd import ops
+    torch.manual_seed(31)
+    x = torch.randn(3, 50, 77, device=DEV)
+    r = ops.to_records(x)                                   # [.., 96]: three records per row, the tail of the last one zero
+    raw = r.view(torch.int16).view(3, 50, 3, 2, 32)         # (record, hi / lo, 32 bf16)
+    hi = (raw[..., 0, :].to(torch.int32) << 16).view(torch.float32).reshape(3, 50, 96)
+    lo = (raw[..., 1, :].to(torch.int32) << 16).view(torch.float32).reshape(3, 50, 96)
+    assert torch.equal(hi[..., :77], x.to(torch.bfloat16).float())
+    assert ((hi + lo)[..., :77] - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+    assert (hi[..., 77:] == 0).all() and (lo[..., 77:] == 0).all()
+    for (b, M, N, K, ks) in ((1, 256, 128, 32, 1), (2, 300, 200, 96, 1), (3, 70, 530, 1000, 1), (2, 257, 129, 640, 3)):
+        A, B = torch.randn(b, M, K, device=DEV), torch.randn(b, N, K, device=DEV)
+        ref = 0.5 * torch.bmm(A.double(), B.double().transpose(1, 2))
+        got = ops.gemm_rec_nt(ops.to_records(A), ops.to_records(B), 0.5, ksplit=ks)
+        assert (got.double() - ref).abs().max().item() < 3e-5 * ref.abs().max().item(), (b, M, N, K, ks)
+        got2 = ops.gemm_rec_nt(ops.to_records(A), ops.to_records(B), 0.5, ksplit=ks, out=got.clone(), accumulate=True)
+        assert (got2.double() - 2 * ref).abs().max().item() < 6e-5 * ref.abs().max().item()
+    for (b, K, M, N, ks) in ((1, 32, 256, 128, 1), (2, 100, 300, 200, 1), (1, 77, 64, 40, 1), (3, 1000, 530, 70, 2)):
+        A, B = torch.randn(b, K, M, device=DEV), torch.randn(b, K, N, device=DEV)
+        ref = 0.5 * torch.bmm(A.double().transpose(1, 2), B.double())
+        got = ops.gemm_rec_tn(ops.to_records(A), ops.to_records(B), M, N, 0.5, ksplit=ks)
+        assert (got.double() - ref).abs().max().item() < 3e-5 * ref.abs().max().item(), (b, K, M, N, ks)
+    # explicit pitches: q and k as record slices of one [N][2D] tensor (the GMA attention call, core/gma.py)
+    qk = torch.randn(2, 150, 256, device=DEV)
+    qkr = ops.to_records(qk)
+    out = torch.full((2, 150, 150), float("nan"), device=DEV)
+    ops.gemm_rec_nt_raw(qkr.data_ptr(), 256, 150 * 256, qkr.data_ptr() + 4 * 128, 256, 150 * 256, out.data_ptr(), 150, 150 * 150, 2, 150, 150, 128, 0.25)
+    ref = 0.25 * torch.bmm(qk[..., :128].double(), qk[..., 128:].double().transpose(1, 2))
+    assert (out.double() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,nlev", [(2, 13, 22, 4), (1, 16, 24, 2), (1, 9, 33, 1), (2, 40, 48, 4)])
+def test_tiled_row_volume_kernels_match_the_row_major_ones(B, H, W, nlev):
+    """The tiled-row layout (csrc/corr_layout.hpp) end to end against round 1's row-major kernels, which the golden fixtures
+    pin: build (fp32-operand and record kernels), lookup forward (coords and flow input), the one-pass gradient volume of a
+    whole step of lookups (fp32 rows and records), and the build backward on both GEMM paths; pad cells of the rows are zero."""
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core.utils.utils import coords_grid
+    torch.manual_seed(41)
+    C, r, T = 64, 4, 3
+    f1, f2 = torch.randn(B, C, H, W, device=DEV), torch.randn(B, C, H, W, device=DEV)
+    levels4 = ops.corr_build(f1, f2, 4)                     # (the row-major kernels exist for four levels only)
+    levels = levels4[:nlev]
+    vol, lay = ops.corr_build_tiled(f1, f2, nlev)
+    recs = (ops.fmap_records(f1), ops.fmap_records(f2))
+    vol_r, _ = ops.corr_build_tiled(f1, f2, nlev, recs=recs)
+    for l in range(nlev):
+        close(lay.level_view(vol, l), levels[l], 2e-5, what=f"tiled build level {l}")
+        close(lay.level_view(vol_r, l), levels[l], 2e-5, what=f"record build level {l}")
+    nq = B * H * W
+    valid = torch.zeros(lay.P, dtype=torch.bool, device=DEV)          # positions of a row that hold a cell of the reference pyramid
+    for l in range(nlev):
+        y, x = torch.meshgrid(torch.arange(lay.h[l], device=DEV), torch.arange(lay.w[l], device=DEV), indexing="ij")
+        valid[lay.off[l] + ((y >> 2) * lay.tw[l] + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)] = True
+    assert int(valid.sum()) == sum(h * w for h, w in zip(lay.h, lay.w))
+    cells = valid.unsqueeze(0).expand(nq, lay.P)
+    # (pad cells of the FORWARD volume are never read -- the lookup masks rows / columns beyond the floor sizes -- and are
+    # not all written; the gradient volume's pad cells are contracted over by the backward GEMMs and must be zero: below)
+    flows = [(torch.rand(B, 2, H, W, device=DEV) - 0.5) * 14 for _ in range(T)]
+    coords = [coords_grid(B, H, W, device=DEV) + f for f in flows]
+    for c, f in zip(coords, flows):
+        ref = ops.corr_lookup_fwd(levels4, c, r, nhwc=True)[..., :nlev * 81].contiguous()
+        close(ops.corr_lookup_tiled_fwd(vol, lay, c, r), ref, 1e-5, what="tiled lookup")
+        close(ops.corr_lookup_tiled_fwd(vol, lay, f, r, is_flow=True), ref, 1e-5, what="tiled lookup, flow input")
+    douts = [torch.randn(B, H, W, nlev * 81, device=DEV) for _ in range(T)]
+    dlv = [torch.zeros_like(l) for l in levels4]
+    for c, g in zip(coords, douts):
+        g4 = torch.zeros(B, H, W, 4 * 81, device=DEV)
+        g4[..., :nlev * 81] = g
+        ops.corr_lookup_bwd_(dlv, c, g4, r, nhwc=True)
+    dvol = ops.corr_dvol_build(douts, coords, lay, B, r)
+    for l in range(nlev):
+        close(lay.level_view(dvol, l), dlv[l], 2e-4, what=f"gradient volume level {l}")
+    assert (dvol[~cells] == 0).all(), "pad cells of the gradient rows"
+    dvol_f = ops.corr_dvol_build(douts, flows, lay, B, r, is_flow=True)
+    close(dvol_f, dvol, 1e-6, what="gradient volume from flow input")
+    d1o, d2o = ops.corr_build_bwd(f1, f2, [d.clone() for d in dlv])
+    d1n, d2n = ops.corr_build_bwd_tiled(f1, f2, dvol, lay)
+    dvol_r = ops.corr_dvol_build(douts, coords, lay, B, r, records=True)
+    d1r, d2r = ops.corr_build_bwd_tiled(f1, f2, dvol_r, lay, records=True, f1r=recs[0])
+    for got, ref, what in ((d1n, d1o, "dfmap1"), (d2n, d2o, "dfmap2"), (d1r, d1o, "dfmap1 (records)"), (d2r, d2o, "dfmap2 (records)")):
+        assert ((got - ref).norm() / ref.norm()).item() < 5e-5, what
+
+
+def test_record_activation_convolution_matches_the_default_kernels():
+    """conv_rec_kernel (csrc/conv_rec.inc: activations supplied as records, staged by LDS-DMA) against the register-staged
+    implicit GEMM on the update block's layer shapes, ragged M, one and two sources, plain and odd-line record pitch."""
+    from flow_supervisor_amd import _lib, ops
+    from flow_supervisor_amd.ops import Dst, V
+    lib = _lib.load()
+    torch.manual_seed(43)
+    B, H, W = 2, 13, 21
+    try:
+        for kh, kw, cs, cout in ((1, 1, [324], 256), (3, 3, [256], 192), (1, 5, [128, 128], 256), (5, 1, [128, 128], 256), (3, 3, [128], 512),
+                                 (3, 3, [126], 256), (1, 1, [98], 128)):
+            bufs = [torch.randn(B, H, W, (c + 3) // 4 * 4, device=DEV) for c in cs]
+            for b, c in zip(bufs, cs):
+                b[..., c:] = 0
+            w = torch.randn(cout, sum(cs), kh, kw, device=DEV) * 0.05
+            bias = torch.randn(cout, device=DEV)
+            wps = ops.pack_weight(w, cs, 10)
+            outs = []
+            for rec in (0, 1, 2):
+                srcs = [V(b, c, 0, ops.to_records(b, pad=rec == 2) if rec else None) for b, c in zip(bufs, cs)]
+                out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=DEV)
+                lib.fsraft_set_tuning(25, 2 if rec else 0)
+                ops.conv_forward(srcs, wps, bias, B, H, W, kh, kw, cout, [Dst.nhwc(out)], relu=True, wpk_split=wps)
+                outs.append(out)
+            for o in outs[1:]:
+                close(o, outs[0], 2e-5 * max(outs[0].abs().max().item(), 1.0), what=f"conv_rec {kh}x{kw} {cs}->{cout}")
+    finally:
+        lib.fsraft_set_tuning(25, 1)
+
+
+def test_frozen_batchnorm_fold_kernels():
+    """fsraft_bn_fold / fsraft_bn_fold_bwd (csrc/norm_cl.hip): scale = w * rsqrt(rv + eps), shift = b - (rm - cbias) * scale and,
+    from the partial sums [2][R][C] of the affine backward, dweight = rs * (S1 - rmc * S0), dbias = S0, dcbias = scale * S0."""
+    from flow_supervisor_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(47)
+    C, R = 96, 24
+    w, b, rm, cb = (torch.randn(C, device=DEV) for _ in range(4))
+    rv = torch.rand(C, device=DEV) + 0.1
+    eps = 1e-5
+    for cbias in (cb, None):
+        out = torch.full((4, C), float("nan"), device=DEV)
+        L.check(lib.fsraft_bn_fold(L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(cbias) if cbias is not None else None, eps, C,
+                                   L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), L.stream()), "bn_fold")
+        rs = torch.rsqrt(rv + eps)
+        rmc = rm - (cbias if cbias is not None else 0)
+        close(out[0], w * rs, 1e-5, what="scale")
+        close(out[1], b - rmc * w * rs, 1e-5, what="shift")
+        close(out[2], rs, 1e-5, what="rs")
+        close(out[3], rmc, 1e-6, what="rmc")
+        part = torch.randn(2, R, C, device=DEV)
+        dpar = torch.full((3, C), float("nan"), device=DEV)
+        L.check(lib.fsraft_bn_fold_bwd(L.ptr(part), R, C, L.ptr(out[2]), L.ptr(out[3]), L.ptr(out[0]), L.ptr(dpar[0]), L.ptr(dpar[1]),
+                                       L.ptr(dpar[2]) if cbias is not None else None, L.stream()), "bn_fold_bwd")
+        s0, s1 = part[0].sum(0), part[1].sum(0)
+        close(dpar[0], rs * (s1 - rmc * s0), 1e-4, what="dweight")
+        close(dpar[1], s0, 1e-4, what="dbias")
+        if cbias is not None:
+            close(dpar[2], w * rs * s0, 1e-4, what="dcbias")
+
+
 def test_batched_pack_jobs_match_the_single_matrix_packer():
     """fsraft_pack_conv_weights (one launch per 16 matrices, parameters read in place) against fsraft_pack_conv_weight on
     torch-assembled weights: fused layers (cat along Cout), channel selections (cat of slices along Cin), the space-to-depth
