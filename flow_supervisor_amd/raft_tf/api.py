@@ -5,8 +5,18 @@ from ..core import update as _upd
 from ..core.raft import convex_upsample
 
 
+def _forward_only(what, *tensors):
+    """The volume / pyramid / lookup twins are forward-only (no autograd.Function behind them, unlike the upsampler and the
+    update block): training through them would silently cut the gradient to the feature encoder, so it fails instead.
+    (The differentiable path for these three steps is core.corr.CorrBlock.)"""
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise RuntimeError(f"flow_supervisor_amd.raft_tf.{what} is forward-only: call it under torch.no_grad() or on detached "
+                           "tensors (use flow_supervisor_amd.core.corr.CorrBlock to train through the volume)")
+
+
 def calc_all_field(a, b, num_pool=0):
     """a, b: [B,H,W,C] feature maps -> list of num_pool+1 volumes [B,H,W,h_l,w_l] (raft/allfield.py:61-92)."""
+    _forward_only("calc_all_field", a, b)
     B, H, W, C = a.shape
     f1 = a.permute(0, 3, 1, 2).contiguous().float()
     f2 = b.permute(0, 3, 1, 2).contiguous().float()
@@ -27,6 +37,7 @@ def _same_needed(h, w, num_pool):
 def transpose_volume(c_volume):
     """tf.transpose(c_volume, [0, 3, 4, 1, 2]) of a [B,H,W,H2,W2] volume (raft/semi.py:250, 257: the backward-flow volume is
     the forward one read the other way), materialised by the tiled transpose kernel instead of a strided copy."""
+    _forward_only("transpose_volume", c_volume)
     B, H, W, H2, W2 = c_volume.shape
     return ops.transpose_batched(c_volume.reshape(B, H * W, H2 * W2).float()).view(B, H2, W2, H, W)
 
@@ -34,6 +45,7 @@ def transpose_volume(c_volume):
 def build_pyramid(c_volume, num_pool=0):
     """[B,H,W,H2,W2] volume -> [c_volume, pooled x2, x4, ...] (raft/allfield.py:94-106), e.g. on transpose_volume(...) for
     the backward flow (raft/semi.py:251, 258) without a second all-pairs GEMM."""
+    _forward_only("build_pyramid", c_volume)
     B, H, W, H2, W2 = c_volume.shape
     levels = ops.corr_pool_pyramid(c_volume.reshape(B * H * W, H2, W2).float(), num_pool + 1, same=_same_needed(H2, W2, num_pool))
     return [lv.view(B, H, W, lv.shape[-2], lv.shape[-1]) for lv in levels]
@@ -47,6 +59,7 @@ class CorrBlock:
         self.corr_pyramid = []
 
     def __call__(self, corr_pyramid, coords, is_coord=True):
+        _forward_only("CorrBlock.__call__", coords, *corr_pyramid)
         B, H, W, _ = coords.shape
         levels = [lv.reshape(B * H * W, 1, lv.shape[-2], lv.shape[-1]) for lv in corr_pyramid]
         c = coords.permute(0, 3, 1, 2)                       # NCHW view of the NHWC coords: strides, no copy

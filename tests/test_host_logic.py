@@ -32,3 +32,17 @@ def test_s2d_weight_grad_is_the_adjoint():
     assert torch.equal(w.grad, _s2d_weight_grad(g, 6))
     # 9 of the 16 (tap, sub-pixel) slots carry weights, 7 are structural zeros
     assert int((_s2d_weight(torch.ones(1, 1, 3, 3)) != 0).sum()) == 9
+
+
+def test_tf_twins_of_the_volume_refuse_to_be_trained_through():
+    """raft_tf.calc_all_field / build_pyramid / transpose_volume / CorrBlock have no autograd behind them: with a tensor that
+    requires grad they must fail loudly instead of returning outputs without grad_fn."""
+    import pytest
+    from flow_supervisor_amd import raft_tf
+    a = torch.randn(1, 8, 8, 16, requires_grad=True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        raft_tf.calc_all_field(a, a.detach(), num_pool=1)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        raft_tf.build_pyramid(torch.randn(1, 4, 4, 4, 4, requires_grad=True), 1)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        raft_tf.CorrBlock(2, 3)([torch.randn(1, 4, 4, 4, 4)], torch.zeros(1, 4, 4, 2, requires_grad=True))
