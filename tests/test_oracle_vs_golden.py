@@ -21,7 +21,7 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def close(a, b, atol, rtol=1e-4):
+def close(a, b, atol, rtol=2e-5):
     a = a if isinstance(a, torch.Tensor) else T(a)
     b = b if isinstance(b, torch.Tensor) else T(b)
     assert a.shape == b.shape, (a.shape, b.shape)
