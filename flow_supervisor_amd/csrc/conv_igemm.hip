@@ -416,13 +416,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
 // Epilogue through LDS for channels-last destinations: the accumulator tile is parked in LDS (row
 // pitch BN+4 floats) and leaves as whole rows, 16 bytes per lane and 512 contiguous bytes per row of a
 // 128-wide tile, instead of 64 four-byte stores per lane.  GRU gate math runs on the float4s.
-template <class Cfg, int EPI>
+// PATCH: the tile's 256 rows are an 8 x 32 patch of pixels (conv_patch.inc): row r is pixel (py0 + r / 32, px0 + r % 32) of
+// image pb, rows outside the image are skipped.  NTW: threads taking part (the workgroup's).
+template <class Cfg, int EPI, int NTW = Cfg::NT, bool PATCH = false>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
-                                                  float* __restrict__ tile) {
+                                                  float* __restrict__ tile, bool owner = true, int pb = 0, int py0 = 0, int px0 = 0) {
   constexpr int LD = Cfg::BN + 4;
   const int HW = a.H * a.W;
   const int M = a.B * HW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // row of the tile -> row of the [M][*] tensors (-1: nothing there)
+  auto row_m = [&](int row) -> int64_t {
+    if constexpr (PATCH) {
+      const int y = py0 + (row >> 5), x = px0 + (row & 31);
+      return (y < a.H && x < a.W) ? (int64_t)(pb * a.H + y) * a.W + x : -1;
+    } else {
+      return m0 + row < M ? (int64_t)m0 + row : -1;
+    }
+  };
   __syncthreads();                                   // the k-loop's last LDS reads are done
 #pragma unroll
   for (int nt = 0; nt < Cfg::TN; ++nt) {
@@ -437,7 +448,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
   }
   __syncthreads();
   constexpr int C4 = Cfg::BN / 4;                    // float4 columns per row
-  constexpr int RPP = Cfg::NT / C4;                  // rows covered per pass
+  constexpr int RPP = NTW / C4;                      // rows covered per pass
+  (void)owner;
   const int c4 = threadIdx.x % C4, rsub = threadIdx.x / C4;
   const int n = n0 + c4 * 4;
   if (n >= a.N) return;
@@ -455,8 +467,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
     const int nv = a.N - n < 4 ? a.N - n : 4;        // valid columns of this float4 (N need not be a multiple of 4)
 #pragma unroll 4
     for (int row = rsub; row < Cfg::BM; row += RPP) {
-      const int m = m0 + row;
-      if (m >= M) break;
+      const int64_t m = row_m(row);
+      if (m < 0) { if (PATCH) continue; else break; }
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
       float* o = dp + (int64_t)m * dps + (n - dn0);
 #pragma unroll
@@ -489,8 +501,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
     const int c = isz ? n : n - a.hid;
 #pragma unroll 4
     for (int row = rsub; row < Cfg::BM; row += RPP) {
-      const int64_t m = m0 + row;
-      if (m >= M) break;
+      const int64_t m = row_m(row);
+      if (m < 0) { if (PATCH) continue; else break; }
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
       if (a.pre) v += gload4(a.pre + m * a.ldpre + n);
 #pragma unroll
@@ -509,8 +521,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
   } else {   // EPI_Q
 #pragma unroll 4
     for (int row = rsub; row < Cfg::BM; row += RPP) {
-      const int64_t m = m0 + row;
-      if (m >= M) break;
+      const int64_t m = row_m(row);
+      if (m < 0) { if (PATCH) continue; else break; }
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
       if (a.pre) v += gload4(a.pre + m * a.ldpre + n);
       const f32x4 hh = gload4(a.h + m * a.ldh + n);
@@ -1634,6 +1646,8 @@ int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
 
 int g_conv_rec = 1;        // record-activation kernel (conv_rec.inc): 0 off, 1 layers with > 128 outputs, 2 every layer it can run
 #include "conv_rec.inc"
+int g_conv_patch = 1;      // resident-patch, channel-streaming kernel for the 3x3 / 1x5 / 5x1 layers (conv_patch.inc, key 26; 2: 128-pixel tiles too)
+#include "conv_patch.inc"
 
 int conv_ktot(const int* C, int nsrc, int taps) {
   int k = 0;
@@ -1739,6 +1753,10 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // the 128x128 kernel needs 131 / 157 / 87 / 78 / 45 us); 128x128 stays selectable (key 3 = 4) and is the
     // fallback for shapes the k-tile table cannot describe.
     const bool narrow = g_conv_buf != 0 || (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
+    if (g_conv_patch && g_conv_split == 1 && d->KH * d->KW > 1 && d->N > 64 && M >= 8192) {
+      const int rc = launch_conv_patch(a, d->epi, stream);
+      if (rc >= 0) return rc;
+    }
     if (g_conv_split == 5 || (g_conv_split == 1 && g_conv_n256 && d->N >= 256 &&
                               ceil_div(d->N, 256) * 256 <= ceil_div(d->N, 128) * 128))
       return launch_conv_split<SCfgN256>(a, d->epi, stream);
@@ -1800,6 +1818,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 22) g_wgrad_xcd = value;
   else if (key == 24) g_conv_bdma = value;
   else if (key == 25) g_conv_rec = value;
+  else if (key == 26) g_conv_patch = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;
