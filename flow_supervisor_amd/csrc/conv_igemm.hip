@@ -501,16 +501,21 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
     const int c = isz ? n : n - a.hid;
 #pragma unroll 4
     for (int row = rsub; row < Cfg::BM; row += RPP) {
-      const int64_t m = row_m(row);
-      if (m < 0) { if (PATCH) continue; else break; }
+      const int64_t mr = row_m(row);
+      if (mr < 0 && !PATCH) break;
+      // (patch tiles: rows outside the image read row 0 and store nothing -- no branch around the loads, so the unrolled
+      //  iterations' loads are issued together; with half as many threads as the 16-wave kernels the loop is latency-bound)
+      const int64_t m = mr < 0 ? 0 : mr;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
       if (a.pre) v += gload4(a.pre + m * a.ldpre + n);
+      f32x4 hh = {0.f, 0.f, 0.f, 0.f};
+      if (!isz) hh = gload4(a.h + m * a.ldh + c);
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
+      if (mr < 0) continue;
       if (isz) {
         *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + c) = v;                 // z
       } else {
-        const f32x4 hh = gload4(a.h + m * a.ldh + c);
         *reinterpret_cast<f32x4*>(a.aux2 + m * a.ld2 + c) = v;                            // r
         f32x4 rh;
 #pragma unroll
