@@ -1520,6 +1520,7 @@ int g_conv_halo_min_m = 65536;
 int g_wgrad_xcd = 1;           // XCD-aware workgroup order in the multi-segment weight gradient (key 22; 2: the few-channel kernel too).
                                // Measured: 10.73 -> 9.72 ms/step of weight-gradient time (15 K-tiles re-read each dY tile)
 int g_conv_bdma = 0;           // LDS-direct weight tiles in the wide implicit-GEMM kernels (key 24, experiment)
+int g_wgrad_patch = 1;         // resident-pixel-block weight gradient for the 3x3 / 1x5 / 5x1 layers (wgrad_patch.inc, key 27)
 int g_wgrad_pack = 1;          // few-channel single-source layers on conv_wgrad_pack_kernel (key 16)
 int g_wgrad_blocks_pack = 1024;   // its workgroup target (key 17)
 int g_wgrad_blocks = 512;   // target workgroup count of the pixel split (key 2); measured 256: 12.9, 512: 11.5, 1024: 12.9, 2048: 14.1 ms/step
@@ -1824,6 +1825,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 24) g_conv_bdma = value;
   else if (key == 25) g_conv_rec = value;
   else if (key == 26) g_conv_patch = value;
+  else if (key == 27) g_wgrad_patch = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;
@@ -1915,6 +1917,8 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
 
 // nseg (dY, X) pairs of identical shape in one launch; src[seg * nsrc + s].  Falls back to one launch per segment when
 // the buffer-addressed split kernel cannot take the shape.
+#include "wgrad_patch.inc"
+
 extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy, int Cout, const float* const* src,
                                        const int* srcC, const int* srcld, int nsrc, float* dwpk, float* dbias, int B,
                                        int H, int W, int KH, int KW, hipStream_t stream) {
@@ -1952,6 +1956,12 @@ extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy
     }
     a.nsrc = nsrc; a.dwpk = dwpk; a.Ktot = conv_ktot(srcC, nsrc, KH * KW);
     a.B = B; a.H = H; a.W = W; a.KH = KH; a.KW = KW; a.dbias = dbias;
+    if (g_wgrad_patch && KH * KW > 1) {
+      m.nseg = n;
+      const int rc = launch_wgrad_patch(m, stream);
+      if (rc == 0) continue;
+      if (rc > 0) return rc;
+    }
     const int ytiles = ceil_div(Cout, 128);
     // ~g_wgrad_blocks workgroups in total, a whole number of pixel splits per segment
     int64_t zs = (g_wgrad_blocks_multi + (int64_t)xt128 * ytiles * n - 1) / ((int64_t)xt128 * ytiles * n);

@@ -12,6 +12,7 @@ from flow_supervisor_amd import ops  # noqa: E402
 from flow_supervisor_amd.ops import Dst, V  # noqa: E402
 
 B, H, W = (int(v) for v in os.environ.get("CONV_MICRO_BHW", "4,55,128").split(","))
+NSEG = int(os.environ.get("CONV_MICRO_NSEG", "1"))   # wgrad: this many (dY, X) segments in one multi launch
 M = B * H * W
 dev = "cuda"
 LAYERS = [  # name, kh, kw, src channels, Cout
@@ -66,13 +67,15 @@ for name, kh, kw, cs, cout in LAYERS:
     wpf = ops.fragment_order(wps)
     out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=dev)
     dy = torch.randn(B, H, W, (cout + 3) // 4 * 4, device=dev)
+    dys = [V(torch.randn_like(dy), cout) for _ in range(NSEG)]
+    xss = [[V(torch.randn_like(v.t), v.C) for v in srcs] for _ in range(NSEG)]
     dwpk = torch.zeros_like(wpk)
     for kind in ("fwd", "wgrad"):
         def run():
             if kind == "fwd":
                 ops.conv_forward(srcs, wpk, bias, B, H, W, kh, kw, cout, [Dst.nhwc(out)], relu=True, wpk_split=wps, wpk_frag=wpf)
             else:
-                ops.conv_wgrad(V(dy, cout), srcs, dwpk, B, H, W, kh, kw)
+                ops.conv_wgrad_multi(dys, xss, dwpk, B, H, W, kh, kw)
         run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -80,5 +83,5 @@ for name, kh, kw, cs, cout in LAYERS:
             run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
-        fl = 2.0 * M * cout * cin * kh * kw
+        fl = 2.0 * M * cout * cin * kh * kw * (NSEG if kind == 'wgrad' else 1)
         print(f"{name:18s} {kind:5s} {dt * 1e6:8.1f} us  {fl / dt / 1e12:6.1f} TF  ({fl / dt / 1e12 / 157.3 * 100:4.1f}% of fp32 MFMA peak)")

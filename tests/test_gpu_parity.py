@@ -1132,6 +1132,48 @@ def test_lds_direct_weight_tiles_variant_matches_default():
         assert torch.equal(res[0], res[1]), (B, H, W, cs, N)
 
 
+@pytest.mark.parametrize("B,H,W,cs,N,kh,kw,nseg", [(2, 13, 37, [128, 128, 128], 256, 1, 5, 3), (1, 21, 40, [256], 192, 3, 3, 2),
+                                                    (2, 9, 33, [128, 128], 128, 5, 1, 2), (1, 7, 70, [126], 96, 3, 3, 4),
+                                                    (3, 55, 128, [64], 126, 3, 3, 2), (1, 3, 5, [48, 20], 40, 1, 5, 2)])
+def test_resident_block_weight_gradient(B, H, W, cs, N, kh, kw, nseg):
+    """conv_wgrad_patch_kernel (csrc/wgrad_patch.inc, fsraft_set_tuning key 27): the multi-segment weight gradient of the
+    3x3 / 1x5 / 5x1 layers over resident pixel blocks, against an fp64 convolution weight gradient and against the per-tap
+    kernel it replaces.  Ragged H / W (partial 4 x 32 blocks, halo clipping), channel counts that are not multiples of 64 or
+    of 4, several sources, several segments, bias gradient."""
+    from flow_supervisor_amd import _lib, ops
+    lib = _lib.load()
+    lib.fsraft_set_tuning(3, 1); lib.fsraft_set_tuning(4, 2)
+    torch.manual_seed(B * 1000 + H * 10 + kh)
+    pad4 = lambda c: (c + 3) // 4 * 4
+    xs = [[torch.randn(B, H, W, pad4(c), device=DEV) for c in cs] for _ in range(nseg)]
+    dys = [torch.randn(B, H, W, pad4(N), device=DEV) for _ in range(nseg)]
+    cin = sum(cs)
+    res = []
+    for flag in (1, 0):
+        lib.fsraft_set_tuning(27, flag)
+        dwpk = torch.zeros_like(ops.pack_weight(torch.zeros(N, cin, kh, kw, device=DEV), cs, 0))
+        dbias = torch.zeros(N, device=DEV)
+        ops.conv_wgrad_multi([ops.V(t, N) for t in dys], [[ops.V(t, c) for t, c in zip(x, cs)] for x in xs], dwpk, B, H, W, kh, kw,
+                             dbias=dbias)
+        res.append((dwpk, dbias))
+    lib.fsraft_set_tuning(27, 1)
+    # fp64 reference: the weight gradient of the same-padded convolution, packed like the weights
+    w = torch.zeros(N, cin, kh, kw, dtype=torch.float64, device=DEV, requires_grad=True)
+    ref_b = torch.zeros(N, dtype=torch.float64, device=DEV)
+    for x, dy in zip(xs, dys):
+        xin = torch.cat([t[..., :c] for t, c in zip(x, cs)], -1).permute(0, 3, 1, 2).double()
+        y = torch.nn.functional.conv2d(xin, w, padding=(kh // 2, kw // 2))
+        y.backward(dy[..., :N].permute(0, 3, 1, 2).double())
+        ref_b += dy[..., :N].double().sum((0, 1, 2))
+    ref = ops.pack_weight(w.grad.float(), cs, 0)
+    real = ops.pack_weight(torch.ones(N, cin, kh, kw, device=DEV), cs, 0)     # 0 in the pad columns of the packed layout: nobody reads those
+    scale = ref.abs().max().item()
+    for (dwpk, dbias), name in zip(res, ("resident blocks", "per tap")):
+        assert ((dwpk - ref) * real).abs().max().item() <= 3e-5 * scale, name
+        close(dbias, ref_b.float(), 1e-5, what="bias gradient, " + name)
+    assert ((res[0][0] - res[1][0]) * real).abs().max().item() <= 2e-5 * scale
+
+
 def test_record_gemms_against_fp64():
     """fsraft_to_records / fsraft_gemm_rec_nt / fsraft_gemm_rec_tn (csrc/gemm_rec.hip, the LDS-DMA record core): ragged shapes,
     split-K with atomics, explicit pitches, accumulate.  Split-bf16 products: relative error ~2^-17 per product."""
