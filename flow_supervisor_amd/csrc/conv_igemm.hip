@@ -1653,6 +1653,7 @@ int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
 int g_conv_rec = 1;        // record-activation kernel (conv_rec.inc): 0 off, 1 layers with > 128 outputs, 2 every layer it can run
 #include "conv_rec.inc"
 int g_conv_patch = 1;      // resident-patch, channel-streaming kernel for the 3x3 / 1x5 / 5x1 layers (conv_patch.inc, key 26; 2: 128-pixel tiles too)
+int g_conv_patch64 = 1;    // ... also for the 3x3 layers with 33..64 outputs (64-column tiles; key 28; 2: 128-pixel tiles)
 #include "conv_patch.inc"
 
 int conv_ktot(const int* C, int nsrc, int taps) {
@@ -1720,6 +1721,13 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (d->epi == EPI_ZR && (!d->h || !d->aux1 || !d->aux2 || d->hid * 2 != d->N)) return FS_ERR_ARG;
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
+  if (g_conv_patch && g_conv_patch64 && g_conv_split == 1 && d->wpk_split && d->epi == EPI_PLAIN && d->KH == 3 && d->KW == 3 &&
+      d->N > 32 && d->N <= 64 && (int64_t)d->B * d->H * d->W >= 8192) {
+    ConvArgs p = a;
+    p.wpk = d->wpk_split;
+    const int rc = launch_conv_patch(p, d->epi, stream);
+    if (rc >= 0) return rc;
+  }
   if (g_conv_halo && g_conv_split == 1 && d->wpk_frag && d->epi == EPI_PLAIN && d->nsrc == 1 && d->KH == 3 && d->KW == 3 &&
       a.PH == 1 && a.PW == 1 &&
       d->srcC[0] % 4 == 0 && d->srcC[0] > 32 && d->srcC[0] <= 64 && d->N <= 128 && d->N > 32 && d->ndst == 1 &&
@@ -1826,6 +1834,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 25) g_conv_rec = value;
   else if (key == 26) g_conv_patch = value;
   else if (key == 27) g_wgrad_patch = value;
+  else if (key == 28) g_conv_patch64 = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;

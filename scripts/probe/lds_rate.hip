@@ -53,7 +53,7 @@ template <int KIND> void run(const char* name, int pitch) {
   (void)hipFree(d); (void)hipFree(s);
 }
 int main() {
-  for (int p : {192, 320, 144, 160, 136, 132, 256, 128, 208, 576}) run<0>("ds_read_b64_tr_b16", p);
+  for (int p : {192, 320, 144, 160, 136, 132, 256, 128, 208, 576, 64, 96}) run<0>("ds_read_b64_tr_b16", p);
   run<1>("ds_read_b64 linear", 64);
   run<2>("ds_read_b128 linear", 64);
 }
