@@ -136,6 +136,30 @@ __global__ __launch_bounds__(256) void to_records_kernel(const float* __restrict
 
 // src [rows][K] fp32 (row pitch ld floats) -> dst [rows][ceil(K/32)] records of [32 hi | 32 lo] bf16 (128 bytes), row pitch
 // dst_ld floats (>= 32 * ceil(K/32), a multiple of 32; 0 = dense)
+namespace {
+// C[b][m][0..N) = 0 for the split-K / accumulate path.  A kernel, not hipMemsetAsync: inside a captured hipGraph the memset
+// node of these calls left the matrix untouched on every replay after the first (the partial tiles were then added to the
+// previous replay's result -- scripts/graph_check.py); a fill kernel is an ordinary graph node.
+__global__ __launch_bounds__(256) void zero_matrices_kernel(float* __restrict__ C, int64_t ldc, int64_t sC, int M, int N) {
+  float* row = C + (int64_t)blockIdx.z * sC + (int64_t)blockIdx.y * ldc;
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) row[n] = 0.f;
+}
+int zero_matrices(float* C, int64_t ldc, int64_t sC, int batch, int M, int N, hipStream_t stream) {
+  if (ldc == N && sC == (int64_t)M * N && (int64_t)batch * M * N < (int64_t)0x7fffffff) {      // dense: one long row
+    const int total = batch * M * N;
+    int gx = (total + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(zero_matrices_kernel, dim3(gx), dim3(256), 0, stream, C, (int64_t)0, (int64_t)0, 1, total);
+  } else {
+    if (M > 65535 || batch > 65535) return FS_ERR_ARG;
+    int gx = (N + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(zero_matrices_kernel, dim3(gx, M, batch), dim3(256), 0, stream, C, ldc, sC, M, N);
+  }
+  return fs_launch_status();
+}
+}  // namespace
+
 extern "C" int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, hipStream_t stream) {
   if (!src || !dst || rows < 1 || K < 1 || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16)) return FS_ERR_ARG;
   const int KR = (K + 31) / 32;
@@ -163,12 +187,8 @@ extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const 
   if (ksplit > KT) ksplit = KT;
   const bool atomic = ksplit > 1 || accumulate;
   if (atomic && !accumulate) {
-    if (ldc == N && sC == (int64_t)M * N) {
-      if (hipMemsetAsync(C, 0, (size_t)batch * M * N * 4, stream) != hipSuccess) return FS_ERR_LAUNCH;
-    } else {
-      for (int b = 0; b < batch; ++b)
-        if (hipMemset2DAsync(C + b * sC, ldc * 4, 0, (size_t)N * 4, M, stream) != hipSuccess) return FS_ERR_LAUNCH;
-    }
+    const int rc = zero_matrices(C, ldc, sC, batch, M, N, stream);
+    if (rc) return rc;
   }
   RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
   dim3 grid(ceil_div(N, G::BN) * ceil_div(M, G::BM), ksplit, batch);
@@ -189,12 +209,8 @@ extern "C" int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const 
   if (ksplit > KT) ksplit = KT;
   const bool atomic = ksplit > 1 || accumulate;
   if (atomic && !accumulate) {
-    if (ldc == N && sC == (int64_t)M * N) {
-      if (hipMemsetAsync(C, 0, (size_t)batch * M * N * 4, stream) != hipSuccess) return FS_ERR_LAUNCH;
-    } else {
-      for (int b = 0; b < batch; ++b)
-        if (hipMemset2DAsync(C + b * sC, ldc * 4, 0, (size_t)N * 4, M, stream) != hipSuccess) return FS_ERR_LAUNCH;
-    }
+    const int rc = zero_matrices(C, ldc, sC, batch, M, N, stream);
+    if (rc) return rc;
   }
   RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
   dim3 grid(ceil_div(N, GT::BN) * ceil_div(M, GT::BM), ksplit, batch);

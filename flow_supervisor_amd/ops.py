@@ -68,11 +68,17 @@ TIMER = None
 class _ZeroPool:
     """Small zero-initialised buffers (atomic-accumulation targets, padded channels) carved out of 32 MB chunks that are
     zero-filled ONCE: a training step used to issue ~285 separate fill kernels of a few KB each.  A chunk lives as long
-    as any buffer carved from it; the pool itself only holds the chunk it is currently carving."""
+    as any buffer carved from it; the pool itself only holds the chunk it is currently carving.
+
+    Under hipGraph capture the same buffers are used again by every replay, so "once" has to mean once per replay: a
+    capture never carves from a chunk that was filled outside it (or inside another capture) -- its first request opens a
+    new chunk, whose fill is recorded in the graph ahead of every use of the buffers carved from it."""
     CHUNK = 32 << 20
 
     def __init__(self):
         self.cur = {}
+        self.epoch = 0                  # bumped whenever the stream's capture status flips: chunks belong to one epoch
+        self.capturing = False
 
     def take(self, shape, device):
         n = 1
@@ -81,17 +87,29 @@ class _ZeroPool:
         nb = (n * 4 + 255) // 256 * 256
         if nb > self.CHUNK // 4 or n == 0 or torch.device(device).type != "cuda":
             return torch.zeros(shape, device=device, dtype=torch.float32)
+        cap = torch.cuda.is_current_stream_capturing()
+        if cap != self.capturing:
+            self.capturing = cap
+            self.epoch += 1
         key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
         ent = self.cur.get(key)
-        if ent is None or ent[1] + nb > self.CHUNK:
-            ent = [torch.zeros(self.CHUNK // 4, device=device, dtype=torch.float32), 0]
+        if ent is None or ent[1] + nb > self.CHUNK or ent[2] != self.epoch:
+            ent = [torch.zeros(self.CHUNK // 4, device=device, dtype=torch.float32), 0, self.epoch]
             self.cur[key] = ent
         o = ent[1] // 4
         ent[1] += nb
         return ent[0][o:o + n].view(shape)
 
+    def new_epoch(self):
+        self.epoch += 1
+
 
 _ZEROS = _ZeroPool()
+
+
+def new_zero_epoch():
+    """Call between two hipGraph captures that follow each other without an eager step in between (see _ZeroPool)."""
+    _ZEROS.new_epoch()
 
 
 def zeros(*shape, device):

@@ -1404,6 +1404,47 @@ def test_weight_packs_follow_a_fused_optimizer_step():
         assert (fresh(im1, im2, iters=3)[-1] - b).abs().max().item() > 1e-2
 
 
+def test_hipgraph_replays_of_the_train_step_follow_the_eager_steps():
+    """bench.py times hipGraph replays of the whole train step (one rank).  Replays reuse every buffer of the capture, so
+    anything zeroed "once" or by a node the graph drops shows up from the second replay on: ops._ZeroPool (chunks filled once
+    per capture, not once per process) and the split-K record GEMMs (their zero fill is a kernel, the hipMemsetAsync node was
+    not replayed).  Six replays against six eager steps from the same start: the losses must follow each other."""
+    import argparse
+    import copy
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.train import TrainStep
+    torch.manual_seed(0)
+    model = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(DEV).train()
+    model.freeze_bn()
+    twin = copy.deepcopy(model)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    im1 = torch.rand(2, 3, 184, 320, device=DEV, generator=g) * 255
+    im2 = torch.rand(2, 3, 184, 320, device=DEV, generator=g) * 255
+    eager = TrainStep(twin, lr=1e-4, iters=4, capturable=True)
+    le = [float(eager(im1, im2)) for _ in range(8)]
+    step = TrainStep(model, lr=1e-4, iters=4, capturable=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step(im1, im2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        loss = step(im1, im2)
+    lg = []
+    for _ in range(6):
+        graph.replay()
+        torch.cuda.synchronize()
+        lg.append(float(loss))
+    del graph
+    # (the first steps of a random-init model on random images move the loss by factors -- 1.2, 12.7, 9.4, 5.1, 1.5, 2.8 ... --
+    #  so a wrong update shows as a different sequence, while summation-order noise stays below 1e-3 relative)
+    for a, b in zip(le[2:], lg):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+
+
 # ----------------------------------------------------------------------------- data parallelism on the real step (row e)
 @pytest.mark.parametrize("global_batch", [4, 3])
 def test_two_process_train_step_matches_single_process(global_batch, tmp_path):
