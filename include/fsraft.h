@@ -218,7 +218,11 @@ int fsraft_conv_small_wgrad(const float* const* dy, const float* const* x, int n
 /* Tuning knobs for experiments (tile selection); not part of the reference interface.
  * key 0: conv tile (0 auto, 1 128x128, 2 64x128, 3 64x64); key 1: wgrad tile (0 128x128, 3 64x64);
  * key 2: target workgroup count of the wgrad pixel split; key 3: 1 = split-bf16 (3 x bf16 MFMA,
- * fp32 accumulate, ~2^-17 relative error per product) core for forward / data-gradient GEMMs with N > 64. */
+ * fp32 accumulate, ~2^-17 relative error per product) core for forward / data-gradient GEMMs with N > 64.
+ * Further keys select kernel variants kept for measurement (csrc/conv_igemm.hip, fsraft_set_tuning; _lib.py maps an
+ * FSRAFT_* environment variable to each): 24 LDS-direct weight tiles, 25 record activations, 26 resident-patch forward /
+ * data-gradient kernel (2: 128-pixel tiles too), 27 resident-block weight gradient (0 off, 1 the 3x3 layers, 2 the
+ * five-tap layers too), 28 64-column patch tiles for 33..64 outputs (1 small grids, 2 / 3 force 128 / 256-pixel tiles). */
 int fsraft_set_tuning(int key, int value);
 int fsraft_get_tuning(int key);   /* keys 3 / 4: arithmetic mode of the forward+data-gradient / weight-gradient convolutions */
 /* volume build arithmetic: 1 (default) split-bf16, 0 exact fp32 MFMA */

@@ -11,7 +11,7 @@ import json
 import sys
 
 raw = json.load(open(sys.argv[1]))
-FAM = [("conv_igemm", "conv_igemm"), ("conv3x3_halo", "conv_igemm"), ("conv_rec", "conv_igemm"), ("conv_wgrad", "conv_wgrad"),
+FAM = [("conv_igemm", "conv_igemm"), ("conv3x3_halo", "conv_igemm"), ("conv_rec", "conv_igemm"), ("conv_patch", "conv_igemm"), ("conv_wgrad", "conv_wgrad"),
        ("gemm_split", "gemm_f32"), ("gemm_kernel", "gemm_f32"), ("gemm_rec", "gemm_f32"),
        ("corr_build_rec", "corr_build"), ("corr_build_tiled", "corr_build"), ("corr_build_split", "corr_build"),
        ("lookup_tiled_fwd", "corr_lookup_fwd"), ("corr_lookup_fwd", "corr_lookup_fwd"),

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Matrix-pipe busy fraction and effective shader clock of the convolution kernels, from one PMC pass with the kernel trace:
-#   busy  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE)      clock = GRBM_GUI_ACTIVE / kernel duration
+#   busy  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)      clock = GRBM_GUI_ACTIVE / 8 / kernel duration
+#   (GRBM_GUI_ACTIVE comes back summed over the 8 XCDs)
 # usage (GPU box, repo root): scripts/mfma_busy.sh <tag> <conv_micro layer> [key=value ...]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -23,8 +24,8 @@ for (did, name), c in per.items():
     agg[short].append((dur[did], c))
 for name, v in agg.items():
     ns, c = v[-1]
-    act = c["GRBM_GUI_ACTIVE"]
-    print(f"{name}\n    {ns / 1e3:8.1f} us  GRBM_GUI_ACTIVE {act:.4g}  -> {act / ns:.2f} GHz   MFMA busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * act):.3f} of the SIMD cycles"
+    act = c["GRBM_GUI_ACTIVE"] / 8.0
+    print(f"{name}\n    {ns / 1e3:8.1f} us  GRBM_GUI_ACTIVE / 8 = {act:.4g} cycles -> {act / ns:.2f} GHz   MFMA busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * act):.3f} of the SIMD cycles"
           f"   ({c['SQ_INSTS_MFMA']:.4g} MFMAs, {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_INSTS_MFMA']:.1f} busy cycles each; at 2.4 GHz the same MFMAs are {c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / 2.4e9 * 1e6:.0f} us)")
 PY
 find gpurun_out/busy_$tag -name "*.csv" -delete; find gpurun_out/busy_$tag -name "*.db" -delete
