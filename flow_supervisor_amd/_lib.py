@@ -72,6 +72,9 @@ SIGNATURES = {
     "fsraft_pack_conv_weights": [POINTER(PackJob), c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_tuning": [c_int, c_int],
+    "fsraft_stem_slots": [],
+    "fsraft_stem7x7s2_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_stem7x7s2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_set_lookup_qb": [c_int],
     "fsraft_set_build_split": [c_int],
     "fsraft_set_gemm_split": [c_int],

@@ -356,7 +356,33 @@ class _ConvCL(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-def _conv(conv, x, bias, link=None):
+class _StemFn(torch.autograd.Function):
+    """conv1 of the encoders (7x7, stride 2, 3 input channels; pytorch/core/extractor.py:135, :212) on csrc/stem.hip: NCHW image
+    in, channels_last activation out; backward is the weight gradient only (the image is the network input)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from .. import ops
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.stem_fwd(x, w.detach()).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        (x,) = ctx.saved_tensors
+        return None, ops.stem_wgrad(x, _as_cl(g).permute(0, 2, 3, 1))
+
+
+def _stem_ok(conv, x):
+    import os
+    return (os.environ.get("FSRAFT_STEM", "1") != "0" and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels == 3
+            and conv.out_channels in (32, 64) and _fast(x) and not x.requires_grad and not torch.is_autocast_enabled()
+            and x.shape[2] >= 7 and x.shape[3] >= 7)
+
+
+def _conv(conv, x, bias, link=None, stem_cl=False):
     """conv(x) with the given bias (None: without).  A channels_last fp32 input of a stride-1 1x1 / 3x3 convolution takes
     the fsraft kernels; anything else is MIOpen on an NCHW tensor (its NHWC fp32 kernels are far slower than its NCHW
     ones on gfx950 -- the backward-weights one by two orders of magnitude -- so a channels_last input is converted)."""
@@ -365,6 +391,8 @@ def _conv(conv, x, bias, link=None):
             and conv.padding == (k[0] // 2, k[1] // 2) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.padding_mode == "zeros" and x.shape[1] % 4 == 0 and not torch.is_autocast_enabled()):
         return _ConvCL.apply(x, conv.weight, bias, _weight_packs(conv), link)
+    if stem_cl and bias is None and _stem_ok(conv, x):
+        return _StemFn.apply(x, conv.weight)
     return F.conv2d(_ToNCHW.apply(x) if _is_cl(x) else x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
@@ -502,7 +530,7 @@ def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=N
     fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
     if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
         if fused:
-            y = _conv(conv, x, None, link)
+            y = _conv(conv, x, None, link, stem_cl=to_cl)
             if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
                 return _InstNormReluCL.apply(y, norm.eps, relu, res, res_link)
             y = _InstNormRelu.apply(y, norm.eps, relu)
@@ -510,7 +538,7 @@ def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=N
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)
         y = norm(y)
     elif isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats and norm.affine and fused:
-        y = _conv(conv, x, None, link)
+        y = _conv(conv, x, None, link, stem_cl=to_cl)
         if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
             return _FrozenBNReluCL.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu, res,
                                          res_link)

@@ -1036,6 +1036,41 @@ def conv_wgrad_multi(dys, srcs, dwpk, B, H, W, KH, KW, dbias=None):
         TIMER.end("conv_wgrad", e0w, 2.0 * n * B * H * W * dy0.C * cin * KH * KW, 4.0 * n * B * H * W * (cin + dy0.C))
 
 
+def stem_fwd(x, w, bias=None):
+    """The encoders' 7x7 stride-2 stem (pytorch/core/extractor.py:135, :212) on csrc/stem.hip: x [B,3,H,W] contiguous fp32,
+    w [N,3,7,7] (N = 32 or 64) -> [B,Ho,Wo,N] channels-last."""
+    L.require_cuda_f32(x, w)
+    B, C, H, W = x.shape
+    N = w.shape[0]
+    if C != 3 or tuple(w.shape[1:]) != (3, 7, 7) or not x.is_contiguous():
+        raise RuntimeError("stem_fwd: x [B,3,H,W] contiguous and w [N,3,7,7] expected")
+    out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, N, device=x.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_stem7x7s2_fwd(L.ptr(x), L.ptr(w.contiguous()), L.ptr(bias), L.ptr(out), B, H, W, N, L.stream()), "stem7x7s2_fwd")
+    if t:
+        t.end("stem", e0, 2.0 * out.numel() * 147, 4.0 * (x.numel() + out.numel()))
+    return out
+
+
+def stem_wgrad(x, dy):
+    """dW [N,3,7,7] of stem_fwd from dy [B,Ho,Wo,N] channels-last (contiguous)."""
+    L.require_cuda_f32(x, dy)
+    B, C, H, W = x.shape
+    N = dy.shape[-1]
+    if not (x.is_contiguous() and dy.is_contiguous()) or tuple(dy.shape[:3]) != (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1):
+        raise RuntimeError("stem_wgrad: contiguous x [B,3,H,W] and dy [B,Ho,Wo,N] expected")
+    lib = _lib()
+    scratch = torch.empty(lib.fsraft_stem_slots() * 64 * 192, device=x.device, dtype=torch.float32)
+    dw = torch.empty(N, 3, 7, 7, device=x.device, dtype=torch.float32)
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(lib.fsraft_stem7x7s2_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(scratch), B, H, W, N, L.stream()), "stem7x7s2_wgrad")
+    if t:
+        t.end("stem", e0, 2.0 * dy.numel() * 147, 4.0 * (x.numel() + dy.numel()))
+    return dw
+
+
 def conv_small_fwd(x, w_oihw, bias, out_nchw):
     """3x3 convolution to 2 output channels as per-pixel dot products; x: V (channels-last), out: [B,2,H,W]."""
     B, N, H, W = out_nchw.shape

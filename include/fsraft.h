@@ -329,6 +329,18 @@ int fsraft_bn_fold(const float* weight, const float* bias, const float* rm, cons
 int fsraft_bn_fold_bwd(const float* part, int R, int C, const float* rs, const float* rmc, const float* scale, float* dweight,
                        float* dbias, float* dcbias, hipStream_t stream);
 
+/* ---- the encoders' stem (next-row f3) ---------------------------------------------------
+ * Replaces `self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3)` and its backward-weights
+ * (pytorch/core/extractor.py:135 BasicEncoder, :212 SmallEncoder with 32 outputs).  x [B][3][H][W] planar fp32, w [N][3][7][7],
+ * N = 32 or 64; out / dy channels-last [B][Ho][Wo][N] with Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1.  The image needs no
+ * gradient (it is the network input).  fsraft_stem7x7s2_wgrad OVERWRITES dw [N][3][7][7]; scratch: fsraft_stem_slots() * 64 *
+ * 192 floats of workspace (per-workgroup partial sums). */
+int fsraft_stem_slots(void);
+int fsraft_stem7x7s2_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int N,
+                         hipStream_t stream);
+int fsraft_stem7x7s2_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int N,
+                           hipStream_t stream);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 /* Space-to-depth by 2 of a channels-last tensor: dst[b][y/2][x/2][(y%2)*2 + x%2][c] = src[b][y][x][c] (inverse != 0: back).

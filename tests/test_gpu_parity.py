@@ -1404,6 +1404,25 @@ def test_weight_packs_follow_a_fused_optimizer_step():
         assert (fresh(im1, im2, iters=3)[-1] - b).abs().max().item() > 1e-2
 
 
+@pytest.mark.parametrize("B,H,W,N", [(2, 440, 1024, 64), (1, 61, 75, 64), (3, 40, 70, 32), (1, 7, 9, 64), (2, 128, 192, 32)])
+def test_stem_convolution_and_weight_gradient(B, H, W, N):
+    """csrc/stem.hip: the encoders' 7x7 stride-2 stem (pytorch/core/extractor.py:135, :212) and its weight gradient against the
+    fp64 convolution: odd sizes (partial tiles, clipped halo on every side), both output widths, bias."""
+    from flow_supervisor_amd import ops
+    torch.manual_seed(H * 7 + W)
+    x = torch.rand(B, 3, H, W, device=DEV) * 2 - 1
+    w = torch.randn(N, 3, 7, 7, device=DEV) * 0.1
+    bias = torch.randn(N, device=DEV)
+    y = ops.stem_fwd(x, w, bias)
+    wd = w.double().requires_grad_()
+    ref = torch.nn.functional.conv2d(x.double(), wd, bias.double(), 2, 3)
+    close(y.permute(0, 3, 1, 2), ref.float(), 1e-6, what="stem forward")
+    dy = torch.randn_like(y)
+    ref.backward(dy.permute(0, 3, 1, 2).double())
+    dw = ops.stem_wgrad(x, dy)
+    close(dw, wd.grad.float(), 1e-6, rtol=3e-5, what="stem weight gradient")
+
+
 def test_hipgraph_replays_of_the_train_step_follow_the_eager_steps():
     """bench.py times hipGraph replays of the whole train step (one rank).  Replays reuse every buffer of the capture, so
     anything zeroed "once" or by a node the graph drops shows up from the second replay on: ops._ZeroPool (chunks filled once
