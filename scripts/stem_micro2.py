@@ -23,3 +23,9 @@ for B in (8, 4):
         us = e0.elapsed_time(e1) * 100
         gb = 4.0 * (x.numel() + y.numel()) / 1e9
         print(f"B={B} {name:5s} {us:7.1f} us   {gb / us * 1e6 / 1e3:5.2f} TB/s of the {gb * 1e3:.0f} MB it has to move")
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn(); torch.cuda.synchronize()
+        for ev in prof.events():
+            if ev.device_type == torch.autograd.DeviceType.CUDA:
+                print(f"         {ev.device_time:8.1f} us  {ev.name[:80]}")
