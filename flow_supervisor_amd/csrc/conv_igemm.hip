@@ -1522,6 +1522,7 @@ int g_wgrad_xcd = 1;           // XCD-aware workgroup order in the multi-segment
 int g_conv_bdma = 0;           // LDS-direct weight tiles in the wide implicit-GEMM kernels (key 24, experiment)
 int g_wgrad_patch = 1;         // resident-pixel-block weight gradient for the 3x3 / 1x5 / 5x1 layers (wgrad_patch.inc, key 27)
 int g_wgrad_pack = 1;          // few-channel single-source layers on conv_wgrad_pack_kernel (key 16)
+int g_wgrad_patch1 = 8192;     // single-segment 3x3 layers with at least this many pixels on the resident-block kernel (key 29; 0: never)
 int g_wgrad_blocks_pack = 1024;   // its workgroup target (key 17)
 int g_wgrad_blocks = 512;   // target workgroup count of the pixel split (key 2); measured 256: 12.9, 512: 11.5, 1024: 12.9, 2048: 14.1 ms/step
 using Cfg32 = GemmCfg<128, 32, 32, 4, 1, 2, 2>;
@@ -1835,6 +1836,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 26) g_conv_patch = value;
   else if (key == 27) g_wgrad_patch = value;
   else if (key == 28) g_conv_patch64 = value;
+  else if (key == 29) g_wgrad_patch1 = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;
@@ -1849,6 +1851,8 @@ extern "C" int fsraft_set_tuning(int key, int value) {
 
 // dwpk[Cout][Ktot] += dY^T * im2col(X)   (same packed layout as the forward weights)
 extern "C" int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s);
+
+namespace { int launch_wgrad_patch(WgradArgsM m, hipStream_t s); }
 
 extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
                                  const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W, int KH,
@@ -1870,6 +1874,17 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
   a.nsrc = nsrc; a.dwpk = dwpk; a.Ktot = conv_ktot(srcC, nsrc, KH * KW);
   a.B = B; a.H = H; a.W = W; a.KH = KH; a.KW = KW;
   const int64_t M = (int64_t)B * H * W;
+  // one segment of a 3x3 layer at encoder size: the resident-block kernel (wgrad_patch.inc) reads dY and X once instead of once
+  // per tap group
+  if (g_wgrad_patch && g_wgrad_patch1 && g_wgrad_split != 0 && KH == 3 && KW == 3 && Cout > 32 && M >= g_wgrad_patch1) {
+    WgradArgsM m{};
+    m.a = a; m.a.dbias = dbias;
+    m.nseg = 1;
+    m.dys[0] = dy;
+    for (int s = 0; s < nsrc; ++s) m.srcs[s][0] = src[s];
+    const int rc = launch_wgrad_patch(m, stream);
+    if (rc >= 0) return rc;
+  }
   if (g_wgrad_pack && g_wgrad_split != 0 && g_wgrad_buf && nsrc == 1 && srcC[0] <= 96 && KH * KW > 1 &&
       (int64_t)(32 * (WGRAD_PACK_WORDS - 2) + 2 * W + 2) * srcld[0] * 4 < 0x7fffffff) {
     // few input channels: several taps per x tile, 64-row dY tiles (conv_wgrad_pack_kernel)
