@@ -159,7 +159,7 @@ def load():
         lib.fsraft_set_build_split(int(bsplit))
     for key, env in ((0, "FSRAFT_CONV_TILE"), (2, "FSRAFT_WGRAD_BLOCKS"), (5, "FSRAFT_CONV_BUF"), (8, "FSRAFT_WGRAD_BUF"), (11, "FSRAFT_WGRAD_BLOCKS_MULTI"), (13, "FSRAFT_CONV_W8"), (14, "FSRAFT_CONV_W8_MIN"), (15, "FSRAFT_WGRAD_W8"),
                      (16, "FSRAFT_WGRAD_PACK"), (17, "FSRAFT_WGRAD_BLOCKS_PACK"), (18, "FSRAFT_CONV_N64"), (20, "FSRAFT_CONV_HALO"),
-                     (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA"), (25, "FSRAFT_CONV_REC"), (26, "FSRAFT_CONV_PATCH"), (27, "FSRAFT_WGRAD_PATCH"), (28, "FSRAFT_CONV_PATCH64"), (29, "FSRAFT_WGRAD_PATCH1")):
+                     (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA"), (25, "FSRAFT_CONV_REC"), (26, "FSRAFT_CONV_PATCH"), (27, "FSRAFT_WGRAD_PATCH"), (28, "FSRAFT_CONV_PATCH64"), (29, "FSRAFT_WGRAD_PATCH1"), (30, "FSRAFT_CONV_C64")):
         if os.environ.get(env) is not None:
             lib.fsraft_set_tuning(key, int(os.environ[env]))
     wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")

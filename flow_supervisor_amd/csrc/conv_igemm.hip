@@ -849,6 +849,8 @@ int launch_halo(const HaloArgs& h, hipStream_t s) {
   return fs_launch_status();
 }
 
+#include "conv_c64.inc"
+
 // ---------------------------------------------------------------- weight gradient
 struct WgradArgs {
   const float* dy; int ldy; int Cout;     // dY (already multiplied by act'), [M][ldy]
@@ -1654,6 +1656,7 @@ int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
 int g_conv_rec = 1;        // record-activation kernel (conv_rec.inc): 0 off, 1 layers with > 128 outputs, 2 every layer it can run
 #include "conv_rec.inc"
 int g_conv_patch = 1;      // resident-patch, channel-streaming kernel for the 3x3 / 1x5 / 5x1 layers (conv_patch.inc, key 26; 2: 128-pixel tiles too)
+int g_conv_c64 = 0;        // experiment (key 30 = minimum pixel count): 64 -> 64 3x3 layers on conv3x3_c64_kernel (resident weights) -- 322 vs 237 us, off
 int g_conv_patch64 = 1;    // ... also for the 3x3 layers with 33..64 outputs (64-column tiles; key 28; 2: 128-pixel tiles)
 #include "conv_patch.inc"
 
@@ -1739,6 +1742,7 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // Measured (scripts/conv_micro.py, halo on / off): 64 -> 64 at 8x220x512 238 vs 442 us.  With three or four channel
     // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
     // GEMM (96 -> 96 at 8x110x256: 249 vs 165 us; 128 -> 128 at 8x55x128: 93 vs 65 us), so only two-group layers come here.
+    if (g_conv_c64 && d->srcC[0] == 64 && d->N == 64 && (int64_t)d->B * d->H * d->W >= g_conv_c64) return launch_conv_c64(h, stream);
     return d->N > 64 ? launch_halo<2, 2>(h, stream) : launch_halo<2, 1>(h, stream);
   }
   if (g_conv_rec && g_conv_split == 1 && d->wpk_split && d->srcr[0] && (d->N > 128 || g_conv_rec == 2) && d->N > 32 &&
@@ -1837,6 +1841,7 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 27) g_wgrad_patch = value;
   else if (key == 28) g_conv_patch64 = value;
   else if (key == 29) g_wgrad_patch1 = value;
+  else if (key == 30) g_conv_c64 = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;

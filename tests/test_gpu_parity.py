@@ -813,6 +813,38 @@ def test_conv3x3_resident_patch_kernel(B, C, N, H, W):
         lib.fsraft_set_tuning(21, 65536)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 20, 32), (1, 13, 37), (3, 33, 70), (1, 3, 5), (2, 220, 96)])
+def test_conv3x3_resident_weights_kernel(B, H, W):
+    """conv3x3_c64_kernel (csrc/conv_c64.inc, fsraft_set_tuning key 30): 64 -> 64 3x3 layers with one 32-column block of the
+    weights resident in LDS and a persistent walk over 4x32 tiles -- forward with bias + ReLU, the data gradient, and the
+    accumulating epilogue (out += result), against F.conv2d; ragged sizes, more tiles than workgroup pairs (2 x 220 x 96 =
+    330 tiles on 128 sequences) and fewer."""
+    from flow_supervisor_amd import _lib, ops
+    lib = _lib.load()
+    lib.fsraft_set_tuning(3, 1); lib.fsraft_set_tuning(4, 2)
+    lib.fsraft_set_tuning(21, 0); lib.fsraft_set_tuning(30, 1)
+    try:
+        C = N = 64
+        torch.manual_seed(11 + H)
+        w = torch.randn(N, C, 3, 3, device=DEV) * 0.1
+        bias = torch.randn(N, device=DEV)
+        x = torch.randn(B, H, W, C, device=DEV)
+        packs = dict(wpk_split=ops.pack_weight(w, [C], 10), wpk_frag=ops.fragment_order(ops.pack_weight(w, [C], 10)))
+        out = torch.full((B, H, W, N), float("nan"), device=DEV)
+        ops.conv_forward([ops.V(x, C)], ops.pack_weight(w, [C], 0), bias, B, H, W, 3, 3, N, [ops.Dst.nhwc(out)], relu=True, **packs)
+        ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=1)).permute(0, 2, 3, 1)
+        close(out, ref, 1e-4, what="resident-weights conv fwd")
+        g = torch.randn(B, H, W, N, device=DEV)
+        base = torch.randn(B, H, W, C, device=DEV)
+        dx = base.clone()
+        ops.conv_forward([ops.V(g, N)], ops.pack_weight(w, [C], 1), None, B, H, W, 3, 3, C, [ops.Dst.nhwc(dx, acc=True)],
+                         wpk_split=ops.pack_weight(w, [C], 11), wpk_frag=ops.fragment_order(ops.pack_weight(w, [C], 11)))
+        dref = torch.nn.grad.conv2d_input((B, C, H, W), w, g.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        close(dx, base + dref, 1e-4, what="resident-weights conv dgrad, accumulating")
+    finally:
+        lib.fsraft_set_tuning(21, 65536); lib.fsraft_set_tuning(30, 0)
+
+
 @pytest.mark.parametrize("B,C,N,H,W", [(2, 64, 96, 20, 32), (1, 96, 128, 6, 10), (2, 8, 16, 14, 4)])
 def test_encoder_strided_pair_space_to_depth(B, C, N, H, W, precision):
     """_StridedPairFn: the 3x3 stride-2 convolution and the 1x1 stride-2 shortcut of a stride-2 residual unit as 2x2 / 1x1
