@@ -285,7 +285,7 @@ def main():
                    "launch": "hipGraph replay of the whole step (the short runs behind value_exact_f32 / value_north_star_encoders and the "
                              "per-kernel timing are eager)" if graph is not None else graph_note,
                    "encoders": ("MIOpen NCHW convolutions (north_star configuration)" if os.environ.get("FSRAFT_ENCODER_CL", "1") == "0"
-                                else "channels_last on the fsraft kernels (stride-2 units via space-to-depth); 7x7 stem on MIOpen; "
+                                else "channels_last on the fsraft kernels (7x7 stem on csrc/stem.hip, stride-2 units via space-to-depth; no MIOpen call left); "
                                      "value_north_star_encoders = the same step with the encoders on MIOpen")},
     }
     out.update(extra)
