@@ -16,6 +16,16 @@ namespace {
 // measured before this, both kernels here ran at the rate L2 delivers nine 1 KB rows per pixel (5.7-5.9 TB/s).
 constexpr int SMALL_RUN = 16;        // weight gradient: long runs (12 segments x 1760 runs keep 2048 waves busy)
 constexpr int SMALL_RUN_FWD = 8;     // forward: the launch is latency-bound, more and shorter runs measured faster (strided pixels 43.9 us, runs of 16: 37.3, two runs of 16 per wave: 51.5, runs of 8: 34.5)
+constexpr int SMALL_CHUNK = 8;       // weight gradient: pixels whose columns are requested together
+
+// Buffer loads with the validity in the lane offset: `ok ? *p : 0` compiles to one branch per load, which serialises the
+// loads of a run (the forward kernel was bound by exactly that: one L2 round trip per pixel, 34 us per launch).
+constexpr unsigned SM_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sm_rsrc(const void* p) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uint64_t)hi << 32 | lo), 0, 0x7fffffff, 0x00020000);
+}
 
 template <int KC, int NOUT, int KH, int KW>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float* __restrict__ x, int ld, int C,
@@ -53,7 +63,9 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float* __rest
     const int y = (int)(by % H), b = (int)(by / H);
     const int n = W - x0 < SMALL_RUN_FWD ? W - x0 : SMALL_RUN_FWD;
     const float* img = x + (int64_t)b * HW * ld;
-    // column xs of the three rows y - 1 .. y + 1 (zeros outside the image); all conditions are wave-uniform
+    // column xs of the three rows y - 1 .. y + 1 (zeros outside the image).  The whole run's columns are requested before
+    // the first one is used.
+    const __amdgpu_buffer_rsrc_t rs = sm_rsrc(img);
     auto load_col = [&](int xs, f32x4 (&col)[3][KC]) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -62,43 +74,47 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float* __rest
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
           const int c = kc * 256 + lane * 4;
-          col[r][kc] = (in && c < C) ? *reinterpret_cast<const f32x4*>(img + ((int64_t)yy * W + xs) * ld + c) : zero;
+          col[r][kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (in && c < C) ? (unsigned)((yy * W + xs) * ld + c) * 4u : SM_OOB, 0, 0));
         }
       }
     };
-    f32x4 c0[3][KC], c1[3][KC], c2[3][KC];
+    f32x4 c0[3][KC], c1[3][KC], cn[SMALL_RUN_FWD][3][KC];
     load_col(x0 - 1, c0);
     load_col(x0, c1);
-    for (int i = 0; i < n; ++i) {
-      load_col(x0 + i + 1, c2);
-      float acc[NOUT];
 #pragma unroll
-      for (int o = 0; o < NOUT; ++o) {
-        f32x4 a4 = zero;
+    for (int i = 0; i < SMALL_RUN_FWD; ++i) load_col(x0 + i + 1, cn[i]);
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+    for (int i = 0; i < SMALL_RUN_FWD; ++i) {
+      if (i < n) {
+        float acc[NOUT];
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc) {
-            a4 += c0[r][kc] * wr[o][3 * r + 0][kc];
-            a4 += c1[r][kc] * wr[o][3 * r + 1][kc];
-            a4 += c2[r][kc] * wr[o][3 * r + 2][kc];
-          }
-        acc[o] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-      }
+        for (int o = 0; o < NOUT; ++o) {
+          f32x4 a4 = zero;
 #pragma unroll
-      for (int o = 0; o < NOUT; ++o) {
+          for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) acc[o] += __shfl_xor(acc[o], sft, 64);
-      }
-      if (lane == 0) {
-        const int pix = y * W + x0 + i;
+            for (int kc = 0; kc < KC; ++kc) {
+              a4 += c0[r][kc] * wr[o][3 * r + 0][kc];
+              a4 += c1[r][kc] * wr[o][3 * r + 1][kc];
+              a4 += cn[i][r][kc] * wr[o][3 * r + 2][kc];
+            }
+          acc[o] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        }
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) out[b * obs + o * ocs + pix * ops] = acc[o] + (bias ? bias[o] : 0.f);
+        for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+          for (int sft = 32; sft > 0; sft >>= 1) acc[o] += __shfl_xor(acc[o], sft, 64);
+        }
+        if (lane == 0) {
+          const int pix = y * W + x0 + i;
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) out[b * obs + o * ocs + pix * ops] = acc[o] + (bias ? bias[o] : 0.f);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) { c0[r][kc] = c1[r][kc]; c1[r][kc] = c2[r][kc]; }
+        for (int kc = 0; kc < KC; ++kc) { c0[r][kc] = c1[r][kc]; c1[r][kc] = cn[i][r][kc]; }
     }
   }
 }
@@ -145,6 +161,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a)
       const int y = (int)(by % a.H), b = (int)(by / a.H);
       const int n = a.W - x0 < SMALL_RUN ? a.W - x0 : SMALL_RUN;
       const float* img = x + (int64_t)b * HW * a.ldx;
+      const __amdgpu_buffer_rsrc_t rs = sm_rsrc(img);
       auto load_col = [&](int xs, f32x4 (&col)[3][KC]) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -153,33 +170,42 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a)
 #pragma unroll
           for (int kc = 0; kc < KC; ++kc) {
             const int c = kc * 256 + lane * 4;
-            col[r][kc] = (in && c < a.C) ? *reinterpret_cast<const f32x4*>(img + ((int64_t)yy * a.W + xs) * a.ldx + c) : zero;
+            col[r][kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (in && c < a.C) ? (unsigned)((yy * a.W + xs) * a.ldx + c) * 4u : SM_OOB, 0, 0));
           }
         }
       };
-      f32x4 c0[3][KC], c1[3][KC], c2[3][KC];
+      f32x4 c0[3][KC], c1[3][KC];
       load_col(x0 - 1, c0);
       load_col(x0, c1);
-      for (int i = 0; i < n; ++i) {
-        load_col(x0 + i + 1, c2);
-        const int64_t m = (int64_t)b * HW + (int64_t)y * a.W + x0 + i;
-        float g[NOUT];
+      for (int i0 = 0; i0 < n; i0 += SMALL_CHUNK) {          // eight pixels at a time: their columns and dY values requested together
+        f32x4 cn[SMALL_CHUNK][3][KC];
+        float g[SMALL_CHUNK][NOUT];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) { g[o] = dy[m * a.ldy + o]; bsum[o] += g[o]; }
+        for (int i = 0; i < SMALL_CHUNK; ++i) {
+          load_col(x0 + i0 + i + 1, cn[i]);
+          const int64_t m = (int64_t)b * HW + (int64_t)y * a.W + x0 + i0 + (i0 + i < n ? i : 0);
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+          for (int o = 0; o < NOUT; ++o) g[i][o] = i0 + i < n ? dy[m * a.ldy + o] : 0.f;
+        }
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc)
+        for (int i = 0; i < SMALL_CHUNK; ++i) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-              acc[o][3 * r + 0][kc] += g[o] * c0[r][kc];
-              acc[o][3 * r + 1][kc] += g[o] * c1[r][kc];
-              acc[o][3 * r + 2][kc] += g[o] * c2[r][kc];
-            }
+          for (int o = 0; o < NOUT; ++o) bsum[o] += g[i][o];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+          for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc) { c0[r][kc] = c1[r][kc]; c1[r][kc] = c2[r][kc]; }
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+              for (int o = 0; o < NOUT; ++o) {
+                acc[o][3 * r + 0][kc] += g[i][o] * c0[r][kc];
+                acc[o][3 * r + 1][kc] += g[i][o] * c1[r][kc];
+                acc[o][3 * r + 2][kc] += g[i][o] * cn[i][r][kc];
+              }
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) { c0[r][kc] = c1[r][kc]; c1[r][kc] = cn[i][r][kc]; }
+        }
       }
     }
   }
