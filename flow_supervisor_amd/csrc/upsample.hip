@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const flo
     for (int jj = 0; jj < 4; ++jj) {
       const int row = (threadIdx.x >> 6) + 4 * jj;
       const int c = row >> 3, r = row & 7;
-      tile[c][r][col] = (xb * 8 + col < W8) ? dup[(((int64_t)n * 2 + c) * H8 + 8 * y + r) * W8 + xb * 8 + col] : 0.f;
+      const int cc = xb * 8 + col < W8 ? xb * 8 + col : W8 - 1;      // (clamped, unconditional: the four loads go out together)
+      const float dv = dup[(((int64_t)n * 2 + c) * H8 + 8 * y + r) * W8 + cc];
+      tile[c][r][col] = (xb * 8 + col < W8) ? dv : 0.f;
     }
   }
   __syncthreads();
@@ -114,12 +116,11 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const flo
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-      float f0 = 0.f, f1 = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const int64_t a = n * flow.bs + ((int64_t)yy * W + xx) * flow.ps;
-        f0 = 8.f * flow.p[a];
-        f1 = 8.f * flow.p[a + flow.cs];
-      }
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+      const int64_t a = n * flow.bs + ((int64_t)yc * W + xc) * flow.ps;
+      const float l0 = flow.p[a], l1 = flow.p[a + flow.cs];          // (address clamped: always loaded)
+      const float f0 = in ? 8.f * l0 : 0.f, f1 = in ? 8.f * l1 : 0.f;
       dp[k] = g0 * f0 + g1 * f1;
       dot += p[k] * dp[k];
     }
