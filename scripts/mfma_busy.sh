@@ -18,7 +18,7 @@ for r in ctr:
     per[(r["Dispatch_Id"], r["Kernel_Name"])][r["Counter_Name"]] = float(r["Counter_Value"])
 agg = collections.defaultdict(list)
 for (did, name), c in per.items():
-    if "conv_" not in name or did not in dur or "GRBM_GUI_ACTIVE" not in c:
+    if ("conv_" not in name and "conv3x3" not in name) or did not in dur or "GRBM_GUI_ACTIVE" not in c:
         continue
     short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
     agg[short].append((dur[did], c))
