@@ -829,14 +829,19 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
       const int n = wn * (32 * TN) + nt * 32 + l31;
       if (n >= a.N) continue;
       const float bv = a.bias ? a.bias[n] : 0.f;
+      float old[16];                               // accumulating epilogue: the 16 old values are requested together
+#pragma unroll                                     // (`*o = acc ? *o + v : v` is a branch and a round trip per element)
+      for (int r = 0; r < 16; ++r) {
+        const int px = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh, pc = px < a.W ? px : a.W - 1;
+        old[r] = a.acc ? outb[(int64_t)(py * a.W + pc) * a.ops + n] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int px = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (px >= a.W) continue;
         float v = acc[mt][nt][r] + bv;
         if (a.relu) v = fmaxf(v, 0.f);
-        float* o = outb + (int64_t)(py * a.W + px) * a.ops + n;
-        *o = a.acc ? *o + v : v;
+        outb[(int64_t)(py * a.W + px) * a.ops + n] = v + old[r];
       }
     }
   }
