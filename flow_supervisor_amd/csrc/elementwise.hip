@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = c0 + ty + 8 * j, p = p0 + tx;
-    t[ty + 8 * j][tx] = (c < C && p < HW) ? src[((int64_t)b * C + c) * HW + p] : 0.f;
+    const float v = src[((int64_t)b * C + (c < C ? c : C - 1)) * HW + (p < HW ? p : HW - 1)];    // (clamped: the four loads go out together)
+    t[ty + 8 * j][tx] = (c < C && p < HW) ? v : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int p = p0 + ty + 8 * j, c = c0 + tx;
-    t[ty + 8 * j][tx] = (c < C && p < HW) ? src[((int64_t)b * HW + p) * ld + coff + c] : 0.f;
+    const float v = src[((int64_t)b * HW + (p < HW ? p : HW - 1)) * ld + coff + (c < C ? c : C - 1)];
+    t[ty + 8 * j][tx] = (c < C && p < HW) ? v : 0.f;
   }
   __syncthreads();
 #pragma unroll
