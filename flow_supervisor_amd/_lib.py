@@ -72,6 +72,8 @@ SIGNATURES = {
     "fsraft_pack_conv_weights": [POINTER(PackJob), c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_tuning": [c_int, c_int],
+    "fsraft_adamw_flat": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_float, c_float, c_float,
+                          c_float, c_void_p, _S],
     "fsraft_stem_slots": [],
     "fsraft_stem7x7s2_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_stem7x7s2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],

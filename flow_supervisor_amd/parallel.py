@@ -75,15 +75,17 @@ class FlatGradients:
         keys = sorted(order, key=rank)
         self.buckets = [[p for n, p in keep if n.split(".", 1)[0] == k] for k in keys]
         self.params = [p for b in self.buckets for p in b]
-        n = sum(p.numel() for p in self.params)
+        pad = lambda k: (k + 63) // 64 * 64              # every tensor starts on a 256-byte boundary (FlatAdamW points the
+        n = sum(pad(p.numel()) for p in self.params)        # parameters at the same offsets of its own buffer; the pad stays zero)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.views, self.slices, o = {}, [], 0
+        self.views, self.slices, self.offsets, o = {}, [], {}, 0
         for b in self.buckets:
             o0 = o
             for p in b:
                 self.views[p] = self.flat[o:o + p.numel()].view_as(p)
-                o += p.numel()
+                self.offsets[p] = o
+                o += pad(p.numel())
             self.slices.append((o0, o))
         self._bucket_of = {p: i for i, b in enumerate(self.buckets) for p in b}
         self._pending = None
@@ -170,6 +172,52 @@ class FlatGradients:
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         self.flat.mul_(coef)
         return total
+
+
+class FlatAdamW:
+    """`clip_grad_norm_` + `torch.optim.AdamW.step()` (pytorch/train.py:137, 280-282) for the parameters of a FlatGradients, as ONE
+    elementwise kernel over flat buffers (csrc/optim.hip): the parameters are moved into a flat fp32 buffer (`p.data` becomes a
+    view of it: names, shapes and state_dict are unchanged), the moments live in two more.  Same update rule as torch's fused
+    AdamW, operation for operation; the step count and the learning rate are device scalars, so the step can be captured in a
+    hipGraph and a scheduler can set `lr` per step (`set_lr`)."""
+
+    def __init__(self, grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.grads = grads
+        self.params = grads.params
+        flat = grads.flat
+        if not flat.is_cuda:
+            raise RuntimeError("FlatAdamW runs on the GPU (csrc/optim.hip); use torch.optim.AdamW on the CPU")
+        self.p = torch.empty_like(flat)
+        self.p.zero_()
+        with torch.no_grad():
+            for q in self.params:
+                o, k = grads.offsets[q], q.numel()
+                self.p[o:o + k].copy_(q.detach().reshape(-1))
+                q.data = self.p[o:o + k].view_as(q)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count = torch.zeros(1, device=flat.device, dtype=torch.float32)
+        self.lr = torch.full((1,), float(lr), device=flat.device, dtype=torch.float32)
+        self.betas, self.eps, self.weight_decay = (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self._state = torch.empty(4, device=flat.device, dtype=torch.float32)
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    def step(self, clip=None):
+        """One update from grads.flat; clip: max gradient norm (None: no clipping).  Returns the gradient norm (0-dim) or None."""
+        import ctypes
+        from . import _lib as L
+        from . import ops
+        g = self.grads.flat
+        norm = g.norm() if clip is not None else None
+        L.check(L.load().fsraft_adamw_flat(L.ptr(self.p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), g.numel(),
+                                           L.ptr(self.step_count), L.ptr(norm), ctypes.c_float(float(clip) if clip is not None else 0.0),
+                                           L.ptr(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
+                                           ctypes.c_float(self.eps), ctypes.c_float(self.weight_decay), L.ptr(self._state), L.stream()),
+                "adamw_flat")
+        ops.parameters_updated(self.params)       # the packed-weight caches key on Parameter._version
+        return norm
 
 
 def _host_staged(t):

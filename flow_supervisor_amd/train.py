@@ -2,7 +2,9 @@
 gradient all-reduce, clip, AdamW.  Callers of the hot path, written with framework ops."""
 import torch
 
-from .parallel import FlatGradients
+import os
+
+from .parallel import FlatAdamW, FlatGradients
 
 
 MAX_FLOW = 400          # pytorch/train.py:55
@@ -77,8 +79,13 @@ class TrainStep:
         named = list(model.named_parameters())
         self.grads = FlatGradients([p for _, p in named], [n for n, _ in named])
         fused = self.grads.flat.is_cuda
-        self.opt = torch.optim.AdamW(self.grads.params, lr=lr, weight_decay=wdecay, eps=eps, fused=fused,
-                                     capturable=bool(capturable and fused))
+        # clip + AdamW as one kernel over flat buffers on the GPU (FSRAFT_FLAT_ADAMW=0: torch's multi-tensor AdamW)
+        self.flat_opt = fused and os.environ.get("FSRAFT_FLAT_ADAMW", "1") != "0"
+        if self.flat_opt:
+            self.opt = FlatAdamW(self.grads, lr=lr, weight_decay=wdecay, eps=eps)
+        else:
+            self.opt = torch.optim.AdamW(self.grads.params, lr=lr, weight_decay=wdecay, eps=eps, fused=fused,
+                                         capturable=bool(capturable and fused))
 
     def __call__(self, image1, image2, flow_gt=None, global_batch=None):
         """image1/image2: this rank's shard.  global_batch: pairs over all ranks (default: equal shards)."""
@@ -90,6 +97,9 @@ class TrainStep:
         loss = raft_sequence_loss(preds, flow_gt)
         loss.backward()                           # bucket hooks start each all-reduce as its gradients complete
         self.grads.all_reduce_mean_()
-        self.grads.clip_norm_(self.clip)
-        self.opt.step()
+        if self.flat_opt:
+            self.opt.step(self.clip)
+        else:
+            self.grads.clip_norm_(self.clip)
+            self.opt.step()
         return loss.detach()

@@ -341,6 +341,15 @@ int fsraft_stem7x7s2_fwd(const float* x, const float* w, const float* bias, floa
 int fsraft_stem7x7s2_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int N,
                            hipStream_t stream);
 
+/* ---- optimizer step of the train step (row e: what the DP step does after the all-reduce) ---------
+ * `torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)` + `optimizer.step()` of `optim.AdamW(model.parameters(),
+ * lr, weight_decay, eps)` (pytorch/train.py:137, 280-282) on FLAT fp32 buffers: parameters p, gradients g (scaled in place
+ * like clip_grad_norm_ does), first / second moments m, v, n elements each.  step: device fp32 step count, incremented here;
+ * norm: device scalar holding the gradients' 2-norm (null: no clipping); lr: device scalar; state: 4 floats of scratch. */
+int fsraft_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, float* step, const float* norm, float max_norm,
+                      const float* lr, float beta1, float beta2, float eps, float weight_decay, float* state,
+                      hipStream_t stream);
+
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
 /* Space-to-depth by 2 of a channels-last tensor: dst[b][y/2][x/2][(y%2)*2 + x%2][c] = src[b][y][x][c] (inverse != 0: back).

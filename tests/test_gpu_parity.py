@@ -1455,6 +1455,38 @@ def test_stem_convolution_and_weight_gradient(B, H, W, N):
     close(dw, wd.grad.float(), 1e-6, rtol=3e-5, what="stem weight gradient")
 
 
+def test_flat_adamw_matches_torch_adamw_with_clipping():
+    """parallel.FlatAdamW (csrc/optim.hip: clip_grad_norm_ + AdamW as one kernel over flat buffers, pytorch/train.py:137, 280-282)
+    against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over six steps: parameters, clipped gradients, returned norm.
+    Tensor sizes that are not multiples of four (the flat layout pads every tensor to 64 floats), a learning-rate change."""
+    from flow_supervisor_amd.parallel import FlatAdamW, FlatGradients
+    torch.manual_seed(3)
+    shapes = [(64, 3, 7, 7), (2,), (17, 5), (1,), (256, 128, 3, 3), (96,), (33,)]
+    ours = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    grads = FlatGradients(ours)
+    opt = FlatAdamW(grads, lr=3e-3, weight_decay=1e-2, eps=1e-8)
+    topt = torch.optim.AdamW(ref, lr=3e-3, weight_decay=1e-2, eps=1e-8)
+    for p, sh in zip(ours, shapes):
+        assert tuple(p.shape) == sh and p.data_ptr() % 256 == 0
+    for it in range(6):
+        gs = [torch.randn(*sh, device=DEV) * (10.0 if it % 2 else 0.01) for sh in shapes]     # clipped / not clipped
+        for p, q, g in zip(ours, ref, gs):
+            grads.views[p].copy_(g)
+            q.grad = g.clone()
+        if it == 3:
+            opt.set_lr(1e-3)
+            for grp in topt.param_groups:
+                grp["lr"] = 1e-3
+        tn = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        topt.step()
+        n = opt.step(1.0)
+        close(n, tn, 0.0, rtol=1e-6, what="gradient norm")
+        for p, q in zip(ours, ref):
+            close(p, q, 1e-7, rtol=1e-6, what=f"parameters after step {it}")
+            close(grads.views[p], q.grad, 1e-9, rtol=1e-6, what="clipped gradient")
+
+
 def test_hipgraph_replays_of_the_train_step_follow_the_eager_steps():
     """bench.py times hipGraph replays of the whole train step (one rank).  Replays reuse every buffer of the capture, so
     anything zeroed "once" or by a node the graph drops shows up from the second replay on: ops._ZeroPool (chunks filled once
