@@ -47,21 +47,14 @@ with torch.cuda.graph(graph, stream=side):
 
 
 def state():
-    st = [p.detach().clone() for p in model.parameters()]
-    for p in step.opt.param_groups[0]["params"]:
-        s = step.opt.state[p]
-        st += [s["exp_avg"].clone(), s["exp_avg_sq"].clone(), s["step"].clone()]
-    return st
+    o = step.opt                                   # parallel.FlatAdamW: everything lives in four flat buffers
+    return [o.p.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.step_count.clone()]
 
 
 def restore(st):
-    i = 0
+    o = step.opt
     with torch.no_grad():
-        for p in model.parameters():
-            p.copy_(st[i]); i += 1
-        for p in step.opt.param_groups[0]["params"]:
-            s = step.opt.state[p]
-            s["exp_avg"].copy_(st[i]); s["exp_avg_sq"].copy_(st[i + 1]); s["step"].copy_(st[i + 2]); i += 3
+        o.p.copy_(st[0]); o.exp_avg.copy_(st[1]); o.exp_avg_sq.copy_(st[2]); o.step_count.copy_(st[3])
 
 
 s0 = state()
