@@ -132,9 +132,8 @@ template <int KC, int NOUT, int KH, int KW>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a) {
   __shared__ float red[4][64 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  constexpr int taps = KH * KW, PH = KH / 2, PW = KW / 2;
+  constexpr int taps = KH * KW;
   const int HW = a.H * a.W;
-  const int64_t M = (int64_t)a.B * HW;
   f32x4 acc[NOUT][taps][KC];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o)
@@ -151,7 +150,6 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a)
   typedef const float* fptr;
   const int rpr = (a.W + SMALL_RUN - 1) / SMALL_RUN;
   const int64_t nrun = (int64_t)a.B * a.H * rpr;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (int seg = 0; seg < a.nseg; ++seg) {      // pointer tables read from the kernarg segment (uniform index)
     const float* dy = ((const fptr __attribute__((address_space(4)))*)(karg + offsetof(SmallWgradArgs, dy)))[seg];
     const float* x = ((const fptr __attribute__((address_space(4)))*)(karg + offsetof(SmallWgradArgs, x)))[seg];
