@@ -93,6 +93,42 @@ def cpu_baseline(height, width, iters, batch):
     return out
 
 
+def corr_isolated(dev, B, H8, W8, iters):
+    """Build + `iters` lookups of the correlation path run BACK TO BACK on their own (no update block in between): inside
+    the step every lookup starts from caches / TLBs the update block has just flushed, so its in-step time (roofline_corr,
+    kernels.corr_lookup_fwd) is higher than what the kernel does on a warm chip.  Same byte model as roofline_corr's
+    forward half (build 275.7 MB, lookup 20.4 MB per pair at 55x128)."""
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core.corr import CorrBlock
+    g = torch.Generator(device=dev).manual_seed(5)
+    f1 = torch.randn(B, 256, H8, W8, device=dev, generator=g)
+    f2 = torch.randn(B, 256, H8, W8, device=dev, generator=g)
+    flows = [torch.randn(B, 2, H8, W8, device=dev, generator=g) * 3.0 for _ in range(iters)]
+    reps = 5
+    with torch.no_grad():
+        for timed in (False, True):
+            timer = ops.KernelTimer()
+            ops.TIMER = timer if timed else None
+            for _ in range(reps if timed else 2):
+                blk = CorrBlock(f1, f2, radius=4)
+                for fl in flows:
+                    blk(fl, channels_last=True, is_flow=True)
+            torch.cuda.synchronize()
+            ops.TIMER = None
+    sm = timer.summary()
+    out = {}
+    tot_b = tot_ms = 0.0
+    for fam in ("corr_build", "corr_lookup_fwd"):
+        if fam in sm:
+            ms = sm[fam]["ms_total"] / reps
+            by = sm[fam]["bytes"] / reps
+            tot_b += by; tot_ms += ms
+            out[fam] = {"avg_launch_us": 1e3 * sm[fam]["ms_avg"], "achieved": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    return {"bound": "hbm", "achieved": tot_b / (tot_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "ms": tot_ms, "kernels": out,
+            "note": f"forward half of the correlation path only (1 build + {iters} lookups, {B} pairs), launched back to back"}
+
+
 def loss_check(dev):
     """The first-step loss of the benchmark's own configuration against the reference: one pair at 440x1024, 12 iterations,
     procedural weights and inputs of tests/golden/train_step_basic_440x1024.npz (generated by running the reference)."""
@@ -121,13 +157,8 @@ def loss_check(dev):
 
 def set_arithmetic(split):
     """Switch every GEMM of the path between the bf16x3 cores (the default) and the exact-fp32 MFMA cores."""
-    from flow_supervisor_amd import _lib, ops
-    lib = _lib.load()
-    lib.fsraft_set_tuning(3, 1 if split else 0)
-    lib.fsraft_set_tuning(4, 2 if split else 0)
-    lib.fsraft_set_build_split(1 if split else 0)
-    lib.fsraft_set_gemm_split(1 if split else 0)
-    ops.SPLIT_VOLUME_BWD = bool(split)
+    from flow_supervisor_amd import ops
+    ops.set_arithmetic(split)
 
 
 def main():
@@ -162,8 +193,8 @@ def main():
     # launches per step; the gaps between dependent kernels of one stream are what the graph removes).  Several ranks stay
     # eager: a graph capture that contains the RCCL all-reduce could not be exercised on the one-GPU boxes this was built on.
     use_graph = a.graph == 1 or (a.graph == -1 and world == 1)
-    # lr = 4e-4 / 25: the first-step learning rate of the reference's one-cycle schedule
-    # (pytorch/train.py: OneCycleLR(max_lr=args.lr, pct_start=0.05), args.lr = 4e-4 for the chairs stage)
+    # lr: a small constant (the reference's recipes: AdamW + StepLR(num_steps // 5, 0.5), pytorch/train.py:134-141, with
+    # --lr 5e-6 .. 4e-4); throughput does not depend on it, the loss of synthetic steps stays finite with it
     step = TrainStep(model, lr=1.6e-5, iters=a.iters, capturable=use_graph)
 
     B = a.batch_per_gpu
@@ -291,6 +322,7 @@ def main():
     out.update(extra)
     if timer is not None:
         kern = {}
+        build_split = split_mode and os.environ.get("FSRAFT_BUILD_SPLIT", "1") != "0"
         split = {"conv_igemm": split_mode, "conv_wgrad": os.environ.get("FSRAFT_WGRAD_SPLIT", "2") != "0", "gemm_f32": True}
         for fam, s in timer.summary().items():
             mfma = fam in ("conv_igemm", "conv_wgrad", "gemm_f32", "altcorr_fwd", "altcorr_bwd")
@@ -314,9 +346,12 @@ def main():
                          "ms_per_step": s["ms_total"] / timer.steps, "avg_launch_us": 1e3 * s["ms_avg"]}
             if basis:
                 kern[fam]["peak_basis"] = basis
-            if fam == "corr_build":     # report both views: HBM (the north-star bound) and fp32 MFMA (the real one)
+            if fam == "corr_build":     # both views: HBM (the north-star bound) and the matrix pipe in the arithmetic actually used
+                mpeak = PEAK_BF16_MFMA_TF / 3.0 if build_split else PEAK_F32_MFMA_TF
                 kern[fam]["mfma_tflops"] = s["flops"] / sec / 1e12
-                kern[fam]["mfma_frac"] = s["flops"] / sec / 1e12 / PEAK_F32_MFMA_TF
+                kern[fam]["mfma_frac"] = s["flops"] / sec / 1e12 / mpeak
+                kern[fam]["mfma_peak_basis"] = ("dense bf16 MFMA peak (2500 TFLOP/s) / 3 products per fp32 product" if build_split
+                                                else "dense fp32 MFMA peak (157.3 TFLOP/s)")
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
         out["roofline"] = dict(kern[dom], kernel=dom)
         out["kernels"] = kern
@@ -336,9 +371,18 @@ def main():
         if os.path.exists(tr):
             t = json.load(open(tr))
             for fam, v in t.items():
-                if fam in kern:
+                if fam in kern:                   # PMC bytes per LAUNCH (family average), like `avg_launch_us`; x launches_per_step = per step
                     kern[fam]["traffic"] = v
-            out["roofline"]["traffic"] = kern[dom]["traffic"]
+                    kern[fam]["traffic_unit"] = "HBM bytes per launch (family average; FETCH_SIZE x 2 + WRITE_SIZE, profiles/README.md)"
+                    kern[fam]["traffic_per_step"] = v * kern[fam]["launches_per_step"]
+            for k in ("traffic", "traffic_unit", "traffic_per_step"):
+                if k in kern[dom]:
+                    out["roofline"][k] = kern[dom][k]
+            if "roofline_corr" in out and all(kern[f].get("traffic_per_step") for f in out["roofline_corr"]["kernels"] if f != "corr_build_bwd"):
+                out["roofline_corr"]["traffic"] = sum(kern[f].get("traffic_per_step") or 0.0 for f in out["roofline_corr"]["kernels"])
+                out["roofline_corr"]["traffic_unit"] = "HBM bytes per step over the families that were profiled (corr_build_bwd: its two GEMMs are counted under gemm_f32)"
+    if world == 1 and not a.no_extra and a.variant == "raft" and timer is not None and "roofline_corr" in out:
+        out["roofline_corr_isolated"] = corr_isolated(dev, B, a.height // 8, a.width // 8, a.iters)
     if world == 1 and not a.no_cpu_baseline and a.variant == "raft":
         out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, B)
     print(json.dumps(out))

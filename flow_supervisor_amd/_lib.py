@@ -57,8 +57,8 @@ SIGNATURES = {
     "fsraft_corr_unpool_bwd": [_PP, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_lookup_fwd": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_lookup_bwd": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_altcorr_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_altcorr_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_altcorr_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_altcorr_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_upsample_fwd": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, _S],
     "fsraft_upsample_bwd": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _S],
     "fsraft_upflow8_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
@@ -71,9 +71,12 @@ SIGNATURES = {
     "fsraft_conv_small_wgrad": [_PP, _PP, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_pack_conv_weights": [POINTER(PackJob), c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
+    "fsraft_set_arithmetic": [c_int],
+    "fsraft_get_arithmetic": [],
     "fsraft_set_tuning": [c_int, c_int],
     "fsraft_adamw_flat": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_float, c_float, c_float,
-                          c_float, c_void_p, _S],
+                          c_float, c_void_p, c_void_p, _S],
+    "fsraft_stream_capture_id": [_S, c_void_p],
     "fsraft_stem_slots": [],
     "fsraft_stem7x7s2_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_stem7x7s2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
@@ -153,6 +156,9 @@ def load():
     # precision / tiling switches: FSRAFT_CONV_SPLIT=1 runs the forward and
     # data-gradient GEMMs of the update block on the split-bf16 core (3 bf16 MFMAs per product,
     # fp32 accumulation); 0 keeps them on exact-fp32 MFMA.
+    arith = os.environ.get("FSRAFT_ARITHMETIC")     # 0: exact fp32 MFMA everywhere; 1 (default): bf16x3 products
+    if arith is not None:
+        lib.fsraft_set_arithmetic(int(arith))
     split = os.environ.get("FSRAFT_CONV_SPLIT")
     if split is not None:
         lib.fsraft_set_tuning(3, int(split))
@@ -162,8 +168,9 @@ def load():
     for key, env in ((0, "FSRAFT_CONV_TILE"), (2, "FSRAFT_WGRAD_BLOCKS"), (5, "FSRAFT_CONV_BUF"), (8, "FSRAFT_WGRAD_BUF"), (11, "FSRAFT_WGRAD_BLOCKS_MULTI"), (13, "FSRAFT_CONV_W8"), (14, "FSRAFT_CONV_W8_MIN"), (15, "FSRAFT_WGRAD_W8"),
                      (16, "FSRAFT_WGRAD_PACK"), (17, "FSRAFT_WGRAD_BLOCKS_PACK"), (18, "FSRAFT_CONV_N64"), (20, "FSRAFT_CONV_HALO"),
                      (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA"), (25, "FSRAFT_CONV_REC"), (26, "FSRAFT_CONV_PATCH"), (27, "FSRAFT_WGRAD_PATCH"), (28, "FSRAFT_CONV_PATCH64"), (29, "FSRAFT_WGRAD_PATCH1"), (30, "FSRAFT_CONV_C64")):
-        if os.environ.get(env) is not None:
-            lib.fsraft_set_tuning(key, int(os.environ[env]))
+        if os.environ.get(env) is not None and lib.fsraft_set_tuning(key, int(os.environ[env])) != 0:
+            raise RuntimeError(f"{env}: tuning key {key} is not in this build of libfsraft (experiment kernels live in "
+                               "libfsraft_ablate.so: make -C flow_supervisor_amd/csrc ablate, FSRAFT_LIB_PATH=...)")
     wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")
     if wsplit is not None:
         lib.fsraft_set_tuning(4, int(wsplit))

@@ -59,9 +59,12 @@ class GMAL2L(RAFTGMA):
                     _, inp, attention = self._context(ci1)
                 net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                 attention = attention.detach()
-            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention)
+            want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_l2l.py:126-127)
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up)
 
             coords1 = coords1 + delta_flow
+            if not want_up:
+                continue
             if up_mask is None:
                 flow_up = upflow8(coords1 - coords0)
             else:

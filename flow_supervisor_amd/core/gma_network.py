@@ -69,12 +69,15 @@ class RAFTGMA(nn.Module):
 
         flow_predictions = []
         flow_up = None
-        for _ in range(iters):
+        for itr in range(iters):
             coords1 = coords1.detach()
             corr = corr_fn(coords1, channels_last=True)
             flow = coords1 - coords0
-            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention)
+            want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_network.py:127-128)
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up)
             coords1 = coords1 + delta_flow
+            if not want_up:
+                continue
             if up_mask is None:
                 flow_up = upflow8(coords1 - coords0)
             else:

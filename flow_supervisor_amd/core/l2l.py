@@ -69,8 +69,9 @@ class L2L(RAFT):
             coords1 = coords1.detach()
             corr = lookup(corr_fn, coords1)
             flow = coords1 - coords0
+            want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (l2l.py:130-131)
             if test_mode or itr < half:
-                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow)
+                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up)
             else:
                 if itr == half:
                     if ci1 is not None:
@@ -93,6 +94,8 @@ class L2L(RAFT):
                 net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow)
 
             coords1 = coords1 + delta_flow
+            if not want_up:
+                continue
             if up_mask is None:
                 flow_up = upflow8(coords1 - coords0)
             else:

@@ -113,11 +113,16 @@ class RAFT(nn.Module):
 
         flow_predictions = []
         flow_up = None
-        for _ in range(iters):
+        for itr in range(iters):
             flow = flow.detach()
             corr = corr_fn(flow, channels_last=True, is_flow=True)
-            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow)
+            # test_mode returns only the last upsampled flow (raft.py:141-142): the mask convolution and the upsampler of
+            # the other iterations are skipped -- same outputs, the reference computes them and drops them (raft.py:134-139)
+            want_up = not test_mode or itr == iters - 1
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up)
             flow = flow + delta_flow
+            if not want_up:
+                continue
             if up_mask is None:
                 flow_up = upflow8(flow)
             else:

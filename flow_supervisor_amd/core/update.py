@@ -336,10 +336,11 @@ class _Engine:
         cst.dsum = {}
         return dinp
 
-    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None):
+    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True):
         """net/corr: channels-last [B,H,W,C]; ctxb: context() of the context features; flow: [B,2,H,W] (any pixel stride).
         Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
-        a dict of the intermediates backward needs."""
+        a dict of the intermediates backward needs.  need_mask=False (inference, every iteration but the last: the
+        reference computes the mask each time and drops it, raft.py:134-139) skips the 256 -> 576 mask convolution."""
         L.require_cuda_f32(net, corr, flow)
         B, H, W, _ = net.shape
         dev = net.device
@@ -414,7 +415,7 @@ class _Engine:
         else:
             conv("fh2", [V(head, self.head_c)], [Dst.nchw(delta)])
         mask = None
-        if self.has_mask:
+        if self.has_mask and (need_mask or save):
             mask = buf(576)
             conv("m2", [V(head, self.head_c, self.head_c)], [Dst.nhwc(mask)], alpha=0.25)
         saved = None
@@ -818,10 +819,11 @@ class _UpdateBlockBase(nn.Module):
             self.__dict__["_cst"] = cst
         return cst
 
-    def forward_cl(self, net, inp, corr, flow, attention=None):
+    def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
-        Returns (net', mask_cl or None, delta)."""
+        Returns (net', mask_cl or None, delta).  need_mask=False: the caller will not upsample this iteration's flow
+        (test_mode, every iteration but the last); honoured when no gradient is being recorded."""
         eng = self._engine()
         params = tuple(eng.params())
         st, anchor = eng.param_state(params)
@@ -837,7 +839,7 @@ class _UpdateBlockBase(nn.Module):
             else:
                 cst = self._ctx_state(eng, None, params, None, inp, False)
                 h, mask, delta, _ = eng.forward(net, cst.bufs, corr, flow, params, save=False, attn=attention,
-                                                attn_t=self._attn_transposed(attention))
+                                                attn_t=self._attn_transposed(attention), need_mask=need_mask)
                 return h, mask, delta
         track = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params))
         cst = self._ctx_state(eng, st, params, anchor, inp, track)

@@ -50,7 +50,7 @@ __device__ __forceinline__ float butterfly64(float (&v)[64]) {
 template <int R>
 __global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           const float* __restrict__ coords, float* __restrict__ corr,
-                                                          int B, int H1, int W1, int H2, int W2, int C) {
+                                                          int B, int N, int H1, int W1, int H2, int W2, int C) {
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN;
   __shared__ float dots[4][NPOS + 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -59,18 +59,23 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restric
   const bool active = q < nq;
   const int64_t qq = active ? q : nq - 1;
   const int b = (int)(qq / (H1 * W1)), pix = (int)(qq % (H1 * W1));
-  float cx = coords[qq * 2], cy = coords[qq * 2 + 1];
-  cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
-  cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
-  const float flx = floorf(cx), fly = floorf(cy);
-  const int x0 = (int)flx, y0 = (int)fly;
-  const float dx = cx - flx, dy = cy - fly;
 
   float a[MAXK];
 #pragma unroll
   for (int k = 0; k < MAXK; ++k) a[k] = (lane + 64 * k < C) ? f1[qq * C + lane + 64 * k] : 0.f;
 
   const float* f2b = f2 + (int64_t)b * H2 * W2 * C;
+  // N coordinate sets per query pixel (coords [B,N,H1,W1,2] -> corr [B,N,RD*RD,H1,W1], correlation_kernel.cu:34,59):
+  // the pixel's feature vector stays in registers across them
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {
+  const int64_t cq = ((int64_t)b * N + n) * H1 * W1 + pix;
+  float cx = coords[cq * 2], cy = coords[cq * 2 + 1];
+  cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+  cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+  const float flx = floorf(cx), fly = floorf(cy);
+  const int x0 = (int)flx, y0 = (int)fly;
+  const float dx = cx - flx, dy = cy - fly;
 #pragma unroll 1
   for (int base = 0; base < NPOS; base += 64) {
     float part[64];
@@ -95,22 +100,23 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restric
     if (base + lane < NPOS) dots[wave][base + lane] = tot;
   }
   __syncthreads();
-  if (!active) return;
-  float* out = corr + (int64_t)b * RD * RD * H1 * W1 + pix;
-  for (int o = lane; o < RD * RD; o += 64) {
+  float* out = corr + ((int64_t)b * N + n) * RD * RD * H1 * W1 + pix;
+  for (int o = lane; active && o < RD * RD; o += 64) {
     const int iyo = o % RD, ixo = o / RD;          // channel = iy + RD*ix
     const float* d = dots[wave] + iyo * WIN + ixo;
     // dot at (iy,ix) contributes to out(iy-1,ix-1)*dy*dx, out(iy-1,ix)*dy*(1-dx), out(iy,ix-1)*(1-dy)*dx, out(iy,ix)*(1-dy)*(1-dx)
     const float v = (1.f - dy) * (1.f - dx) * d[0] + (1.f - dy) * dx * d[1] + dy * (1.f - dx) * d[WIN] + dy * dx * d[WIN + 1];
     out[(int64_t)o * H1 * W1] = v;
   }
+  __syncthreads();
+  }
 }
 
 template <int R>
 __global__ __launch_bounds__(256) void altcorr_bwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           const float* __restrict__ coords, const float* __restrict__ cg,
-                                                          float* __restrict__ g1, float* __restrict__ g2, int B, int H1,
-                                                          int W1, int H2, int W2, int C) {
+                                                          float* __restrict__ g1, float* __restrict__ g2, int B, int N,
+                                                          int H1, int W1, int H2, int W2, int C) {
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN;
   __shared__ float gout[4][RD * RD + 3];
   __shared__ float gpos[4][NPOS + 4];
@@ -120,50 +126,54 @@ __global__ __launch_bounds__(256) void altcorr_bwd_kernel(const float* __restric
   const bool active = q < nq;
   const int64_t qq = active ? q : nq - 1;
   const int b = (int)(qq / (H1 * W1)), pix = (int)(qq % (H1 * W1));
-  float cx = coords[qq * 2], cy = coords[qq * 2 + 1];
-  cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
-  cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
-  const float flx = floorf(cx), fly = floorf(cy);
-  const int x0 = (int)flx, y0 = (int)fly;
-  const float dx = cx - flx, dy = cy - fly;
-
-  const float* gin = cg + (int64_t)b * RD * RD * H1 * W1 + pix;
-  for (int o = lane; o < RD * RD; o += 64) gout[wave][o] = active ? gin[(int64_t)o * H1 * W1] : 0.f;
-  __syncthreads();
-  for (int p = lane; p < NPOS; p += 64) {
-    const int iy = p / WIN, ix = p % WIN;
-    float g = 0.f;
-    // position (iy,ix) is tap (a,c) of output (iy-a, ix-c); channel = iyo + RD*ixo
-#pragma unroll
-    for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const int iyo = iy - aa, ixo = ix - cc;
-        if (iyo >= 0 && iyo < RD && ixo >= 0 && ixo < RD)
-          g += gout[wave][iyo + RD * ixo] * (aa ? dy : 1.f - dy) * (cc ? dx : 1.f - dx);
-      }
-    gpos[wave][p] = g;
-  }
-  __syncthreads();
-  if (!active) return;
-
   float a[MAXK], acc[MAXK];
 #pragma unroll
   for (int k = 0; k < MAXK; ++k) { a[k] = (lane + 64 * k < C) ? f1[qq * C + lane + 64 * k] : 0.f; acc[k] = 0.f; }
   const float* f2b = f2 + (int64_t)b * H2 * W2 * C;
   float* g2b = g2 + (int64_t)b * H2 * W2 * C;
-  for (int p = 0; p < NPOS; ++p) {
-    const int h2 = y0 - R + p / WIN, w2 = x0 - R + p % WIN;
-    if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2) continue;
-    const float g = gpos[wave][p];
-    const int64_t off = ((int64_t)h2 * W2 + w2) * C + lane;
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {                      // the N coordinate sets of a pixel add into the same fmap1_grad row
+    const int64_t cq = ((int64_t)b * N + n) * H1 * W1 + pix;
+    float cx = coords[cq * 2], cy = coords[cq * 2 + 1];
+    cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+    cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+    const float flx = floorf(cx), fly = floorf(cy);
+    const int x0 = (int)flx, y0 = (int)fly;
+    const float dx = cx - flx, dy = cy - fly;
+
+    const float* gin = cg + ((int64_t)b * N + n) * RD * RD * H1 * W1 + pix;
+    for (int o = lane; o < RD * RD; o += 64) gout[wave][o] = active ? gin[(int64_t)o * H1 * W1] : 0.f;
+    __syncthreads();
+    for (int p = lane; p < NPOS; p += 64) {
+      const int iy = p / WIN, ix = p % WIN;
+      float g = 0.f;
+      // position (iy,ix) is tap (a,c) of output (iy-a, ix-c); channel = iyo + RD*ixo
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-      if (lane + 64 * k < C) {
-        acc[k] += g * f2b[off + 64 * k];
-        atomicAdd(g2b + off + 64 * k, g * a[k]);
-      }
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int iyo = iy - aa, ixo = ix - cc;
+          if (iyo >= 0 && iyo < RD && ixo >= 0 && ixo < RD)
+            g += gout[wave][iyo + RD * ixo] * (aa ? dy : 1.f - dy) * (cc ? dx : 1.f - dx);
+        }
+      gpos[wave][p] = g;
+    }
+    __syncthreads();
+    for (int p = 0; active && p < NPOS; ++p) {
+      const int h2 = y0 - R + p / WIN, w2 = x0 - R + p % WIN;
+      if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2) continue;
+      const float g = gpos[wave][p];
+      const int64_t off = ((int64_t)h2 * W2 + w2) * C + lane;
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k)
+        if (lane + 64 * k < C) {
+          acc[k] += g * f2b[off + 64 * k];
+          atomicAdd(g2b + off + 64 * k, g * a[k]);
+        }
+    }
+    __syncthreads();
   }
+  if (!active) return;
 #pragma unroll
   for (int k = 0; k < MAXK; ++k)
     if (lane + 64 * k < C) g1[qq * C + lane + 64 * k] = acc[k];
@@ -357,27 +367,27 @@ int g_alt_tile = 1;       // 1: tile kernel where it applies (C a multiple of 64
 
 }  // namespace
 
-extern "C" int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
+extern "C" int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B, int N,
                                   int H1, int W1, int H2, int W2, int C, int radius, hipStream_t stream) {
-  if (!fmap1 || !fmap2 || !coords || !corr || B < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || C > 64 * MAXK)
+  if (!fmap1 || !fmap2 || !coords || !corr || B < 1 || N < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || C > 64 * MAXK)
     return FS_ERR_ARG;
   const int64_t nq = (int64_t)B * H1 * W1;
   dim3 grid((unsigned)((nq + 3) / 4));
-  if (radius == 4) hipLaunchKernelGGL(altcorr_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr, B, H1, W1, H2, W2, C);
-  else if (radius == 3) hipLaunchKernelGGL(altcorr_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr, B, H1, W1, H2, W2, C);
+  if (radius == 4) hipLaunchKernelGGL(altcorr_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr, B, N, H1, W1, H2, W2, C);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr, B, N, H1, W1, H2, W2, C);
   else return FS_ERR_ARG;
   return fs_launch_status();
 }
 
 extern "C" int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
-                                  float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C,
-                                  int radius, hipStream_t stream) {
-  if (!fmap1 || !fmap2 || !coords || !corr_grad || !fmap1_grad || !fmap2_grad || B < 1 || C < 1 || C > 64 * MAXK)
+                                  float* fmap1_grad, float* fmap2_grad, int B, int N, int H1, int W1, int H2, int W2,
+                                  int C, int radius, hipStream_t stream) {
+  if (!fmap1 || !fmap2 || !coords || !corr_grad || !fmap1_grad || !fmap2_grad || B < 1 || N < 1 || C < 1 || C > 64 * MAXK)
     return FS_ERR_ARG;
   const int64_t nq = (int64_t)B * H1 * W1;
   dim3 grid((unsigned)((nq + 3) / 4));
-  if (radius == 4) hipLaunchKernelGGL(altcorr_bwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, H1, W1, H2, W2, C);
-  else if (radius == 3) hipLaunchKernelGGL(altcorr_bwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, H1, W1, H2, W2, C);
+  if (radius == 4) hipLaunchKernelGGL(altcorr_bwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, N, H1, W1, H2, W2, C);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_bwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, N, H1, W1, H2, W2, C);
   else return FS_ERR_ARG;
   return fs_launch_status();
 }

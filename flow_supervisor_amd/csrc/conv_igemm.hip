@@ -854,7 +854,9 @@ int launch_halo(const HaloArgs& h, hipStream_t s) {
   return fs_launch_status();
 }
 
-#include "conv_c64.inc"
+#ifdef FSRAFT_EXPERIMENTS
+#include "conv_c64.inc"      // lost its A/B (322 vs 237 us): only in the experiment build (make ablate)
+#endif
 
 // ---------------------------------------------------------------- weight gradient
 struct WgradArgs {
@@ -1526,7 +1528,9 @@ int g_conv_halo = 1;           // resident-patch 3x3 kernel for few-channel laye
 int g_conv_halo_min_m = 65536;
 int g_wgrad_xcd = 1;           // XCD-aware workgroup order in the multi-segment weight gradient (key 22; 2: the few-channel kernel too).
                                // Measured: 10.73 -> 9.72 ms/step of weight-gradient time (15 K-tiles re-read each dY tile)
+#ifdef FSRAFT_EXPERIMENTS
 int g_conv_bdma = 0;           // LDS-direct weight tiles in the wide implicit-GEMM kernels (key 24, experiment)
+#endif
 int g_wgrad_patch = 1;         // resident-pixel-block weight gradient for the 3x3 / 1x5 / 5x1 layers (wgrad_patch.inc, key 27)
 int g_wgrad_pack = 1;          // few-channel single-source layers on conv_wgrad_pack_kernel (key 16)
 int g_wgrad_patch1 = 8192;     // single-segment 3x3 layers with at least this many pixels on the resident-block kernel (key 29; 0: never)
@@ -1603,12 +1607,14 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256 || Cfg::NT != 256;
   if (buf && build_ktab_uniform(a, t)) {
     t.a.swz = swz;
+#ifdef FSRAFT_EXPERIMENTS
     if constexpr (Cfg::NT != 256 && Cfg::PITCH == 128 && Cfg::BN == 128) {
       if (g_conv_bdma && epi == EPI_PLAIN) {      // experiment (key 24): weight tiles by LDS-direct loads
         hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 3>), grid, dim3(Cfg::NT), 0, s, t);
         return fs_launch_status();
       }
     }
+#endif
     if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(Cfg::NT), 0, s, t);
@@ -1658,10 +1664,14 @@ int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
   return fs_launch_status();
 }
 
+#ifdef FSRAFT_EXPERIMENTS
 int g_conv_rec = 1;        // record-activation kernel (conv_rec.inc): 0 off, 1 layers with > 128 outputs, 2 every layer it can run
 #include "conv_rec.inc"
+#endif
 int g_conv_patch = 1;      // resident-patch, channel-streaming kernel for the 3x3 / 1x5 / 5x1 layers (conv_patch.inc, key 26; 2: 128-pixel tiles too)
+#ifdef FSRAFT_EXPERIMENTS
 int g_conv_c64 = 0;        // experiment (key 30 = minimum pixel count): 64 -> 64 3x3 layers on conv3x3_c64_kernel (resident weights) -- 322 vs 237 us, off
+#endif
 int g_conv_patch64 = 1;    // ... also for the 3x3 layers with 33..64 outputs (64-column tiles; key 28; 2: 128-pixel tiles)
 #include "conv_patch.inc"
 
@@ -1747,9 +1757,12 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // Measured (scripts/conv_micro.py, halo on / off): 64 -> 64 at 8x220x512 238 vs 442 us.  With three or four channel
     // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
     // GEMM (96 -> 96 at 8x110x256: 249 vs 165 us; 128 -> 128 at 8x55x128: 93 vs 65 us), so only two-group layers come here.
+#ifdef FSRAFT_EXPERIMENTS
     if (g_conv_c64 && d->srcC[0] == 64 && d->N == 64 && (int64_t)d->B * d->H * d->W >= g_conv_c64) return launch_conv_c64(h, stream);
+#endif
     return d->N > 64 ? launch_halo<2, 2>(h, stream) : launch_halo<2, 1>(h, stream);
   }
+#ifdef FSRAFT_EXPERIMENTS
   if (g_conv_rec && g_conv_split == 1 && d->wpk_split && d->srcr[0] && (d->N > 128 || g_conv_rec == 2) && d->N > 32 &&
       (d->epi != EPI_PLAIN || epilogue_rows_ok_host(a))) {
     ConvArgs r = a;
@@ -1764,6 +1777,7 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
       if (rc >= 0) return rc;
     }
   }
+#endif
   if (d->N <= 32 && d->epi == EPI_PLAIN) return launch_conv<Cfg32>(a, d->epi, stream);
   // 33..64 outputs: half of a 64x128 split tile is padding, still ~2x faster than the exact 64-wide kernel
   if (d->N <= 64 && d->epi == EPI_PLAIN && !(g_conv_split && d->wpk_split && g_conv_buf)) return launch_conv<Cfg64>(a, d->epi, stream);
@@ -1825,6 +1839,19 @@ extern "C" int fsraft_get_tuning(int key) {
   return -1;
 }
 
+// fsraft.h: one switch for the arithmetic of every GEMM-shaped kernel of the library
+extern "C" int fsraft_set_build_split(int on);
+extern "C" int fsraft_set_gemm_split(int on);
+extern "C" int fsraft_set_arithmetic(int mode) {
+  if (mode != 0 && mode != 1) return FS_ERR_ARG;
+  g_conv_split = mode ? 1 : 0;
+  g_wgrad_split = mode ? 2 : 0;
+  fsraft_set_build_split(mode);
+  fsraft_set_gemm_split(mode);
+  return FS_OK;
+}
+extern "C" int fsraft_get_arithmetic(void) { return g_conv_split != 0 ? 1 : 0; }
+
 extern "C" int fsraft_set_tuning(int key, int value) {
   if (key == 0) g_conv_tile = value;
   else if (key == 1) g_wgrad_tile = value;
@@ -1840,13 +1867,15 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 20) g_conv_halo = value;
   else if (key == 21) g_conv_halo_min_m = value;
   else if (key == 22) g_wgrad_xcd = value;
+#ifdef FSRAFT_EXPERIMENTS
   else if (key == 24) g_conv_bdma = value;
   else if (key == 25) g_conv_rec = value;
+  else if (key == 30) g_conv_c64 = value;
+#endif
   else if (key == 26) g_conv_patch = value;
   else if (key == 27) g_wgrad_patch = value;
   else if (key == 28) g_conv_patch64 = value;
   else if (key == 29) g_wgrad_patch1 = value;
-  else if (key == 30) g_conv_c64 = value;
   else if (key == 16) g_wgrad_pack = value;
   else if (key == 17) g_wgrad_blocks_pack = value;
   else if (key == 12) g_conv_uniform = value;

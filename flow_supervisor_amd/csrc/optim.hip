@@ -30,9 +30,12 @@ __global__ void adamw_prepare_kernel(float* __restrict__ step, const float* __re
 // with g the clipped gradient, which is also written back (clip_grad_norm_ scales the gradients in place).
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, int64_t n4, int64_t n, const AdamState* __restrict__ st,
-                                                         float beta1, float beta2, float eps) {
+                                                         float beta1, float beta2, float eps, const unsigned char* __restrict__ skip) {
   const AdamState s = *st;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    // skip[j] != 0: elements [64 j, 64 j + 64) belong to a tensor that received no gradient this step; torch's AdamW leaves
+    // such a parameter and its moments untouched (no weight decay either), so do we
+    if (skip && skip[i >> 4]) continue;
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<f32x4*>(g)[i], mv = reinterpret_cast<f32x4*>(m)[i],
           vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     reinterpret_cast<f32x4*>(p)[i] = pv; reinterpret_cast<f32x4*>(g)[i] = gv; reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {              // tail (the flat buffers need not be a multiple of four)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3) && !(skip && skip[n4 >> 4])) {   // tail (n need not be a multiple of four)
     const int64_t i = n4 * 4 + threadIdx.x;
     const float gg = g[i] * s.coef;
     g[i] = gg;
@@ -63,10 +66,11 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
 }  // namespace
 
 // One AdamW step on flat fp32 buffers of n elements (16-byte aligned).  step: device fp32 step count (incremented here);
-// norm: device scalar, the gradient's 2-norm (null: no clipping); lr: device scalar; state: 4 floats of scratch.
+// norm: device scalar, the gradient's 2-norm (null: no clipping); lr: device scalar; state: 4 floats of scratch;
+// skip64 (nullable): ceil(n / 64) bytes, non-zero = leave that 64-element block alone (a parameter without a gradient).
 extern "C" int fsraft_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, float* step, const float* norm, float max_norm,
                                  const float* lr, float beta1, float beta2, float eps, float weight_decay, float* state,
-                                 hipStream_t stream) {
+                                 const unsigned char* skip64, hipStream_t stream) {
   if (!p || !g || !m || !v || !step || !lr || !state || n < 1) return FS_ERR_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return FS_ERR_ARG;
   hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, stream, step, norm, max_norm, lr, beta1, beta2, weight_decay,
@@ -78,6 +82,17 @@ extern "C" int fsraft_adamw_flat(float* p, float* g, float* m, float* v, int64_t
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n4, n,
-                     reinterpret_cast<const AdamState*>(state), beta1, beta2, eps);
+                     reinterpret_cast<const AdamState*>(state), beta1, beta2, eps, skip64);
   return fs_launch_status();
+}
+
+// 0 when `stream` is not being captured, else the id of the capture (hipStreamGetCaptureInfo): the host-side zero pool
+// (ops._ZeroPool) keys its chunks on it, so that two captures never share a chunk whose fill node lives in only one of them.
+extern "C" int fsraft_stream_capture_id(hipStream_t stream, unsigned long long* id) {
+  if (!id) return FS_ERR_ARG;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long cid = 0;
+  if (hipStreamGetCaptureInfo(stream, &st, &cid) != hipSuccess) { (void)hipGetLastError(); *id = 0; return FS_ERR_LAUNCH; }
+  *id = st == hipStreamCaptureStatusActive ? (cid ? cid : 1ull) : 0ull;
+  return FS_OK;
 }

@@ -71,14 +71,26 @@ class _ZeroPool:
     as any buffer carved from it; the pool itself only holds the chunk it is currently carving.
 
     Under hipGraph capture the same buffers are used again by every replay, so "once" has to mean once per replay: a
-    capture never carves from a chunk that was filled outside it (or inside another capture) -- its first request opens a
-    new chunk, whose fill is recorded in the graph ahead of every use of the buffers carved from it."""
+    capture never carves from a chunk that was filled outside it (or inside another capture) -- chunks are keyed on the
+    capture's id, so its first request opens a new chunk, whose fill is recorded in the graph ahead of every use of the
+    buffers carved from it."""
     CHUNK = 32 << 20
+    SMALL = 64 << 10            # 1-element anchors and other <= 256-byte requests: their own chunk, so that an anchor that
+                                # lives for a whole step does not pin 32 MB
 
     def __init__(self):
         self.cur = {}
-        self.epoch = 0                  # bumped whenever the stream's capture status flips: chunks belong to one epoch
-        self.capturing = False
+        self.epoch = 0                  # bumped by new_epoch(); chunks belong to one (epoch, capture id)
+
+    @staticmethod
+    def _capture_id(device):
+        """0 outside a capture, else the id of the hipGraph capture the current stream is in (fsraft_stream_capture_id):
+        two captures back to back differ in it even when no eager take() ran in between."""
+        if not torch.cuda.is_current_stream_capturing():
+            return 0
+        cid = ctypes.c_ulonglong(0)
+        L.check(_lib().fsraft_stream_capture_id(L.stream(), ctypes.byref(cid)), "stream_capture_id")
+        return int(cid.value) or 1
 
     def take(self, shape, device):
         n = 1
@@ -87,14 +99,13 @@ class _ZeroPool:
         nb = (n * 4 + 255) // 256 * 256
         if nb > self.CHUNK // 4 or n == 0 or torch.device(device).type != "cuda":
             return torch.zeros(shape, device=device, dtype=torch.float32)
-        cap = torch.cuda.is_current_stream_capturing()
-        if cap != self.capturing:
-            self.capturing = cap
-            self.epoch += 1
-        key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+        small = nb <= 256
+        size = self.SMALL if small else self.CHUNK
+        tag = (self.epoch, self._capture_id(device))
+        key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream, small)
         ent = self.cur.get(key)
-        if ent is None or ent[1] + nb > self.CHUNK or ent[2] != self.epoch:
-            ent = [torch.zeros(self.CHUNK // 4, device=device, dtype=torch.float32), 0, self.epoch]
+        if ent is None or ent[1] + nb > size or ent[2] != tag:
+            ent = [torch.zeros(size // 4, device=device, dtype=torch.float32), 0, tag]
             self.cur[key] = ent
         o = ent[1] // 4
         ent[1] += nb
@@ -108,7 +119,8 @@ _ZEROS = _ZeroPool()
 
 
 def new_zero_epoch():
-    """Call between two hipGraph captures that follow each other without an eager step in between (see _ZeroPool)."""
+    """Force the next zero-pool request to open a fresh chunk (captures are told apart by their id; this is for callers
+    that want buffers of one phase not to share a chunk with the next)."""
     _ZEROS.new_epoch()
 
 
@@ -623,6 +635,13 @@ def corr_build_bwd(fmap1, fmap2, dlevels):
 
 
 # ------------------------------------------------------------------ alternate (on-the-fly) correlation
+def _altcorr_sets(coords, B, H1, W1):
+    """N of coords [B,N,H1,W1,2] (correlation.cpp:23-33: any number of coordinate sets per query pixel)."""
+    if coords.dim() != 5 or coords.shape[0] != B or tuple(coords.shape[2:]) != (H1, W1, 2) or coords.shape[1] < 1:
+        raise RuntimeError(f"coords must be [B,N,H1,W1,2] with B={B}, H1={H1}, W1={W1}, got {tuple(coords.shape)}")
+    return int(coords.shape[1])
+
+
 def altcorr_fwd(fmap1, fmap2, coords, radius):
     L.require_cuda_f32(fmap1, fmap2, coords)
     for t, n in ((fmap1, "fmap1"), (fmap2, "fmap2"), (coords, "coords")):
@@ -630,11 +649,10 @@ def altcorr_fwd(fmap1, fmap2, coords, radius):
             raise RuntimeError(f"{n} must be contiguous")       # correlation.cpp:19-21
     B, H1, W1, C = fmap1.shape
     _, H2, W2, _ = fmap2.shape
-    if coords.shape[1] != 1:
-        raise RuntimeError("only N=1 coordinate sets are supported (all the reference ever passes)")
+    N = _altcorr_sets(coords, B, H1, W1)
     rd = 2 * radius + 1
-    corr = torch.empty(B, 1, rd * rd, H1, W1, device=fmap1.device, dtype=torch.float32)
-    L.check(_lib().fsraft_altcorr_fwd(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(corr), B, H1, W1, H2, W2, C,
+    corr = torch.empty(B, N, rd * rd, H1, W1, device=fmap1.device, dtype=torch.float32)
+    L.check(_lib().fsraft_altcorr_fwd(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(corr), B, N, H1, W1, H2, W2, C,
                                       radius, L.stream()), "altcorr_fwd")
     return corr
 
@@ -646,10 +664,14 @@ def altcorr_bwd(fmap1, fmap2, coords, corr_grad, radius):
             raise RuntimeError(f"{n} must be contiguous")
     B, H1, W1, C = fmap1.shape
     _, H2, W2, _ = fmap2.shape
+    N = _altcorr_sets(coords, B, H1, W1)
+    rd = 2 * radius + 1
+    if tuple(corr_grad.shape) != (B, N, rd * rd, H1, W1):
+        raise RuntimeError(f"corr_grad must be [B,N,(2r+1)^2,H1,W1] = {(B, N, rd * rd, H1, W1)}, got {tuple(corr_grad.shape)}")
     g1 = torch.empty_like(fmap1)
     g2 = torch.zeros_like(fmap2)
     L.check(_lib().fsraft_altcorr_bwd(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(corr_grad), L.ptr(g1),
-                                      L.ptr(g2), B, H1, W1, H2, W2, C, radius, L.stream()), "altcorr_bwd")
+                                      L.ptr(g2), B, N, H1, W1, H2, W2, C, radius, L.stream()), "altcorr_bwd")
     return g1, g2, torch.zeros_like(coords)
 
 
@@ -886,9 +908,17 @@ def unpack_weight_grads(items, device):
 
 
 def exact_mode():
-    """True while the exact-fp32 convolution kernels are selected (fsraft_set_tuning key 3 = 0); in split-bf16 mode only
+    """True while the exact-fp32 convolution kernels are selected (fsraft_set_arithmetic(0)); in split-bf16 mode only
     layers with <= 32 outputs still read the fp32 packs."""
     return _lib().fsraft_get_tuning(3) == 0
+
+
+def set_arithmetic(split):
+    """fsraft_set_arithmetic: True / 1 = every GEMM-shaped kernel on bf16x3 products (the default), False / 0 = exact fp32
+    MFMA.  Also picks the matching host-side routes (record operands for the volume backward and the GMA GEMMs)."""
+    global SPLIT_VOLUME_BWD
+    L.check(_lib().fsraft_set_arithmetic(1 if split else 0), "set_arithmetic")
+    SPLIT_VOLUME_BWD = bool(split)
 
 
 def pack_pair(w, srcC, dgrad=False):

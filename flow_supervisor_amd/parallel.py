@@ -92,16 +92,26 @@ class FlatGradients:
         self._handles = []
         self._weight = 1.0
         self._active = False
+        self.missing = []                 # parameters that received no gradient in the last step (FlatAdamW leaves them alone)
+        # FSRAFT_DP_BUCKETS=0: no exchange from the backward hooks -- ONE all-reduce of the whole flat buffer in finish()
+        self.bucketed = os.environ.get("FSRAFT_DP_BUCKETS", "1") != "0"
+        # FSRAFT_DP_FORCE_COLLECTIVE=1: issue the all-reduces at world size 1 too (a -m gpu test runs the RCCL stream
+        # ordering of the hook-time launches on a one-GPU box this way)
+        self.force_collective = os.environ.get("FSRAFT_DP_FORCE_COLLECTIVE", "0") == "1"
         for p in self.params:
             p.grad = self.views[p]
             p.register_post_accumulate_grad_hook(self._hook)
 
     # ---- per step -------------------------------------------------------------------------------------------------
-    def begin(self, local_batch=None, global_batch=None):
-        """Call before backward: arms the bucket hooks for this step."""
+    def begin(self, local_batch=None, global_batch=None, backward_passes=1):
+        """Call before backward: arms the bucket hooks for this step.  backward_passes: how many backward() calls feed this
+        optimizer step (the flow-supervisor step runs a labelled and an unlabelled forward/backward before
+        optimizer.step(), pytorch/train.py:270-277); a bucket is exchanged once its gradients have arrived that many
+        times, parameters that take part in fewer passes hold their bucket back until finish()."""
         for p in self.params:
             p.grad = None
-        self._pending = [len(b) for b in self.buckets]
+        self.missing = []
+        self._pending = [len(b) * int(backward_passes) for b in self.buckets]
         self._done = [False] * len(self.buckets)
         self._handles = []
         world = dist.get_world_size() if dist.is_initialized() else 1
@@ -116,8 +126,13 @@ class FlatGradients:
         if not self._active:
             return
         i = self._bucket_of[p]
+        if self._done[i]:
+            # the bucket was already copied out (and reduced): this gradient would be added, unreduced, on one rank only
+            raise RuntimeError("FlatGradients: a gradient arrived for a bucket that was already exchanged -- more backward "
+                               "passes than begin(backward_passes=...) announced (gradient accumulation, a second loss, "
+                               "retain_graph); call begin(backward_passes=k) or finish() between them")
         self._pending[i] -= 1
-        if self._pending[i] == 0:
+        if self._pending[i] == 0 and self.bucketed:
             self._launch(i)
 
     def _launch(self, i):
@@ -131,16 +146,22 @@ class FlatGradients:
             torch._foreach_copy_([self.views[p] for p in have], [p.grad for p in have])
         if missing:                                   # (parameters that took no part in this step, e.g. biases in front of InstanceNorm)
             torch._foreach_zero_([self.views[p] for p in missing])
+            self.missing += missing
         for p in self.buckets[i]:
             p.grad = self.views[p]
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if self.bucketed and self._exchanging():
             a, b = self.slices[i]
-            seg = self.flat[a:b]
-            seg.mul_(self._weight)
-            if _host_staged(seg):
-                _all_reduce_sum_(seg)
-            else:
-                self._handles.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+            self._exchange(self.flat[a:b])
+
+    def _exchanging(self):
+        return dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective)
+
+    def _exchange(self, seg):
+        seg.mul_(self._weight)
+        if _host_staged(seg):
+            _all_reduce_sum_(seg)
+        else:
+            self._handles.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """Launch the buckets whose hooks did not complete (unused parameters) and wait for every exchange."""
@@ -148,6 +169,8 @@ class FlatGradients:
             return
         for i in range(len(self.buckets)):
             self._launch(i)
+        if not self.bucketed and self._exchanging():
+            self._exchange(self.flat)
         for h in self._handles:
             h.wait()
         self._handles = []
@@ -174,19 +197,27 @@ class FlatGradients:
         return total
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     """`clip_grad_norm_` + `torch.optim.AdamW.step()` (pytorch/train.py:137, 280-282) for the parameters of a FlatGradients, as ONE
     elementwise kernel over flat buffers (csrc/optim.hip): the parameters are moved into a flat fp32 buffer (`p.data` becomes a
-    view of it: names, shapes and state_dict are unchanged), the moments live in two more.  Same update rule as torch's fused
-    AdamW, operation for operation; the step count and the learning rate are device scalars, so the step can be captured in a
-    hipGraph and a scheduler can set `lr` per step (`set_lr`)."""
+    view of it: names, shapes and the model's state_dict are unchanged), the moments live in two more.  Same update rule as
+    torch's fused AdamW, operation for operation; the step count and the learning rate are device scalars, so the step can
+    be captured in a hipGraph.
+
+    It IS a `torch.optim.Optimizer` (one param group), so the reference's `StepLR(optimizer, ...)` / `scheduler.step()`
+    (pytorch/train.py:139, 283) attaches to it: `step()` copies `param_groups[0]["lr"]` to the device scalar when it
+    changed (`sync_lr()` does the same for hipGraph replays, which do not re-run Python).  `state_dict()` /
+    `load_state_dict()` carry the moments, the step count and the hyper-parameters (checkpoint / resume).  Parameters
+    that received no gradient in a step are left alone with their moments, as torch's AdamW skips `p.grad is None`."""
 
     def __init__(self, grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        self.grads = grads
-        self.params = grads.params
         flat = grads.flat
         if not flat.is_cuda:
             raise RuntimeError("FlatAdamW runs on the GPU (csrc/optim.hip); use torch.optim.AdamW on the CPU")
+        super().__init__(grads.params, dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
+                                            weight_decay=float(weight_decay)))
+        self.grads = grads
+        self.params = grads.params
         self.p = torch.empty_like(flat)
         self.p.zero_()
         with torch.no_grad():
@@ -198,26 +229,108 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = torch.zeros(1, device=flat.device, dtype=torch.float32)
         self.lr = torch.full((1,), float(lr), device=flat.device, dtype=torch.float32)
-        self.betas, self.eps, self.weight_decay = (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self._lr_host = float(lr)
         self._state = torch.empty(4, device=flat.device, dtype=torch.float32)
+        self._skip = None                 # uint8 per 64-element block: parameters without a gradient this step
+        self._skip_key = None
+
+    # -- hyper-parameters live in the (single) param group, like any torch optimizer
+    @property
+    def betas(self):
+        return self.param_groups[0]["betas"]
+
+    @property
+    def eps(self):
+        return self.param_groups[0]["eps"]
+
+    @property
+    def weight_decay(self):
+        return self.param_groups[0]["weight_decay"]
 
     def set_lr(self, lr):
-        self.lr.fill_(float(lr))
+        self.param_groups[0]["lr"] = float(lr)
+        self.sync_lr()
 
-    def step(self, clip=None):
-        """One update from grads.flat; clip: max gradient norm (None: no clipping).  Returns the gradient norm (0-dim) or None."""
+    def sync_lr(self):
+        """param_groups[0]['lr'] (what an lr_scheduler writes) -> the device scalar the kernel reads."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
+            self.lr.fill_(lr)
+            self._lr_host = lr
+
+    def _check_bound(self):
+        base = self.p.data_ptr()
+        for q in self.params:
+            if q.data_ptr() != base + 4 * self.grads.offsets[q]:
+                raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimizer's flat buffer (model.to() / .float() / "
+                                   "load_state_dict(assign=True) or a re-created Parameter after the optimizer was built); "
+                                   "the kernel would update memory the module does not read.  Rebuild TrainStep / FlatAdamW.")
+
+    def _skip_table(self):
+        missing = self.grads.missing
+        if not missing:
+            return None
+        key = tuple(id(q) for q in missing)
+        if key != self._skip_key:
+            if self._skip is None:
+                self._skip = torch.zeros((self.p.numel() + 63) // 64, device=self.p.device, dtype=torch.uint8)
+            else:
+                self._skip.zero_()
+            for q in missing:
+                o = self.grads.offsets[q]
+                self._skip[o // 64:(o + q.numel() + 63) // 64] = 1
+            self._skip_key = key
+        return self._skip
+
+    @torch.no_grad()
+    def step(self, closure=None, clip=None):
+        """One update from grads.flat; clip: max gradient norm (None: no clipping).  Returns the gradient norm (0-dim) or None
+        (with a closure: its loss, like torch optimizers)."""
         import ctypes
         from . import _lib as L
         from . import ops
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._check_bound()
+        self.sync_lr()
         g = self.grads.flat
         norm = g.norm() if clip is not None else None
+        skip = self._skip_table()
+        b1, b2 = self.betas
         L.check(L.load().fsraft_adamw_flat(L.ptr(self.p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), g.numel(),
                                            L.ptr(self.step_count), L.ptr(norm), ctypes.c_float(float(clip) if clip is not None else 0.0),
-                                           L.ptr(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
-                                           ctypes.c_float(self.eps), ctypes.c_float(self.weight_decay), L.ptr(self._state), L.stream()),
+                                           L.ptr(self.lr), ctypes.c_float(b1), ctypes.c_float(b2),
+                                           ctypes.c_float(self.eps), ctypes.c_float(self.weight_decay), L.ptr(self._state),
+                                           L.ptr(skip), L.stream()),
                 "adamw_flat")
         ops.parameters_updated(self.params)       # the packed-weight caches key on Parameter._version
-        return norm
+        return loss if closure is not None else norm
+
+    def zero_grad(self, set_to_none=True):
+        """Gradients live in FlatGradients (begin() resets them before every step); kept for `optimizer.zero_grad()` callers."""
+        for q in self.params:
+            q.grad = None
+
+    def state_dict(self):
+        """Moments, step count and hyper-parameters.  `layout` (numel per parameter, in buffer order) guards load_state_dict
+        against a different model."""
+        g = self.param_groups[0]
+        return {"step": float(self.step_count.item()), "exp_avg": self.exp_avg.detach().clone(),
+                "exp_avg_sq": self.exp_avg_sq.detach().clone(), "layout": [int(q.numel()) for q in self.params],
+                "param_groups": [{k: v for k, v in g.items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        if list(sd["layout"]) != [int(q.numel()) for q in self.params]:
+            raise ValueError("FlatAdamW.load_state_dict: the checkpoint's parameter layout differs from this model's")
+        with torch.no_grad():
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.step_count.fill_(float(sd["step"]))
+        for k, v in sd["param_groups"][0].items():
+            self.param_groups[0][k] = v
+        self.sync_lr()
 
 
 def _host_staged(t):

@@ -87,6 +87,18 @@ class TrainStep:
             self.opt = torch.optim.AdamW(self.grads.params, lr=lr, weight_decay=wdecay, eps=eps, fused=fused,
                                          capturable=bool(capturable and fused))
 
+    def set_lr(self, lr):
+        """Learning rate of the next step (what `scheduler.step()` does through param_groups; for hipGraph replays call this
+        -- or opt.sync_lr() after the scheduler -- BEFORE the replay: the kernel reads a device scalar)."""
+        if self.flat_opt:
+            self.opt.set_lr(lr)
+        else:
+            for g in self.opt.param_groups:
+                if isinstance(g["lr"], torch.Tensor):
+                    g["lr"].fill_(float(lr))
+                else:
+                    g["lr"] = float(lr)
+
     def __call__(self, image1, image2, flow_gt=None, global_batch=None):
         """image1/image2: this rank's shard.  global_batch: pairs over all ranks (default: equal shards)."""
         if global_batch is None:
@@ -98,7 +110,7 @@ class TrainStep:
         loss.backward()                           # bucket hooks start each all-reduce as its gradients complete
         self.grads.all_reduce_mean_()
         if self.flat_opt:
-            self.opt.step(self.clip)
+            self.opt.step(clip=self.clip)
         else:
             self.grads.clip_norm_(self.clip)
             self.opt.step()

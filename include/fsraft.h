@@ -103,14 +103,15 @@ int fsraft_corr_lookup_bwd(float* const* dlevels, int num_levels, const float* c
 /* ---- memory-efficient correlation (no N x N volume) ----------------------------------
  * Replaces alt_cuda_corr.forward / .backward, pytorch/alt_cuda_corr/correlation.cpp:23-54
  * (kernels correlation_kernel.cu:18-119, 122-256).  Same argument meaning:
- * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last, coords [B,1,H1,W1,2] (x,y),
- * corr [B,1,(2r+1)^2,H1,W1], UNSCALED (caller divides by sqrt(C), corr.py:91). */
-int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B, int H1,
+ * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last, coords [B,N,H1,W1,2] (x,y; N coordinate sets per query
+ * pixel, correlation_kernel.cu:34,59 -- the reference's caller passes N = 1, corr.py:84),
+ * corr [B,N,(2r+1)^2,H1,W1], UNSCALED (caller divides by sqrt(C), corr.py:91). */
+int fsraft_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B, int N, int H1,
                        int W1, int H2, int W2, int C, int radius, hipStream_t stream);
 /* fmap1_grad [B,H1,W1,C] is overwritten; fmap2_grad [B,H2,W2,C] must be zeroed by the caller
  * (it is accumulated with atomics); coords get no gradient (the reference returns zeros). */
 int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
-                       float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C,
+                       float* fmap1_grad, float* fmap2_grad, int B, int N, int H1, int W1, int H2, int W2, int C,
                        int radius, hipStream_t stream);
 
 /* AlternateCorrBlock.__call__ (pytorch/core/corr.py:74-91: four alt_cuda_corr.forward calls, stack, reshape, / sqrt(C)) as ONE
@@ -119,8 +120,6 @@ int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const float* coor
 int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_levels, int num_levels, const float* coords,
                              int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B, int H, int W,
                              int C, int radius, hipStream_t stream);
-
-int fsraft_set_alt_tile(int on);   /* 1 (default): 4x4-query tile kernel with an LDS-staged target region; 0: wave per query */
 
 /* ---- convex 8x upsampler -------------------------------------------------------------
  * Replaces RAFT.upsample_flow, pytorch/core/raft.py:72-83 and UpsampleConvexWithMask,
@@ -215,20 +214,15 @@ int fsraft_conv_small_fwd(const float* x, int ld, int C, const float* w_oihw, co
 int fsraft_conv_small_wgrad(const float* const* dy, const float* const* x, int nseg, int ldy, int ldx, int C, float* dwpk,
                             float* dbias, int N, int B, int H, int W, int KH, int KW, hipStream_t stream);
 
-/* Tuning knobs for experiments (tile selection); not part of the reference interface.
- * key 0: conv tile (0 auto, 1 128x128, 2 64x128, 3 64x64); key 1: wgrad tile (0 128x128, 3 64x64);
- * key 2: target workgroup count of the wgrad pixel split; key 3: 1 = split-bf16 (3 x bf16 MFMA,
- * fp32 accumulate, ~2^-17 relative error per product) core for forward / data-gradient GEMMs with N > 64.
- * Further keys select kernel variants kept for measurement (csrc/conv_igemm.hip, fsraft_set_tuning; _lib.py maps an
- * FSRAFT_* environment variable to each): 24 LDS-direct weight tiles, 25 record activations, 26 resident-patch forward /
- * data-gradient kernel (2: 128-pixel tiles too), 27 resident-block weight gradient (0 off, 1 the 3x3 layers, 2 the
- * five-tap layers too), 28 64-column patch tiles for 33..64 outputs (1 small grids, 2 / 3 force 128 / 256-pixel tiles). */
-int fsraft_set_tuning(int key, int value);
-int fsraft_get_tuning(int key);   /* keys 3 / 4: arithmetic mode of the forward+data-gradient / weight-gradient convolutions */
-/* volume build arithmetic: 1 (default) split-bf16, 0 exact fp32 MFMA */
-int fsraft_set_build_split(int on);
-/* queries per workgroup of the lookup kernels: 0 auto, 8, 16 or 32 */
-int fsraft_set_lookup_qb(int qb);
+/* ---- arithmetic of the dense contractions -------------------------------------------------------------------------
+ * Storage and accumulation are fp32 everywhere.  mode 1 (default): every fp32 product of the GEMM-shaped kernels (volume
+ * build and its backward, the update block's / encoders' convolutions, their weight gradients, the GMA GEMMs) is evaluated
+ * as three bf16 MFMA products with fp32 accumulation (hi*hi + hi*lo + lo*hi, ~2^-17 relative error per product);
+ * mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a pure fmaf chain) -- the test / reference mode.  Process-wide; not
+ * to be flipped while kernels of another thread are being enqueued.  Replaces nothing in the reference (its
+ * torch.backends.cuda.matmul.allow_tf32 default plays the same role on the reference's hardware). */
+int fsraft_set_arithmetic(int mode);
+int fsraft_get_arithmetic(void);   /* 1 / 0 as above */
 
 /* ---- batched fp32 GEMM (volume backward: autograd of torch.matmul, corr.py:57) ------- */
 int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
@@ -239,8 +233,6 @@ int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, in
 int fsraft_gemm_tn_split(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
                          int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int accumulate,
                          hipStream_t stream);
-/* 1 (default): fsraft_gemm_f32 with trans_b uses the split-bf16 core when its operands are 16-byte aligned */
-int fsraft_set_gemm_split(int on);
 
 /* ---- GEMM on pre-split ("record") operands -------------------------------------------------------------------------
  * A record is 32 consecutive k of one row as [32 x bf16 hi | 32 x bf16 lo] (hi = bf16(x), lo = bf16(x - hi)): 128 bytes, the
@@ -310,7 +302,6 @@ int fsraft_forward_interpolate(const float* flow, float* out, int H, int W, hipS
  * Fused residual unit (pytorch/core/extractor.py:43-56, "return self.relu(x+y)"): res != NULL makes the forward write
  * y = relu(res + relu?(norm(x))); the backward then takes out = that y and writes the shortcut's gradient g * (out > 0)
  * to dres before continuing into the norm branch (out and dres both NULL: plain norm + ReLU). */
-int fsraft_set_norm_blocks(int target_workgroups);   /* tuning hook: workgroups per launch of the channels-last norm kernels (default 4096) */
 int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B, int HW,
                              int C, float eps, int relu, hipStream_t stream);
 int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2, float* dx,
@@ -345,10 +336,15 @@ int fsraft_stem7x7s2_wgrad(const float* x, const float* dy, float* dw, float* sc
  * `torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)` + `optimizer.step()` of `optim.AdamW(model.parameters(),
  * lr, weight_decay, eps)` (pytorch/train.py:137, 280-282) on FLAT fp32 buffers: parameters p, gradients g (scaled in place
  * like clip_grad_norm_ does), first / second moments m, v, n elements each.  step: device fp32 step count, incremented here;
- * norm: device scalar holding the gradients' 2-norm (null: no clipping); lr: device scalar; state: 4 floats of scratch. */
+ * norm: device scalar holding the gradients' 2-norm (null: no clipping); lr: device scalar; state: 4 floats of scratch;
+ * skip64 (nullable): ceil(n / 64) bytes, non-zero = the 64-element block belongs to a parameter that received no gradient
+ * this step and is left untouched with its moments (torch's AdamW skips `p.grad is None`). */
 int fsraft_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, float* step, const float* norm, float max_norm,
                       const float* lr, float beta1, float beta2, float eps, float weight_decay, float* state,
-                      hipStream_t stream);
+                      const unsigned char* skip64, hipStream_t stream);
+/* Host helper (no device work): *id = 0 when `stream` is not being captured into a hipGraph, else the capture's id.  The
+ * binding keys per-capture scratch (zero-filled accumulation targets) on it. */
+int fsraft_stream_capture_id(hipStream_t stream, unsigned long long* id);
 
 /* ---- layout / elementwise helpers around the GEMMs ----------------------------------- */
 int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);

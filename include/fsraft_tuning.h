@@ -1,0 +1,39 @@
+/* fsraft_tuning.h -- measurement and test knobs of libfsraft.so.
+ *
+ * NOT part of the drop-in boundary (include/fsraft.h): nothing here corresponds to an interface of the reference, and a
+ * maintainer integrating the library never calls these.  They exist so that tests can reach a kernel at sizes its
+ * selection heuristic would not pick (e.g. the resident-patch 3x3 kernel at a 16x16 test grid), so that scripts/ can A/B
+ * kernel variants inside one process, and so that the parity suite can run the GEMM families in either arithmetic mode
+ * one by one (fsraft_set_arithmetic of fsraft.h switches them together).
+ *
+ * Kernels that lost their A/B (LDS-direct weight tiles, key 24; record-activation convolution, key 25; resident-weight
+ * 64 -> 64 kernel, key 30) are compiled only into the experiment build (`make -C flow_supervisor_amd/csrc ablate` ->
+ * libfsraft_ablate.so, -DFSRAFT_EXPERIMENTS); in libfsraft.so those keys return FSRAFT_ERR_ARG.
+ */
+#ifndef FSRAFT_TUNING_H
+#define FSRAFT_TUNING_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* key 0: conv tile (0 auto, 1 128x128, 2 64x128, 3 64x64); 1: wgrad tile (0 128x128, 3 64x64); 2 / 11 / 17: target
+ * workgroup counts of the weight-gradient pixel splits; 3: arithmetic of the forward / data-gradient convolutions (0 exact
+ * fp32, 1 bf16x3; 3 / 4 / 5 force a tile shape); 4: arithmetic of the weight gradients (0 exact, 2 bf16x3); 5 / 8:
+ * buffer-addressed loaders; 7: XCD swizzle; 9 / 13 / 14 / 15 / 18 / 19: tile-shape thresholds; 12: uniform k-tile table;
+ * 16: few-channel weight-gradient kernel; 20 / 21: resident-patch 3x3 encoder kernel and its minimum pixel count; 22:
+ * XCD-aware weight-gradient order; 26: resident-patch forward / data-gradient kernel; 27: resident-block weight gradient
+ * (0 off, 1 the 3x3 layers, 2 the five-tap layers too); 28: 64-column patch tiles; 29: single-segment resident-block
+ * weight gradient, minimum pixel count. */
+int fsraft_set_tuning(int key, int value);
+int fsraft_get_tuning(int key);   /* keys 3 / 4 */
+int fsraft_set_build_split(int on);   /* volume build: 1 bf16x3 (default), 0 exact fp32 MFMA */
+int fsraft_set_gemm_split(int on);    /* fsraft_gemm_f32 with trans_b: 1 bf16x3 when operands are 16-byte aligned */
+int fsraft_set_lookup_qb(int qb);     /* queries per workgroup of the row-major lookup kernels: 0 auto, 8, 16 or 32 */
+int fsraft_set_norm_blocks(int target_workgroups);   /* workgroups per launch of the channels-last norm kernels (default 4096) */
+int fsraft_set_alt_tile(int on);      /* alt-corr forward: 1 (default) 4x4-query tile kernel, 0 wave per query */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -12,9 +12,21 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "fsraft.h")).read()
+def header_symbols(which=("fsraft.h", "fsraft_tuning.h")):
+    """fsraft.h = the drop-in boundary; fsraft_tuning.h = measurement / test knobs (not part of the boundary)."""
+    txt = "".join(open(os.path.join(ROOT, "include", h)).read() for h in which)
     return sorted(set(re.findall(r"^int (fsraft_\w+)\(", txt, flags=re.M)))
+
+
+def test_boundary_header_carries_no_tuning_knobs():
+    names = header_symbols(("fsraft.h",))
+    assert not [n for n in names if "tuning" in n or n.startswith("fsraft_set_") and n != "fsraft_set_arithmetic"], names
+    from flow_supervisor_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    if os.path.basename(_lib.LIB_PATH) == "libfsraft.so":
+        lib.fsraft_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+        for key in (24, 25, 30):               # experiment kernels are not in the shipped library
+            assert lib.fsraft_set_tuning(key, 0) == 1
 
 
 def test_library_exports_every_declared_symbol():

@@ -113,3 +113,70 @@ def test_unequal_shards_are_weighted_by_local_batch(tmp_path):
     x = torch.randn(5, 3, 10, 12)
     _toy_loss([model(x), 0.5 * model(x)]).backward()
     assert torch.allclose(got["flat"], grads.flat, atol=1e-6, rtol=1e-5)
+
+
+def _worker_two_passes(rank, world, port, out, bucketed):
+    """The flow-supervisor step: a labelled and an unlabelled forward/backward feed ONE optimizer step
+    (pytorch/train.py:270-277).  begin(backward_passes=2) holds every bucket back until both have arrived; a third
+    backward must raise instead of adding unreduced gradients into the already-exchanged views."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      FSRAFT_DP_BUCKETS="1" if bucketed else "0")
+    torch.set_num_threads(1)
+    from flow_supervisor_amd.parallel import FlatGradients, broadcast_parameters, init_distributed, shard_batch
+    init_distributed("cpu")
+    torch.manual_seed(300 + rank)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    broadcast_parameters(model)
+    grads = FlatGradients([p for _, p in model.named_parameters()], [n for n, _ in model.named_parameters()])
+    assert grads.bucketed == bucketed
+    torch.manual_seed(9)
+    x, xu = torch.randn(4, 3, 10, 12), torch.randn(4, 3, 10, 12)
+    s, n = shard_batch(4, rank, world)
+    grads.begin(backward_passes=2)
+    _toy_loss([model(x[s:s + n])]).backward()
+    assert not any(grads._done), "a bucket was exchanged after the first of two backward passes"
+    _toy_loss([0.25 * model(xu[s:s + n])]).backward()
+    assert all(grads._done) == bucketed                # bucketed: both buckets left from the hooks of the second pass
+    grads.all_reduce_mean_()
+    flat = grads.flat.clone()
+    raised = False
+    if bucketed:                                       # next step: one pass announced, two made
+        grads.begin()
+        _toy_loss([model(x[s:s + n])]).backward()
+        try:
+            _toy_loss([model(x[s:s + n])]).backward()
+        except RuntimeError as e:
+            raised = "already exchanged" in str(e)
+        grads.all_reduce_mean_()
+    if rank == 0:
+        torch.save({"flat": flat, "raised": raised}, out)
+
+
+def _two_pass_reference():
+    sys.path.insert(0, ROOT)
+    from flow_supervisor_amd.parallel import FlatGradients
+    torch.manual_seed(300)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    grads = FlatGradients(model.parameters())
+    torch.manual_seed(9)
+    x, xu = torch.randn(4, 3, 10, 12), torch.randn(4, 3, 10, 12)
+    _toy_loss([model(x)]).backward()
+    _toy_loss([0.25 * model(xu)]).backward()
+    return grads.flat
+
+
+def test_two_backward_passes_per_step_and_unannounced_third(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_two_passes, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["raised"], "a gradient for an already-exchanged bucket must raise"
+    assert torch.allclose(got["flat"], _two_pass_reference(), atol=1e-6, rtol=1e-5)
+
+
+def test_single_flat_allreduce_switch(tmp_path):
+    """FSRAFT_DP_BUCKETS=0: nothing is exchanged from the hooks, one all-reduce of the flat buffer in finish()."""
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_two_passes, args=(2, _free_port(), out, False), nprocs=2, join=True)
+    got = torch.load(out)
+    assert torch.allclose(got["flat"], _two_pass_reference(), atol=1e-6, rtol=1e-5)
