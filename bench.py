@@ -47,9 +47,14 @@ def parse():
     ap.add_argument("--height", type=int, default=440)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--variant", choices=["raft", "gma", "alt"], default="raft",
+    ap.add_argument("--variant", choices=["raft", "gma", "alt", "l2l", "gma_l2l"], default="raft",
                     help="raft: BASELINE.json config 3 (the default, the judged line); gma: config 5 (RAFT-GMA); "
-                         "alt: config 4 (AlternateCorrBlock, use --height 376 --width 1248 --batch-per-gpu 1)")
+                         "alt: config 4 (AlternateCorrBlock, use --height 376 --width 1248 --batch-per-gpu 1); "
+                         "l2l / gma_l2l: the flow-supervisor step of the reference recipe (train_semi.sh:3-11): L2L / GMAL2L, one "
+                         "labelled + one unlabelled sample per step, crop 368x768 inside a 432x1024 frame, 12 + 12 iterations, "
+                         "two backward passes, one AdamW step (use --batch-per-gpu 1, the recipe's batch size)")
+    ap.add_argument("--crop-height", type=int, default=368)
+    ap.add_argument("--crop-width", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the exact-fp32 / north_star-encoder short runs and the loss check")
@@ -178,7 +183,20 @@ def main():
     torch.backends.cudnn.benchmark = False
 
     torch.manual_seed(0)
-    if a.variant == "gma":
+    semi = a.variant in ("l2l", "gma_l2l")
+    if semi:
+        if (a.height, a.width) == (440, 1024):
+            a.height = 432                               # the recipe's uncropped frame: 436x1024 floored to a multiple of 8 (augmentor.py:561-565)
+        if a.variant == "l2l":
+            from flow_supervisor_amd.core.l2l import L2L
+            model = L2L(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(dev).train()
+        else:
+            from flow_supervisor_amd.core.gma_l2l import GMAL2L
+            model = GMAL2L(argparse.Namespace(mixed_precision=False, num_heads=1, position_only=False,
+                                              position_and_content=False)).to(dev).train()
+            with torch.no_grad():
+                model.update_block.aggregator.gamma.fill_(0.1)
+    elif a.variant == "gma":
         from flow_supervisor_amd.core.gma_network import RAFTGMA
         model = RAFTGMA(argparse.Namespace(mixed_precision=False, num_heads=1, position_only=False,
                                            position_and_content=False)).to(dev).train()
@@ -195,12 +213,36 @@ def main():
     use_graph = a.graph == 1 or (a.graph == -1 and world == 1)
     # lr: a small constant (the reference's recipes: AdamW + StepLR(num_steps // 5, 0.5), pytorch/train.py:134-141, with
     # --lr 5e-6 .. 4e-4); throughput does not depend on it, the loss of synthetic steps stays finite with it
-    step = TrainStep(model, lr=1.6e-5, iters=a.iters, capturable=use_graph)
-
     B = a.batch_per_gpu
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    im1 = torch.rand(B, 3, a.height, a.width, device=dev, generator=g) * 255.0
-    im2 = (torch.roll(im1, shifts=(3, -5), dims=(2, 3)) + 2.0 * torch.randn(B, 3, a.height, a.width, device=dev, generator=g)).clamp(0, 255)
+
+    def pair():
+        i1 = torch.rand(B, 3, a.height, a.width, device=dev, generator=g) * 255.0
+        i2 = (torch.roll(i1, shifts=(3, -5), dims=(2, 3)) + 2.0 * torch.randn(B, 3, a.height, a.width, device=dev, generator=g)).clamp(0, 255)
+        return i1, i2
+
+    im1, im2 = pair()
+    if semi:
+        from flow_supervisor_amd.train import SemiTrainStep
+        lr, lam, gam = (5e-6, 1.0, 0.8) if a.variant == "l2l" else (1e-6, 0.25, 0.85)      # train_semi.sh:3-11
+        sstep = SemiTrainStep(model, lr=lr, wdecay=0.0, iters=a.iters, gamma=gam, unsup_lambda=lam, capturable=use_graph)
+        ch, cw = a.crop_height, a.crop_width
+
+        def sample(frame, oy, ox):
+            f1, f2 = frame
+            c1 = (f1[:, :, oy:oy + ch, ox:ox + cw] + 3.0 * torch.randn(B, 3, ch, cw, device=dev, generator=g)).clamp(0, 255).contiguous()
+            c2 = (f2[:, :, oy:oy + ch, ox:ox + cw] + 3.0 * torch.randn(B, 3, ch, cw, device=dev, generator=g)).clamp(0, 255).contiguous()
+            flow = torch.randn(B, 2, ch, cw, device=dev, generator=g) * 4.0
+            valid = (torch.rand(B, ch, cw, device=dev, generator=g) > 0.1).float()
+            return (c1, c2, f1, f2, ox, oy, flow, valid)        # offsets as python ints: no device sync in the step
+
+        sup, unsup = sample((im1, im2), 40, 136), sample(pair(), 16, 200)
+
+        def step(_a, _b):
+            ls, lu = sstep(sup, unsup)
+            return ls + lu
+    else:
+        step = TrainStep(model, lr=1.6e-5, iters=a.iters, capturable=use_graph)
 
     graph = None
     loss = None
@@ -296,10 +338,12 @@ def main():
 
     if rank != 0:
         return
-    pairs = B * world * a.steps
+    pairs = B * world * a.steps * (2 if semi else 1)     # flow-supervisor step: a labelled and an unlabelled pair
     shape_note = " (Sintel 436x1024 padded)" if (a.height, a.width) == (440, 1024) else (" (KITTI 375x1242 padded)" if (a.height, a.width) == (376, 1248) else "")
     out = {
-        "metric": f"image-pairs/s fwd+bwd, {a.iters} GRU iters, " + ("436x1024" if (a.height, a.width) == (440, 1024) else f"{a.height}x{a.width}"),
+        "metric": f"image-pairs/s fwd+bwd, {a.iters} GRU iters, " + ("436x1024" if (a.height, a.width) == (440, 1024) else f"{a.height}x{a.width}")
+                  + (f" (flow-supervisor step: {a.iters}+{a.iters} iters, crop {a.crop_height}x{a.crop_width})" if semi else ""),
+        "variant": a.variant,
         "value": pairs / dt, "unit": "image-pairs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -309,9 +353,13 @@ def main():
                        "value_exact_f32 = the same step on the exact-fp32 MFMA cores")
                       if split_mode else "exact fp32 MFMA",
         "data": "synthetic",
-        "config": {"workload": {"raft": "RAFT full", "gma": "RAFT-GMA (config 5)", "alt": "RAFT full, AlternateCorrBlock (config 4)"}[a.variant] +
-                               f", {a.height}x{a.width}{shape_note}, {a.iters} GRU iters, "
-                               f"{B} pairs/GPU, train step = fwd + sequence loss + bwd + RCCL all-reduce + clip + AdamW",
+        "config": {"workload": ({"raft": "RAFT full", "gma": "RAFT-GMA (config 5)", "alt": "RAFT full, AlternateCorrBlock (config 4)"}[a.variant] +
+                                f", {a.height}x{a.width}{shape_note}, {a.iters} GRU iters, "
+                                f"{B} pairs/GPU, train step = fwd + sequence loss + bwd + RCCL all-reduce + clip + AdamW") if not semi else
+                               (f"flow-supervisor step ({'L2L' if a.variant == 'l2l' else 'GMAL2L'}, pytorch/train.py:246-284): per GPU {B} labelled + {B} "
+                                f"unlabelled pair(s), crop {a.crop_height}x{a.crop_width} inside a {a.height}x{a.width} frame, {a.iters} student + "
+                                f"{a.iters} supervisor iterations each, sequence_loss / sequence_loss_unsup, two backward passes, RCCL "
+                                f"all-reduce, clip, one AdamW step"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v,
                    "launch": "hipGraph replay of the whole step (the short runs behind value_exact_f32 / value_north_star_encoders and the "
                              "per-kernel timing are eager)" if graph is not None else graph_note,

@@ -16,13 +16,18 @@ from .update import BasicUpdateBlock, to_channels_last
 from .utils.utils import upflow8
 
 
+def _offset(v):
+    """ox / oy arrive as per-sample tensors in the reference (`ox[0]`, l2l.py:87-88); python ints are accepted too (no device sync)."""
+    return int(v) if isinstance(v, int) else int(v[0])
+
+
 class L2L(RAFT):
     def __init__(self, args):
         super().__init__(args)
         self.grad_update_block = BasicUpdateBlock(self.args, hidden_dim=self.hidden_dim)   # l2l.py:27
 
     def forward(self, image1, image2, ci1=None, ci2=None, ox=None, oy=None, iters=24, flow_init=None,
-                upsample=True, test_mode=False):
+                upsample=True, test_mode=False, supervisor_grad=True):
         norm = lambda im: (2 * (im / 255.0) - 1.0).contiguous()
         image1, image2 = norm(image1), norm(image2)
         if ci1 is not None:
@@ -65,45 +70,54 @@ class L2L(RAFT):
         flow_up = None
         half = iters // 2
         crop = None
-        for itr in range(iters):
-            coords1 = coords1.detach()
-            corr = lookup(corr_fn, coords1)
-            flow = coords1 - coords0
-            want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (l2l.py:130-131)
-            if test_mode or itr < half:
-                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up)
-            else:
-                if itr == half:
-                    if ci1 is not None:
-                        orig_h, orig_w = image1.shape[-2:]
-                        targ_h, targ_w = ci1.shape[-2:]
-                        ox_, oy_ = int(ox[0]), int(oy[0])
-                        crop = (oy_, orig_h, ox_, orig_w)
-                        l, r = ox_ // 8, (targ_w - ox_ - orig_w) // 8
-                        t, b = oy_ // 8, (targ_h - oy_ - orig_h) // 8
-                        net = F.pad(net, (0, 0, l, r, t, b))            # channels-last: pad W then H   (l2l.py:90)
-                        flow = F.pad(flow, (l, r, t, b))                #                               (l2l.py:92)
-                        coords0, _ = self.initialize_flow(ci1)
-                        coords1 = flow + coords0
-                        tfmap1, tfmap2 = features(ci1, ci2)
-                        corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)   # second volume (l2l.py:101)
-                        corr = lookup(corr_fn, coords1)
-                        _, inp = context(ci1)
-                        inp = to_channels_last(torch.relu(inp))
-                    net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
-                net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow)
+        grad_mode = torch.is_grad_enabled()
+        try:
+            for itr in range(iters):
+                if itr == half and not supervisor_grad and not test_mode:
+                    # (extension, default off) the caller's loss does not reach the supervisor's predictions -- sequence_loss_unsup
+                    # only reads the last one, detached (train.py:110-111) -- so the second half records no graph
+                    torch.set_grad_enabled(False)
+                coords1 = coords1.detach()
+                if test_mode or itr != half:          # (at the switch the reference looks up the crop's volume and drops it, l2l.py:73/102)
+                    corr = lookup(corr_fn, coords1)
+                flow = coords1 - coords0
+                want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (l2l.py:130-131)
+                if test_mode or itr < half:
+                    net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up)
+                else:
+                    if itr == half:
+                        if ci1 is not None:
+                            orig_h, orig_w = image1.shape[-2:]
+                            targ_h, targ_w = ci1.shape[-2:]
+                            ox_, oy_ = _offset(ox), _offset(oy)
+                            crop = (oy_, orig_h, ox_, orig_w)
+                            l, r = ox_ // 8, (targ_w - ox_ - orig_w) // 8
+                            t, b = oy_ // 8, (targ_h - oy_ - orig_h) // 8
+                            net = F.pad(net, (0, 0, l, r, t, b))            # channels-last: pad W then H   (l2l.py:90)
+                            flow = F.pad(flow, (l, r, t, b))                #                               (l2l.py:92)
+                            coords0, _ = self.initialize_flow(ci1)
+                            coords1 = flow + coords0
+                            tfmap1, tfmap2 = features(ci1, ci2)
+                            corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)   # second volume (l2l.py:101)
+                            corr = lookup(corr_fn, coords1)
+                            _, inp = context(ci1)
+                            inp = to_channels_last(torch.relu(inp))
+                        net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
+                    net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow)
 
-            coords1 = coords1 + delta_flow
-            if not want_up:
-                continue
-            if up_mask is None:
-                flow_up = upflow8(coords1 - coords0)
-            else:
-                flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
-            if not test_mode and itr >= half:
-                oy_, orig_h, ox_, orig_w = crop
-                flow_up = flow_up[:, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w]
-            flow_predictions.append(flow_up)
+                coords1 = coords1 + delta_flow
+                if not want_up:
+                    continue
+                if up_mask is None:
+                    flow_up = upflow8(coords1 - coords0)
+                else:
+                    flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+                if not test_mode and itr >= half:
+                    oy_, orig_h, ox_, orig_w = crop
+                    flow_up = flow_up[:, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w]
+                flow_predictions.append(flow_up)
+        finally:
+            torch.set_grad_enabled(grad_mode)
 
         if test_mode:
             return coords1 - coords0, flow_up

@@ -50,8 +50,9 @@ def weighted_sequence_loss(flow_preds, weights, flow_gt=None, valid=None, max_fl
     return _SeqLossFn.apply(list(weights), flow_gt, valid, max_flow, eps, metric_idx, *flow_preds)
 
 
-def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8, gamma2=1.0, max_flow=MAX_FLOW):
-    """pytorch/train.py:60-96, same signature and return value (loss, metrics dict).  The first half of the predictions
+def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8, gamma2=1.0, max_flow=MAX_FLOW, metrics=True):
+    """pytorch/train.py:60-96, same signature and return value (loss, metrics dict; metrics=False: (loss, None) without the
+    host read-back of the statistics).  The first half of the predictions
     (the student's, in the flow-supervisor forward) is weighted gamma^(n-i-1), the second half (the supervisor's)
     gamma2^(n-i-1) with n = len(flow_preds) // 2; Charbonnier penalty with eps = 1e-3; pixels with valid < 0.5 or
     |gt| >= max_flow are excluded; metrics (epe, 1px, 3px, 5px) come from prediction n-1 over valid > 0.5."""
@@ -59,6 +60,28 @@ def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8, gamma2=1.0, max_flow=MA
     n = nm // 2
     weights = [gamma ** (n - i - 1) for i in range(n)] + [gamma2 ** (n - i - 1) for i in range(nm - n)]
     loss, stats = weighted_sequence_loss(flow_preds, weights, flow_gt, valid, max_flow, 1e-3, n - 1)
+    if not metrics:
+        return loss, None
+    _, epe_sum, n1, n3, n5, nv = stats.tolist()
+    nv = max(nv, 1.0)
+    return loss, {"epe": epe_sum / nv, "1px": n1 / nv, "3px": n3 / nv, "5px": n5 / nv}
+
+
+def sequence_loss_unsup(flow_preds, flow_gt, valid, gamma=0.8, unsup_weight=1.0, max_flow=MAX_FLOW, metrics=True):
+    """pytorch/train.py:99-129, same signature and return value: the unlabelled half of the flow-supervisor step.  The pseudo
+    label is the LAST prediction (the supervisor's), detached; only the first half of the predictions (the student's) is
+    penalised, weight unsup_weight * gamma^(n-i-1), Charbonnier eps = 1e-3, no mask.  Metrics (epe, 1px, 3px, 5px) are
+    those of prediction n-1 against flow_gt over valid > 0.5, as in the reference (metrics=False skips them and their
+    host read-back: the benchmark's steps stay free of synchronisation)."""
+    nm = len(flow_preds)
+    n = nm // 2
+    pseudo = flow_preds[-1].detach()
+    weights = [unsup_weight * gamma ** (n - i - 1) for i in range(n)]
+    loss, _ = weighted_sequence_loss(list(flow_preds[:n]), weights, pseudo, None, float("inf"), 1e-3, None)
+    if not metrics:
+        return loss, None
+    with torch.no_grad():
+        _, stats = weighted_sequence_loss([flow_preds[n - 1].detach()], [0.0], flow_gt, valid, max_flow, 1e-3, 0)
     _, epe_sum, n1, n3, n5, nv = stats.tolist()
     nv = max(nv, 1.0)
     return loss, {"epe": epe_sum / nv, "1px": n1 / nv, "3px": n3 / nv, "5px": n5 / nv}
@@ -115,3 +138,43 @@ class TrainStep:
             self.grads.clip_norm_(self.clip)
             self.opt.step()
         return loss.detach()
+
+
+class SemiTrainStep(TrainStep):
+    """The flow-supervisor optimisation step (pytorch/train.py:246-284) around L2L / GMAL2L: a labelled sample through
+    the two-phase forward (student on the crop, supervisor on the uncropped frame) with `sequence_loss`, backward; an
+    unlabelled sample through the same forward with `sequence_loss_unsup` (the supervisor's last prediction is the
+    student's pseudo label), backward; then ONE clip + AdamW step on the accumulated gradients.  Both backward passes feed
+    the same gradient buckets (FlatGradients.begin(backward_passes=2)).
+
+    sup / unsup: (image1, image2, ci1, ci2, ox, oy, flow, valid) -- the crop pair, the uncropped pair, the crop's offsets
+    (python ints or CPU tensors keep the step free of device synchronisation; the reference passes CUDA tensors and
+    syncs on them), ground-truth flow and validity of the crop."""
+
+    def __init__(self, model, lr=5e-6, wdecay=0.0, eps=1e-8, clip=1.0, iters=12, gamma=0.8, unsup_lambda=1.0,
+                 capturable=False):
+        super().__init__(model, lr=lr, wdecay=wdecay, eps=eps, clip=clip, iters=iters, capturable=capturable)
+        self.gamma, self.unsup_lambda = gamma, unsup_lambda
+
+    def __call__(self, sup, unsup, global_batch=None):
+        if global_batch is None:
+            self.grads.begin(backward_passes=2)
+        else:
+            self.grads.begin(sup[0].shape[0], global_batch, backward_passes=2)
+        im1, im2, ci1, ci2, ox, oy, flow, valid = sup
+        preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters)
+        loss, _ = sequence_loss(preds, flow, valid, self.gamma, metrics=False)
+        loss.backward()
+        del preds
+        im1, im2, ci1, ci2, ox, oy, flow, valid = unsup
+        preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters, supervisor_grad=False)
+        loss_u, _ = sequence_loss_unsup(preds, flow, valid, unsup_weight=self.unsup_lambda, metrics=False)
+        loss_u.backward()
+        del preds
+        self.grads.all_reduce_mean_()
+        if self.flat_opt:
+            self.opt.step(clip=self.clip)
+        else:
+            self.grads.clip_norm_(self.clip)
+            self.opt.step()
+        return loss.detach(), loss_u.detach()

@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_parity.py::test_two_process_train_step_matches_single_process: one data-parallel rank
 running the REAL TrainStep (HIP path) on its shard.  Ranks share cuda:0, so the exchange goes over gloo staged through
 host memory (RCCL refuses two ranks on one device); everything else is the code path bench.py runs at N > 1.
-usage: _dp_worker.py rank world port global_batch out.pt"""
+usage: _dp_worker.py rank world port global_batch out.pt [H W iters]"""
 import os
 import sys
 
@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     rank, world, port, gb, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    H, W, iters = (int(v) for v in sys.argv[6:9]) if len(sys.argv) >= 9 else (128, 192, 3)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import argparse
     import torch
@@ -26,8 +27,8 @@ def main():
     m.load_state_dict(procedural_state_dict(shapes("raft_basic"), 650 + 7 * rank))
     m = m.to("cuda").train()
     m.freeze_bn()
-    im1, im2 = (t.to("cuda") for t in synthetic_pair(gb, 128, 192, 651))
-    step = TrainStep(m, lr=1e-4, iters=3)
+    im1, im2 = (t.to("cuda") for t in synthetic_pair(gb, H, W, 651))
+    step = TrainStep(m, lr=1e-4, iters=iters)
     # a forward BEFORE the broadcast fills the packed-weight caches with the pre-broadcast values (a broadcast
     # through .data would leave them stale)
     with torch.no_grad():

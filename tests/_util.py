@@ -34,3 +34,50 @@ def close(a, b, atol, rtol=2e-5, what=""):
             f.write(f"{test}\t{what}\terr {err:.3e}\tlimit {lim:.3e} (atol {atol:g} + {rtol:g} * max|ref| {ref:.3g})\tused {err / lim if lim else 0:.3f}\n")
     assert err <= lim, f"{what}: max abs err {err:.3e} > {lim:.3e}"
     return err
+
+
+def _log_margin(what, err, lim, detail):
+    log = os.environ.get("FSRAFT_PARITY_LOG")
+    if log:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+        with open(log, "a") as f:
+            f.write(f"{test}\t{what}\terr {err:.3e}\tlimit {lim:.3e} ({detail})\tused {err / lim if lim else 0:.3f}\n")
+
+
+def grad_digest_check(named_params, g, rtol_norm, rtol_head, prefix="gnorm.", hprefix="ghead.", skip=(), atol_norm=1e-5):
+    """Every parameter-gradient norm (and, where the fixture has it, the first 32 elements) against a reference-generated
+    digest.  norm: |ours - ref| <= rtol_norm * ref + atol_norm (atol: biases in front of InstanceNorm have a zero gradient in
+    exact arithmetic and ~1e-6 of rounding noise in the reference); head: max abs error <= rtol_head * max|head| + the
+    share of rtol_norm * ref one element carries.  The worst margins go to the parity log.  Returns the offenders."""
+    import math
+    bad, worst_n, worst_h = [], (0.0, ""), (0.0, "")
+    for k, p in named_params:
+        if any(t in k for t in skip) or prefix + k not in g:
+            continue
+        ref = float(g[prefix + k])
+        gn = 0.0 if p.grad is None else p.grad.norm().item()
+        lim = rtol_norm * max(ref, 1e-6) + atol_norm
+        err = abs(gn - ref)
+        if err / lim > worst_n[0]:
+            worst_n = (err / lim, f"{k}: {gn:.6g} vs {ref:.6g}")
+        if not err <= lim:
+            bad.append((k, "norm", gn, ref))
+        if hprefix and hprefix + k in g and p.grad is not None and ref > 1e-4:
+            head = T(g[hprefix + k]).float()
+            herr = (p.grad.reshape(-1)[:32].cpu() - head).abs().max().item()
+            hlim = rtol_head * head.abs().max().item() + rtol_norm * ref / math.sqrt(p.numel()) + 1e-7
+            if herr / hlim > worst_h[0]:
+                worst_h = (herr / hlim, k)
+            if not herr <= hlim:
+                bad.append((k, "head", herr, head.abs().max().item()))
+    _log_margin(f"{prefix}* worst ({worst_n[1]})", worst_n[0] * rtol_norm, rtol_norm, "relative to the reference norm")
+    if hprefix:
+        _log_margin(f"{hprefix}* worst ({worst_h[1]})", worst_h[0] * rtol_head, rtol_head, "relative to max|head|")
+    return bad
+
+
+def rel_check(value, ref, rtol, what):
+    """|value - ref| <= rtol * |ref| for scalars (losses), logged like close()."""
+    err, lim = abs(float(value) - float(ref)), rtol * abs(float(ref))
+    _log_margin(what, err, lim, f"{rtol:g} * |ref| {abs(float(ref)):.6g}")
+    assert err <= lim, f"{what}: {float(value)!r} vs reference {float(ref)!r} (rel {err / max(abs(float(ref)), 1e-30):.2e} > {rtol:g})"

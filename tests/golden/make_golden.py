@@ -210,6 +210,81 @@ def gen_l2l():
     save("l2l_basic", **d)
 
 
+def _ref_train_fn(name):
+    """A pure-torch function of pytorch/train.py (the module imports cv2 / tensorflow and cannot be imported here): its
+    FunctionDef is taken out of the syntax tree and executed with only `torch` and MAX_FLOW in scope."""
+    import ast
+    tree = ast.parse(open("/root/reference/pytorch/train.py").read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+    scope = {"torch": torch, "MAX_FLOW": 400}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "train.py:" + name, "exec"), scope)
+    return scope[name]
+
+
+def l2l_recipe_inputs(seed, H=432, W=1024, h=368, w=768):
+    """One labelled and one unlabelled sample of the flow-supervisor step at the reference recipe (train_semi.sh:3-6:
+    --batch_size 1 --image_size 368 768): the uncropped frame is the Sintel frame floored to a multiple of 8
+    (436x1024 -> 432x1024, raft_utils/augmentor.py:561-565 get_proc_size_floor), the crop sits at offsets that are
+    multiples of 8 (augmentor.py:621-622) and carries photometric noise (the colour augmentation's stand-in)."""
+    out = {}
+    for tag, sd, oy, ox in (("sup", seed + 1, 40, 136), ("unsup", seed + 5, 16, 200)):
+        ci1, ci2 = synthetic_pair(1, H, W, sd)
+        im1 = (ci1[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), sd + 1, 3.0)).clamp(0, 255).contiguous()
+        im2 = (ci2[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), sd + 2, 3.0)).clamp(0, 255).contiguous()
+        flow = rand_tensor((1, 2, h, w), sd + 3, 4.0)
+        valid = (rand_uniform((1, h, w), sd + 4, 0.0, 1.0) > 0.1).float()
+        out[tag] = (im1, im2, ci1, ci2, torch.tensor([ox]), torch.tensor([oy]), flow, valid)
+    return out
+
+
+def gen_l2l_recipe():
+    """The flow-supervisor optimisation step itself at the reference recipe's size: L2L / GMAL2L,
+    B = 1, crop 368x768 inside the 432x1024 frame, iters = 12 + 12, labelled pass with sequence_loss + backward, unlabelled
+    pass with sequence_loss_unsup + backward (pytorch/train.py:270-277), gradients of both passes accumulated.  Stored:
+    both losses, strided student / supervisor predictions, every parameter's gradient norm and head after the labelled
+    pass alone and after both."""
+    from core.gma_l2l import GMAL2L
+    from core.l2l import L2L
+    seq, seq_u = _ref_train_fn("sequence_loss"), _ref_train_fn("sequence_loss_unsup")
+    for name, cls, ns, seed, gamma, lam in (("l2l_recipe_basic", L2L, args_ns(False), 711, 0.8, 1.0),
+                                            ("l2l_recipe_gma", GMAL2L, gma_ns(), 712, 0.85, 0.25)):
+        model = cls(ns)
+        shapes = shapes_of(model)
+        with open(os.path.join(HERE, name + "_shapes.json"), "w") as f:
+            json.dump({k: list(v) for k, v in shapes.items()}, f, indent=0)
+        model.load_state_dict(procedural_state_dict(shapes, seed), strict=False)
+        if cls is GMAL2L:
+            with torch.no_grad():
+                model.update_block.aggregator.gamma.fill_(0.1)
+        model.train()
+        model.freeze_bn()
+        inp = l2l_recipe_inputs(seed)
+        d = dict(seed=seed, H=432, W=1024, h=368, w=768, iters=24, B=1, gamma=gamma, unsup_lambda=lam, stride=4)
+        for tag in ("sup", "unsup"):
+            im1, im2, ci1, ci2, ox, oy, flow, valid = inp[tag]
+            preds = model(im1, im2, ci1, ci2, ox, oy, iters=24)
+            assert len(preds) == 24 and tuple(preds[-1].shape) == (1, 2, 368, 768)
+            if tag == "sup":
+                loss, metrics = seq(preds, flow, valid, gamma)
+            else:
+                loss, metrics = seq_u(preds, flow, valid, unsup_weight=lam)     # (train.py:276: gamma stays at its default)
+            loss.backward()
+            d[tag + "_loss"] = loss.detach()
+            d[tag + "_epe"] = np.float64(metrics["epe"])
+            d[tag + "_ox"], d[tag + "_oy"] = int(ox[0]), int(oy[0])
+            for i in (0, 11, 12, 23):
+                d[f"{tag}_pred{i}"] = preds[i].detach()[:, :, ::4, ::4].contiguous()
+                d[f"{tag}_pred{i}_absmean"] = preds[i].detach().abs().mean()
+            for k, p in model.named_parameters():
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                sfx = "" if tag == "unsup" else "_sup"
+                d[f"gnorm{sfx}." + k] = g.norm()
+                d[f"ghead{sfx}." + k] = g.reshape(-1)[:32].clone()
+            del preds, loss
+        save(name, **d)
+        del model
+
+
 # ---------------------------------------------------------------- G7 (GMA, benchmark config 5)
 def gma_ns():
     return argparse.Namespace(small=False, mixed_precision=False, dropout=0, num_heads=1, position_only=False,
@@ -407,6 +482,37 @@ def gen_seq_loss():
     save("sequence_loss", **d)
 
 
+def gen_seq_loss_unsup():
+    """sequence_loss_unsup of pytorch/train.py:99-129 (the unlabelled half of the flow-supervisor step), same extraction."""
+    ref = _ref_train_fn("sequence_loss_unsup")
+    d = {}
+    for name, B, H, W, n, gamma, lam, seed in (("a", 2, 24, 40, 24, 0.8, 1.0, 911), ("b", 1, 17, 23, 6, 0.85, 0.25, 912)):
+        preds = [rand_tensor((B, 2, H, W), seed + 10 + i, 3.0).requires_grad_(True) for i in range(n)]
+        gt = rand_tensor((B, 2, H, W), seed + 1, 4.0)
+        valid = (rand_uniform((B, H, W), seed + 2, 0.0, 1.0) > 0.2).float()
+        valid[:, 2, 2] = 0.5
+        loss, metrics = ref(preds, gt, valid, gamma=gamma, unsup_weight=lam)
+        loss.backward()
+        d.update({f"{name}_cfg": np.array([B, H, W, n, seed], dtype=np.int64), f"{name}_gamma": np.array([gamma, lam]),
+                  f"{name}_loss": loss.detach(),
+                  f"{name}_metrics": np.array([metrics["epe"], metrics["1px"], metrics["3px"], metrics["5px"]])})
+        for i, p in enumerate(preds):
+            d[f"{name}_dpred{i}"] = p.grad if p.grad is not None else torch.zeros_like(p)
+    save("sequence_loss_unsup", **d)
+
+
+def gen_chairs_b8():
+    """BASELINE.json config 2 at its own batch size (VERDICT r2 weak #2): RAFT, 8 pairs, 368x496, 3 iterations, fwd + bwd."""
+    seed, H, W, B, iters = 621, 368, 496, 8, 3
+    model = RAFT(args_ns(False))
+    model.load_state_dict(procedural_state_dict(shapes_of(model), seed))
+    model.train()
+    model.freeze_bn()
+    im1, im2 = synthetic_pair(B, H, W, seed + 1)
+    preds = model(im1, im2, iters=iters)
+    save("train_step_basic_368x496_b8", small=False, H=H, W=W, iters=iters, seed=seed, B=B, **_train_digest(model, preds))
+
+
 def gen_warm_start():
     """forward_interpolate of the reference (core/utils/utils.py:26-54) on seeded flows: smooth + noise, a case where
     many vectors leave the image, and a constant shift (whole columns of the grid inherit their nearest landed neighbour)."""
@@ -424,7 +530,8 @@ def gen_warm_start():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "kitti", "l2l", "gma", "train", "warm", "seqloss", "bench"]
+    which = sys.argv[1:] or ["corr", "update", "upsample", "e2e", "kitti", "l2l", "gma", "train", "warm", "seqloss", "bench",
+                             "l2l_recipe", "seqloss_unsup", "chairs_b8"]
     if "warm" in which:
         gen_warm_start()
     if "corr" in which:
@@ -447,3 +554,9 @@ if __name__ == "__main__":
         gen_seq_loss()
     if "bench" in which:
         gen_bench_scale()
+    if "l2l_recipe" in which:
+        gen_l2l_recipe()
+    if "seqloss_unsup" in which:
+        gen_seq_loss_unsup()
+    if "chairs_b8" in which:
+        gen_chairs_b8()

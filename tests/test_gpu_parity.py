@@ -11,12 +11,18 @@ import numpy as np
 import pytest
 import torch
 
-from _util import T, close, load, shapes
+from _util import T, close, grad_digest_check, load, rel_check, shapes
 from oracle import raft_torch as O
 from oracle.weights import procedural_state_dict, rand_tensor, rand_uniform, synthetic_pair
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+# Limits of the train-step comparisons, per arithmetic mode: (loss rel, prediction abs [px], gradient-norm rel, gradient-head rel).
+# Set to ~4x the worst error measured on MI355X over the whole suite (profiles/r03_parity_margins.txt lists every comparison
+# with the share of its limit it used); round 2 ran these checks at 1e-4 / 4e-3 / 5e-3 / 2e-2.
+TRAIN_TOL = {"exact": dict(loss=2e-5, pred=1e-3, gnorm=5e-3, ghead=2e-2),
+             "split": dict(loss=1e-4, pred=4e-3, gnorm=5e-3, ghead=2e-2)}
 
 
 @pytest.fixture(params=["exact", "split"])
@@ -295,44 +301,25 @@ def test_train_step_loss_and_grads(tag, precision):
     m.freeze_bn()
     im1, im2 = synthetic_pair(2, int(g["H"]), int(g["W"]), seed + 1)
     preds = m(im1.to(DEV), im2.to(DEV), iters=int(g["iters"]))
+    tol = TRAIN_TOL[precision]
     loss = O.sequence_loss_zero_gt(preds)
-    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (loss.item(), float(g["loss"]))
+    rel_check(loss.item(), g["loss"], tol["loss"], "loss")
     loss.backward()
-    close(preds[-1], g["last"], 1e-3, what="last prediction")
-    bad = []
-    for k, p in m.named_parameters():
-        if "gnorm." + k not in g:
-            continue
-        ref = float(g["gnorm." + k])
-        gn = 0.0 if p.grad is None else p.grad.norm().item()
-        if abs(gn - ref) > 5e-3 * max(ref, 1e-6) + 1e-6:
-            bad.append((k, gn, ref))
+    close(preds[-1], g["last"], tol["pred"], rtol=0.0, what="last prediction")
+    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"])
     assert not bad, bad[:8]
 
 
 def _check_train_digest(m, preds, g, precision, skip=()):
-    """loss, first / last prediction (strided) and every parameter-gradient norm against a `_train_digest` fixture."""
+    """loss, first / last prediction (strided) and every parameter-gradient norm + head against a `_train_digest` fixture."""
+    tol = TRAIN_TOL[precision]
     loss = O.sequence_loss_zero_gt(preds)
-    ref = float(g["loss"])
-    assert abs(loss.item() - ref) <= 1e-4 * abs(ref), (loss.item(), ref)
+    rel_check(loss.item(), g["loss"], tol["loss"], "loss")
     loss.backward()
     s = int(g["stride"])
-    tol = 1e-3 if precision == "exact" else 4e-3
-    close(preds[0][:, :, ::s, ::s], g["first"], tol, what="first prediction")
-    close(preds[-1][:, :, ::s, ::s], g["last"], tol, what="last prediction")
-    bad = []
-    for k, p in m.named_parameters():
-        if any(t in k for t in skip):
-            continue
-        ref = float(g["gnorm." + k])
-        gn = 0.0 if p.grad is None else p.grad.norm().item()
-        if abs(gn - ref) > 5e-3 * max(ref, 1e-6) + 1e-5:      # (1e-5: biases in front of InstanceNorm have a zero gradient
-            bad.append((k, gn, ref))                          #  in exact arithmetic, ~1e-6 of rounding noise in the reference)
-        if p.grad is not None and ref > 1e-4:
-            head = T(g["ghead." + k]).float()
-            err = (p.grad.reshape(-1)[:32].cpu() - head).abs().max().item()
-            if err > 2e-2 * head.abs().max().item() + 1e-3 * ref / math.sqrt(p.numel()) + 1e-7:
-                bad.append((k, "head", err, head.abs().max().item()))
+    close(preds[0][:, :, ::s, ::s], g["first"], tol["pred"], rtol=0.0, what="first prediction")
+    close(preds[-1][:, :, ::s, ::s], g["last"], tol["pred"], rtol=0.0, what="last prediction")
+    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"], skip=skip)
     assert not bad, bad[:8]
 
 
@@ -374,24 +361,149 @@ def test_l2l_two_phase_forward_and_grads(precision):
         m(im1, im2, iters=iters)
     preds = m(im1, im2, ci1, ci2, torch.tensor([ox] * B), torch.tensor([oy] * B), iters=iters)
     assert len(preds) == iters and all(tuple(p.shape) == (B, 2, h, w) for p in preds)
+    tol = TRAIN_TOL[precision]
     loss = O.sequence_loss_zero_gt(preds)
-    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (loss.item(), float(g["loss"]))
+    rel_check(loss.item(), g["loss"], tol["loss"], "loss")
     loss.backward()
-    tol = 1e-3 if precision == "exact" else 4e-3
-    close(preds[iters // 2 - 1][:, :, ::2, ::2], g["mid"], tol, what="last student prediction")
-    close(preds[-1][:, :, ::2, ::2], g["last"], tol, what="last supervisor prediction")
-    bad = []
-    for k, p in m.named_parameters():
-        ref = float(g["gnorm." + k])
-        gn = 0.0 if p.grad is None else p.grad.norm().item()
-        if abs(gn - ref) > 5e-3 * max(ref, 1e-6) + 1e-6:
-            bad.append((k, gn, ref))
+    close(preds[iters // 2 - 1][:, :, ::2, ::2], g["mid"], tol["pred"], rtol=0.0, what="last student prediction")
+    close(preds[-1][:, :, ::2, ::2], g["last"], tol["pred"], rtol=0.0, what="last supervisor prediction")
+    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"], hprefix=None)
     assert not bad, bad[:8]
     m.eval()
     with torch.no_grad():
         low, up = m(im1, im2, iters=iters, test_mode=True)
     assert O.epe(low.cpu(), T(g["test_low"])).item() <= 1e-3
     assert O.epe(up[:, :, ::2, ::2].cpu(), T(g["test_up"])).item() <= 1e-3
+
+
+
+def _recipe_sample(g, tag, seed):
+    """Inputs of tests/golden/make_golden.py::l2l_recipe_inputs, regenerated."""
+    H, W, h, w = (int(g[k]) for k in ("H", "W", "h", "w"))
+    sd = seed + (1 if tag == "sup" else 5)
+    oy, ox = int(g[tag + "_oy"]), int(g[tag + "_ox"])
+    ci1, ci2 = synthetic_pair(1, H, W, sd)
+    im1 = (ci1[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), sd + 1, 3.0)).clamp(0, 255).contiguous()
+    im2 = (ci2[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), sd + 2, 3.0)).clamp(0, 255).contiguous()
+    flow = rand_tensor((1, 2, h, w), sd + 3, 4.0)
+    valid = (rand_uniform((1, h, w), sd + 4, 0.0, 1.0) > 0.1).float()
+    return tuple(t.to(DEV) for t in (im1, im2, ci1, ci2)) + (ox, oy, flow.to(DEV), valid.to(DEV))
+
+
+@pytest.mark.parametrize("tag", ["basic", "gma"])
+def test_flow_supervisor_step_at_the_reference_recipe(tag, precision):
+    """VERDICT r2 next #3: the optimisation step the reference repo exists for, at its own operating point
+    (train_semi.sh:3-11: batch 1, crop 368x768 inside the 432x1024 frame, 12 student + 12 supervisor iterations), against
+    the reference's L2L / GMAL2L run on the same inputs (tests/golden/l2l_recipe_*.npz): labelled pass with sequence_loss,
+    unlabelled pass with sequence_loss_unsup, gradients of both passes accumulated through FlatGradients' two-pass
+    buckets exactly as train.SemiTrainStep does.  Checked: both losses, student / supervisor predictions at iterations
+    0, 11, 12, 23, every parameter-gradient norm and head after the labelled pass and after both (update_block AND
+    grad_update_block; for GMAL2L the second half stays on update_block and grad_update_block gets none)."""
+    from flow_supervisor_amd.parallel import FlatGradients
+    from flow_supervisor_amd.train import sequence_loss, sequence_loss_unsup
+    g = load("l2l_recipe_" + tag)
+    seed = int(g["seed"])
+    if tag == "basic":
+        from flow_supervisor_amd.core.l2l import L2L
+        m = L2L(ns(False))
+    else:
+        from flow_supervisor_amd.core.gma_l2l import GMAL2L
+        m = GMAL2L(gma_ns())
+    sd = procedural_state_dict(shapes("l2l_recipe_" + tag), seed)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rel_ind" in k for k in missing), (missing, unexpected)
+    if tag == "gma":
+        with torch.no_grad():
+            m.update_block.aggregator.gamma.fill_(0.1)
+    m = m.to(DEV).train()
+    m.freeze_bn()
+    tol = TRAIN_TOL[precision]
+    named = list(m.named_parameters())
+    grads = FlatGradients([p for _, p in named], [n for n, _ in named])
+    grads.begin(backward_passes=2)
+    skip = ("pos_emb",)
+    for which in ("sup", "unsup"):
+        im1, im2, ci1, ci2, ox, oy, flow, valid = _recipe_sample(g, which, seed)
+        preds = m(im1, im2, ci1, ci2, ox, oy, iters=24, supervisor_grad=which == "sup")
+        assert len(preds) == 24 and all(tuple(p.shape) == (1, 2, 368, 768) for p in preds)
+        if which == "sup":
+            loss, metrics = sequence_loss(preds, flow, valid, float(g["gamma"]))
+        else:
+            loss, metrics = sequence_loss_unsup(preds, flow, valid, unsup_weight=float(g["unsup_lambda"]))
+        rel_check(loss.item(), g[which + "_loss"], tol["loss"], which + " loss")
+        rel_check(metrics["epe"], g[which + "_epe"], 1e-4, which + " epe metric")
+        for i in (0, 11, 12, 23):
+            close(preds[i][:, :, ::4, ::4], g[f"{which}_pred{i}"], tol["pred"], rtol=0.0, what=f"{which} prediction {i}")
+        loss.backward()
+        del preds
+        if which == "sup":
+            # gradients of the first pass alone (autograd's own tensors at this point: the buckets wait for the second pass)
+            bad = grad_digest_check(named, g, tol["gnorm"], tol["ghead"], prefix="gnorm_sup.", hprefix="ghead_sup.", skip=skip)
+            assert not bad, ("after the labelled pass", bad[:8])
+    grads.finish()
+    bad = grad_digest_check(named, g, tol["gnorm"], tol["ghead"], skip=skip)
+    assert not bad, ("after both passes", bad[:8])
+    if tag == "gma":
+        assert all(p in grads.missing for n, p in named if n.startswith("grad_update_block."))
+
+
+def test_chairs_batch8_train_step(precision):
+    """BASELINE.json config 2 at its own batch size (8 pairs, 368x496; VERDICT r2 weak #2), 3 iterations, fwd + bwd."""
+    g = load("train_step_basic_368x496_b8")
+    seed = int(g["seed"])
+    m = _model(False, seed).train()
+    m.freeze_bn()
+    im1, im2 = synthetic_pair(int(g["B"]), int(g["H"]), int(g["W"]), seed + 1)
+    preds = m(im1.to(DEV), im2.to(DEV), iters=int(g["iters"]))
+    _check_train_digest(m, preds, g, precision)
+
+
+def test_sequence_loss_unsup_vs_reference_function():
+    """train.sequence_loss_unsup (the fused loss kernel with the supervisor's last prediction as target) against outputs of
+    the reference's sequence_loss_unsup (pytorch/train.py:99-129): loss, metrics, d loss / d prediction (zero for the
+    supervisor's half and for the pseudo label)."""
+    from flow_supervisor_amd.train import sequence_loss_unsup
+    g = load("sequence_loss_unsup")
+    for name in ("a", "b"):
+        B, H, W, n, seed = (int(v) for v in g[name + "_cfg"])
+        gamma, lam = (float(v) for v in g[name + "_gamma"])
+        preds = [rand_tensor((B, 2, H, W), seed + 10 + i, 3.0).to(DEV).requires_grad_(True) for i in range(n)]
+        gt = rand_tensor((B, 2, H, W), seed + 1, 4.0).to(DEV)
+        valid = (rand_uniform((B, H, W), seed + 2, 0.0, 1.0) > 0.2).float()
+        valid[:, 2, 2] = 0.5
+        loss, metrics = sequence_loss_unsup(preds, gt, valid.to(DEV), gamma, lam)
+        loss.backward()
+        rel_check(loss.item(), g[name + "_loss"], 2e-6, f"unsup loss {name}")
+        for k, r in zip(("epe", "1px", "3px", "5px"), g[name + "_metrics"]):
+            assert abs(metrics[k] - float(r)) <= 1e-5 + 1e-5 * abs(float(r)), (name, k, metrics[k], float(r))
+        for i, p in enumerate(preds):
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            close(got, g[f"{name}_dpred{i}"], 1e-9, 1e-5, what=f"unsup dpred{i}")
+
+
+def test_test_mode_skips_the_dropped_upsamples_with_identical_outputs():
+    """VERDICT r2 next #9: test_mode returns only the last flow_up (raft.py:141-142); the mask convolution and the upsampler of
+    the other iterations are skipped.  Outputs must equal the last training-mode prediction of the same weights bit for bit
+    (same kernels, same inputs), and the update block must have produced no mask on the skipped iterations."""
+    torch.manual_seed(1)
+    m = _model(False, 55).eval()
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(1, 128, 192, 56))
+    calls = []
+    orig = m.update_block.forward_cl
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        calls.append(out[1] is not None)
+        return out
+    m.update_block.forward_cl = spy
+    with torch.no_grad():
+        low, up = m(im1, im2, iters=5, test_mode=True)
+        assert calls == [False] * 4 + [True]
+        calls.clear()
+        preds = m(im1, im2, iters=5)
+        assert calls == [True] * 5
+    assert torch.equal(up, preds[-1])
+    assert tuple(low.shape) == (1, 2, 16, 24)
 
 
 # ----------------------------------------------------------------------------- GMA (row a11, config 5)
@@ -498,18 +610,12 @@ def test_gma_train_step_loss_and_grads(precision):
     m.freeze_bn()
     im1, im2 = synthetic_pair(2, int(g["H"]), int(g["W"]), seed + 1)
     preds = m(im1.to(DEV), im2.to(DEV), iters=int(g["iters"]))
+    tol = TRAIN_TOL[precision]
     loss = O.sequence_loss_zero_gt(preds)
-    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (loss.item(), float(g["loss"]))
+    rel_check(loss.item(), g["loss"], tol["loss"], "loss")
     loss.backward()
-    close(preds[-1], g["last"], 1e-3, what="last prediction")
-    bad = []
-    for k, p in m.named_parameters():
-        if "pos_emb" in k:
-            continue
-        ref = float(g["gnorm." + k])
-        gn = 0.0 if p.grad is None else p.grad.norm().item()
-        if abs(gn - ref) > 5e-3 * max(ref, 1e-6) + 1e-6:
-            bad.append((k, gn, ref))
+    close(preds[-1], g["last"], tol["pred"], rtol=0.0, what="last prediction")
+    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"], hprefix=None, skip=("pos_emb",))
     assert not bad, bad[:8]
 
 
@@ -1623,12 +1729,13 @@ def test_hipgraph_replays_of_the_train_step_follow_the_eager_steps():
 
 
 # ----------------------------------------------------------------------------- data parallelism on the real step (row e)
-@pytest.mark.parametrize("global_batch", [4, 3])
-def test_two_process_train_step_matches_single_process(global_batch, tmp_path):
+@pytest.mark.parametrize("global_batch,H,W,iters", [(4, 128, 192, 3), (3, 128, 192, 3), (2, 440, 1024, 12)])
+def test_two_process_train_step_matches_single_process(global_batch, H, W, iters, tmp_path):
     """Two fresh processes (tests/_dp_worker.py), each running the real TrainStep on its shard of `global_batch` pairs at
     128x192 x 3 iterations and exchanging the flat gradient (gloo staged through the host: both ranks sit on cuda:0),
     against one process on the whole batch: reduced + clipped flat gradient and post-AdamW weights.  global_batch = 3
-    gives shards of 2 and 1 (gradients weighted by local / global batch)."""
+    gives shards of 2 and 1 (gradients weighted by local / global batch); the third case is the benchmark's own shape and
+    iteration count with one pair per rank."""
     import os
     import socket
     import subprocess
@@ -1637,14 +1744,15 @@ def test_two_process_train_step_matches_single_process(global_batch, tmp_path):
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     out = str(tmp_path / "r0.pt")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(global_batch), out]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(global_batch), out, str(H), str(W), str(iters)])
+             for r in range(2)]
     rcs = [p.wait(timeout=900) for p in procs]
     assert rcs == [0, 0], rcs
     got = torch.load(out)
     m = _model(False, 650).train()
     m.freeze_bn()
-    im1, im2 = (t.to(DEV) for t in synthetic_pair(global_batch, 128, 192, 651))
-    step = TrainStep(m, lr=1e-4, iters=3)
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(global_batch, H, W, 651))
+    step = TrainStep(m, lr=1e-4, iters=iters)
     loss = step(im1, im2)
     ref_g = step.grads.flat.cpu()
     ref_p = torch.cat([p.detach().reshape(-1).cpu() for p in step.grads.params])
@@ -1653,6 +1761,48 @@ def test_two_process_train_step_matches_single_process(global_batch, tmp_path):
     print("dp2 vs single: grad rel", rel_g, "param rel", rel_p, "loss(rank 0 shard)", got["loss"], "loss(all)", float(loss))
     assert rel_g <= 2e-3, rel_g          # split-bf16 products + a different summation order over the batch
     assert rel_p <= 2e-4, rel_p          # one AdamW step of lr 1e-4: where a gradient is ~0 its sign, hence the update, can differ
+
+
+def test_rccl_exchange_at_world_size_one(tmp_path):
+    """VERDICT r2 next #4 / ADVICE r2: the asynchronous bucket all-reduces issued from the backward hooks had only ever run
+    through gloo.  A fresh process (tests/_rccl_worker.py) initialises the nccl (= RCCL) backend with one rank, forces the
+    collectives on (FSRAFT_DP_FORCE_COLLECTIVE=1) and runs three real TrainSteps: RCCL's stream ordering against the
+    hook-time copies and against clip + AdamW is what N > 1 ranks execute, and a sum over one rank is the identity, so
+    gradients and weights must follow the no-collective run (to the run-to-run noise of the atomics in the weight
+    gradients).  What one rank cannot show is a data race that only corrupts values when a peer contributes; what it does
+    show is that the API sequence (async work handles from autograd's hook thread, wait() before the optimizer, capture)
+    runs on RCCL.  The same worker captures a step WITH the
+    collectives in a hipGraph and replays it: bench.py enables graphs at N > 1 only because this passes (if RCCL refuses
+    capture on some stack the worker records the failure mode and the test reports it)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    out = str(tmp_path / "rccl.json")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rc = subprocess.run([sys.executable, worker, str(port), out], env=env, timeout=900).returncode
+    assert rc == 0, rc
+    res = json.load(open(out))
+    print("rccl world-1:", json.dumps(res))
+    assert res["backend"] == "nccl"
+    # (not bit-equal even without a collective: the weight gradients add with fp32 atomics, so two runs of the same three
+    #  steps differ in the last bits and AdamW amplifies sign flips of ~0 gradients)
+    assert res["eager"]["grad_rel"] <= 2e-3 and res["eager"]["param_rel"] <= 2e-4, res["eager"]
+    assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(res["eager"]["losses_plain"], res["eager"]["losses_rccl"])), res["eager"]
+    assert res["eager_unbucketed"]["grad_rel"] <= 2e-3 and res["eager_unbucketed"]["param_rel"] <= 2e-4, res["eager_unbucketed"]
+    log = os.environ.get("FSRAFT_RCCL_LOG")
+    if log:
+        with open(log, "w") as f:
+            json.dump(res, f, indent=1)
+    if res["graph"]["ok"]:
+        # replays re-run the same kernels on the same buffers; atomics in the weight gradients reorder sums
+        assert res["graph"]["param_rel_vs_eager"] <= 2e-4, res["graph"]
+        assert all(r <= 2e-3 for r in res["graph"]["loss_rel_vs_eager"]), res["graph"]
+    else:
+        pytest.xfail("hipGraph capture of a step containing RCCL all-reduces failed: " + res["graph"]["error"])
 
 
 def test_nchw_entry_does_not_reuse_context_of_a_freed_tensor():

@@ -247,3 +247,88 @@ def test_sequence_loss_restatement_vs_reference_function():
             assert abs(metrics[k] - float(r)) <= 1e-6 + 1e-6 * abs(float(r)), (name, k)
         for i, p in enumerate(preds):
             close(p.grad, g[f"{name}_dpred{i}"], 1e-9, 1e-5)
+
+
+# ----------------------------------------------------------------------------- flow-supervisor (L2L) restatement
+def _l2l_grad_sd(shapes, seed, gma=False):
+    sd = procedural_state_dict(shapes, seed)
+    if gma:
+        sd["update_block.aggregator.gamma"] = torch.full((1,), 0.1)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    return sd
+
+
+def test_l2l_two_phase_forward_and_grads():
+    """oracle.l2l_forward against the reference's own L2L (tests/golden/l2l_basic.npz: 160x256 frame, 128x192 crop, 3 + 3
+    iterations, loss, student / supervisor predictions, every parameter-gradient norm incl. grad_update_block's)."""
+    g = load("l2l_basic")
+    shapes = json.load(open(os.path.join(G, "l2l_basic_shapes.json")))
+    seed, H, W, h, w, oy, ox, iters, B = (int(g[k]) for k in ("seed", "H", "W", "h", "w", "oy", "ox", "iters", "B"))
+    sd = _l2l_grad_sd(shapes, seed)
+    ci1, ci2 = synthetic_pair(B, H, W, seed + 1)
+    im1 = ci1[:, :, oy:oy + h, ox:ox + w].contiguous()
+    im2 = ci2[:, :, oy:oy + h, ox:ox + w].contiguous()
+    preds = O.l2l_forward(sd, im1, im2, ci1, ci2, [ox] * B, [oy] * B, iters=iters)
+    loss = O.sequence_loss_zero_gt(preds)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    close(preds[iters // 2 - 1][:, :, ::2, ::2], g["mid"], 2e-4)
+    close(preds[-1][:, :, ::2, ::2], g["last"], 2e-4)
+    loss.backward()
+    bad = []
+    for k in g:
+        if k.startswith("gnorm."):
+            gr = sd[k[6:]].grad
+            gn, ref = (0.0 if gr is None else gr.norm().item()), float(g[k])
+            if abs(gn - ref) > 1e-3 * max(ref, 1e-6) + 1e-7:
+                bad.append((k, gn, ref))
+    assert not bad, bad[:5]
+
+
+def test_sequence_loss_unsup_restatement_vs_reference_function():
+    from oracle.weights import rand_uniform
+    g = load("sequence_loss_unsup")
+    for name in ("a", "b"):
+        B, H, W, n, seed = (int(v) for v in g[name + "_cfg"])
+        gamma, lam = (float(v) for v in g[name + "_gamma"])
+        preds = [rand_tensor((B, 2, H, W), seed + 10 + i, 3.0).requires_grad_(True) for i in range(n)]
+        gt = rand_tensor((B, 2, H, W), seed + 1, 4.0)
+        valid = (rand_uniform((B, H, W), seed + 2, 0.0, 1.0) > 0.2).float()
+        valid[:, 2, 2] = 0.5
+        loss, metrics = O.sequence_loss_unsup(preds, gt, valid, gamma, lam)
+        loss.backward()
+        ref = float(g[name + "_loss"])
+        assert abs(loss.item() - ref) <= 1e-6 * abs(ref), (name, loss.item(), ref)
+        for k, r in zip(("epe", "1px", "3px", "5px"), g[name + "_metrics"]):
+            assert abs(metrics[k] - float(r)) <= 1e-6 + 1e-6 * abs(float(r)), (name, k)
+        for i, p in enumerate(preds):
+            close(p.grad if p.grad is not None else torch.zeros_like(p), g[f"{name}_dpred{i}"], 1e-9, 1e-5)
+
+
+@pytest.mark.parametrize("tag", ["basic", "gma"])
+def test_l2l_recipe_scale_forward(tag):
+    """The labelled pass of the flow-supervisor step at the reference recipe's size (B = 1, crop 368x768 in a 432x1024 frame,
+    12 + 12 iterations; tests/golden/l2l_recipe_*.npz hold the reference's outputs): the oracle's forward and sequence_loss
+    (forward only here -- the CPU suite stays in minutes; the backward of this restatement is pinned at the small size above
+    and the GPU suite checks every gradient norm of the fixture)."""
+    from oracle.weights import rand_uniform
+    g = load("l2l_recipe_" + tag)
+    shapes = json.load(open(os.path.join(G, f"l2l_recipe_{tag}_shapes.json")))
+    seed, H, W, h, w = (int(g[k]) for k in ("seed", "H", "W", "h", "w"))
+    sd = procedural_state_dict(shapes, seed)
+    if tag == "gma":
+        sd["update_block.aggregator.gamma"] = torch.full((1,), 0.1)
+    oy, ox, s = int(g["sup_oy"]), int(g["sup_ox"]), seed + 1
+    ci1, ci2 = synthetic_pair(1, H, W, s)
+    im1 = (ci1[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), s + 1, 3.0)).clamp(0, 255).contiguous()
+    im2 = (ci2[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), s + 2, 3.0)).clamp(0, 255).contiguous()
+    flow = rand_tensor((1, 2, h, w), s + 3, 4.0)
+    valid = (rand_uniform((1, h, w), s + 4, 0.0, 1.0) > 0.1).float()
+    with torch.no_grad():
+        preds = O.l2l_forward(sd, im1, im2, ci1, ci2, [ox], [oy], iters=24, gma=tag == "gma")
+        loss, metrics = O.sequence_loss(preds, flow, valid, float(g["gamma"]))
+    np.testing.assert_allclose(loss.item(), float(g["sup_loss"]), rtol=2e-5)
+    for i in (0, 11, 12, 23):
+        e = O.epe(preds[i][:, :, ::4, ::4], T(g[f"sup_pred{i}"])).item()
+        assert e < 2e-4, (i, e)
