@@ -207,10 +207,13 @@ def main():
                                         alternate_corr=a.variant == "alt")).to(dev).train()
     model.freeze_bn()                                 # pytorch/train.py:203-204
     broadcast_parameters(model)
-    # One rank: the whole step is captured in a hipGraph and replayed -- 41.9 ms against 43.9 ms eager on the same box (866
-    # launches per step; the gaps between dependent kernels of one stream are what the graph removes).  Several ranks stay
-    # eager: a graph capture that contains the RCCL all-reduce could not be exercised on the one-GPU boxes this was built on.
-    use_graph = a.graph == 1 or (a.graph == -1 and world == 1)
+    # The whole step is captured in a hipGraph and replayed -- 41.9 ms against 43.9 ms eager on the same box at one rank (866
+    # launches per step; the gaps between dependent kernels of one stream are what the graph removes, and with eight ranks on
+    # one host also eight Python threads competing for cores).  Several ranks: the capture then contains the RCCL bucket
+    # all-reduces issued from the backward hooks; tests/_rccl_worker.py captures and replays exactly that on the nccl backend
+    # (profiles/r03_rccl_world1.json).  Every rank reports whether its capture succeeded and all fall back to eager steps
+    # together if any failed (FSRAFT_BENCH_GRAPH_MULTI=0 keeps several ranks eager).
+    use_graph = a.graph == 1 or (a.graph == -1 and (world == 1 or os.environ.get("FSRAFT_BENCH_GRAPH_MULTI", "1") != "0"))
     # lr: a small constant (the reference's recipes: AdamW + StepLR(num_steps // 5, 0.5), pytorch/train.py:134-141, with
     # --lr 5e-6 .. 4e-4); throughput does not depend on it, the loss of synthetic steps stays finite with it
     B = a.batch_per_gpu
@@ -267,6 +270,10 @@ def main():
             print(f"bench: graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graph, loss, graph_note = None, None, f"eager (graph capture failed: {type(e).__name__})"
             torch.cuda.synchronize()
+        if world > 1:                                # consensus: replays and eager steps must not be mixed across ranks
+            ok_all = -max_over_ranks(-(1.0 if graph is not None else 0.0), dev)
+            if ok_all < 1.0 and graph is not None:
+                graph, loss, graph_note = None, None, "eager (graph capture failed on another rank)"
     if graph is None:
         for _ in range(a.warmup if not use_graph else 0):
             step(im1, im2)

@@ -44,35 +44,42 @@ def _log_margin(what, err, lim, detail):
             f.write(f"{test}\t{what}\terr {err:.3e}\tlimit {lim:.3e} ({detail})\tused {err / lim if lim else 0:.3f}\n")
 
 
-def grad_digest_check(named_params, g, rtol_norm, rtol_head, prefix="gnorm.", hprefix="ghead.", skip=(), atol_norm=1e-5):
+def grad_digest_check(named_params, g, tol, prefix="gnorm.", hprefix="ghead.", skip=(), atol_norm=1e-5):
     """Every parameter-gradient norm (and, where the fixture has it, the first 32 elements) against a reference-generated
-    digest.  norm: |ours - ref| <= rtol_norm * ref + atol_norm (atol: biases in front of InstanceNorm have a zero gradient in
-    exact arithmetic and ~1e-6 of rounding noise in the reference); head: max abs error <= rtol_head * max|head| + the
-    share of rtol_norm * ref one element carries.  The worst margins go to the parity log.  Returns the offenders."""
+    digest.  tol: dict(gnorm, ghead, gnorm_fnet, ghead_fnet) -- the feature encoder's gradients pass through InstanceNorm
+    and the volume backward and carry ~1e-3 of summation-order noise in the REFERENCE itself (scripts/encoder_grad_noise.py),
+    so `fnet.*` has its own, wider pair of limits; everything else (update blocks, context encoder, GMA attention) is held
+    to the tighter pair.  norm: |ours - ref| <= rtol * ref + atol_norm (atol: biases in front of InstanceNorm have a zero
+    gradient in exact arithmetic and ~1e-6 of rounding noise in the reference); head: max abs error <= rtol_head *
+    max|head| + the share of rtol * ref one element carries.  The worst margin of each group goes to the parity log.
+    Returns the offenders."""
     import math
-    bad, worst_n, worst_h = [], (0.0, ""), (0.0, "")
+    bad = []
+    worst = {}
     for k, p in named_params:
         if any(t in k for t in skip) or prefix + k not in g:
             continue
+        grp = "fnet" if k.startswith("fnet.") else "rest"
+        rn, rh = (tol["gnorm_fnet"], tol["ghead_fnet"]) if grp == "fnet" else (tol["gnorm"], tol["ghead"])
         ref = float(g[prefix + k])
         gn = 0.0 if p.grad is None else p.grad.norm().item()
-        lim = rtol_norm * max(ref, 1e-6) + atol_norm
+        lim = rn * max(ref, 1e-6) + atol_norm
         err = abs(gn - ref)
-        if err / lim > worst_n[0]:
-            worst_n = (err / lim, f"{k}: {gn:.6g} vs {ref:.6g}")
+        if err / lim >= worst.get(("n", grp), (-1.0,))[0]:
+            worst[("n", grp)] = (err / lim, rn, f"{k}: {gn:.6g} vs {ref:.6g}")
         if not err <= lim:
             bad.append((k, "norm", gn, ref))
         if hprefix and hprefix + k in g and p.grad is not None and ref > 1e-4:
             head = T(g[hprefix + k]).float()
             herr = (p.grad.reshape(-1)[:32].cpu() - head).abs().max().item()
-            hlim = rtol_head * head.abs().max().item() + rtol_norm * ref / math.sqrt(p.numel()) + 1e-7
-            if herr / hlim > worst_h[0]:
-                worst_h = (herr / hlim, k)
+            hlim = rh * head.abs().max().item() + rn * ref / math.sqrt(p.numel()) + 1e-7
+            if herr / hlim >= worst.get(("h", grp), (-1.0,))[0]:
+                worst[("h", grp)] = (herr / hlim, rh, k)
             if not herr <= hlim:
                 bad.append((k, "head", herr, head.abs().max().item()))
-    _log_margin(f"{prefix}* worst ({worst_n[1]})", worst_n[0] * rtol_norm, rtol_norm, "relative to the reference norm")
-    if hprefix:
-        _log_margin(f"{hprefix}* worst ({worst_h[1]})", worst_h[0] * rtol_head, rtol_head, "relative to max|head|")
+    for (kind, grp), (used, r, what) in sorted(worst.items()):
+        _log_margin(f"{prefix if kind == 'n' else hprefix}* worst of {grp} ({what})", used * r, r,
+                    "relative to the reference norm" if kind == "n" else "relative to max|head|")
     return bad
 
 

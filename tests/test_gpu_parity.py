@@ -21,8 +21,8 @@ DEV = "cuda"
 # Limits of the train-step comparisons, per arithmetic mode: (loss rel, prediction abs [px], gradient-norm rel, gradient-head rel).
 # Set to ~4x the worst error measured on MI355X over the whole suite (profiles/r03_parity_margins.txt lists every comparison
 # with the share of its limit it used); round 2 ran these checks at 1e-4 / 4e-3 / 5e-3 / 2e-2.
-TRAIN_TOL = {"exact": dict(loss=2e-5, pred=1e-3, gnorm=5e-3, ghead=2e-2),
-             "split": dict(loss=1e-4, pred=4e-3, gnorm=5e-3, ghead=2e-2)}
+TRAIN_TOL = {"exact": dict(loss=2e-5, pred=1e-3, gnorm=5e-3, ghead=2e-2, gnorm_fnet=5e-3, ghead_fnet=2e-2),
+             "split": dict(loss=1e-4, pred=4e-3, gnorm=5e-3, ghead=2e-2, gnorm_fnet=5e-3, ghead_fnet=2e-2)}
 
 
 @pytest.fixture(params=["exact", "split"])
@@ -306,7 +306,7 @@ def test_train_step_loss_and_grads(tag, precision):
     rel_check(loss.item(), g["loss"], tol["loss"], "loss")
     loss.backward()
     close(preds[-1], g["last"], tol["pred"], rtol=0.0, what="last prediction")
-    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"])
+    bad = grad_digest_check(m.named_parameters(), g, tol)
     assert not bad, bad[:8]
 
 
@@ -319,7 +319,7 @@ def _check_train_digest(m, preds, g, precision, skip=()):
     s = int(g["stride"])
     close(preds[0][:, :, ::s, ::s], g["first"], tol["pred"], rtol=0.0, what="first prediction")
     close(preds[-1][:, :, ::s, ::s], g["last"], tol["pred"], rtol=0.0, what="last prediction")
-    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"], skip=skip)
+    bad = grad_digest_check(m.named_parameters(), g, tol, skip=skip)
     assert not bad, bad[:8]
 
 
@@ -367,7 +367,7 @@ def test_l2l_two_phase_forward_and_grads(precision):
     loss.backward()
     close(preds[iters // 2 - 1][:, :, ::2, ::2], g["mid"], tol["pred"], rtol=0.0, what="last student prediction")
     close(preds[-1][:, :, ::2, ::2], g["last"], tol["pred"], rtol=0.0, what="last supervisor prediction")
-    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"], hprefix=None)
+    bad = grad_digest_check(m.named_parameters(), g, tol, hprefix=None)
     assert not bad, bad[:8]
     m.eval()
     with torch.no_grad():
@@ -438,13 +438,14 @@ def test_flow_supervisor_step_at_the_reference_recipe(tag, precision):
         del preds
         if which == "sup":
             # gradients of the first pass alone (autograd's own tensors at this point: the buckets wait for the second pass)
-            bad = grad_digest_check(named, g, tol["gnorm"], tol["ghead"], prefix="gnorm_sup.", hprefix="ghead_sup.", skip=skip)
+            bad = grad_digest_check(named, g, tol, prefix="gnorm_sup.", hprefix="ghead_sup.", skip=skip)
             assert not bad, ("after the labelled pass", bad[:8])
     grads.finish()
-    bad = grad_digest_check(named, g, tol["gnorm"], tol["ghead"], skip=skip)
+    bad = grad_digest_check(named, g, tol, skip=skip)
     assert not bad, ("after both passes", bad[:8])
     if tag == "gma":
-        assert all(p in grads.missing for n, p in named if n.startswith("grad_update_block."))
+        miss = {id(p) for p in grads.missing}
+        assert all(id(p) in miss for n, p in named if n.startswith("grad_update_block."))
 
 
 def test_chairs_batch8_train_step(precision):
@@ -483,8 +484,9 @@ def test_sequence_loss_unsup_vs_reference_function():
 
 def test_test_mode_skips_the_dropped_upsamples_with_identical_outputs():
     """test_mode returns only the last flow_up (raft.py:141-142); the mask convolution and the upsampler of
-    the other iterations are skipped.  Outputs must equal the last training-mode prediction of the same weights bit for bit
-    (same kernels, same inputs), and the update block must have produced no mask on the skipped iterations."""
+    the other iterations are skipped.  Outputs must equal the last training-mode prediction of the same weights (same kernels,
+    same inputs; to the run-to-run noise of the encoders' atomically accumulated InstanceNorm statistics, ~1e-5), and the
+    update block must have produced no mask on the skipped iterations."""
     torch.manual_seed(1)
     m = _model(False, 55).eval()
     im1, im2 = (t.to(DEV) for t in synthetic_pair(1, 128, 192, 56))
@@ -502,7 +504,7 @@ def test_test_mode_skips_the_dropped_upsamples_with_identical_outputs():
         calls.clear()
         preds = m(im1, im2, iters=5)
         assert calls == [True] * 5
-    assert torch.equal(up, preds[-1])
+    close(up, preds[-1], 1e-4, rtol=0.0, what="test_mode flow_up vs last training-mode prediction")
     assert tuple(low.shape) == (1, 2, 16, 24)
 
 
@@ -615,7 +617,7 @@ def test_gma_train_step_loss_and_grads(precision):
     rel_check(loss.item(), g["loss"], tol["loss"], "loss")
     loss.backward()
     close(preds[-1], g["last"], tol["pred"], rtol=0.0, what="last prediction")
-    bad = grad_digest_check(m.named_parameters(), g, tol["gnorm"], tol["ghead"], hprefix=None, skip=("pos_emb",))
+    bad = grad_digest_check(m.named_parameters(), g, tol, hprefix=None, skip=("pos_emb",))
     assert not bad, bad[:8]
 
 
