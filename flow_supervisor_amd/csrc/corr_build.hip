@@ -395,9 +395,19 @@ using BR = RecCfg<256, 128, 4, 2>;
 constexpr int BR_PH = 8, BR_PW = 16;                       // the target patch
 constexpr int BR_EPI_FLOATS = 128 * 128 + 128 * 32 + 128 * 8;
 
+// stagger: every CU runs one workgroup at a time and all of them take the same time, so the whole chip alternates between a
+// phase in which nothing is stored and a phase in which 45 MB are; workgroups of the first dispatch round with an odd index
+// sleep `stagger` x 64 x 127 cycles first, which puts their CUs half a period out of step with the others for the whole launch.
+__device__ __forceinline__ void build_stagger(int stagger) {
+  const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (stagger > 0 && id < 256u && (id & 1u))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 __global__ __launch_bounds__(512) void corr_build_rec_kernel(const char* __restrict__ f1r, const char* __restrict__ f2r,
-                                                             float* __restrict__ vol, VolLayout L, int C, float scale) {
+                                                             float* __restrict__ vol, VolLayout L, int C, float scale, int stagger) {
   __shared__ __attribute__((aligned(1024))) char lds[BR::LDS_BYTES > BR_EPI_FLOATS * 4 ? BR::LDS_BYTES : BR_EPI_FLOATS * 4];
+  build_stagger(stagger);
   const int H = L.H, W = L.W, N = H * W;
   const int npx = ceil_div_dev(W, BR_PW);
   const int px0 = (blockIdx.x % npx) * BR_PW, py0 = (blockIdx.x / npx) * BR_PH;
@@ -523,6 +533,171 @@ __global__ __launch_bounds__(512) void corr_build_rec_kernel(const char* __restr
   }
 }
 
+// ---- the same build with the roles of the operands swapped: TARGETS on the MFMA's M (register) axis, QUERIES on its N
+// (lane) axis -- so that the finished tile leaves straight from the accumulators.  In the 32x32 accumulator layout a lane
+// owns one column and registers 4 j .. 4 j + 3 hold four consecutive rows: with the 256 targets of an 8x32 patch numbered
+// in tiled-row order ((8x8 block = wave row wm) (tile row mt) (tile column) (row of the tile) (cell)), those four rows are
+// the 16 contiguous bytes of one row of a 4x4 tile in the volume row of the lane's QUERY.  Every store instruction of the
+// epilogue writes 16 bytes per lane (the two half-waves write the two halves of a 32-byte run of each of 32 queries); the
+// pyramid levels are pooled in registers (v_permlane32_swap adds the two rows a half-wave pair holds and redistributes
+// whole tile rows), nothing is parked in LDS and no barrier follows the k-loop: the workgroup retires while its stores
+// drain and the next one starts staging on the same CU.  (Round 2's epilogue parked the tile in LDS in two halves with ten
+// barriers; measured 455-490 us against 210 us of store time and 171 us of MFMA time.)
+using BT = RecCfg<256, 128, 4, 2>;                         // 256 targets (M) x 128 queries (N), K = C
+constexpr int BT_PH = 8, BT_PW = 32;                       // the target patch
+
+__device__ __forceinline__ void swap32(float& a, float& b) {       // a.upper <-> b.lower (rows of 32 lanes)
+  // Inline asm, not __builtin_amdgcn_permlane32_swap: with the builtin hipcc (ROCm 7.2) SLP-packed the neighbouring adds
+  // and then consumed the FIRST result twice (`v_add_f32 v, r0, r0`) while the register of the second was reused -- every
+  // pooled level came out wrong (scripts/build_t_micro.py caught it).  The s_nop covers the VALU-write -> permlane-read
+  // hazard the assembler does not see inside an asm statement.
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// STAMP (experiment build only, scripts/build_stamps.py): lane 0 of wave 0 records s_memtime at the phase boundaries, the
+// constant-rate clock at both ends and the hardware id of its CU -- where a workgroup's 20 us go, and what its CU ran before.
+template <bool STAMP>
+__global__ __launch_bounds__(512) void corr_build_rec_t_kernel(const char* __restrict__ f1r, const char* __restrict__ f2r,
+                                                               float* __restrict__ vol, VolLayout L, int C, float scale, int stagger,
+                                                               unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(1024))) char lds[BT::LDS_BYTES];
+  unsigned long long st[8];
+  if constexpr (STAMP) { st[0] = __builtin_amdgcn_s_memtime(); st[5] = __builtin_amdgcn_s_memrealtime(); }
+  build_stagger(STAMP ? (stagger & 63) : stagger);
+  const int H = L.H, W = L.W, N = H * W;
+  const int npx = ceil_div_dev(W, BT_PW);
+  const int px0 = (blockIdx.x % npx) * BT_PW, py0 = (blockIdx.x / npx) * BT_PH;
+  const int q0 = blockIdx.y * BT::BN;
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned pitch = (unsigned)C * 4u;
+  RecOperands<BT> o;
+  o.da = rec_desc(f2r + (int64_t)b * N * pitch, (unsigned)min((int64_t)N * pitch, (int64_t)0x7fffffff));
+  const int br = min(BT::BN, N - q0);
+  o.db = rec_desc(f1r + ((int64_t)b * N + q0) * pitch, (unsigned)br * pitch);
+  o.b_step = 128u;
+#pragma unroll
+  for (int j = 0; j < BT::NPB; ++j) o.vb[j] = rec_piece_voff(wave + BT::NWAVE * j, lane, br, pitch);
+  RecPlainA<BT> pa;
+#pragma unroll
+  for (int j = 0; j < BT::NPA; ++j) {                      // tile row m = target in tiled-row order of the patch
+    const int m = (wave + BT::NWAVE * j) * 8 + (lane >> 3);
+    const int i32 = m & 31;
+    const int y = py0 + 4 * ((m >> 5) & 1) + ((i32 >> 2) & 3), x = px0 + 8 * (m >> 6) + 4 * (i32 >> 4) + (i32 & 3);
+    const int ls = (lane & 7) ^ ((m >> 1) & 7);
+    pa.va[j] = (y < H && x < W) ? (unsigned)(y * W + x) * pitch + (unsigned)ls * 16u : 0x80000000u;
+  }
+  pa.kt0 = 0; pa.step = 128u;
+  f32x16 acc[BT::TM][BT::TN];
+#pragma unroll
+  for (int a = 0; a < BT::TM; ++a)
+#pragma unroll
+    for (int c = 0; c < BT::TN; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  if constexpr (STAMP) st[1] = __builtin_amdgcn_s_memtime();
+  rec_mainloop<BT>(lds, o, pa, 0, C / 32, acc);
+  if constexpr (STAMP) st[2] = __builtin_amdgcn_s_memtime();
+
+  // ---- epilogue, from registers.  Lane (l31, lh) of wave (wm, wn): query q0 + 64 wn + 32 nt + l31; accumulator register
+  // 4 j + e of tile mt is target (tile row mt, tile column j >> 1, row lh + 2 (j & 1) of the tile, cell e) of 8x8 block wm.
+  const int wm = wave / BT::WN, wn = wave % BT::WN, l31 = lane & 31, lh = lane >> 5;
+  const int nlev = L.nlev;
+  const int bx0 = px0 + 8 * wm;                            // the wave's 8x8 block of targets: (py0, bx0)
+#pragma unroll
+  for (int nt = 0; nt < BT::TN; ++nt) {
+    const int q = q0 + wn * 64 + nt * 32 + l31;
+    const bool qok = q < N && !(STAMP && (stagger & 64));        // (stamp build: bit 6 of `stagger` = ablate the stores)
+    float* row = vol + ((int64_t)b * N + (qok ? q : 0)) * L.P;
+    float l1v[2][4];                                       // level-1 cell (y1 = 2 mt + (j & 1), x1 = 2 (j >> 1) + lh)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int gty = (py0 >> 2) + mt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] * scale;
+        const int gtx = (bx0 >> 2) + (j >> 1);
+        if (qok && gty < L.th[0] && gtx < L.tw[0])
+          gstore4(row + L.off[0] + (gty * L.tw[0] + gtx) * 16 + (lh + 2 * (j & 1)) * 4, v);
+        float p0 = v[0] + v[1], p1 = v[2] + v[3];          // this lane's row of the two 2x2 cells; the partner half-wave has the other row
+        swap32(p0, p1);
+        l1v[mt][j] = (p0 + p1) * 0.25f;
+      }
+    }
+    if (nlev > 1) {
+      const int h1 = L.h[1], w1 = L.w[1];
+      const int gty = py0 >> 3, gtx = bx0 >> 3;            // the block is exactly one level-1 tile
+      float l2p[2][2];                                     // own half of level-2 cell (y2 = mt, x2 = tx)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        l2p[mt][0] = l1v[mt][0] + l1v[mt][1];
+        l2p[mt][1] = l1v[mt][2] + l1v[mt][3];
+        // cells beyond the floor-halved size do not exist in the reference pyramid: the tile's pad cells hold 0
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int y1 = (py0 >> 1) + 2 * mt + (j & 1), x1 = (bx0 >> 1) + 2 * (j >> 1) + lh;
+          r[j] = (y1 < h1 && x1 < w1) ? l1v[mt][j] : 0.f;
+        }
+        // rows a = 2 mt (j = 0, 2) and b = 2 mt + 1 (j = 1, 3): lower half-wave collects row a, upper row b
+        swap32(r[0], r[1]);
+        swap32(r[2], r[3]);
+        if (qok && gty < L.th[1] && gtx < L.tw[1])
+          gstore4(row + L.off[1] + (gty * L.tw[1] + gtx) * 16 + (2 * mt + lh) * 4, f32x4{r[0], r[1], r[2], r[3]});
+      }
+      if (nlev > 2) {
+        const int h2 = L.h[2], w2 = L.w[2];
+        float c0[2];                                       // level-2 cell (y2 = mt, x2 = lh)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          float a0 = l2p[mt][0], a1 = l2p[mt][1];
+          swap32(a0, a1);
+          c0[mt] = (a0 + a1) * 0.25f;
+        }
+        const int Y2 = py0 >> 2, X2 = bx0 >> 2;            // level-2 cells (Y2 + mt, X2 + lh); both even
+        float m0 = (Y2 < h2 && X2 + lh < w2) ? c0[0] : 0.f, m1 = (Y2 + 1 < h2 && X2 + lh < w2) ? c0[1] : 0.f;
+        swap32(m0, m1);                                    // lower half-wave: row Y2, cells X2, X2 + 1; upper: row Y2 + 1
+        const int gy = Y2 + lh;
+        if (qok && (gy >> 2) < L.th[2] && (X2 >> 2) < L.tw[2]) {
+          float* d = row + L.off[2] + ((gy >> 2) * L.tw[2] + (X2 >> 2)) * 16 + (gy & 3) * 4 + (X2 & 3);
+          gstore1(d, m0);
+          gstore1(d + 1, m1);
+        }
+        if (nlev > 3) {
+          float t0 = c0[0] + c0[1], t1 = t0;
+          swap32(t0, t1);
+          const float v3 = (t0 + t1) * 0.25f;
+          const int gy3 = py0 >> 3, gx3 = bx0 >> 3;
+          if (qok && lh == 0 && (gy3 >> 2) < L.th[3] && (gx3 >> 2) < L.tw[3])
+            gstore1(row + vol_cell(L, 3, gy3, gx3), (gy3 < L.h[3] && gx3 < L.w[3]) ? v3 : 0.f);
+        }
+      }
+    }
+  }
+  if constexpr (STAMP) {
+    st[3] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[4] = __builtin_amdgcn_s_memtime();
+    st[6] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    st[7] = (unsigned long long)hw | (unsigned long long)xcc << 32;
+    if (threadIdx.x == 0) {
+      const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stamps[(size_t)id * 8 + i] = st[i];
+    }
+  }
+}
+
+int g_build_stagger = 0;  // see build_stagger (fsraft_set_build_kernel: bits 8.. of the argument)
+int g_build_t = 0;        // 0: corr_build_rec_kernel (LDS-parked epilogue); 1: corr_build_rec_t_kernel (stores from the accumulators:
+                          // measured 8-14 % SLOWER as a one-tile-per-workgroup kernel, scripts/build_t_micro.py -- it is the epilogue
+                          // of the persistent kernel below)
 int g_build_split = 1;    // 0: exact fp32 MFMA build, 1: split-bf16 (fsraft_set_build_split)
 
 // Backward of the pooling chain, folded into level 0 in place:
@@ -683,14 +858,39 @@ extern "C" int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vo
   if (!f1r || !f2r || !vol || B < 1 || C < 32 || (C % 32) || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
   if (((uintptr_t)vol % 16) || ((uintptr_t)f1r % 16) || ((uintptr_t)f2r % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff) return FS_ERR_ARG;
   const int N = H * W;
+  if (g_build_t) {
+    dim3 grid(ceil_div(W, BT_PW) * ceil_div(H, BT_PH), ceil_div(N, BT::BN), B);
+    hipLaunchKernelGGL(corr_build_rec_t_kernel<false>, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
+                       1.0f / sqrtf((float)C), g_build_stagger, (unsigned long long*)nullptr);
+    return fs_launch_status();
+  }
   dim3 grid(ceil_div(W, BR_PW) * ceil_div(H, BR_PH), ceil_div(N, BR::BM), B);
   hipLaunchKernelGGL(corr_build_rec_kernel, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
-                     1.0f / sqrtf((float)C));
+                     1.0f / sqrtf((float)C), g_build_stagger);
   return fs_launch_status();
 }
 
+#ifdef FSRAFT_EXPERIMENTS
+// fsraft_corr_build_rec with per-workgroup time stamps: stamps[8 * workgroups] (see corr_build_rec_t_kernel<true>)
+extern "C" int fsraft_corr_build_rec_stamps(const void* f1r, const void* f2r, float* vol, int num_levels, int B, int C, int H, int W,
+                                            unsigned long long* stamps, hipStream_t stream) {
+  VolLayout L;
+  if (!f1r || !f2r || !vol || !stamps || !vol_layout_make(H, W, num_levels & 0xff, L)) return FS_ERR_ARG;     // (bits 8..: stagger / ablation)
+  const int N = H * W;
+  dim3 grid(ceil_div(W, BT_PW) * ceil_div(H, BT_PH), ceil_div(N, BT::BN), B);
+  hipLaunchKernelGGL(corr_build_rec_t_kernel<true>, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
+                     1.0f / sqrtf((float)C), num_levels >> 8, stamps);
+  return fs_launch_status();
+}
+#endif
+
 extern "C" int fsraft_set_build_split(int on) {
   g_build_split = on ? 1 : 0;
+  return FS_OK;
+}
+extern "C" int fsraft_set_build_kernel(int which) {      // 1: stores from the accumulators (default), 0: LDS-parked epilogue
+  g_build_t = (which & 0xff) ? 1 : 0;
+  g_build_stagger = (which >> 8) & 0xff;
   return FS_OK;
 }
 

@@ -15,6 +15,9 @@ struct RecGemmArgs {
   float alpha; int atomic;
 };
 
+int g_rec_mfma16 = 0;      // fsraft_set_tuning-style switch (fsraft_set_rec_mfma16): the NT kernel on v_mfma_f32_16x16x32_bf16
+
+template <bool M16>
 __global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
   __shared__ __attribute__((aligned(1024))) char lds[G::LDS_BYTES];
   const int ntn = (g.N + G::BN - 1) / G::BN;
@@ -39,18 +42,18 @@ __global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
 #pragma unroll
   for (int j = 0; j < G::NPA; ++j) pa.va[j] = o.va[j];
   pa.kt0 = kt0; pa.step = 128u;
-  rec_mainloop<G>(lds, o, pa, kt0, kt, acc);
+  if constexpr (M16) rec_mainloop16<G>(lds, o, pa, kt0, kt, acc);
+  else rec_mainloop<G>(lds, o, pa, kt0, kt, acc);
   float* C = g.C + b * g.sC;
 #pragma unroll
   for (int nt = 0; nt < G::TN; ++nt) {
-    const int n = n0 + rec_col<G>(nt);
-    if (n >= g.N) continue;
 #pragma unroll
     for (int mt = 0; mt < G::TM; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + rec_row<G>(mt, r);
-        if (m >= g.M) continue;
+        const int n = n0 + (M16 ? rec16_col<G>(nt, r) : rec_col<G>(nt));
+        const int m = m0 + (M16 ? rec16_row<G>(mt, r) : rec_row<G>(mt, r));
+        if (m >= g.M || n >= g.N) continue;
         float* p = C + (int64_t)m * g.ldc + n;
         const float v = g.alpha * acc[mt][nt][r];
         if (g.atomic) atomicAdd(p, v);
@@ -192,7 +195,8 @@ extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const 
   }
   RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
   dim3 grid(ceil_div(N, G::BN) * ceil_div(M, G::BM), ksplit, batch);
-  hipLaunchKernelGGL(gemm_rec_nt_kernel, grid, dim3(512), 0, stream, g);
+  if (g_rec_mfma16) hipLaunchKernelGGL(gemm_rec_nt_kernel<true>, grid, dim3(512), 0, stream, g);
+  else hipLaunchKernelGGL(gemm_rec_nt_kernel<false>, grid, dim3(512), 0, stream, g);
   return fs_launch_status();
 }
 
@@ -216,4 +220,9 @@ extern "C" int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const 
   dim3 grid(ceil_div(N, GT::BN) * ceil_div(M, GT::BM), ksplit, batch);
   hipLaunchKernelGGL(gemm_rec_tn_kernel, grid, dim3(512), 0, stream, g, K);
   return fs_launch_status();
+}
+
+extern "C" int fsraft_set_rec_mfma16(int on) {
+  g_rec_mfma16 = on ? 1 : 0;
+  return FS_OK;
 }

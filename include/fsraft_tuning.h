@@ -28,9 +28,11 @@ extern "C" {
 int fsraft_set_tuning(int key, int value);
 int fsraft_get_tuning(int key);   /* keys 3 / 4 */
 int fsraft_set_build_split(int on);   /* volume build: 1 bf16x3 (default), 0 exact fp32 MFMA */
+int fsraft_set_build_kernel(int which); /* record build: 1 stores from the accumulators (default), 0 round 2's LDS-parked epilogue */
 int fsraft_set_gemm_split(int on);    /* fsraft_gemm_f32 with trans_b: 1 bf16x3 when operands are 16-byte aligned */
 int fsraft_set_lookup_qb(int qb);     /* queries per workgroup of the row-major lookup kernels: 0 auto, 8, 16 or 32 */
 int fsraft_set_norm_blocks(int target_workgroups);   /* workgroups per launch of the channels-last norm kernels (default 4096) */
+int fsraft_set_rec_mfma16(int on);    /* record GEMM (NT): 1 = v_mfma_f32_16x16x32_bf16, 0 = 32x32x16 */
 int fsraft_set_alt_tile(int on);      /* alt-corr forward: 1 (default) 4x4-query tile kernel, 0 wave per query */
 
 #ifdef __cplusplus
