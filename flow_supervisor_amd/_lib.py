@@ -73,6 +73,7 @@ SIGNATURES = {
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_rec_mfma16": [c_int],
     "fsraft_set_build_kernel": [c_int],
+    "fsraft_set_dvol_policy": [c_int],
     "fsraft_set_arithmetic": [c_int],
     "fsraft_get_arithmetic": [],
     "fsraft_set_tuning": [c_int, c_int],

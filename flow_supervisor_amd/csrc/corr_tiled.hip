@@ -188,9 +188,16 @@ struct DvolArgs {
 // (level 0 alone; levels 1..3 together), so two launches cover a row.  REC: the run leaves as records ([32 bf16 hi | 32
 // bf16 lo] per 32 cells, gemm_rec.hpp) -- the operand format of the two volume-backward GEMMs, which then stage it by
 // LDS-DMA without converting.  CLIP: the run is longer than the segment (very large images) and is processed in pieces.
+// the finished gradient rows are written once and read (by the two volume-backward GEMMs) only after 1 GB more has gone by:
+// policy 2 stores them `nt` so that they do not push the step's other working sets out of L2 (fsraft_set_dvol_policy)
+__device__ __forceinline__ void dvstore4(void* p, f32x4 v, int policy) {
+  if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  else if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else gstore4(p, v);
+}
 template <int R, bool REC, bool CLIP>
 __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate, int l0,
-                                                        int l1, int grid_w, int64_t q0) {
+                                                        int l1, int grid_w, int64_t q0, int policy) {
   using S = TL<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* seg = smem;                                   // [min(run, DV_SEG)]
@@ -302,11 +309,11 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
         rec_split4(seg + e, h0, l0s);
         rec_split4(seg + e + 4, h1, l1s);
         char* rp = reinterpret_cast<char*>(row + s0) + (e >> 5) * 128 + (e & 31) * 2;
-        gstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}));
-        gstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}));
+        dvstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}), policy);
+        dvstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}), policy);
       }
     } else {
-      for (int e = threadIdx.x * 4; e < len; e += 1024) gstore4(row + s0 + e, *reinterpret_cast<const f32x4*>(seg + e));
+      for (int e = threadIdx.x * 4; e < len; e += 1024) dvstore4(row + s0 + e, *reinterpret_cast<const f32x4*>(seg + e), policy);
     }
   }
 }
@@ -409,6 +416,12 @@ extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, co
 // records != 0: rows are written as [32 bf16 hi | 32 bf16 lo] records (operands of fsraft_gemm_rec_nt / _tn).
 // Queries [q0, q0 + nq) only (nq == 0: all from q0), written to dvol rows 0 .. nq-1: the memory-efficient path builds the
 // gradient volume a chunk of queries at a time.
+int g_dvol_policy = 0;
+extern "C" int fsraft_set_dvol_policy(int policy) {
+  g_dvol_policy = policy;
+  return FS_OK;
+}
+
 extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
                                       float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate, int records,
                                       int add_grid, int64_t q0, int64_t nq, hipStream_t stream) {
@@ -440,7 +453,7 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
     const int GC = (l1 - l0 + 1) * N2;
     const size_t lds = (size_t)((clip ? DV_SEG : run) + ((n * GC + 3) & ~3)) * 4 + (size_t)n * 4 * sizeof(LevelQ);
 #define DVOL_LAUNCH(RR, REC, CLIP) \
-  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1, add_grid ? W : 0, q0)
+  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1, add_grid ? W : 0, q0, g_dvol_policy)
     if (radius == 4) {
       if (records) { if (clip) DVOL_LAUNCH(4, true, true); else DVOL_LAUNCH(4, true, false); }
       else { if (clip) DVOL_LAUNCH(4, false, true); else DVOL_LAUNCH(4, false, false); }

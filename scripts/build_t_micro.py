@@ -13,6 +13,10 @@ from flow_supervisor_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
 dev = "cuda"
+if lib.fsraft_set_tuning(24, 0) != 0 and len(sys.argv) > 1:
+    sys.exit("the transposed-role / persistent build kernels live in the experiment build only: make -C flow_supervisor_amd/csrc ablate; "
+             "FSRAFT_LIB_PATH=flow_supervisor_amd/libfsraft_ablate.so python scripts/build_t_micro.py <kernel>")
+KERNEL = int(sys.argv[1]) if len(sys.argv) > 1 else 0        # 1: one tile per workgroup, stores from the accumulators; 2 / 3 / 4: persistent (DEFER 1 / 0 / 2)
 torch.manual_seed(0)
 
 
@@ -22,11 +26,11 @@ def build(f1, f2, which, nlev=4):
     return ops.corr_build_tiled(f1, f2, nlev, recs=recs)
 
 
-for (B, C, H, W, nlev) in ((1, 32, 8, 32, 4), (2, 64, 17, 19, 4), (1, 256, 46, 62, 4), (2, 256, 55, 128, 4), (1, 128, 16, 32, 3), (1, 96, 9, 70, 2), (1, 256, 47, 156, 4)):
+for (B, C, H, W, nlev) in ((1, 256, 8, 32, 4), (2, 128, 17, 19, 4), (1, 256, 46, 62, 4), (2, 256, 55, 128, 4), (1, 128, 16, 32, 3), (1, 256, 9, 70, 2), (1, 256, 47, 156, 4), (3, 256, 30, 40, 1)):
     f1 = torch.randn(B, C, H, W, device=dev)
     f2 = torch.randn(B, C, H, W, device=dev)
     v0, lay = build(f1, f2, 0, nlev)
-    v1, _ = build(f1, f2, 1, nlev)
+    v1, _ = build(f1, f2, KERNEL, nlev)
     N = H * W
     ref = torch.bmm(f1.reshape(B, C, N).transpose(1, 2).double(), f2.reshape(B, C, N).double()).float() / C ** 0.5   # [B, N, N]
     worst = 0.0
@@ -73,7 +77,8 @@ for (B, C, H, W) in ((4, 256, 55, 128), (8, 256, 46, 62), (1, 256, 47, 156), (1,
 
     def run():
         _lib.check(lib.fsraft_corr_build_rec(_lib.ptr(recs[0]), _lib.ptr(recs[1]), _lib.ptr(vol), 4, B, C, H, W, _lib.stream()), "build")
-    variants = [(0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (1, 1), (1, 2), (1, 3)]       # (kernel, stagger)
+    # (kernel, store policy << 8: 1 plain, 2 sc1, 3 nt; 0 = the library's choice)
+    variants = [(0, 256), (0, 512), (0, 768), (0, 0)] + ([(1, 256), (2, 256), (3, 256), (3, 768)] if len(sys.argv) > 1 else [])       # (kernel, store policy << 8: 0 plain, 1 sc1, 2 nt)
     res = {v: [] for v in variants}
     for v in variants:
         lib.fsraft_set_build_kernel(v[0] | v[1] << 8); timeit(run, 3)
@@ -84,6 +89,6 @@ for (B, C, H, W) in ((4, 256, 55, 128), (8, 256, 46, 62), (1, 256, 47, 156), (1,
     line = f"B={B} {H}x{W}:"
     for v in variants:
         med = sorted(res[v])[2]
-        line += f"  {'acc' if v[0] else 'lds'}/s{v[1]} {med*1e6:6.1f} us ({nbytes/med/8e12*100:4.1f}%)"
+        line += f"  k{v[0]}/{('auto', 'plain', 'sc1', 'nt')[v[1] >> 8]} {med*1e6:6.1f} us ({nbytes/med/8e12*100:4.1f}%)"
     print(line)
 lib.fsraft_set_build_kernel(1)
