@@ -318,6 +318,21 @@ def main():
 
     split_mode = os.environ.get("FSRAFT_CONV_SPLIT", "1") != "0"
     extra = {}
+    if semi and world == 1 and not a.no_extra:
+        # the same optimisation step in the reference's order (two forward / backward passes of one pair each, eager)
+        was = sstep.batched
+        sstep.batched = not was
+        for _ in range(3):
+            step(im1, im2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step(im1, im2)
+        torch.cuda.synchronize()
+        extra["value_sequential_passes" if was else "value_batched_passes"] = 2 * B * 5 / (time.perf_counter() - t1)
+        sstep.batched = was
+        extra["semi_step"] = ("labelled + unlabelled sample as ONE batch of two (per-sample crop offsets), one backward" if was else
+                              "two forward / backward passes (the reference's order)")
     if world == 1 and a.variant == "raft" and not a.no_extra:
         # the same step with every GEMM on the exact-fp32 MFMA cores, and with the encoders as BASELINE.json's north_star has
         # them (PyTorch-ROCm / MIOpen convolutions): short runs, reported next to `value`

@@ -8,14 +8,10 @@ import torch.nn.functional as F
 
 from .corr import CorrBlock
 from .gma_network import RAFTGMA
+from .l2l import _crop_back, _offsets, _pad_state
 from .raft import convex_upsample
 from .update import GMAUpdateBlock
 from .utils.utils import upflow8
-
-
-def _offset(v):
-    """ox / oy arrive as per-sample tensors in the reference (`ox[0]`, l2l.py:87-88); python ints are accepted too (no device sync)."""
-    return int(v) if isinstance(v, int) else int(v[0])
 
 
 class GMAL2L(RAFTGMA):
@@ -56,14 +52,8 @@ class GMAL2L(RAFTGMA):
                 flow = coords1 - coords0
                 if not (test_mode or itr < half) and itr == half:
                     if ci1 is not None:
-                        orig_h, orig_w = image1.shape[-2:]
-                        targ_h, targ_w = ci1.shape[-2:]
-                        ox_, oy_ = _offset(ox), _offset(oy)
-                        crop = (oy_, orig_h, ox_, orig_w)
-                        l, r = ox_ // 8, (targ_w - ox_ - orig_w) // 8
-                        t, b = oy_ // 8, (targ_h - oy_ - orig_h) // 8
-                        net = F.pad(net, (0, 0, l, r, t, b))
-                        flow = F.pad(flow, (l, r, t, b))
+                        crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
+                        net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))
                         coords0, _ = self.initialize_flow(ci1)
                         coords1 = flow + coords0
                         tfmap1, tfmap2 = self._features(ci1, ci2)
@@ -83,8 +73,7 @@ class GMAL2L(RAFTGMA):
                 else:
                     flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
                 if not test_mode and itr >= half:
-                    oy_, orig_h, ox_, orig_w = crop
-                    flow_up = flow_up[:, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w]
+                    flow_up = _crop_back(flow_up, *crop)
                 flow_predictions.append(flow_up)
         finally:
             torch.set_grad_enabled(grad_mode)

@@ -16,9 +16,41 @@ from .update import BasicUpdateBlock, to_channels_last
 from .utils.utils import upflow8
 
 
-def _offset(v):
-    """ox / oy arrive as per-sample tensors in the reference (`ox[0]`, l2l.py:87-88); python ints are accepted too (no device sync)."""
-    return int(v) if isinstance(v, int) else int(v[0])
+def _offsets(v, B):
+    """Crop offsets per sample.  The reference reads `ox[0]` / `oy[0]` for the whole batch (l2l.py:87-88): a tensor or a
+    python int means that.  A python list / tuple gives every sample its own offset (extension: lets the labelled and the
+    unlabelled sample of the flow-supervisor step share one batched forward, train.SemiTrainStep)."""
+    if isinstance(v, (list, tuple)):
+        if len(v) != B:
+            raise ValueError(f"{len(v)} crop offsets for a batch of {B}")
+        return [int(x) for x in v]
+    return [int(v) if isinstance(v, int) else int(v[0])] * B
+
+
+def _pad_state(net, flow, ox_l, oy_l, orig, targ):
+    """Zero-pad the hidden state (channels-last) and the flow from the crop's grid into the uncropped frame's grid
+    (l2l.py:90-93), sample by sample when the offsets differ."""
+    (orig_h, orig_w), (targ_h, targ_w) = orig, targ
+
+    def pads(ox_, oy_):
+        return ox_ // 8, (targ_w - ox_ - orig_w) // 8, oy_ // 8, (targ_h - oy_ - orig_h) // 8
+    if len(set(zip(ox_l, oy_l))) == 1:
+        l, r, t, b = pads(ox_l[0], oy_l[0])
+        return F.pad(net, (0, 0, l, r, t, b)), F.pad(flow, (l, r, t, b))
+    nets, flows = [], []
+    for i, (ox_, oy_) in enumerate(zip(ox_l, oy_l)):
+        l, r, t, b = pads(ox_, oy_)
+        nets.append(F.pad(net[i:i + 1], (0, 0, l, r, t, b)))
+        flows.append(F.pad(flow[i:i + 1], (l, r, t, b)))
+    return torch.cat(nets, 0), torch.cat(flows, 0)
+
+
+def _crop_back(flow_up, ox_l, oy_l, orig):
+    """The supervisor's full-frame prediction cut back to the student's window (l2l.py:124-125)."""
+    orig_h, orig_w = orig
+    if len(set(zip(ox_l, oy_l))) == 1:
+        return flow_up[:, :, oy_l[0]: oy_l[0] + orig_h, ox_l[0]: ox_l[0] + orig_w]
+    return torch.cat([flow_up[i:i + 1, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w] for i, (ox_, oy_) in enumerate(zip(ox_l, oy_l))], 0)
 
 
 class L2L(RAFT):
@@ -87,14 +119,8 @@ class L2L(RAFT):
                 else:
                     if itr == half:
                         if ci1 is not None:
-                            orig_h, orig_w = image1.shape[-2:]
-                            targ_h, targ_w = ci1.shape[-2:]
-                            ox_, oy_ = _offset(ox), _offset(oy)
-                            crop = (oy_, orig_h, ox_, orig_w)
-                            l, r = ox_ // 8, (targ_w - ox_ - orig_w) // 8
-                            t, b = oy_ // 8, (targ_h - oy_ - orig_h) // 8
-                            net = F.pad(net, (0, 0, l, r, t, b))            # channels-last: pad W then H   (l2l.py:90)
-                            flow = F.pad(flow, (l, r, t, b))                #                               (l2l.py:92)
+                            crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
+                            net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))   # (l2l.py:90-93)
                             coords0, _ = self.initialize_flow(ci1)
                             coords1 = flow + coords0
                             tfmap1, tfmap2 = features(ci1, ci2)
@@ -113,8 +139,7 @@ class L2L(RAFT):
                 else:
                     flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
                 if not test_mode and itr >= half:
-                    oy_, orig_h, ox_, orig_w = crop
-                    flow_up = flow_up[:, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w]
+                    flow_up = _crop_back(flow_up, *crop)
                 flow_predictions.append(flow_up)
         finally:
             torch.set_grad_enabled(grad_mode)
