@@ -393,7 +393,8 @@ def main():
     if timer is not None:
         kern = {}
         build_split = split_mode and os.environ.get("FSRAFT_BUILD_SPLIT", "1") != "0"
-        split = {"conv_igemm": split_mode, "conv_wgrad": os.environ.get("FSRAFT_WGRAD_SPLIT", "2") != "0", "gemm_f32": True}
+        split = {"conv_igemm": split_mode, "conv_wgrad": os.environ.get("FSRAFT_WGRAD_SPLIT", "2") != "0", "gemm_f32": True,
+                 "altcorr_fwd": split_mode, "altcorr_bwd": split_mode}
         for fam, s in timer.summary().items():
             mfma = fam in ("conv_igemm", "conv_wgrad", "gemm_f32", "altcorr_fwd", "altcorr_bwd")
             sec = s["ms_total"] * 1e-3
@@ -403,6 +404,11 @@ def main():
                 # ALGORITHMIC flops is the dense bf16 MFMA peak / 3
                 ach, peak, unit = s["flops"] / sec / 1e12, PEAK_BF16_MFMA_TF / 3.0, "TFLOP/s"
                 basis = "algorithmic fp32 FLOPs vs dense bf16 MFMA peak (2500 TFLOP/s) / 3 MFMA products per fp32 product"
+                if fam == "altcorr_fwd":
+                    basis += ("; algorithmic = the (2r+2)^2 window products per query and level (alt_cuda_corr's count) -- the tile GEMM "
+                              "multiplies whole regions, ~2.6x that")
+                if fam == "altcorr_bwd":
+                    basis += "; algorithmic = alt_cuda_corr.backward's window products; computed as chunks of the gradient volume + record GEMMs"
             elif mfma:
                 ach, peak, unit = s["flops"] / sec / 1e12, PEAK_F32_MFMA_TF, "TFLOP/s"
                 basis = ("algorithmic fp32 FLOPs vs the fp32 vector / MFMA peak (157.3 TFLOP/s); the kernel is a vector-ALU dot-product "

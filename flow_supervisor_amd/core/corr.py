@@ -174,7 +174,7 @@ class _AltBuildFn(torch.autograd.Function):
 class _AltLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, coords, block, channels_last, is_flow):
-        out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow)
+        out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow, recs=block._recs)
         ctx.block, ctx.cl, ctx.is_flow = block, channels_last, is_flow
         ctx.save_for_backward(coords)
         return out if channels_last else ops.nhwc_to_nchw(out)
@@ -221,6 +221,12 @@ class AlternateCorrBlock:
             # channels-last copies once per pair instead of once per level per iteration (corr.py:82-83)
             self._f1 = ops.nchw_to_nhwc(fmap1.detach())
             self._f2 = [ops.nchw_to_nhwc(self.pyramid[i][1].detach()) for i in range(self.num_levels)]
+            # ... and the same maps pre-split to records for the tile GEMM of the lookup (bf16x3, as the volume build)
+            self._recs = None
+            C = fmap1.shape[1]
+            if C % 32 == 0 and C <= 256 and fmap1.is_cuda:
+                B = fmap1.shape[0]
+                self._recs = (ops.to_records(self._f1.view(B, -1, C)), [ops.to_records(f.view(B, -1, C)) for f in self._f2])
 
     def __call__(self, coords, channels_last=False, is_flow=False):
         coords = coords.float()
@@ -228,5 +234,5 @@ class AlternateCorrBlock:
             if not self._stash:
                 self._stash_is_flow = is_flow
             return _AltLookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow)
-        out = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow)
+        out = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs)
         return out if channels_last else ops.nhwc_to_nchw(out)

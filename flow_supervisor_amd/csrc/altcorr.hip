@@ -18,6 +18,7 @@
 // g * fmap2 rows in registers; fmap2_grad receives g * fmap1 via fp32 atomics issued as
 // 256-byte contiguous wave instructions (the shape that runs at the full atomic rate).
 #include "common.hpp"
+#include "gemm_rec.hpp"
 
 namespace {
 
@@ -363,6 +364,156 @@ __global__ __launch_bounds__(1024) void altcorr_tile_fwd_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The tile lookup on the matrix pipe.  Per tile of 6 x 4 queries and pyramid level, the dot products of
+// the tile's queries with a REGION of target rows are one small GEMM -- region rows (<= 256) x queries (24 of 32) x C -- on
+// the record core (gemm_rec.hpp: operands pre-split to [hi | lo] bf16 once per pair, staged by LDS-DMA, bf16x3 products,
+// fp32 accumulation: the arithmetic of the volume build this path must agree with).  The region is anchored at the
+// component-wise minimum of the tile's window origins and sized per level for the spread of a smooth flow plus two cells
+// of slack (17 x 15, 14 x 13, 13 x 12, 12 x 12: coarser levels see the tile shrink); rows outside the image are not
+// fetched (zero fill = the reference's zero padding).  The products are parked in LDS [query][region cell]; every wave then
+// gathers its queries' (2r+2)^2 window positions out of them -- a position the region does not cover (flow discontinuity
+// inside the tile) is computed the slow way from the fp32 maps -- and blends the (2r+1)^2 outputs as before.
+// One workgroup (4 waves) per (tile, level): 1248 workgroups of ~8 k-tiles at 47 x 156.
+using AM = RecCfg<256, 32, 4, 1>;
+constexpr int AM_TW = 6, AM_TH = 4, AM_NQ = AM_TW * AM_TH;
+constexpr int AM_DP = 257;                                  // pitch of a query's row of parked products (odd: conflict-free)
+
+struct AltRecLevels {
+  const char* f2r[4];       // [B][h_l * w_l][C / 32] records of the pooled target maps
+  const float* f2[4];       // the same maps in fp32 channels-last (positions outside the region)
+  int h[4], w[4];
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __restrict__ f1r, const float* __restrict__ f1, AltRecLevels lv,
+                                                               AltCoords co, float* __restrict__ out, int nlev, int H, int W, int C,
+                                                               float scale) {
+  constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN, NRND = (NPOS + 63) / 64;
+  constexpr int PARK = AM_NQ * AM_DP * 4;
+  __shared__ __attribute__((aligned(1024))) char lds[AM::LDS_BYTES > PARK ? AM::LDS_BYTES : PARK];
+  __shared__ float win[4][NPOS + 4];
+  __shared__ int org[2];
+  __shared__ float qxy[AM_NQ][2];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tiles_x = (W + AM_TW - 1) / AM_TW;
+  const int b = blockIdx.z, l = blockIdx.y, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int H2 = lv.h[l], W2 = lv.w[l], N = H * W;
+  const unsigned pitch = (unsigned)C * 4u;
+  const int RW = l == 0 ? AM_TW + 2 * R + 3 : l == 1 ? 14 : l == 2 ? 13 : 12;       // region width / height per level
+  const int RH = l == 0 ? AM_TH + 2 * R + 3 : l == 1 ? 13 : 12;
+  const float sl = 1.0f / (float)(1 << l);
+  // window origins of the tile's queries at this level; the region starts at their component-wise minimum
+  if (wave == 0) {
+    const int n = lane < AM_NQ ? lane : 0;
+    const int qx = tx * AM_TW + n % AM_TW, qy = ty * AM_TH + n / AM_TW;
+    const bool act = lane < AM_NQ && qx < W && qy < H;
+    float cx = 0.f, cy = 0.f;
+    if (act) {
+      const int pix = qy * W + qx;
+      cx = co.p[b * co.bs + pix * co.ps]; cy = co.p[b * co.bs + co.cs + pix * co.ps];
+      if (co.grid_w > 0) { cx += (float)qx; cy += (float)qy; }
+      cx *= sl; cy *= sl;
+      cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+      cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+    }
+    if (lane < AM_NQ) { qxy[lane][0] = cx; qxy[lane][1] = cy; }
+    int mx = act ? (int)floorf(cx) - R : 0x7fffffff, my = act ? (int)floorf(cy) - R : 0x7fffffff;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) { mx = min(mx, __shfl_xor(mx, d, 64)); my = min(my, __shfl_xor(my, d, 64)); }
+    if (lane == 0) { org[0] = mx; org[1] = my; }
+  }
+  __syncthreads();
+  const int rx0 = org[0], ry0 = org[1];
+
+  // ---- region rows (A, 256) x queries (B, 32) x C on the record core
+  RecOperands<AM> o;
+  o.da = rec_desc(lv.f2r[l] + (int64_t)b * H2 * W2 * pitch, (unsigned)min((int64_t)H2 * W2 * pitch, (int64_t)0x7fffffff));
+  o.db = rec_desc(f1r + (int64_t)b * N * pitch, (unsigned)min((int64_t)N * pitch, (int64_t)0x7fffffff));
+  o.b_step = 128u;
+  RecPlainA<AM> pa;
+#pragma unroll
+  for (int j = 0; j < AM::NPA; ++j) {
+    const int m = (wave + AM::NWAVE * j) * 8 + (lane >> 3);
+    const int uy = m / RW, ux = m - uy * RW, gx = rx0 + ux, gy = ry0 + uy;
+    const int ls = (lane & 7) ^ ((m >> 1) & 7);
+    pa.va[j] = (uy < RH && gx >= 0 && gx < W2 && gy >= 0 && gy < H2) ? (unsigned)(gy * W2 + gx) * pitch + (unsigned)ls * 16u : 0x80000000u;
+  }
+  pa.kt0 = 0; pa.step = 128u;
+  {
+    const int n = wave * 8 + (lane >> 3);
+    const int qx = tx * AM_TW + n % AM_TW, qy = ty * AM_TH + n / AM_TW;
+    const int ls = (lane & 7) ^ ((n >> 1) & 7);
+    o.vb[0] = (n < AM_NQ && qx < W && qy < H) ? (unsigned)(qy * W + qx) * pitch + (unsigned)ls * 16u : 0x80000000u;
+  }
+  f32x16 acc[AM::TM][AM::TN];
+#pragma unroll
+  for (int a = 0; a < AM::TM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
+  rec_mainloop<AM>(lds, o, pa, 0, C / 32, acc);
+  // park [query][region cell] (the ring is free: rec_mainloop ends behind a barrier)
+  float* dots = reinterpret_cast<float*>(lds);
+  {
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (l31 < AM_NQ) {
+#pragma unroll
+      for (int mt = 0; mt < AM::TM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dots[l31 * AM_DP + wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[mt][0][r];
+    }
+  }
+  __syncthreads();
+
+  // ---- every wave: its six queries, one after the other (lane = window position, then lane = output channel)
+  const int CH = nlev * RD * RD;
+  const float* f2b = lv.f2[l] + (int64_t)b * H2 * W2 * C;
+  for (int qi = 0; qi < AM_NQ / 4; ++qi) {
+    const int n = wave * (AM_NQ / 4) + qi;
+    const int qx = tx * AM_TW + n % AM_TW, qy = ty * AM_TH + n / AM_TW;
+    if (qx >= W || qy >= H) continue;                     // (wave-uniform)
+    const int64_t q = (int64_t)b * N + qy * W + qx;
+    const float cx = qxy[n][0], cy = qxy[n][1];
+    const float flx = floorf(cx), fly = floorf(cy);
+    const int wx0 = (int)flx - R, wy0 = (int)fly - R;
+    const float dx = cx - flx, dy = cy - fly;
+#pragma unroll
+    for (int k = 0; k < NRND; ++k) {
+      const int p = lane + 64 * k;
+      if (p >= NPOS) continue;
+      const int iy = p / WIN, ix = p - iy * WIN;
+      const int gx = wx0 + ix, gy = wy0 + iy, ux = gx - rx0, uy = gy - ry0;
+      float v = 0.f;
+      if (gx >= 0 && gx < W2 && gy >= 0 && gy < H2) {
+        if (ux >= 0 && ux < RW && uy >= 0 && uy < RH) {
+          v = dots[n * AM_DP + uy * RW + ux];
+        } else {                                           // outside the staged region: fp32 rows from L2
+          const float* a = f1 + q * C;
+          const float* row = f2b + (int64_t)(gy * W2 + gx) * C;
+          for (int c = 0; c < C; c += 4) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + c), rv = *reinterpret_cast<const f32x4*>(row + c);
+            v += av[0] * rv[0] + av[1] * rv[1] + av[2] * rv[2] + av[3] * rv[3];
+          }
+        }
+      }
+      win[wave][p] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float* op = out + q * CH + l * RD * RD;
+    for (int oc = lane; oc < RD * RD; oc += 64) {
+      const int iyo = oc % RD, ixo = oc / RD;             // channel = iy + RD * ix (x offset slow, as the reference)
+      const float* d = win[wave] + iyo * WIN + ixo;
+      op[oc] = scale * ((1.f - dy) * (1.f - dx) * d[0] + (1.f - dy) * dx * d[1] + dy * (1.f - dx) * d[WIN] + dy * dx * d[WIN + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
 int g_alt_tile = 1;       // 1: tile kernel where it applies (C a multiple of 64), 0: wave-per-query kernel
 
 }  // namespace
@@ -422,6 +573,34 @@ extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* 
   }
   if (radius == 4) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
   else if (radius == 3) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
+  else return FS_ERR_ARG;
+  return fs_launch_status();
+}
+
+// The same lookup with the region products on the matrix pipe: f1r [B][H*W][C/32] and f2r_levels[l] [B][(H>>l)*(W>>l)][C/32]
+// are the records (fsraft_to_records) of the channels-last maps, which are passed too (window positions a tile's region
+// does not cover are taken from them).  C % 32 == 0, C <= 256.
+extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
+                                       int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
+                                       int add_grid, float* out, int B, int H, int W, int C, int radius, hipStream_t stream) {
+  if (!f1r || !f2r_levels || !fmap1 || !fmap2_levels || !coords || !out || num_levels < 1 || num_levels > 4 || B < 1 || H < 1 || W < 1 ||
+      C < 32 || C % 32 || C > 256 || ((uintptr_t)f1r % 16) || ((uintptr_t)fmap1 % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff)
+    return FS_ERR_ARG;
+  AltRecLevels lv;
+  int h = H, w = W;
+  for (int l = 0; l < 4; ++l) {
+    lv.f2r[l] = l < num_levels ? (const char*)f2r_levels[l] : nullptr;
+    lv.f2[l] = l < num_levels ? fmap2_levels[l] : nullptr;
+    lv.h[l] = h; lv.w[l] = w;
+    if (l < num_levels && (!f2r_levels[l] || !fmap2_levels[l] || h < 1 || w < 1 || ((uintptr_t)f2r_levels[l] % 16) || ((uintptr_t)fmap2_levels[l] % 16)))
+      return FS_ERR_ARG;
+    h /= 2; w /= 2;
+  }
+  AltCoords co{coords, coords_bs, coords_cs, coords_ps, add_grid ? W : 0};
+  dim3 grid((unsigned)(((W + AM_TW - 1) / AM_TW) * ((H + AM_TH - 1) / AM_TH)), (unsigned)num_levels, (unsigned)B);
+  const float scale = 1.0f / sqrtf((float)C);
+  if (radius == 4) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<4>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<3>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale);
   else return FS_ERR_ARG;
   return fs_launch_status();
 }

@@ -316,8 +316,13 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
     return out
 
 
-def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False):
-    """f1_cl [B,H,W,C], f2_levels[l] [B,H>>l,W>>l,C] channels-last -> [B,H,W,L*(2r+1)^2] (scaled by 1/sqrt(C))."""
+ALT_MFMA = True      # AlternateCorrBlock lookups on the matrix pipe (fsraft_altcorr_mfma_fwd) when the records are supplied
+
+
+def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None):
+    """f1_cl [B,H,W,C], f2_levels[l] [B,H>>l,W>>l,C] channels-last -> [B,H,W,L*(2r+1)^2] (scaled by 1/sqrt(C)).
+    recs = (f1r, [f2r per level]): the same maps as records -> the tile GEMM kernel (bf16x3); without them, or with the
+    exact-fp32 arithmetic selected, the fp32 dot-product kernels."""
     L.require_cuda_f32(f1_cl, coords, *f2_levels)
     B, H, W, C = f1_cl.shape
     bs, cs, ps = _planar2_strides(coords)
@@ -326,8 +331,13 @@ def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False):
     pp, keep = L.ptr_array(f2_levels)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(_lib().fsraft_altcorr_fused_fwd(L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out), B, H, W, C,
-                                            radius, L.stream()), "altcorr_fused_fwd")
+    if recs is not None and ALT_MFMA and SPLIT_VOLUME_BWD and C % 32 == 0 and C <= 256:
+        pr, keep2 = L.ptr_array(recs[1])
+        L.check(_lib().fsraft_altcorr_mfma_fwd(L.ptr(recs[0]), pr, L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out),
+                                               B, H, W, C, radius, L.stream()), "altcorr_mfma_fwd")
+    else:
+        L.check(_lib().fsraft_altcorr_fused_fwd(L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out), B, H, W, C,
+                                                radius, L.stream()), "altcorr_fused_fwd")
     if t:   # compulsory bytes of the alt path per iteration = fmap1 + the pooled fmap2 pyramid + coords + out
         t.end("altcorr_fwd", e0, 2.0 * B * H * W * nl * (2 * radius + 2) ** 2 * C,
               4.0 * B * (H * W * C + sum(f.shape[1] * f.shape[2] for f in f2_levels) * C + H * W * (2 + out.shape[-1])))

@@ -121,6 +121,14 @@ int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_level
                              int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B, int H, int W,
                              int C, int radius, hipStream_t stream);
 
+/* The same lookup with the dot products of a tile of queries against a region of target rows as one small GEMM on the matrix
+ * pipe (bf16x3 on pre-split operands, the arithmetic of the volume build): f1r [B][H*W][C/32 records] and f2r_levels[l]
+ * [B][(H>>l)*(W>>l)][C/32 records] = fsraft_to_records of the channels-last maps, which are passed as well (window positions
+ * outside a tile's region -- flow discontinuities -- are taken from them in fp32).  C % 32 == 0, C <= 256. */
+int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
+                            int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
+                            int add_grid, float* out, int B, int H, int W, int C, int radius, hipStream_t stream);
+
 /* ---- convex 8x upsampler -------------------------------------------------------------
  * Replaces RAFT.upsample_flow, pytorch/core/raft.py:72-83 and UpsampleConvexWithMask,
  * raft/upsample.py:11-41.  flow element (n,c,pix) at flow[n*bs + c*cs + pix*ps];

@@ -129,6 +129,39 @@ def test_alt_cuda_corr_module_contract():
         acc.forward(f1.permute(0, 2, 1, 3), f2, co, 4)         # CHECK_CONTIGUOUS
 
 
+@pytest.mark.parametrize("B,C,H,W,nlev", [(1, 256, 47, 156, 4), (2, 128, 17, 19, 4), (1, 64, 8, 12, 3), (1, 96, 5, 7, 2)])
+def test_alt_lookup_on_the_matrix_pipe(B, C, H, W, nlev):
+    """altcorr_mfma_fwd_kernel (tiles of 6 x 4 queries, the products with a region of target rows as a
+    bf16x3 GEMM on records) against the oracle's lookup of the dense volume (what AlternateCorrBlock must equal,
+    SURVEY.md 8c) and against the fp32 tile kernel: smooth flow, motion boundaries inside tiles (window positions outside a
+    tile's region take the fp32 route), rough flow, flow that leaves the image; ragged tiles and 2..4 levels."""
+    import torch.nn.functional as F
+    from flow_supervisor_amd import ops
+    torch.manual_seed(11)
+    f1 = torch.randn(B, C, H, W, device=DEV)
+    f2 = torch.randn(B, C, H, W, device=DEV)
+    f1c = ops.nchw_to_nhwc(f1)
+    lv, x = [], f2
+    for _ in range(nlev):
+        lv.append(ops.nchw_to_nhwc(x))
+        x = F.avg_pool2d(x, 2, stride=2)
+    recs = (ops.to_records(f1c.view(B, -1, C)), [ops.to_records(f.view(B, -1, C)) for f in lv])
+    pyr = O.corr_pyramid(f1.cpu(), f2.cpu(), nlev)
+    step = torch.zeros(B, 2, H, W, device=DEV)
+    step[:, 0, :, W // 2:] = 11.0
+    step[:, 1, H // 2:] -= 7.0
+    cases = (("smooth", torch.tensor([3.3, -1.7], device=DEV).view(1, 2, 1, 1) + 0.3 * torch.randn(B, 2, H, W, device=DEV)),
+             ("motion boundaries", step + 0.2 * torch.randn(B, 2, H, W, device=DEV)),
+             ("rough", 8.0 * torch.randn(B, 2, H, W, device=DEV)),
+             ("leaving the image", 200.0 * torch.randn(B, 2, H, W, device=DEV)))
+    for name, flow in cases:
+        got = ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True, recs=recs)
+        ref = O.corr_lookup(pyr, (flow.cpu() + O.coords_grid(B, H, W)), 4)
+        close(got.permute(0, 3, 1, 2), ref, 1e-4, what=f"matrix-pipe alt lookup vs oracle, {name}")
+        fp32 = ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True)
+        close(got, fp32, 1e-4, what=f"matrix-pipe alt lookup vs fp32 tile kernel, {name}")
+
+
 def test_alt_cuda_corr_several_coordinate_sets():
     """coords [B,N,H1,W1,2] with N > 1 (correlation_kernel.cu:34,59; the C ABI carries N): every set against the oracle's
     restatement of one extension call, and the backward against autograd of that restatement."""
