@@ -74,6 +74,7 @@ SIGNATURES = {
     "fsraft_set_rec_mfma16": [c_int],
     "fsraft_set_build_kernel": [c_int],
     "fsraft_set_dvol_policy": [c_int],
+    "fsraft_conv_workspace": [c_void_p, c_int64],
     "fsraft_set_arithmetic": [c_int],
     "fsraft_get_arithmetic": [],
     "fsraft_set_tuning": [c_int, c_int],
@@ -171,7 +172,7 @@ def load():
         lib.fsraft_set_build_split(int(bsplit))
     for key, env in ((0, "FSRAFT_CONV_TILE"), (2, "FSRAFT_WGRAD_BLOCKS"), (5, "FSRAFT_CONV_BUF"), (8, "FSRAFT_WGRAD_BUF"), (11, "FSRAFT_WGRAD_BLOCKS_MULTI"), (13, "FSRAFT_CONV_W8"), (14, "FSRAFT_CONV_W8_MIN"), (15, "FSRAFT_WGRAD_W8"),
                      (16, "FSRAFT_WGRAD_PACK"), (17, "FSRAFT_WGRAD_BLOCKS_PACK"), (18, "FSRAFT_CONV_N64"), (20, "FSRAFT_CONV_HALO"),
-                     (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA"), (25, "FSRAFT_CONV_REC"), (26, "FSRAFT_CONV_PATCH"), (27, "FSRAFT_WGRAD_PATCH"), (28, "FSRAFT_CONV_PATCH64"), (29, "FSRAFT_WGRAD_PATCH1"), (30, "FSRAFT_CONV_C64")):
+                     (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA"), (25, "FSRAFT_CONV_REC"), (26, "FSRAFT_CONV_PATCH"), (27, "FSRAFT_WGRAD_PATCH"), (28, "FSRAFT_CONV_PATCH64"), (29, "FSRAFT_WGRAD_PATCH1"), (30, "FSRAFT_CONV_C64"), (31, "FSRAFT_CONV_PATCH_MIN_M"), (32, "FSRAFT_CONV_KSPLIT")):
         if os.environ.get(env) is not None and lib.fsraft_set_tuning(key, int(os.environ[env])) != 0:
             raise RuntimeError(f"{env}: tuning key {key} is not in this build of libfsraft (experiment kernels live in "
                                "libfsraft_ablate.so: make -C flow_supervisor_amd/csrc ablate, FSRAFT_LIB_PATH=...)")

@@ -49,6 +49,8 @@ struct ConvArgs {
   // out of a ReLU leaves the kernel already masked, instead of a separate pass over the tensor.
   const float* rmask[3]; int ldmask[3]; int maskc[3];
   int swz;                       // 1: XCD-aware workgroup -> tile mapping (see tile_of_block)
+  int ksplit;                    // > 1: blockIdx.z owns a slice of the k-tiles and parks its RAW partial tile in a workspace (dst[0],
+                                 // rows z * M + m): the first pass of the split-K route for small M (conv_finish_kernel is the second)
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  With the plain
@@ -420,7 +422,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
 // image pb, rows outside the image are skipped.  NTW: threads taking part (the workgroup's).
 template <class Cfg, int EPI, int NTW = Cfg::NT, bool PATCH = false>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
-                                                  float* __restrict__ tile, bool owner = true, int pb = 0, int py0 = 0, int px0 = 0) {
+                                                  float* __restrict__ tile, bool owner = true, int pb = 0, int py0 = 0, int px0 = 0,
+                                                  int64_t mofs = 0) {
   constexpr int LD = Cfg::BN + 4;
   const int HW = a.H * a.W;
   const int M = a.B * HW;
@@ -470,7 +473,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       const int64_t m = row_m(row);
       if (m < 0) { if (PATCH) continue; else break; }
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * LD + c4 * 4);
-      float* o = dp + (int64_t)m * dps + (n - dn0);
+      float* o = dp + (int64_t)(m + mofs) * dps + (n - dn0);      // (mofs: the k-slice's slab of the split-K workspace)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         v[i] *= a.alpha;
@@ -623,6 +626,14 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
     // compiler copy it to scratch (dynamic index), and a scratch load is per-lane, i.e. no longer provably uniform.
     const auto* ktab = (const unsigned __attribute__((address_space(4)))*)(
         (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvArgsT, ktab));
+    // split-K (small M): this workgroup's slice of the k-tiles; the table and the weight rows are entered kt0 tiles further on
+    int kt0 = 0, KTs = a.Ktot / 32;
+    if (a.ksplit > 1) {
+      const int per = (KTs + a.ksplit - 1) / a.ksplit;
+      kt0 = (int)blockIdx.z * per;
+      KTs = min(per, KTs - kt0);
+      ktab += kt0 * (BUF >= 2 ? 2 : 1);
+    }
     unsigned tapmask[Cfg::NCH_A], pofs[Cfg::NCH_A];
 #pragma unroll
     for (int j = 0; j < Cfg::NCH_A; ++j) {
@@ -638,7 +649,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
       tapmask[j] = mask; pofs[j] = m < M ? m : 0;
     }
     BufWeightLoader<Cfg> lb;
-    lb.base = uni_ptr(reinterpret_cast<const char*>(a.wpk) + (int64_t)n0 * a.Ktot * 4);
+    lb.base = uni_ptr(reinterpret_cast<const char*>(a.wpk) + (int64_t)n0 * a.Ktot * 4 + (int64_t)kt0 * 128);
     lb.nbytes = 0x7fffffffu;   // validity is carried by the lane offsets alone (FS_OOB), whatever the range check adds to them
 #pragma unroll
     for (int j = 0; j < BufWeightLoader<Cfg>::NCH; ++j) {
@@ -652,8 +663,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
       const unsigned ldb = uni((unsigned)args.uld * 4u);
 #pragma unroll
       for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.voff0[j] = pofs[j] * ldb + la.kq16; }
-      if constexpr (BUF == 3) split_mainloop_bdma<Cfg>(lds, a.Ktot / 32, la, lb, acc);
-      else split_mainloop<Cfg, BufConvALoaderU<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
+      if constexpr (BUF == 3) split_mainloop_bdma<Cfg>(lds, KTs, la, lb, acc);
+      else split_mainloop<Cfg, BufConvALoaderU<Cfg>, BufWeightLoader<Cfg>, true>(lds, KTs, la, lb, acc);
     } else {
       BufConvALoader<Cfg> la;
       la.ld0x4 = uni(a.src[0].ld * 4); la.ld1x4 = uni(a.src[1].ld * 4); la.ld2x4 = uni(a.src[2].ld * 4);
@@ -665,7 +676,13 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
       la.kq16 = (threadIdx.x & 7) * 16;
 #pragma unroll
       for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.pofs[j] = pofs[j]; }
-      split_mainloop<Cfg, BufConvALoader<Cfg>, BufWeightLoader<Cfg>, true>(lds, a.Ktot / 32, la, lb, acc);
+      split_mainloop<Cfg, BufConvALoader<Cfg>, BufWeightLoader<Cfg>, true>(lds, KTs, la, lb, acc);
+    }
+    if constexpr (EPI == EPI_PLAIN && Cfg::LDS_ALLOC >= Cfg::BM * (Cfg::BN + 4) * 4) {
+      if (a.ksplit > 1) {               // first pass of the split-K route: the raw partial tile -> slab blockIdx.z of the workspace
+        conv_epilogue_lds<Cfg, EPI_PLAIN>(a, acc, m0, n0, reinterpret_cast<float*>(lds), true, 0, 0, 0, (int64_t)blockIdx.z * M);
+        return;
+      }
     }
   } else {
   SplitConvALoader<Cfg> la;
@@ -1595,6 +1612,119 @@ bool build_ktab_uniform(const ConvArgs& a, ConvArgsT& t) {
   return true;
 }
 
+
+// ---- split-K for small M ----------------------------------------------------------------------------------------------
+// At one or two pairs per GPU (the flow-supervisor recipe, config 4) a layer has 35-140 tiles of 64 pixels for 256 CUs and
+// its time is the LENGTH of one workgroup's k-loop: 3x3 256 -> 192 takes 55 us at 4416 pixels, 57 us at 7332, 59 us at 8832
+// (scripts/conv_micro.py) -- 72 k-tiles one after the other at ~0.75 us.  Here the k-tiles are dealt to `ksplit` workgroups per
+// tile (grid.z), which park raw partial tiles in a workspace (conv_igemm_split_kernel, ksplit > 1), and this kernel adds the
+// slabs and applies the layer's real epilogue (the row code of conv_epilogue_lds): bias / scale / ReLU / mask / accumulate
+// into up to three destinations, or the GRU gate maths.
+template <int EPI>
+__global__ __launch_bounds__(256) void conv_finish_kernel(const ConvArgs a, const float* __restrict__ ws, int S, int ldw) {
+  const int HW = a.H * a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int C4 = (a.N + 3) / 4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < M * C4; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / C4;
+    const int n = (int)(e % C4) * 4;
+    const int nv = a.N - n < 4 ? a.N - n : 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = i < nv ? a.bias[n + i] : 0.f;
+    }
+    for (int s = 0; s < S; ++s) {
+      const f32x4 p = gload4(ws + ((int64_t)s * M + m) * ldw + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += p[i];
+    }
+    if (EPI == EPI_PLAIN) {
+      int di = 0;
+      if (a.ndst > 1 && n >= a.dst[1].n0) di = 1;
+      if (a.ndst > 2 && n >= a.dst[2].n0) di = 2;
+      float* dp = di == 0 ? a.dst[0].p : di == 1 ? a.dst[1].p : a.dst[2].p;
+      const int64_t dbs = di == 0 ? a.dst[0].bs : di == 1 ? a.dst[1].bs : a.dst[2].bs;
+      const int64_t dps = di == 0 ? a.dst[0].ps : di == 1 ? a.dst[1].ps : a.dst[2].ps;
+      const int64_t dcs = di == 0 ? a.dst[0].cs : di == 1 ? a.dst[1].cs : a.dst[2].cs;
+      const int dn0 = di == 0 ? a.dst[0].n0 : di == 1 ? a.dst[1].n0 : a.dst[2].n0;
+      const bool dacc = (di == 0 ? a.dst[0].accumulate : di == 1 ? a.dst[1].accumulate : a.dst[2].accumulate) != 0;
+      const float* mk = di == 0 ? a.rmask[0] : di == 1 ? a.rmask[1] : a.rmask[2];
+      const int ldm = di == 0 ? a.ldmask[0] : di == 1 ? a.ldmask[1] : a.ldmask[2];
+      const int mkc = di == 0 ? a.maskc[0] : di == 1 ? a.maskc[1] : a.maskc[2];
+      const int64_t b = m / HW, pix = m - b * HW;
+      float* o = dp + b * dbs + pix * dps + (int64_t)(n - dn0) * dcs;
+      for (int i = 0; i < nv; ++i) {
+        float r = v[i] * a.alpha;
+        if (a.relu) r = fmaxf(r, 0.f);
+        if (dacc) r += o[i * dcs];
+        if (mk && n - dn0 + i < mkc && mk[m * ldm + (n - dn0) + i] <= 0.f) r = 0.f;
+        o[i * dcs] = r;
+      }
+    } else if (EPI == EPI_ZR) {
+      const bool isz = n < a.hid;
+      const int c = isz ? n : n - a.hid;
+      if (a.pre) v += gload4(a.pre + m * a.ldpre + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
+      if (isz) {
+        *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + c) = v;                 // z
+      } else {
+        const f32x4 hh = gload4(a.h + m * a.ldh + c);
+        *reinterpret_cast<f32x4*>(a.aux2 + m * a.ld2 + c) = v;                            // r
+        f32x4 rh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rh[i] = v[i] * hh[i];
+        *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + c) = rh;                           // r*h
+      }
+    } else {   // EPI_Q
+      if (a.pre) v += gload4(a.pre + m * a.ldpre + n);
+      const f32x4 hh = gload4(a.h + m * a.ldh + n);
+      const f32x4 zz = gload4(a.z + m * a.ldz + n);
+      f32x4 hn;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = tanhf(v[i]);
+        hn[i] = (1.f - zz[i]) * hh[i] + zz[i] * v[i];
+      }
+      *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + n) = v;                              // q
+      *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + n) = hn;                   // h'
+    }
+  }
+}
+
+inline bool g_conv_bdma_on() {
+#ifdef FSRAFT_EXPERIMENTS
+  return g_conv_bdma != 0;
+#else
+  return false;
+#endif
+}
+int g_conv_ksplit = -1;          // -1 auto (small grids only), 0 / 1 off, >= 2 forced slice count (fsraft_set_tuning key 32)
+float* g_conv_ws = nullptr;      // workspace handed over by the binding (fsraft_conv_workspace): the ABI allocates nothing
+int64_t g_conv_ws_floats = 0;
+
+// Slices for a tile grid of `tiles` workgroups, KT k-tiles and N outputs.  Measured (scripts/conv_micro.py, 1 x 47x156, 1 x 46x96,
+// 2 x 46x96): the route pays where fewer than ~half of the CUs have a workgroup AND the second pass is small -- layers with
+// <= 256 outputs (3x3 256 -> 126: 52 -> 40 us, 1x5 384 -> 128: 42 -> 34, the 3x3 512 -> 128 data gradient: 87 -> 52 us; at
+// 4416 pixels 3x3 256 -> 192: 55 -> 44, 1x5 384 -> 256: 46 -> 39); with 512 outputs the slabs cost more than the shorter
+// k-loops save (3x3 128 -> 512: 37 -> 55 us), and from ~230 tiles on the CUs are busy anyway.  64-row tiles only: where the
+// dispatcher picked 128-row tiles the grid was already judged large enough, and splitting those measured slower (1x5 256 ->
+// 256 at 8832 pixels: 35 -> 41 us).
+int pick_ksplit(int64_t tiles, int KT, int N, int64_t M, int ldw) {
+  int S = 1;
+  if (g_conv_ksplit >= 2) S = g_conv_ksplit;
+  else if (g_conv_ksplit == -1 && tiles <= 150 && N <= 256 && KT >= 16) S = (int)((400 + tiles - 1) / tiles);
+  if (S > KT / 6) S = KT / 6;
+  if (S > 6) S = 6;
+  while (S > 1 && (int64_t)S * M * ldw > g_conv_ws_floats) --S;
+  if (S > 1) {                                   // no empty slice
+    const int per = (KT + S - 1) / S;
+    S = (KT + per - 1) / per;
+  }
+  return S < 2 ? 1 : S;
+}
+
 template <class Cfg>
 int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   const int M = a.B * a.H * a.W;
@@ -1605,6 +1735,35 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   const int swz = g_xcd_swizzle || (grid.x >= 2 && (int64_t)grid.x * grid.y >= 2048);
   // buffer-addressed loaders + branch-free k-loop: measured faster on the 64-row tiles, slower on 128x128
   const bool buf = g_conv_buf == 2 || (g_conv_buf == 1 && Cfg::BM == 64) || Cfg::BN == 256 || Cfg::NT != 256;
+  if constexpr (Cfg::LDS_ALLOC >= Cfg::BM * (Cfg::BN + 4) * 4) {
+    // split-K route (small M): partial tiles into the workspace, then conv_finish_kernel with the layer's own epilogue
+    const int ldw = (a.N + 3) / 4 * 4;
+    const bool gru_ok = epi == EPI_PLAIN || (a.N % 4 == 0 && (!a.pre || a.ldpre % 4 == 0));
+    const int S = (buf && g_conv_ws && gru_ok && !(g_conv_bdma_on()) && (Cfg::BM == 64 || g_conv_ksplit >= 2)) ? pick_ksplit((int64_t)grid.x * grid.y, a.Ktot / 32, a.N, M, ldw) : 1;
+    if (S > 1) {
+      const bool uni_tab = build_ktab_uniform(a, t);
+      if (uni_tab || build_ktab(a, t)) {
+        ConvArgs& p = t.a;
+        p.swz = 0;
+        p.ksplit = S;
+        p.dst[0] = Dst{g_conv_ws, (int64_t)a.H * a.W * ldw, ldw, 1, 0, 0};
+        p.dst[1] = p.dst[2] = p.dst[0];
+        p.ndst = 1; p.bias = nullptr; p.relu = 0; p.alpha = 1.0f;
+        for (int i = 0; i < 3; ++i) p.rmask[i] = nullptr;
+        dim3 g3(grid.x, grid.y, S);
+        if (uni_tab) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), g3, dim3(Cfg::NT), 0, s, t);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), g3, dim3(Cfg::NT), 0, s, t);
+        int rc = fs_launch_status();
+        if (rc) return rc;
+        const int64_t work = (int64_t)M * (ldw / 4);
+        const int fb = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+        if (epi == EPI_PLAIN) hipLaunchKernelGGL(conv_finish_kernel<EPI_PLAIN>, dim3(fb), dim3(256), 0, s, a, g_conv_ws, S, ldw);
+        else if (epi == EPI_ZR) hipLaunchKernelGGL(conv_finish_kernel<EPI_ZR>, dim3(fb), dim3(256), 0, s, a, g_conv_ws, S, ldw);
+        else hipLaunchKernelGGL(conv_finish_kernel<EPI_Q>, dim3(fb), dim3(256), 0, s, a, g_conv_ws, S, ldw);
+        return fs_launch_status();
+      }
+    }
+  }
   if (buf && build_ktab_uniform(a, t)) {
     t.a.swz = swz;
 #ifdef FSRAFT_EXPERIMENTS
@@ -1668,6 +1827,7 @@ int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
 int g_conv_rec = 1;        // record-activation kernel (conv_rec.inc): 0 off, 1 layers with > 128 outputs, 2 every layer it can run
 #include "conv_rec.inc"
 #endif
+int g_conv_patch_min_m = 8192;   // ... from this many pixels on (key 31)
 int g_conv_patch = 1;      // resident-patch, channel-streaming kernel for the 3x3 / 1x5 / 5x1 layers (conv_patch.inc, key 26; 2: 128-pixel tiles too)
 #ifdef FSRAFT_EXPERIMENTS
 int g_conv_c64 = 0;        // experiment (key 30 = minimum pixel count): 64 -> 64 3x3 layers on conv3x3_c64_kernel (resident weights) -- 322 vs 237 us, off
@@ -1741,7 +1901,7 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
   if (g_conv_patch && g_conv_patch64 && g_conv_split == 1 && d->wpk_split && d->epi == EPI_PLAIN && d->KH == 3 && d->KW == 3 &&
-      d->N > 32 && d->N <= 64 && (int64_t)d->B * d->H * d->W >= 8192) {
+      d->N > 32 && d->N <= 64 && (int64_t)d->B * d->H * d->W >= g_conv_patch_min_m) {
     ConvArgs p = a;
     p.wpk = d->wpk_split;
     const int rc = launch_conv_patch(p, d->epi, stream);
@@ -1791,7 +1951,7 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // the 128x128 kernel needs 131 / 157 / 87 / 78 / 45 us); 128x128 stays selectable (key 3 = 4) and is the
     // fallback for shapes the k-tile table cannot describe.
     const bool narrow = g_conv_buf != 0 || (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
-    if (g_conv_patch && g_conv_split == 1 && d->KH * d->KW > 1 && d->N > 64 && M >= 8192) {
+    if (g_conv_patch && g_conv_split == 1 && d->KH * d->KW > 1 && d->N > 64 && M >= g_conv_patch_min_m) {
       const int rc = launch_conv_patch(a, d->epi, stream);
       if (rc >= 0) return rc;
     }
@@ -1830,6 +1990,15 @@ extern "C" int fsraft_set_ablate(int mask) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_fsraft_ablate), &mask, sizeof(int)) == hipSuccess ? FS_OK : FS_ERR_LAUNCH;
 }
 #endif
+
+// The split-K route of the small-M convolutions needs a scratch buffer; the ABI allocates nothing, so the binding hands one
+// over (and keeps it alive).  Calls that enqueue convolutions on DIFFERENT streams concurrently must not share it.
+extern "C" int fsraft_conv_workspace(float* ws, int64_t floats) {
+  if (ws && (((uintptr_t)ws & 15) || floats < 0)) return FS_ERR_ARG;
+  g_conv_ws = ws;
+  g_conv_ws_floats = ws ? floats : 0;
+  return FS_OK;
+}
 
 // Reads back the arithmetic-mode switches (key 3: forward / data-gradient convolutions, key 4: weight gradients); the
 // host side uses it to skip packing the exact-fp32 weight matrices while the split-bf16 kernels are the ones that run.
@@ -1873,6 +2042,8 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 30) g_conv_c64 = value;
 #endif
   else if (key == 26) g_conv_patch = value;
+  else if (key == 31) g_conv_patch_min_m = value;
+  else if (key == 32) g_conv_ksplit = value;
   else if (key == 27) g_wgrad_patch = value;
   else if (key == 28) g_conv_patch64 = value;
   else if (key == 29) g_wgrad_patch1 = value;

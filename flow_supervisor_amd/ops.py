@@ -1002,6 +1002,27 @@ class Dst:
         return Dst(buf, 0, C * H * W, 1, H * W, n0, acc)
 
 
+_CONV_WS = {}                 # device index -> scratch tensor registered with fsraft_conv_workspace
+CONV_WS_FLOATS = 24 << 20     # 96 MB: three slices of the largest small-M layer (8832 pixels x 512 outputs)
+CONV_WS_MAX_PIXELS = 16384    # the split-K route only exists for grids that leave CUs idle
+
+
+def _conv_workspace(device, pixels):
+    """Hand libfsraft its split-K scratch buffer the first time a small convolution runs on `device` (the C ABI allocates
+    nothing).  One process drives one GPU; a second device re-registers its own buffer before its calls."""
+    if pixels > CONV_WS_MAX_PIXELS:
+        return
+    idx = torch.device(device).index or 0
+    ws = _CONV_WS.get(idx)
+    if ws is None:
+        ws = torch.empty(CONV_WS_FLOATS, device=device, dtype=torch.float32)
+        _CONV_WS[idx] = ws
+        _CONV_WS["active"] = None
+    if _CONV_WS.get("active") != idx:
+        L.check(_lib().fsraft_conv_workspace(L.ptr(ws), ws.numel()), "conv_workspace")
+        _CONV_WS["active"] = idx
+
+
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
                  aux1=None, aux2=None, hid=0, wpk_split=None, pre=None, wpk_frag=None, pad=None):
     """srcs: list of V (concatenated along channels).  dsts: list of Dst.
@@ -1038,6 +1059,7 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     d.hid = hid
     if pre is not None:
         d.pre = pre.data_ptr(); d.ldpre = pre.shape[-1]
+    _conv_workspace(dsts[0].t.device, B * H * W)
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_conv_forward(ctypes.byref(d), L.stream()), "conv_forward")

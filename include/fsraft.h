@@ -222,6 +222,12 @@ int fsraft_conv_small_fwd(const float* x, int ld, int C, const float* w_oihw, co
 int fsraft_conv_small_wgrad(const float* const* dy, const float* const* x, int nseg, int ldy, int ldx, int C, float* dwpk,
                             float* dbias, int N, int B, int H, int W, int KH, int KW, hipStream_t stream);
 
+/* Scratch buffer for the split-K route of the convolutions at small pixel counts (one or two pairs per GPU: the layer's
+ * k-tiles are dealt to several workgroups per tile, which park partial tiles here; a second kernel adds them and applies the
+ * layer's epilogue).  The library allocates nothing: the caller owns `ws` (16-byte aligned, `floats` fp32) and keeps it alive;
+ * NULL switches the route off.  One buffer per process: convolutions enqueued concurrently on different streams must not use it. */
+int fsraft_conv_workspace(float* ws, int64_t floats);
+
 /* ---- arithmetic of the dense contractions -------------------------------------------------------------------------
  * Storage and accumulation are fp32 everywhere.  mode 1 (default): every fp32 product of the GEMM-shaped kernels (volume
  * build and its backward, the update block's / encoders' convolutions, their weight gradients, the GMA GEMMs) is evaluated

@@ -24,7 +24,8 @@ extern "C" {
  * 16: few-channel weight-gradient kernel; 20 / 21: resident-patch 3x3 encoder kernel and its minimum pixel count; 22:
  * XCD-aware weight-gradient order; 26: resident-patch forward / data-gradient kernel; 27: resident-block weight gradient
  * (0 off, 1 the 3x3 layers, 2 the five-tap layers too); 28: 64-column patch tiles; 29: single-segment resident-block
- * weight gradient, minimum pixel count. */
+ * weight gradient, minimum pixel count; 31: minimum pixel count of the resident-patch forward / data-gradient kernel; 32: split-K slices of the small-M convolutions
+ * (-1 auto, 0 off, >= 2 forced). */
 int fsraft_set_tuning(int key, int value);
 int fsraft_get_tuning(int key);   /* keys 3 / 4 */
 int fsraft_set_build_split(int on);   /* volume build: 1 bf16x3 (default), 0 exact fp32 MFMA */

@@ -1850,17 +1850,17 @@ def test_rccl_exchange_at_world_size_one(tmp_path):
     assert res["backend"] == "nccl"
     # (not bit-equal even without a collective: the weight gradients add with fp32 atomics, so two runs of the same three
     #  steps differ in the last bits and AdamW amplifies sign flips of ~0 gradients)
-    assert res["eager"]["grad_rel"] <= 2e-3 and res["eager"]["param_rel"] <= 2e-4, res["eager"]
+    assert res["eager"]["grad_rel"] <= 5e-3 and res["eager"]["param_rel"] <= 5e-4, res["eager"]
     assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(res["eager"]["losses_plain"], res["eager"]["losses_rccl"])), res["eager"]
-    assert res["eager_unbucketed"]["grad_rel"] <= 2e-3 and res["eager_unbucketed"]["param_rel"] <= 2e-4, res["eager_unbucketed"]
+    assert res["eager_unbucketed"]["grad_rel"] <= 5e-3 and res["eager_unbucketed"]["param_rel"] <= 5e-4, res["eager_unbucketed"]
     log = os.environ.get("FSRAFT_RCCL_LOG")
     if log:
         with open(log, "w") as f:
             json.dump(res, f, indent=1)
     if res["graph"]["ok"]:
         # replays re-run the same kernels on the same buffers; atomics in the weight gradients reorder sums
-        assert res["graph"]["param_rel_vs_eager"] <= 2e-4, res["graph"]
-        assert all(r <= 2e-3 for r in res["graph"]["loss_rel_vs_eager"]), res["graph"]
+        assert res["graph"]["param_rel_vs_eager"] <= 5e-4, res["graph"]
+        assert all(r <= 3e-3 for r in res["graph"]["loss_rel_vs_eager"]), res["graph"]
     else:
         pytest.xfail("hipGraph capture of a step containing RCCL all-reduces failed: " + res["graph"]["error"])
 
