@@ -74,6 +74,7 @@ SIGNATURES = {
     "fsraft_set_rec_mfma16": [c_int],
     "fsraft_set_build_kernel": [c_int],
     "fsraft_set_dvol_policy": [c_int],
+    "fsraft_set_dvol_box": [c_int],
     "fsraft_conv_workspace": [c_void_p, c_int64],
     "fsraft_set_arithmetic": [c_int],
     "fsraft_get_arithmetic": [],
@@ -129,7 +130,7 @@ SIGNATURES = {
     "fsraft_corr_build_rec": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_lookup_tiled_fwd": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_dvol_build": [_PP, _PP, POINTER(c_int64), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
-                               c_int64, _S],
+                               c_int64, c_void_p, _S],
     "fsraft_set_alt_tile": [c_int],
     "fsraft_altcorr_fused_fwd": [c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_altcorr_mfma_fwd": [c_void_p, _PP, c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
@@ -161,6 +162,8 @@ def load():
     # precision / tiling switches: FSRAFT_CONV_SPLIT=1 runs the forward and
     # data-gradient GEMMs of the update block on the split-bf16 core (3 bf16 MFMAs per product,
     # fp32 accumulation); 0 keeps them on exact-fp32 MFMA.
+    if os.environ.get("FSRAFT_DVOL_BOX") is not None:
+        lib.fsraft_set_dvol_box(int(os.environ["FSRAFT_DVOL_BOX"]))
     arith = os.environ.get("FSRAFT_ARITHMETIC")     # 0: exact fp32 MFMA everywhere; 1 (default): bf16x3 products
     if arith is not None:
         lib.fsraft_set_arithmetic(int(arith))

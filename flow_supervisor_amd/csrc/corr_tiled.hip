@@ -197,9 +197,15 @@ __device__ __forceinline__ void dvstore4(void* p, f32x4 v, int policy) {
 }
 template <int R, bool REC, bool CLIP>
 __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int accumulate, int l0,
-                                                        int l1, int grid_w, int64_t q0, int policy) {
+                                                        int l1, int grid_w, int64_t q0, int policy, const unsigned* __restrict__ qlist) {
   using S = TL<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // qlist (nullable): [0] = count, [1 ..] = query numbers relative to q0 that corr_dvol_box_kernel left for this kernel
+  // (their lookups spread further than its box); workgroup i then takes list slot i instead of query i
+  // (one workgroup per list slot, surplus workgroups leave at once: a loop over the list inside the kernel tripled its
+  //  register count -- 49 -> 158 VGPRs, 7 -> 3 waves per SIMD -- and cost 35 % on the plain route)
+  if (qlist && blockIdx.x >= qlist[0]) return;
+  const unsigned qrel = qlist ? qlist[1 + blockIdx.x] : blockIdx.x;
   float* seg = smem;                                   // [min(run, DV_SEG)]
   const int nlev = L.nlev, CH = nlev * S::N2, n = a.n, nl = l1 - l0 + 1;
   const int rbeg = L.off[l0], rend = (l1 + 1 < nlev) ? L.off[l1 + 1] : L.P;       // the run, in floats of the row
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
   const int GC = nl * S::N2;                           // channels of dOut this job needs: [l0 * N2, (l1 + 1) * N2)
   float* g = smem + seglen;                            // [n][GC]
   LevelQ* qi = reinterpret_cast<LevelQ*>(g + ((n * GC + 3) & ~3));   // [n][4]
-  const int64_t q = q0 + blockIdx.x;                   // rows of dvol are numbered from q0 (a chunk of queries per call)
+  const int64_t q = q0 + qrel;                         // rows of dvol are numbered from q0 (a chunk of queries per call)
   const int b = (int)(q / HW), pix = (int)(q % HW);
   // dOut slices of the n lookups -> LDS; the lookup index is wave-uniform (pointer from the kernarg table by scalar loads)
   // and ALL loads are in flight before the first LDS store: one memory latency per workgroup, not one per lookup
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
     query_xy(a.co[t], b, pix, grid_w, cx, cy);
     qi[threadIdx.x] = level_query(cx, cy, l, R);
   }
-  float* row = dvol + (int64_t)blockIdx.x * L.P;
+  float* row = dvol + (int64_t)qrel * L.P;
   for (int s0 = rbeg; s0 < rend; s0 += seglen) {
     const int len = min(seglen, rend - s0);
     __syncthreads();
@@ -317,6 +323,183 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
     }
   }
 }
+
+// ---- the same gradient rows without the whole row segment in LDS ---------------------------------------------------------
+// corr_dvol_kernel parks a level-0 row segment (28 KB at 55x128) in LDS although the twelve lookups of a query touch a few
+// hundred cells of it: five queries per CU are in flight, each a chain of [loads | zero | 12 x (read-add-write, barrier) |
+// convert, store], and the kernel runs at 2-3 TB/s of its own traffic (544 us for 1.5 GB).  Here ONE WAVE owns a query and
+// keeps, per level, only the bounding box of the lookups' windows (DVB x DVB cells, 2.3 KB) plus the level's slice of the
+// gradients; everything outside the box leaves as zeros straight from registers.  ~8 KB of LDS per wave -> twenty waves
+// per CU, no workgroup barrier (a wave's LDS operations execute in order).  A query whose lookups spread further than the box
+// at some level (a flow that jumped between iterations) is appended to a work list that corr_dvol_kernel then walks.
+constexpr int DVB = 24;
+
+template <int R, bool REC>
+__global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int grid_w, int64_t q0,
+                                                            unsigned nq, unsigned* __restrict__ qlist, int policy) {
+  using S = TL<R>;
+  __shared__ float box_s[4][DVB * DVB];
+  __shared__ float g_s[4][DV_MAXN * S::N2];
+  __shared__ float cxy[4][DV_MAXN][2];
+  __shared__ LevelQ lq_s[4][DV_MAXN];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __shared__ unsigned wl_s[6];                           // work-list hand-over: [wave] = 1 if it does not fit, [4] = base slot
+  const unsigned qrel = blockIdx.x * 4u + (unsigned)wave;
+  const bool active = qrel < nq;                         // (wave-uniform)
+  const int64_t q = q0 + (active ? qrel : 0);
+  const int b = (int)(q / HW), pix = (int)(q % HW);
+  const int n = a.n, nlev = L.nlev, CH = nlev * S::N2;
+  float* box = box_s[wave];
+  float* g = g_s[wave];
+  // query positions of the n lookups (wave-uniform pointers: the lookup index is a compile-time constant per iteration)
+#pragma unroll
+  for (int t = 0; t < DV_MAXN; ++t)
+    if (t < n && lane == 0) {
+      float cx, cy;
+      query_xy(a.co[t], b, pix, grid_w, cx, cy);
+      cxy[wave][t][0] = cx; cxy[wave][t][1] = cy;
+    }
+  wave_lds_sync();
+  // bounding boxes of all levels first: a query either fits everywhere or goes to the work list untouched
+  int bx0[4], by0[4];
+  bool fits = true;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    bx0[l] = by0[l] = 0;
+    if (l < nlev) {
+      const int tt = lane < n ? lane : 0;
+      const LevelQ v = level_query(cxy[wave][tt][0], cxy[wave][tt][1], l, R);
+      int mnx = v.wx0, mny = v.wy0, mxx = v.wx0, mxy = v.wy0;
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) {                // n <= 16: lanes 0..15 (the others repeat lookup 0)
+        mnx = min(mnx, __shfl_xor(mnx, d, 64)); mny = min(mny, __shfl_xor(mny, d, 64));
+        mxx = max(mxx, __shfl_xor(mxx, d, 64)); mxy = max(mxy, __shfl_xor(mxy, d, 64));
+      }
+      mnx = __builtin_amdgcn_readfirstlane(mnx); mny = __builtin_amdgcn_readfirstlane(mny);
+      mxx = __builtin_amdgcn_readfirstlane(mxx); mxy = __builtin_amdgcn_readfirstlane(mxy);
+      bx0[l] = mnx; by0[l] = mny;
+      fits = fits && (mxx - mnx + S::WIN <= DVB) && (mxy - mny + S::WIN <= DVB);
+    }
+  }
+  // one list append per WORKGROUP (a counter word takes ~90 atomics per microsecond: 28 K single appends are 0.3 ms)
+  if (lane == 0) wl_s[wave] = (active && !fits) ? 1u : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned c = wl_s[0] + wl_s[1] + wl_s[2] + wl_s[3];
+    wl_s[4] = c ? atomicAdd(qlist, c) : 0u;
+  }
+  __syncthreads();
+  if (!active) return;
+  if (!fits) {
+    unsigned slot = wl_s[4];
+    for (int w = 0; w < wave; ++w) slot += wl_s[w];
+    if (lane == 0) qlist[1 + slot] = qrel;
+    return;
+  }
+  char* rowb = reinterpret_cast<char*>(dvol + (int64_t)qrel * L.P);
+  // this lane's window cells (wy, wx): window cell (wy, wx) is tap (ay, ax) of output (j = wy - ay, i = wx - ax), channel i * N1 + j;
+  // a tap that does not exist gets weight 0 and re-reads the other one
+  constexpr int KC = (S::WIN * S::WIN + 63) / 64;
+  int c_wy[KC], c_wx[KC], c_g[KC], c_b[KC], c_di[KC], c_dj[KC], c_dij[KC];
+  bool c_ok[KC];
+  float c_m[KC][4];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    const int c = lane + 64 * k, wy = c / S::WIN, wx = c - wy * S::WIN;
+    c_ok[k] = c < S::WIN * S::WIN;
+    c_wy[k] = wy; c_wx[k] = wx; c_b[k] = wy * DVB + wx;
+    const int i0 = wx >= 1 ? wx - 1 : 0, j0 = wy >= 1 ? wy - 1 : 0;
+    c_g[k] = i0 * S::N1 + j0;
+    c_m[k][0] = wx < S::N1 ? 1.f : 0.f; c_m[k][1] = wx >= 1 ? 1.f : 0.f;
+    c_m[k][2] = wy < S::N1 ? 1.f : 0.f; c_m[k][3] = wy >= 1 ? 1.f : 0.f;
+    c_di[k] = (wx < S::N1 && wx >= 1) ? S::N1 : 0;
+    c_dj[k] = (wy < S::N1 && wy >= 1) ? 1 : 0;
+    c_dij[k] = c_di[k] + c_dj[k];
+  }
+#pragma unroll 1
+  for (int l = 0; l < nlev; ++l) {
+    const int off = L.off[l], tw = L.tw[l], hl = L.h[l], wl = L.w[l];
+    const int seg = (l + 1 < nlev ? L.off[l + 1] : L.P) - off;       // floats of this level's section (the last one incl. the row's pad)
+    const int ox = l == 0 ? bx0[0] : l == 1 ? bx0[1] : l == 2 ? bx0[2] : bx0[3];
+    const int oy = l == 0 ? by0[0] : l == 1 ? by0[1] : l == 2 ? by0[2] : by0[3];
+    for (int i = lane; i < DVB * DVB; i += 64) box[i] = 0.f;
+    if (lane < n) lq_s[wave][lane] = level_query(cxy[wave][lane][0], cxy[wave][lane][1], l, R);
+    // this level's slice of every lookup's gradient: all loads in flight before the first LDS store
+    {
+      float v[DV_MAXN][2];
+#pragma unroll
+      for (int t = 0; t < DV_MAXN; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int c = lane + 64 * k;
+          if (t < n && c < S::N2) v[t][k] = gload1(a.dout[t] + q * CH + l * S::N2 + c);
+        }
+#pragma unroll
+      for (int t = 0; t < DV_MAXN; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int c = lane + 64 * k;
+          if (t < n && c < S::N2) g[t * S::N2 + c] = v[t][k];
+        }
+    }
+    wave_lds_sync();
+    // the lookups one after the other (inside one lookup the window cells are distinct): lane = window cell, KC rounds.
+    // What depends on the lane only (its cells, which taps exist, where they sit in a gradient slice) was decoded before the
+    // level loop; what depends on the lookup only (window origin, fractions) is read out of lane t's registers into SGPRs.
+    const LevelQ mine = lq_s[wave][lane < n ? lane : 0];
+    for (int t = 0; t < n; ++t) {
+      const int wx0 = __builtin_amdgcn_readlane(mine.wx0, t), wy0 = __builtin_amdgcn_readlane(mine.wy0, t);
+      const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.fx), t));
+      const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.fy), t));
+      const float* gt = g + t * S::N2;
+      const int bbase = (wy0 - oy) * DVB + (wx0 - ox);
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int gy = wy0 + c_wy[k], gx = wx0 + c_wx[k];
+        if (c_ok[k] && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) {
+          const float* gp = gt + c_g[k];
+          const float wx1 = c_m[k][0] * (1.f - fx), wx0f = c_m[k][1] * fx, wy1 = c_m[k][2] * (1.f - fy), wy0f = c_m[k][3] * fy;
+          box[bbase + c_b[k]] += wy1 * (wx1 * gp[c_dij[k]] + wx0f * gp[c_dj[k]]) + wy0f * (wx1 * gp[c_di[k]] + wx0f * gp[0]);
+        }
+      }
+      wave_lds_sync();
+    }
+    // the level's section of the row: eight cells (two rows of a 4x4 tile) per lane and trip, zeros outside the box
+    const int ntile = L.th[l] * tw;
+    for (int e = lane * 8; e < seg; e += 512) {
+      const int T = e >> 4, ty = T / tw, tx = T - ty * tw;
+      const int yb = 4 * ty + 2 * ((e >> 3) & 1) - oy, xb = 4 * tx - ox;          // this lane's 2 x 4 cells, relative to the box
+      const bool touch = T < ntile && yb > -2 && yb < DVB && xb > -4 && xb < DVB;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+      if (__builtin_amdgcn_ballot_w64(touch)) {           // most trips of a level-0 section lie outside the box: zeros, no LDS read
+        if (touch) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if ((unsigned)(yb + j) < (unsigned)DVB && (unsigned)(xb + i) < (unsigned)DVB) v[4 * j + i] = box[(yb + j) * DVB + xb + i];
+        }
+      }
+      if (REC) {
+        uint2 h0, l0s, h1, l1s;
+        rec_split4(v, h0, l0s);
+        rec_split4(v + 4, h1, l1s);
+        const int f = off + e;
+        char* rp = rowb + (f >> 5) * 128 + (f & 31) * 2;
+        dvstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}), policy);
+        dvstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}), policy);
+      } else {
+        dvstore4(rowb + (off + e) * 4, f32x4{v[0], v[1], v[2], v[3]}, policy);
+        dvstore4(rowb + (off + e + 4) * 4, f32x4{v[4], v[5], v[6], v[7]}, policy);
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+__global__ void dvol_list_reset_kernel(unsigned* qlist) { qlist[0] = 0u; }
 
 // F2cat[b][c][p]: the target-side operand of dF1 = s * F2cat . dV^T in the row layout -- level-l cell = mean of f2 over its
 // 2^l x 2^l pixels where the cell exists in the floor pyramid, 0 in pad cells.
@@ -422,9 +605,15 @@ extern "C" int fsraft_set_dvol_policy(int policy) {
   return FS_OK;
 }
 
+int g_dvol_box = 1;       // 1: corr_dvol_box_kernel + work list where a scratch list is supplied, 0: corr_dvol_kernel for every query
+extern "C" int fsraft_set_dvol_box(int on) {
+  g_dvol_box = on;
+  return FS_OK;
+}
+
 extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
                                       float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate, int records,
-                                      int add_grid, int64_t q0, int64_t nq, hipStream_t stream) {
+                                      int add_grid, int64_t q0, int64_t nq, unsigned* qlist, hipStream_t stream) {
   VolLayout L;
   if (!dout || !coords || !coords_str || !dvol || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) ||
       ((uintptr_t)dvol % 16))
@@ -440,7 +629,19 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   for (int t = n; t < DV_MAXN; ++t) { a.dout[t] = nullptr; a.co[t] = Coords{nullptr, 0, 0, 0}; }
   const int N1 = 2 * radius + 1, N2 = N1 * N1;
   if (q0 < 0 || nq < 0 || q0 + nq > (int64_t)B * H * W) return FS_ERR_ARG;
-  const unsigned grid = (unsigned)(nq > 0 ? nq : (int64_t)B * H * W - q0);
+  unsigned grid = (unsigned)(nq > 0 ? nq : (int64_t)B * H * W - q0);
+  // fast route: one wave per query with only the lookups' bounding boxes in LDS; queries that do not fit go to `qlist`
+  // (caller-owned scratch of 1 + rows unsigned), which the row-segment kernel below then walks
+  const unsigned* list = nullptr;
+  if (g_dvol_box && qlist && !accumulate && (L.P % 8) == 0) {
+    hipLaunchKernelGGL(dvol_list_reset_kernel, dim3(1), dim3(1), 0, stream, qlist);
+#define DVBOX(RR, REC) hipLaunchKernelGGL((corr_dvol_box_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, \
+                                          add_grid ? W : 0, q0, grid, qlist, g_dvol_policy)
+    if (radius == 4) { if (records) DVBOX(4, true); else DVBOX(4, false); }
+    else { if (records) DVBOX(3, true); else DVBOX(3, false); }
+#undef DVBOX
+    list = qlist;
+  }
   // jobs: runs of whole levels that fit the LDS segment (records need a run to start and end on a multiple of 32 floats)
   int l0 = 0;
   while (l0 < L.nlev) {
@@ -453,7 +654,7 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
     const int GC = (l1 - l0 + 1) * N2;
     const size_t lds = (size_t)((clip ? DV_SEG : run) + ((n * GC + 3) & ~3)) * 4 + (size_t)n * 4 * sizeof(LevelQ);
 #define DVOL_LAUNCH(RR, REC, CLIP) \
-  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1, add_grid ? W : 0, q0, g_dvol_policy)
+  hipLaunchKernelGGL((corr_dvol_kernel<RR, REC, CLIP>), dim3(grid), dim3(256), lds, stream, a, L, dvol, H * W, accumulate, l0, l1, add_grid ? W : 0, q0, g_dvol_policy, list)
     if (radius == 4) {
       if (records) { if (clip) DVOL_LAUNCH(4, true, true); else DVOL_LAUNCH(4, true, false); }
       else { if (clip) DVOL_LAUNCH(4, false, true); else DVOL_LAUNCH(4, false, false); }

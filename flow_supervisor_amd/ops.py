@@ -254,6 +254,8 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
     H, W = lay.H, lay.W
     rows = nq if nq else B * H * W - q0
     dvol = torch.empty(rows, lay.P, device=douts[0].device, dtype=torch.float32)
+    # scratch for the work list of queries whose lookups spread beyond the bounding-box kernel's box (1 + rows unsigned)
+    qlist = torch.empty(rows + 1, device=douts[0].device, dtype=torch.int32) if len(douts) <= 16 else None
     t = TIMER
     e0 = t.begin() if t else None
     for g0 in range(0, len(douts), 16):
@@ -267,7 +269,8 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
             st += list(_planar2_strides(c))
         a_s = (ctypes.c_int64 * (3 * n))(*st)
         L.check(_lib().fsraft_corr_dvol_build(ctypes.cast(a_d, L._PP), ctypes.cast(a_c, L._PP), a_s, n, L.ptr(dvol), lay.nlev, B, H,
-                                              W, radius, int(g0 > 0), int(records), int(is_flow), q0, rows, L.stream()), "corr_dvol_build")
+                                              W, radius, int(g0 > 0), int(records), int(is_flow), q0, rows, L.ptr(qlist), L.stream()),
+                "corr_dvol_build")
     if t:   # per lookup read dOut + read-modify-write the window taps; plus the zero fill of the dense gradient
         nl = lay.nlev
         t.end("corr_lookup_bwd", e0, 0.0, 4.0 * rows * (len(douts) * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2)

@@ -75,10 +75,12 @@ int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* 
  * (s0, s1, s2) = coords_str[3t .. 3t+2].  n <= 16 per call.  Each row is accumulated in LDS and written once; records != 0:
  * as [32 bf16 hi | 32 bf16 lo] records, the operand format of fsraft_gemm_rec_nt / _tn below.  Only queries [q0, q0 + nq)
  * (nq == 0: all from q0) are built, into dvol rows 0 .. nq-1 -- AlternateCorrBlock's backward walks the queries in chunks so
- * that no O(N^2) buffer exists. */
+ * that no O(N^2) buffer exists.  qlist (nullable): caller-owned scratch of 1 + rows unsigned.  With it, one wave per query
+ * builds the row from the bounding boxes of its lookups' windows (a few KB of LDS instead of the whole row) and queries whose
+ * lookups spread beyond the box are listed there for the row-at-a-time kernel; without it every query takes that kernel. */
 int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
                            int num_levels, int B, int H, int W, int radius, int accumulate, int records, int add_grid,
-                           int64_t q0, int64_t nq, hipStream_t stream);
+                           int64_t q0, int64_t nq, unsigned* qlist, hipStream_t stream);
 /* Backward of matmul + avg_pool2d chain (pytorch/core/corr.py:21-27, 52-60) without un-pooling the volume gradient:
  *   f2cat [B][C][P]: level-l cell = mean of fmap2 over its 2^l x 2^l pixels (0 in pad cells), so that
  *   dF1[b][c][i] = s * sum_p f2cat[b][c][p] * dvol[b][i][p]   (one NT GEMM, K = P)  and

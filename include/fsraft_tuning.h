@@ -30,6 +30,7 @@ int fsraft_set_tuning(int key, int value);
 int fsraft_get_tuning(int key);   /* keys 3 / 4 */
 int fsraft_set_build_split(int on);   /* volume build: 1 bf16x3 (default), 0 exact fp32 MFMA */
 int fsraft_set_build_kernel(int which); /* record build: 1 stores from the accumulators (default), 0 round 2's LDS-parked epilogue */
+int fsraft_set_dvol_box(int on);        /* gradient volume: 1 (default) bounding-box kernel + work list, 0 row-segment kernel only */
 int fsraft_set_dvol_policy(int policy); /* cache policy of the gradient-volume stores: 0 plain, 1 sc1, 2 nt */
 int fsraft_set_gemm_split(int on);    /* fsraft_gemm_f32 with trans_b: 1 bf16x3 when operands are 16-byte aligned */
 int fsraft_set_lookup_qb(int qb);     /* queries per workgroup of the row-major lookup kernels: 0 auto, 8, 16 or 32 */

@@ -32,19 +32,38 @@ def timeit(fn, n):
 
 
 ref = None
-res = {0: [], 1: [], 2: []}
-resb = {0: [], 1: [], 2: []}
-for rnd in range(4):
-    for pol in (0, 1, 2):
-        lib.fsraft_set_dvol_policy(pol)
-        dv = ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True)
-        if ref is None:
-            ref = dv.clone()
-        else:
-            assert torch.equal(dv, ref), pol
-        res[pol].append(timeit(lambda: ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True), 5))
-        resb[pol].append(timeit(lambda: (ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True),
-                                         ops.corr_build_bwd_tiled(f1, f2, dv, lay, records=True, f1r=f1r)), 3))
-for pol in (0, 1, 2):
-    print(f"policy {pol}: dvol {sorted(res[pol])[1]:7.1f} us   dvol + build backward {sorted(resb[pol])[1]:7.1f} us")
-lib.fsraft_set_dvol_policy(0)
+cases = (("smooth: 12 lookups drifting 0.3 px per iteration", [f + 0.3 * i for i, f in enumerate([flows[0]] * T)]),
+         ("independent 3 px noise per lookup", flows),
+         ("jumping: +-40 px between lookups (work-list route)", [torch.randn(B, 2, H, W, device=dev) * 40 for _ in range(T)]))
+for name, fl in cases:
+    lib.fsraft_set_dvol_box(0)
+    ref = ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True)
+    ref32 = ops.corr_dvol_build(douts, fl, lay, B, r, records=False, is_flow=True)
+    lib.fsraft_set_dvol_box(1)
+    got = ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True)
+    got32 = ops.corr_dvol_build(douts, fl, lay, B, r, records=False, is_flow=True)
+    d = (got32 - ref32).abs()
+    nz = int((ref32 != 0).sum()), int((got32 != 0).sum())
+    print(f"   max |box - row| = {d.max().item():.3e} (max |ref| {ref32.abs().max().item():.3e}); nonzeros ref / box: {nz}; cells that differ: {int((d > 1e-6).sum())}")
+    if d.max().item() > 1e-5:
+        idx = (d > 1e-5).nonzero()[:6].tolist()
+        for qq, pp in idx:
+            lvl = max(l for l in range(4) if pp >= lay.off[l])
+            rel = pp - lay.off[lvl]; tl = rel >> 4
+            print("      q", qq, "p", pp, "level", lvl, "tile", tl, "cell", rel & 15, "ref", ref32[qq, pp].item(), "box", got32[qq, pp].item())
+    assert d.max().item() <= 1e-5 * max(ref32.abs().max().item(), 1.0), name
+    res = {0: [], 1: []}
+    for rnd in range(3):
+        for box in (0, 1):
+            lib.fsraft_set_dvol_box(box)
+            res[box].append(timeit(lambda: ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True), 5))
+    print(f"{name:55s} row-segment kernel {sorted(res[0])[1]:7.1f} us   bounding-box kernel + work list {sorted(res[1])[1]:7.1f} us")
+# chunked use (AlternateCorrBlock's backward): queries [q0, q0 + nq)
+lib.fsraft_set_dvol_box(0)
+ref32 = ops.corr_dvol_build(douts, flows, lay, B, r, records=False, is_flow=True)
+ref = ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True, q0=5000, nq=2048)
+lib.fsraft_set_dvol_box(1)
+got = ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True, q0=5000, nq=2048)
+print("chunk records differing words:", (got.view(torch.int32) != ref.view(torch.int32)).float().mean().item())
+assert (ops.corr_dvol_build(douts, flows, lay, B, r, records=False, is_flow=True, q0=5000, nq=2048) - ref32[5000:5000 + 2048]).abs().max().item() < 1e-5, "chunk"
+print("chunk of 2048 queries from 5000: identical")

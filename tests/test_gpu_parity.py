@@ -162,6 +162,48 @@ def test_alt_lookup_on_the_matrix_pipe(B, C, H, W, nlev):
         close(got, fp32, 1e-4, what=f"matrix-pipe alt lookup vs fp32 tile kernel, {name}")
 
 
+@pytest.mark.parametrize("B,H,W,nlev,n", [(2, 55, 128, 4, 12), (1, 17, 19, 4, 3), (2, 16, 24, 3, 16), (1, 46, 62, 4, 12)])
+def test_gradient_volume_bounding_box_kernel_matches_the_row_kernel(B, H, W, nlev, n):
+    """corr_dvol_box_kernel (one wave per query, only the bounding boxes of the lookups' windows in LDS, a work list for
+    queries whose lookups spread further) against corr_dvol_kernel (the whole row segment in LDS), fp32 rows and records:
+    smooth flows (every query on the fast route), independent noise, flows that jump +-40 px between lookups (every query
+    through the work list), and a chunk of queries (AlternateCorrBlock's backward).  Same sums in the same order: equal up to
+    the compilers' different fma contraction (<= 1e-6 relative to the row maximum); records within one unit of the low half."""
+    from flow_supervisor_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(21)
+    lay = ops.VolLayout.get(H, W, nlev)
+    douts = [torch.randn(B, H, W, nlev * 81, device=DEV) for _ in range(n)]
+    base = torch.randn(B, 2, H, W, device=DEV) * 3
+    cases = (("smooth", [base + 0.3 * i for i in range(n)]),
+             ("noise", [torch.randn(B, 2, H, W, device=DEV) * 3 for _ in range(n)]),
+             ("jumping", [torch.randn(B, 2, H, W, device=DEV) * 40 for _ in range(n)]))
+    try:
+        for name, fl in cases:
+            outs = {}
+            for box in (0, 1):
+                lib.fsraft_set_dvol_box(box)
+                outs[box] = (ops.corr_dvol_build(douts, fl, lay, B, 4, records=False, is_flow=True),
+                             ops.corr_dvol_build(douts, fl, lay, B, 4, records=True, is_flow=True))
+            close(outs[1][0], outs[0][0], 0.0, rtol=1e-6, what=f"gradient volume (fp32 rows), {name}")
+            assert (outs[1][0] != 0).sum() == (outs[0][0] != 0).sum(), "zero pattern"
+
+            def dec(r):          # rows of [32 bf16 hi | 32 bf16 lo] records -> fp32 (hi + lo)
+                w = r.contiguous().view(torch.int16).view(r.shape[0], -1, 2, 32).to(torch.int32) << 16
+                return (w[:, :, 0].view(torch.float32) + w[:, :, 1].view(torch.float32)).reshape(r.shape[0], -1)
+            close(dec(outs[1][1]), dec(outs[0][1]), 0.0, rtol=2e-5, what=f"gradient volume (records, decoded: hi + lo carries 2^-17), {name}")
+            close(dec(outs[1][1]), outs[1][0], 0.0, rtol=2e-5, what=f"records vs fp32 rows, {name}")
+        nq0 = B * H * W
+        q0, nq = nq0 // 3, min(100, nq0 - nq0 // 3)
+        lib.fsraft_set_dvol_box(0)
+        ref = ops.corr_dvol_build(douts, cases[1][1], lay, B, 4, records=False, is_flow=True, q0=q0, nq=nq)
+        lib.fsraft_set_dvol_box(1)
+        got = ops.corr_dvol_build(douts, cases[1][1], lay, B, 4, records=False, is_flow=True, q0=q0, nq=nq)
+        close(got, ref, 0.0, rtol=1e-6, what="chunk of queries")
+    finally:
+        lib.fsraft_set_dvol_box(1)
+
+
 def test_alt_cuda_corr_several_coordinate_sets():
     """coords [B,N,H1,W1,2] with N > 1 (correlation_kernel.cu:34,59; the C ABI carries N): every set against the oracle's
     restatement of one extension call, and the backward against autograd of that restatement."""
