@@ -18,11 +18,15 @@ from oracle.weights import procedural_state_dict, rand_tensor, rand_uniform, syn
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# Limits of the train-step comparisons, per arithmetic mode: (loss rel, prediction abs [px], gradient-norm rel, gradient-head rel).
+# Limits of the train-step comparisons, per arithmetic mode: loss rel, prediction abs [px], gradient-norm rel and gradient-head
+# rel for everything except the feature encoder (gnorm / ghead), and the same pair for `fnet.*` (see grad_digest_check).
 # Set to ~4x the worst error measured on MI355X over the whole suite (profiles/r03_parity_margins.txt lists every comparison
-# with the share of its limit it used); round 2 ran these checks at 1e-4 / 4e-3 / 5e-3 / 2e-2.
-TRAIN_TOL = {"exact": dict(loss=2e-5, pred=1e-3, gnorm=5e-3, ghead=2e-2, gnorm_fnet=5e-3, ghead_fnet=2e-2),
-             "split": dict(loss=1e-4, pred=4e-3, gnorm=5e-3, ghead=2e-2, gnorm_fnet=5e-3, ghead_fnet=2e-2)}
+# with the share of its limit it used).  Worst observed, exact / split: loss 7e-7 / 6e-6, prediction 1.2e-4 / 2.2e-4 px,
+# gnorm 3.1e-4 / 3.8e-4, ghead 2.3e-3 / 3.6e-3; fnet: gnorm ~1e-3, ghead 1.9e-2 in BOTH modes (the reference's own
+# run-to-run noise on those gradients, scripts/encoder_grad_noise.py) -- so the fnet pair is not mode dependent.
+# Round 2 ran all of these at 1e-4 / 4e-3 / 5e-3 / 2e-2.
+TRAIN_TOL = {"exact": dict(loss=5e-6, pred=5e-4, gnorm=1.5e-3, ghead=1e-2, gnorm_fnet=5e-3, ghead_fnet=3e-2),
+             "split": dict(loss=3e-5, pred=1e-3, gnorm=1.5e-3, ghead=1.5e-2, gnorm_fnet=5e-3, ghead_fnet=3e-2)}
 
 
 @pytest.fixture(params=["exact", "split"])
