@@ -31,9 +31,9 @@ class GMAL2L(RAFTGMA):
         fmap1, fmap2 = self._features(image1, image2)
         corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
         net, inp, attention = self._context(image1)
-        coords0, coords1 = self.initialize_flow(image1)
-        if flow_init is not None:
-            coords1 = coords1 + flow_init
+        # the loop carries the flow (see core/l2l.py): lookups add the pixel grid themselves
+        B, _, Hi, Wi = image1.shape
+        flow = flow_init.float() if flow_init is not None else torch.zeros(B, 2, Hi // 8, Wi // 8, device=image1.device)
 
         flow_predictions = []
         flow_up = None
@@ -46,32 +46,29 @@ class GMAL2L(RAFTGMA):
                     # (extension, default off) the caller's loss does not reach the supervisor's predictions -- sequence_loss_unsup
                     # only reads the last one, detached (train.py:110-111) -- so the second half records no graph
                     torch.set_grad_enabled(False)
-                coords1 = coords1.detach()
+                flow = flow.detach()
                 if test_mode or itr != half:          # (at the switch the reference looks up the crop's volume and drops it)
-                    corr = corr_fn(coords1, channels_last=True)
-                flow = coords1 - coords0
+                    corr = corr_fn(flow, channels_last=True, is_flow=True)
                 if not (test_mode or itr < half) and itr == half:
                     if ci1 is not None:
                         crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
                         net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))
-                        coords0, _ = self.initialize_flow(ci1)
-                        coords1 = flow + coords0
                         tfmap1, tfmap2 = self._features(ci1, ci2)
                         corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)
-                        corr = corr_fn(coords1, channels_last=True)
+                        corr = corr_fn(flow, channels_last=True, is_flow=True)
                         _, inp, attention = self._context(ci1)
                     net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                     attention = attention.detach()
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_l2l.py:126-127)
                 net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up)
 
-                coords1 = coords1 + delta_flow
+                flow = flow + delta_flow
                 if not want_up:
                     continue
                 if up_mask is None:
-                    flow_up = upflow8(coords1 - coords0)
+                    flow_up = upflow8(flow)
                 else:
-                    flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+                    flow_up = convex_upsample(flow, up_mask, channels_last=True)
                 if not test_mode and itr >= half:
                     flow_up = _crop_back(flow_up, *crop)
                 flow_predictions.append(flow_up)
@@ -79,5 +76,5 @@ class GMAL2L(RAFTGMA):
             torch.set_grad_enabled(grad_mode)
 
         if test_mode:
-            return coords1 - coords0, flow_up
+            return flow, flow_up
         return flow_predictions

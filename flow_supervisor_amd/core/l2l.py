@@ -45,12 +45,35 @@ def _pad_state(net, flow, ox_l, oy_l, orig, targ):
     return torch.cat(nets, 0), torch.cat(flows, 0)
 
 
+class _CropBackFn(torch.autograd.Function):
+    """Per-sample windows of the full-frame prediction as ONE autograd node: a strided copy per sample forward, one zero
+    fill + a copy per sample backward (slicing + cat costs five framework launches per prediction in backward: two
+    zero-filled full frames, two copies, one add)."""
+
+    @staticmethod
+    def forward(ctx, flow_up, ox_l, oy_l, orig):
+        h, w = orig
+        out = torch.empty(flow_up.shape[0], flow_up.shape[1], h, w, device=flow_up.device, dtype=flow_up.dtype)
+        for i, (ox_, oy_) in enumerate(zip(ox_l, oy_l)):
+            out[i].copy_(flow_up[i, :, oy_: oy_ + h, ox_: ox_ + w])
+        ctx.win = (tuple(ox_l), tuple(oy_l), h, w, tuple(flow_up.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ox_l, oy_l, h, w, shape = ctx.win
+        d = torch.zeros(shape, device=g.device, dtype=g.dtype)
+        for i, (ox_, oy_) in enumerate(zip(ox_l, oy_l)):
+            d[i, :, oy_: oy_ + h, ox_: ox_ + w].copy_(g[i])
+        return d, None, None, None
+
+
 def _crop_back(flow_up, ox_l, oy_l, orig):
     """The supervisor's full-frame prediction cut back to the student's window (l2l.py:124-125)."""
     orig_h, orig_w = orig
     if len(set(zip(ox_l, oy_l))) == 1:
         return flow_up[:, :, oy_l[0]: oy_l[0] + orig_h, ox_l[0]: ox_l[0] + orig_w]
-    return torch.cat([flow_up[i:i + 1, :, oy_: oy_ + orig_h, ox_: ox_ + orig_w] for i, (ox_, oy_) in enumerate(zip(ox_l, oy_l))], 0)
+    return _CropBackFn.apply(flow_up, ox_l, oy_l, orig)
 
 
 class L2L(RAFT):
@@ -80,11 +103,6 @@ class L2L(RAFT):
                 c = self.cnet(a)
             return torch.split(c.float(), [hdim, cdim], dim=1)
 
-        def lookup(fn, coords):
-            if isinstance(fn, AlternateCorrBlock):
-                return to_channels_last(fn(coords))
-            return fn(coords, channels_last=True)
-
         fmap1, fmap2 = features(image1, image2)
         if self.args.alternate_corr:
             corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
@@ -94,9 +112,11 @@ class L2L(RAFT):
         net = to_channels_last(torch.tanh(net))
         inp = to_channels_last(torch.relu(inp))
 
-        coords0, coords1 = self.initialize_flow(image1)
-        if flow_init is not None:
-            coords1 = coords1 + flow_init
+        # As in RAFT.forward the loop carries the FLOW, not coords1 = coords0 + flow (l2l.py:66-70, 110-122): the lookups add
+        # the pixel grid themselves, so an iteration has one framework op (flow + delta) instead of three; same gradient
+        # structure -- the flow entering an iteration is detached.
+        B, _, Hi, Wi = image1.shape
+        flow = flow_init.float() if flow_init is not None else torch.zeros(B, 2, Hi // 8, Wi // 8, device=image1.device)
 
         flow_predictions = []
         flow_up = None
@@ -109,10 +129,9 @@ class L2L(RAFT):
                     # (extension, default off) the caller's loss does not reach the supervisor's predictions -- sequence_loss_unsup
                     # only reads the last one, detached (train.py:110-111) -- so the second half records no graph
                     torch.set_grad_enabled(False)
-                coords1 = coords1.detach()
+                flow = flow.detach()
                 if test_mode or itr != half:          # (at the switch the reference looks up the crop's volume and drops it, l2l.py:73/102)
-                    corr = lookup(corr_fn, coords1)
-                flow = coords1 - coords0
+                    corr = corr_fn(flow, channels_last=True, is_flow=True)
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (l2l.py:130-131)
                 if test_mode or itr < half:
                     net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up)
@@ -121,23 +140,21 @@ class L2L(RAFT):
                         if ci1 is not None:
                             crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
                             net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))   # (l2l.py:90-93)
-                            coords0, _ = self.initialize_flow(ci1)
-                            coords1 = flow + coords0
                             tfmap1, tfmap2 = features(ci1, ci2)
                             corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)   # second volume (l2l.py:101)
-                            corr = lookup(corr_fn, coords1)
+                            corr = corr_fn(flow, channels_last=True, is_flow=True)
                             _, inp = context(ci1)
                             inp = to_channels_last(torch.relu(inp))
                         net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                     net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow)
 
-                coords1 = coords1 + delta_flow
+                flow = flow + delta_flow
                 if not want_up:
                     continue
                 if up_mask is None:
-                    flow_up = upflow8(coords1 - coords0)
+                    flow_up = upflow8(flow)
                 else:
-                    flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+                    flow_up = convex_upsample(flow, up_mask, channels_last=True)
                 if not test_mode and itr >= half:
                     flow_up = _crop_back(flow_up, *crop)
                 flow_predictions.append(flow_up)
@@ -145,5 +162,5 @@ class L2L(RAFT):
             torch.set_grad_enabled(grad_mode)
 
         if test_mode:
-            return coords1 - coords0, flow_up
+            return flow, flow_up
         return flow_predictions

@@ -1705,16 +1705,19 @@ float* g_conv_ws = nullptr;      // workspace handed over by the binding (fsraft
 int64_t g_conv_ws_floats = 0;
 
 // Slices for a tile grid of `tiles` workgroups, KT k-tiles and N outputs.  Measured (scripts/conv_micro.py, 1 x 47x156, 1 x 46x96,
-// 2 x 46x96): the route pays where fewer than ~half of the CUs have a workgroup AND the second pass is small -- layers with
-// <= 256 outputs (3x3 256 -> 126: 52 -> 40 us, 1x5 384 -> 128: 42 -> 34, the 3x3 512 -> 128 data gradient: 87 -> 52 us; at
-// 4416 pixels 3x3 256 -> 192: 55 -> 44, 1x5 384 -> 256: 46 -> 39); with 512 outputs the slabs cost more than the shorter
-// k-loops save (3x3 128 -> 512: 37 -> 55 us), and from ~230 tiles on the CUs are busy anyway.  64-row tiles only: where the
-// dispatcher picked 128-row tiles the grid was already judged large enough, and splitting those measured slower (1x5 256 ->
-// 256 at 8832 pixels: 35 -> 41 us).
-int pick_ksplit(int64_t tiles, int KT, int N, int64_t M, int ldw) {
+// 2 x 46x96, 2 x 54x128; scripts/tmp/smallm_sweep.sh): the route pays where fewer than ~half of the CUs have a workgroup AND
+// the second pass is small -- layers with <= 256 outputs (3x3 256 -> 126: 52 -> 40 us, 1x5 384 -> 128: 42 -> 34, the 3x3
+// 512 -> 128 data gradient: 87 -> 52 us; at 4416 pixels 3x3 256 -> 192: 55 -> 44, 1x5 384 -> 256: 46 -> 39); with 512 outputs
+// the slabs cost more than the shorter k-loops save (3x3 128 -> 512: 37 -> 55 us), and from ~230 tiles on the CUs are busy
+// anyway.  128-row tiles (eight waves): the one-column layers of a two-pair batch leave 69-108 workgroups for 256 CUs and
+// gain 15-45 % from two or three slices when the k-loop is long enough to share (3x3 256 -> 126 at 2 x 46x96: 59 -> 38 us,
+// 3x3 512 -> 128 data gradient 100 -> 56, 1x5 384 -> 128: 45 -> 32); two-column layers only with >= 48 k-tiles (1x5 384 -> 256
+// at 1 x 47x156: 47 -> 41 us, but the 20-tile data gradient 1x5 128 -> 256: 23 -> 29); above ~120 tiles nothing gains.
+int pick_ksplit(int64_t tiles, int KT, int N, int64_t M, int ldw, int bm) {
   int S = 1;
   if (g_conv_ksplit >= 2) S = g_conv_ksplit;
-  else if (g_conv_ksplit == -1 && tiles <= 150 && N <= 256 && KT >= 16) S = (int)((400 + tiles - 1) / tiles);
+  else if (g_conv_ksplit == -1 && bm == 64 && tiles <= 150 && N <= 256 && KT >= 16) S = (int)((400 + tiles - 1) / tiles);
+  else if (g_conv_ksplit == -1 && bm == 128 && tiles <= 120 && N <= 256 && KT >= (N <= 128 ? 36 : 48)) S = tiles <= 115 ? (int)(230 / tiles) : 2;
   if (S > KT / 6) S = KT / 6;
   if (S > 6) S = 6;
   while (S > 1 && (int64_t)S * M * ldw > g_conv_ws_floats) --S;
@@ -1739,7 +1742,7 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
     // split-K route (small M): partial tiles into the workspace, then conv_finish_kernel with the layer's own epilogue
     const int ldw = (a.N + 3) / 4 * 4;
     const bool gru_ok = epi == EPI_PLAIN || (a.N % 4 == 0 && (!a.pre || a.ldpre % 4 == 0));
-    const int S = (buf && g_conv_ws && gru_ok && !(g_conv_bdma_on()) && (Cfg::BM == 64 || g_conv_ksplit >= 2)) ? pick_ksplit((int64_t)grid.x * grid.y, a.Ktot / 32, a.N, M, ldw) : 1;
+    const int S = (buf && g_conv_ws && gru_ok && !(g_conv_bdma_on()) && (Cfg::BM == 64 || (Cfg::BM == 128 && Cfg::NT == 512) || g_conv_ksplit >= 2)) ? pick_ksplit((int64_t)grid.x * grid.y, a.Ktot / 32, a.N, M, ldw, Cfg::BM) : 1;
     if (S > 1) {
       const bool uni_tab = build_ktab_uniform(a, t);
       if (uni_tab || build_ktab(a, t)) {

@@ -44,6 +44,70 @@ class _SeqLossFn(torch.autograd.Function):
         return (None,) * 6 + tuple(dps)
 
 
+class _SemiLossFn(torch.autograd.Function):
+    """Both losses of the batched flow-supervisor step on the UNSLICED predictions [2*bs, 2, H, W]: samples [0, bs) against the
+    ground truth (sequence_loss), samples [bs, 2*bs) against the last prediction of their own half (sequence_loss_unsup), as two
+    fsraft_sequence_loss launches on pointer offsets that write straight into one gradient tensor per prediction.  Slicing
+    the predictions instead costs autograd five framework launches per prediction and half in backward (two zero-filled
+    batches, two copies, one add): ~240 launches of a ~2000-launch step."""
+
+    @staticmethod
+    def forward(ctx, bs, w_sup, w_unsup, gt, valid, max_flow, eps, *preds):
+        import ctypes
+        from . import _lib as L
+        preds = [p.contiguous() for p in preds]
+        L.require_cuda_f32(*preds)
+        B2, _, H, W = preds[0].shape
+        n = len(preds)
+        if B2 != 2 * bs or len(w_sup) != n or len(w_unsup) != n:
+            raise ValueError("batched flow-supervisor loss: predictions must hold bs labelled then bs unlabelled samples")
+        dps = [torch.empty_like(p) for p in preds]
+        out = torch.zeros(12, device=preds[0].device, dtype=torch.float32)
+        gt = gt.contiguous().float()
+        valid = valid.contiguous().float() if valid is not None else None
+        L.require_cuda_f32(gt)
+        half = bs * 2 * H * W * 4                     # bytes from sample 0 to sample bs
+        lib = L.load()
+        for k, (w, ofs) in enumerate(((w_sup, 0), (w_unsup, half))):
+            a_p = (ctypes.c_void_p * n)(*[p.data_ptr() + ofs for p in preds])
+            a_d = (ctypes.c_void_p * n)(*[d.data_ptr() + ofs for d in dps])
+            a_w = (ctypes.c_float * n)(*[float(x) for x in w])
+            if k == 0:
+                g, v, mf = L.ptr(gt), L.ptr(valid), float(max_flow)
+            else:                                     # pseudo label: the last prediction of the unlabelled samples (train.py:110-111)
+                g, v, mf = ctypes.c_void_p(preds[-1].data_ptr() + ofs), None, float("inf")
+            L.check(lib.fsraft_sequence_loss(ctypes.cast(a_p, L._PP), ctypes.cast(a_d, L._PP), a_w, n, -1, g, v, mf, float(eps),
+                                             bs, H, W, ctypes.c_void_p(out.data_ptr() + 24 * k), L.stream()), "sequence_loss")
+        ctx.dps, ctx.bs = dps, bs
+        return out[0].clone(), out[6].clone()
+
+    @staticmethod
+    def backward(ctx, g_sup, g_unsup):
+        dps, ctx.dps = ctx.dps, None
+        bs = ctx.bs
+        if g_sup is not None:
+            torch._foreach_mul_([d[:bs] for d in dps], g_sup)
+        else:
+            for d in dps:
+                d[:bs].zero_()
+        if g_unsup is not None:
+            torch._foreach_mul_([d[bs:] for d in dps], g_unsup)
+        else:
+            for d in dps:
+                d[bs:].zero_()
+        return (None,) * 7 + tuple(dps)
+
+
+def semi_sequence_losses(flow_preds, bs, flow_gt, valid, gamma=0.8, gamma2=1.0, unsup_weight=1.0, max_flow=MAX_FLOW):
+    """(sequence_loss of samples [0, bs), sequence_loss_unsup of samples [bs, 2*bs)) of batched flow-supervisor predictions:
+    same values and gradients as the two functions on the two slices (pytorch/train.py:60-129), without the slices."""
+    nm = len(flow_preds)
+    n = nm // 2
+    w_sup = [gamma ** (n - i - 1) for i in range(n)] + [gamma2 ** (n - i - 1) for i in range(nm - n)]
+    w_unsup = [unsup_weight * gamma ** (n - i - 1) for i in range(n)] + [0.0] * (nm - n)
+    return _SemiLossFn.apply(bs, w_sup, w_unsup, flow_gt, valid, max_flow, 1e-3, *flow_preds)
+
+
 def weighted_sequence_loss(flow_preds, weights, flow_gt=None, valid=None, max_flow=MAX_FLOW, eps=1e-3, metric_idx=None):
     """sum_i weights[i] * mean(mask * sqrt((pred_i - gt)^2 + eps^2)) on the fused kernel.  Returns (loss, stats) with
     stats = [loss, epe_sum, n<1px, n<3px, n<5px, n_valid] of prediction `metric_idx` (device tensor, no sync)."""
@@ -183,8 +247,11 @@ class SemiTrainStep(TrainStep):
         ox = _offsets(sup[4], bs) + _offsets(unsup[4], unsup[0].shape[0])
         oy = _offsets(sup[5], bs) + _offsets(unsup[5], unsup[0].shape[0])
         preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters)
-        loss, _ = sequence_loss([p[:bs] for p in preds], sup[6], sup[7], self.gamma, metrics=False)
-        loss_u, _ = sequence_loss_unsup([p[bs:] for p in preds], unsup[6], unsup[7], unsup_weight=self.unsup_lambda, metrics=False)
+        if preds[0].is_cuda and unsup[0].shape[0] == bs:
+            loss, loss_u = semi_sequence_losses(preds, bs, sup[6], sup[7], self.gamma, unsup_weight=self.unsup_lambda)
+        else:
+            loss, _ = sequence_loss([p[:bs] for p in preds], sup[6], sup[7], self.gamma, metrics=False)
+            loss_u, _ = sequence_loss_unsup([p[bs:] for p in preds], unsup[6], unsup[7], unsup_weight=self.unsup_lambda, metrics=False)
         (loss + loss_u).backward()
         del preds
         self.grads.all_reduce_mean_()

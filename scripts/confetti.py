@@ -3,7 +3,7 @@
 Part 1: every kernel of one profiled step that is not one of this library's (at::native, memcpy, memset, MIOpen helpers),
 counted by name.  Part 2: every non-view ATen op of one step seen by a dispatch mode, grouped by the innermost frame of
 this repository on the Python stack (ops issued by the autograd engine itself have no such frame).
-usage: python scripts/confetti.py [raft|gma|alt]   (GPU box)"""
+usage: python scripts/confetti.py [raft|gma|alt|l2l]   (GPU box)"""
 import argparse
 import collections
 import os
@@ -25,15 +25,30 @@ torch.manual_seed(0)
 if variant == "gma":
     from flow_supervisor_amd.core.gma_network import RAFTGMA
     model = RAFTGMA(argparse.Namespace(mixed_precision=False, num_heads=1, position_only=False, position_and_content=False))
+elif variant == "l2l":
+    from flow_supervisor_amd.core.l2l import L2L
+    model = L2L(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False))
 else:
     from flow_supervisor_amd.core.raft import RAFT
     model = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=variant == "alt"))
 model = model.to(dev).train()
 model.freeze_bn()
-step = TrainStep(model, lr=1.6e-5, iters=12)
-B, H, W = (1, 376, 1248) if variant == "alt" else (4, 440, 1024)
-im1 = torch.rand(B, 3, H, W, device=dev) * 255
-im2 = torch.rand(B, 3, H, W, device=dev) * 255
+if variant == "l2l":                      # the flow-supervisor step of bench.py --variant l2l (one labelled + one unlabelled sample)
+    from flow_supervisor_amd.train import SemiTrainStep
+    sstep = SemiTrainStep(model, lr=5e-6, wdecay=0.0, iters=12, gamma=0.8, unsup_lambda=1.0)
+
+    def sample(oy, ox):
+        f1, f2 = torch.rand(1, 3, 432, 1024, device=dev) * 255, torch.rand(1, 3, 432, 1024, device=dev) * 255
+        c1, c2 = f1[:, :, oy:oy + 368, ox:ox + 768].contiguous(), f2[:, :, oy:oy + 368, ox:ox + 768].contiguous()
+        return (c1, c2, f1, f2, ox, oy, torch.randn(1, 2, 368, 768, device=dev), torch.ones(1, 368, 768, device=dev))
+    sup, unsup = sample(40, 136), sample(16, 200)
+    step = lambda _a, _b: sstep(sup, unsup)
+    im1 = im2 = None
+else:
+    step = TrainStep(model, lr=1.6e-5, iters=12)
+    B, H, W = (1, 376, 1248) if variant == "alt" else (4, 440, 1024)
+    im1 = torch.rand(B, 3, H, W, device=dev) * 255
+    im2 = torch.rand(B, 3, H, W, device=dev) * 255
 for _ in range(3):
     step(im1, im2)
 torch.cuda.synchronize()

@@ -12,6 +12,7 @@ from flow_supervisor_amd import ops  # noqa: E402
 from flow_supervisor_amd.ops import Dst, V  # noqa: E402
 
 B, H, W = (int(v) for v in os.environ.get("CONV_MICRO_BHW", "4,55,128").split(","))
+GRAPH = os.environ.get("CONV_MICRO_GRAPH", "0") == "1"
 NSEG = int(os.environ.get("CONV_MICRO_NSEG", "1"))   # wgrad: this many (dY, X) segments in one multi launch
 M = B * H * W
 dev = "cuda"
@@ -47,6 +48,13 @@ LAYERS = [  # name, kh, kw, src channels, Cout
     ("x5 1x5 384->256 one src", 1, 5, [384], 256),
     ("x9 3x3 224->256", 3, 3, [224], 256),
     ("xw 1x5 384->512", 1, 5, [384], 512),
+    # fixed cost of a launch: one k-tile, 128 / 256 / 512 outputs
+    ("y1 1x1 32->128", 1, 1, [32], 128),
+    ("y2 1x1 32->256", 1, 1, [32], 256),
+    ("y3 1x1 32->512", 1, 1, [32], 512),
+    ("y4 1x1 256->256", 1, 1, [256], 256),
+    ("y5 1x1 512->256", 1, 1, [512], 256),
+    ("y6 1x1 1024->256", 1, 1, [1024], 256),
 ]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
@@ -78,10 +86,23 @@ for name, kh, kw, cs, cout in LAYERS:
                 ops.conv_wgrad_multi(dys, xss, dwpk, B, H, W, kh, kw)
         run()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            run()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        if GRAPH:                      # `reps` launches captured in one hipGraph: GPU time per launch without the host's ~10 us per call
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(reps):
+                    run()
+            gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                gr.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps / 5
+        else:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
         fl = 2.0 * M * cout * cin * kh * kw * (NSEG if kind == 'wgrad' else 1)
         print(f"{name:18s} {kind:5s} {dt * 1e6:8.1f} us  {fl / dt / 1e12:6.1f} TF  ({fl / dt / 1e12 / 157.3 * 100:4.1f}% of fp32 MFMA peak)")

@@ -586,6 +586,31 @@ def test_sequence_loss_unsup_vs_reference_function():
             close(got, g[f"{name}_dpred{i}"], 1e-9, 1e-5, what=f"unsup dpred{i}")
 
 
+@pytest.mark.parametrize("bs", [1, 2])
+def test_batched_flow_supervisor_losses_equal_the_two_functions_on_slices(bs):
+    """train.semi_sequence_losses (both losses of the batched step on unsliced predictions, two kernel launches on pointer
+    offsets) against train.sequence_loss on samples [0, bs) and train.sequence_loss_unsup on samples [bs, 2 bs) -- which are
+    pinned to the reference's functions above: same loss values and bit-equal gradients (same kernel, same per-pixel order)
+    for every prediction, with different upstream factors on the two losses."""
+    from flow_supervisor_amd.train import semi_sequence_losses, sequence_loss, sequence_loss_unsup
+    H, W, n = 24, 40, 6
+    vals = [rand_tensor((2 * bs, 2, H, W), 300 + i, 3.0).to(DEV) for i in range(n)]
+    gt = rand_tensor((bs, 2, H, W), 290, 4.0).to(DEV)
+    valid = (rand_uniform((bs, H, W), 291, 0.0, 1.0) > 0.2).float().to(DEV)
+    a = [v.clone().requires_grad_(True) for v in vals]
+    ls, lu = semi_sequence_losses(a, bs, gt, valid, 0.8, unsup_weight=0.25)
+    (2.0 * ls + 3.0 * lu).backward()
+    b = [v.clone().requires_grad_(True) for v in vals]
+    rs, _ = sequence_loss([p[:bs] for p in b], gt, valid, 0.8, metrics=False)
+    ru, _ = sequence_loss_unsup([p[bs:] for p in b], gt, valid, 0.8, 0.25, metrics=False)
+    (2.0 * rs + 3.0 * ru).backward()
+    rel_check(ls.item(), rs.item(), 2e-6, "labelled loss")           # (block sums meet in float atomics: not bit-equal run to run)
+    rel_check(lu.item(), ru.item(), 2e-6, "unlabelled loss")
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x.grad, y.grad), i
+    assert float(a[-1].grad[bs:].abs().max()) == 0.0          # the supervisor's half of the unlabelled samples: no gradient
+
+
 def test_test_mode_skips_the_dropped_upsamples_with_identical_outputs():
     """test_mode returns only the last flow_up (raft.py:141-142); the mask convolution and the upsampler of
     the other iterations are skipped.  Outputs must equal the last training-mode prediction of the same weights (same kernels,
