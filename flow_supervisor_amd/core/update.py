@@ -425,7 +425,7 @@ class _Engine:
         return h, mask, delta, saved
 
     # ---- backward -----------------------------------------------------------------
-    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None, cst=None):
+    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None, cst=None, need_dflow=True):
         """Accumulates parameter gradients into the packed arena of `st` and the gate gradients into `cst.dsum`
         (the context part's backward runs once per step, context_backward); returns (dnet, dcorr, dflow)."""
         B, H, W = S["B"], S["H"], S["W"]
@@ -570,8 +570,11 @@ class _Engine:
             dgrad("av", V(dv, mc), [Dst.nhwc(dmotion, 0, 0, True)])
 
         # ---- motion encoder
-        dflow = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
-        ops.nhwc_to_flow(dmotion, self.cv, dflow, False)
+        # (the loops detach the flow that enters an iteration, raft.py:123: its gradient -- the pass-through channels of the
+        #  motion features plus the 7x7 convolution's data gradient -- is then three launches per iteration nobody reads)
+        dflow = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32) if need_dflow else None
+        if need_dflow:
+            ops.nhwc_to_flow(dmotion, self.cv, dflow, False)
         if self.gma:      # (GMA adds to dmotion after the GRU, so the mask cannot ride on a GRU epilogue)
             relu_bwd(V(dmotion, self.cv), V(motion, self.cv))
         corflo = S["corflo"]
@@ -585,9 +588,10 @@ class _Engine:
         dgrad("f2", V(dcorflo, self.f2, cor_out), [Dst.nhwc(dflo1).masked(V(flo1, self.f1))])
         cols = S["cols"]
         wgrad("f1", V(dflo1, self.f1), [V(cols, 98)])
-        dcols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)     # (col2im7 reads the 98 channels only)
-        dgrad("f1", V(dflo1, self.f1), [Dst.nhwc(dcols)])
-        ops.col2im7(dcols, dflow, True)
+        if need_dflow:
+            dcols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)     # (col2im7 reads the 98 channels only)
+            dgrad("f1", V(dflo1, self.f1), [Dst.nhwc(dcols)])
+            ops.col2im7(dcols, dflow, True)
         corr = S["corr"]
         dcorr = buf(self.corr_c) if need_input_grads else None
         if self.c2:
@@ -725,8 +729,8 @@ class _UpdateFn(torch.autograd.Function):
         dmask = dmask if ctx.has_mask else None
         dh = dh.contiguous() if dh is not None else None
         cst = ctx.cst
-        dnet, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta, ast=ctx.ast,
-                                          cst=cst if cst.anchor is not None else None)
+        dnet, dcorr, dflow = eng.backward(S, ctx.P, ctx.st, dh, dmask, ddelta, need_input_grads=ctx.needs_input_grad[7], ast=ctx.ast,
+                                          cst=cst if cst.anchor is not None else None, need_dflow=ctx.needs_input_grad[8])
         # the three anchors get no gradient tensor: autograd still runs their producers (_ParamFn, _CtxFn, _AttnFn) once
         # every consumer is done -- that ordering is all they are for -- and skips 3 x 12 one-element accumulation kernels
         return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None)
