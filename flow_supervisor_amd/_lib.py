@@ -75,6 +75,7 @@ SIGNATURES = {
     "fsraft_set_build_kernel": [c_int],
     "fsraft_set_dvol_policy": [c_int],
     "fsraft_set_dvol_box": [c_int],
+    "fsraft_set_ktile_exact": [c_int],
     "fsraft_conv_workspace": [c_void_p, c_int64],
     "fsraft_set_arithmetic": [c_int],
     "fsraft_get_arithmetic": [],
@@ -130,7 +131,7 @@ SIGNATURES = {
     "fsraft_corr_build_rec": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_lookup_tiled_fwd": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_dvol_build": [_PP, _PP, POINTER(c_int64), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
-                               c_int64, c_void_p, _S],
+                               c_int64, c_void_p, c_void_p, _S],
     "fsraft_set_alt_tile": [c_int],
     "fsraft_altcorr_fused_fwd": [c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_altcorr_mfma_fwd": [c_void_p, _PP, c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
@@ -141,6 +142,12 @@ SIGNATURES = {
                            c_float, c_int, c_int, _S],
     "fsraft_gemm_rec_nt": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                            c_float, c_int, c_int, _S],
+    "fsraft_gemm_rec_nt_list": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                                c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, _S],
+    "fsraft_gemm_rec_tn_list": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                                c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, _S],
+    "fsraft_corr_bwd_ktiles": [_PP, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                               c_void_p, c_void_p, c_int, c_void_p, _S],
 }
 
 
@@ -164,6 +171,8 @@ def load():
     # fp32 accumulation); 0 keeps them on exact-fp32 MFMA.
     if os.environ.get("FSRAFT_DVOL_BOX") is not None:
         lib.fsraft_set_dvol_box(int(os.environ["FSRAFT_DVOL_BOX"]))
+    if os.environ.get("FSRAFT_KTILE_EXACT") is not None:
+        lib.fsraft_set_ktile_exact(int(os.environ["FSRAFT_KTILE_EXACT"]))
     arith = os.environ.get("FSRAFT_ARITHMETIC")     # 0: exact fp32 MFMA everywhere; 1 (default): bf16x3 products
     if arith is not None:
         lib.fsraft_set_arithmetic(int(arith))

@@ -66,10 +66,13 @@ class _BuildFn(torch.autograd.Function):
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None, None
         stash, st.stash = st.stash, []
         rec = ops.SPLIT_VOLUME_BWD             # (off = the exact-fp32 test mode: fp32 gradient volume, exact GEMMs)
+        # which k-tiles of the two volume-backward GEMMs the step's lookups can reach: the GEMMs walk those only, and the gradient
+        # volume is only written where they will read (the rest would be zero records)
+        kt = ops.corr_bwd_ktiles([c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius, st.is_flow) if rec and ops.BWD_KSKIP else None
         dvol = ops.corr_dvol_build([d for _, d in stash], [c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius, records=rec,
-                                   is_flow=st.is_flow)
+                                   is_flow=st.is_flow, wmask=kt.wmask if kt is not None and ops.DVOL_WMASK else None)
         del stash
-        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay, records=rec, f1r=ctx.f1r if rec else None)
+        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay, records=rec, f1r=ctx.f1r if rec else None, ktiles=kt)
         ctx.f1r = None
         return d1, d2, None, None, None
 

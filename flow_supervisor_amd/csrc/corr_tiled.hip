@@ -336,7 +336,8 @@ constexpr int DVB = 24;
 
 template <int R, bool REC>
 __global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int grid_w, int64_t q0,
-                                                            unsigned nq, unsigned* __restrict__ qlist, int policy) {
+                                                            unsigned nq, unsigned* __restrict__ qlist, int policy,
+                                                            const unsigned* __restrict__ wmask) {
   using S = TL<R>;
   __shared__ float box_s[4][DVB * DVB];
   __shared__ float g_s[4][DV_MAXN * S::N2];
@@ -397,6 +398,9 @@ __global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayou
     return;
   }
   char* rowb = reinterpret_cast<char*>(dvol + (int64_t)qrel * L.P);
+  // wmask (nullable, records only): bit r of this query's 32-query block = record r of the row will be read by a list GEMM
+  // (fsraft_corr_bwd_ktiles); the others are not written at all -- most of a row is zero records outside every list
+  const unsigned* wm = wmask ? wmask + ((int64_t)b * ((HW + 31) >> 5) + (pix >> 5)) * (((L.P >> 5) + 31) >> 5) : nullptr;
   // this lane's window cells (wy, wx): window cell (wy, wx) is tap (ay, ax) of output (j = wy - ay, i = wx - ax), channel i * N1 + j;
   // a tap that does not exist gets weight 0 and re-reads the other one
   constexpr int KC = (S::WIN * S::WIN + 63) / 64;
@@ -467,6 +471,10 @@ __global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayou
     // the level's section of the row: eight cells (two rows of a 4x4 tile) per lane and trip, zeros outside the box
     const int ntile = L.th[l] * tw;
     for (int e = lane * 8; e < seg; e += 512) {
+      if (REC && wm) {
+        const int r = (off + e) >> 5;
+        if (!((wm[r >> 5] >> (r & 31)) & 1u)) continue;
+      }
       const int T = e >> 4, ty = T / tw, tx = T - ty * tw;
       const int yb = 4 * ty + 2 * ((e >> 3) & 1) - oy, xb = 4 * tx - ox;          // this lane's 2 x 4 cells, relative to the box
       const bool touch = T < ntile && yb > -2 && yb < DVB && xb > -4 && xb < DVB;
@@ -500,6 +508,141 @@ __global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayou
 }
 
 __global__ void dvol_list_reset_kernel(unsigned* qlist) { qlist[0] = 0u; }
+
+// ---- which k-tiles of the volume-backward GEMMs can hold anything but zeros ---------------------------------------------
+// The gradient rows are zero outside the windows of the step's lookups (>= 80 % zero records at the bench shape), and both
+// GEMMs contract over them: dF1 = s * F2cat . dV^T walks the records of 128 query rows at a time (the N tile of
+// gemm_rec_nt_kernel), d2cat = s * dV^T . f1 walks, for 256 cells (its M tile), the queries in blocks of 32.  This pre-pass
+// marks, from the lookups' coordinates alone, every (128-query tile, record) and every (256-cell tile, 32-query block) that a
+// window can reach -- per query and level the bounding rectangle of its lookups' windows, a superset of what the gradient
+// kernel writes -- and compacts the marks into ascending k-tile lists for fsraft_gemm_rec_nt_list / _tn_list.
+int g_ktile_exact = 0;            // levels whose windows are marked lookup by lookup instead of by bounding rectangle (fsraft_set_ktile_exact)
+constexpr int KT_NQ = 128;        // queries per NT list
+constexpr int KT_MC = 256;        // cells per TN list
+constexpr int KT_MAXW = 256;      // words of a workgroup's record bitmap: P <= 256 * 32 * 32 floats
+constexpr int KT_MAXM = 32;       // words of its cell-tile bitmap:      P <= 32 * 32 * 256 floats
+struct KtArgs {
+  Coords co[DV_MAXN];
+  int n;
+};
+
+__device__ __forceinline__ void kt_mark(unsigned* bits, int i) {
+  const unsigned m = 1u << (i & 31);
+  if (!(bits[i >> 5] & m)) atomicOr(bits + (i >> 5), m);       // (most marks are already set: the read is a broadcast)
+}
+
+template <int EXACT>      // levels below EXACT: every lookup's window marked on its own; from EXACT on: the bounding rectangle of all
+__global__ __launch_bounds__(KT_NQ) void corr_ktiles_mark_kernel(KtArgs a, VolLayout L, int HW, int R, int grid_w, int* __restrict__ nt_list,
+                                                                 int* __restrict__ nt_count, int nt_stride, unsigned* __restrict__ tn_bits,
+                                                                 int mw, unsigned* __restrict__ wmask) {
+  __shared__ unsigned rb[KT_MAXW];
+  __shared__ unsigned mb[KT_NQ / 32][KT_MAXM];
+  __shared__ int wpre[KT_MAXW + 1];
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int nrec = L.P >> 5, nw = (nrec + 31) >> 5, nlev = L.nlev;
+  for (int i = tid; i < nw; i += KT_NQ) rb[i] = 0u;
+  for (int i = tid; i < (KT_NQ / 32) * KT_MAXM; i += KT_NQ) mb[i / KT_MAXM][i % KT_MAXM] = 0u;
+  __syncthreads();
+  const int pix = tile * KT_NQ + tid;
+  if (pix < HW) {
+    int mnx[4], mny[4], mxx[4], mxy[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { mnx[l] = mny[l] = 0x7fffffff; mxx[l] = mxy[l] = -0x7fffffff; }
+#pragma unroll
+    for (int t = 0; t < DV_MAXN; ++t)
+      if (t < a.n) {
+        float cx, cy;
+        query_xy(a.co[t], b, pix, grid_w, cx, cy);
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+          if (l < nlev) {
+            const LevelQ q = level_query(cx, cy, l, R);
+            if (l < EXACT) {
+              const int x0 = max(q.wx0, 0), x1 = min(q.wx0 + 2 * R + 1, L.w[l] - 1);
+              const int y0 = max(q.wy0, 0), y1 = min(q.wy0 + 2 * R + 1, L.h[l] - 1);
+              if (x0 <= x1 && y0 <= y1)
+                for (int ty = y0 >> 2; ty <= (y1 >> 2); ++ty)
+                  for (int tx = x0 >> 2; tx <= (x1 >> 2); ++tx) {
+                    const int cell = L.off[l] + (ty * L.tw[l] + tx) * 16;
+                    kt_mark(rb, cell >> 5);
+                    kt_mark(mb[tid >> 5], cell / KT_MC);
+                  }
+            } else {
+              mnx[l] = min(mnx[l], q.wx0); mxx[l] = max(mxx[l], q.wx0);
+              mny[l] = min(mny[l], q.wy0); mxy[l] = max(mxy[l], q.wy0);
+            }
+          }
+      }
+#pragma unroll
+    for (int l = EXACT; l < 4; ++l)
+      if (l < nlev) {
+        const int x0 = max(mnx[l], 0), x1 = min(mxx[l] + 2 * R + 1, L.w[l] - 1);
+        const int y0 = max(mny[l], 0), y1 = min(mxy[l] + 2 * R + 1, L.h[l] - 1);
+        if (x0 > x1 || y0 > y1) continue;
+        for (int ty = y0 >> 2; ty <= (y1 >> 2); ++ty)
+          for (int tx = x0 >> 2; tx <= (x1 >> 2); ++tx) {
+            const int cell = L.off[l] + (ty * L.tw[l] + tx) * 16;
+            kt_mark(rb, cell >> 5);
+            kt_mark(mb[tid >> 5], cell / KT_MC);
+          }
+      }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < nw; ++i) { wpre[i] = acc; acc += __popc(rb[i]); }
+    wpre[nw] = acc;
+    nt_count[b * gridDim.x + tile] = acc;
+  }
+  __syncthreads();
+  int* list = nt_list + (int64_t)(b * gridDim.x + tile) * nt_stride;
+  for (int k = tid; k < nrec; k += KT_NQ) {
+    const unsigned w = rb[k >> 5];
+    if (w >> (k & 31) & 1u) list[wpre[k >> 5] + __popc(w & ((1u << (k & 31)) - 1u))] = k;
+  }
+  // the cell-tile marks of this workgroup's four 32-query blocks: rows of the bit matrix corr_ktiles_tn_kernel reads
+  const int ktq = (HW + 31) >> 5;
+  for (int i = tid; i < (KT_NQ / 32) * mw; i += KT_NQ) {
+    const int qb = tile * (KT_NQ / 32) + i / mw;
+    if (qb < ktq) tn_bits[((int64_t)b * ktq + qb) * mw + i % mw] = mb[i / mw][i % mw];
+  }
+  // wmask [B][32-query block][nw]: the records of a query's row that either GEMM will read -- those of its 128-query tile's NT
+  // list plus the eight records of every cell tile its 32-query block is listed for.  The gradient-volume kernel writes
+  // these and nothing else (the rest of the row would be zero records nobody reads).
+  if (wmask)
+    for (int i = tid; i < (KT_NQ / 32) * nw; i += KT_NQ) {
+      const int ql = i / nw, w = i % nw, qb = tile * (KT_NQ / 32) + ql;
+      if (qb >= ktq) continue;
+      const unsigned nib = (mb[ql][(4 * w) >> 5] >> ((4 * w) & 31)) & 0xFu;          // cell tiles 4 w .. 4 w + 3 = records 32 w .. 32 w + 31
+      const unsigned ex = (nib & 1u ? 0xFFu : 0u) | (nib & 2u ? 0xFF00u : 0u) | (nib & 4u ? 0xFF0000u : 0u) | (nib & 8u ? 0xFF000000u : 0u);
+      wmask[((int64_t)b * ktq + qb) * nw + w] = rb[w] | ex;
+    }
+}
+
+// list of the 32-query blocks that reach cell tile blockIdx.x of batch entry blockIdx.y, ascending
+__global__ __launch_bounds__(256) void corr_ktiles_tn_kernel(const unsigned* __restrict__ tn_bits, int mw, int ktq, int* __restrict__ tn_list,
+                                                             int* __restrict__ tn_count, int tn_stride) {
+  __shared__ int wsum[4];
+  __shared__ int base_s;
+  const int mt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* list = tn_list + (int64_t)(b * gridDim.x + mt) * tn_stride;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < ktq; k0 += 256) {
+    const int kb = k0 + tid;
+    const bool on = kb < ktq && (tn_bits[((int64_t)b * ktq + kb) * mw + (mt >> 5)] >> (mt & 31) & 1u);
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int pre = base_s;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (on) list[pre + __popcll(bal & ((1ull << lane) - 1ull))] = kb;
+    __syncthreads();
+    if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) tn_count[b * gridDim.x + mt] = base_s;
+}
 
 // F2cat[b][c][p]: the target-side operand of dF1 = s * F2cat . dV^T in the row layout -- level-l cell = mean of f2 over its
 // 2^l x 2^l pixels where the cell exists in the floor pyramid, 0 in pad cells.
@@ -606,6 +749,11 @@ extern "C" int fsraft_set_dvol_policy(int policy) {
 }
 
 int g_dvol_box = 1;       // 1: corr_dvol_box_kernel + work list where a scratch list is supplied, 0: corr_dvol_kernel for every query
+extern "C" int fsraft_set_ktile_exact(int levels) {
+  if (levels < 0 || levels > 2) return FS_ERR_ARG;
+  g_ktile_exact = levels;
+  return FS_OK;
+}
 extern "C" int fsraft_set_dvol_box(int on) {
   g_dvol_box = on;
   return FS_OK;
@@ -613,7 +761,7 @@ extern "C" int fsraft_set_dvol_box(int on) {
 
 extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
                                       float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate, int records,
-                                      int add_grid, int64_t q0, int64_t nq, unsigned* qlist, hipStream_t stream) {
+                                      int add_grid, int64_t q0, int64_t nq, unsigned* qlist, const unsigned* wmask, hipStream_t stream) {
   VolLayout L;
   if (!dout || !coords || !coords_str || !dvol || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) ||
       ((uintptr_t)dvol % 16))
@@ -633,10 +781,11 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   // fast route: one wave per query with only the lookups' bounding boxes in LDS; queries that do not fit go to `qlist`
   // (caller-owned scratch of 1 + rows unsigned), which the row-segment kernel below then walks
   const unsigned* list = nullptr;
+  if (wmask && !(g_dvol_box && qlist && !accumulate && records && q0 == 0 && grid == (unsigned)((int64_t)B * H * W))) return FS_ERR_ARG;
   if (g_dvol_box && qlist && !accumulate && (L.P % 8) == 0) {
     hipLaunchKernelGGL(dvol_list_reset_kernel, dim3(1), dim3(1), 0, stream, qlist);
 #define DVBOX(RR, REC) hipLaunchKernelGGL((corr_dvol_box_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, \
-                                          add_grid ? W : 0, q0, grid, qlist, g_dvol_policy)
+                                          add_grid ? W : 0, q0, grid, qlist, g_dvol_policy, wmask)
     if (radius == 4) { if (records) DVBOX(4, true); else DVBOX(4, false); }
     else { if (records) DVBOX(3, true); else DVBOX(3, false); }
 #undef DVBOX
@@ -665,6 +814,39 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
 #undef DVOL_LAUNCH
     l0 = l1 + 1;
   }
+  return fs_launch_status();
+}
+
+// k-tile lists of the two volume-backward GEMMs from the coordinates of the step's n <= 16 lookups (same arguments as
+// fsraft_corr_dvol_build).  nt_list [B][ceil(HW / 128)][nt_stride >= P / 32] + nt_count: records per 128-query tile, for
+// fsraft_gemm_rec_nt_list(..., kl_by_n = 1) with dV as the B operand; tn_list [B][ceil(P / 256)][tn_stride >= ceil(HW / 32)] +
+// tn_count: 32-query blocks per 256-cell tile, for fsraft_gemm_rec_tn_list(..., kl_by_n = 0) with dV as the A operand;
+// tn_bits: scratch of B * ceil(HW / 32) * ceil(ceil(P / 256) / 32) unsigned; wmask (nullable): [B][ceil(HW / 32)][ceil(P / 1024)]
+// unsigned, the records of each 32-query block's rows that the two list GEMMs read (for fsraft_corr_dvol_build).  Returns
+// FS_ERR_ARG for shapes beyond the kernels' bitmaps (P > 262144 floats): the caller then runs the dense GEMMs.
+extern "C" int fsraft_corr_bwd_ktiles(const float* const* coords, const int64_t* coords_str, int n, int num_levels, int B, int H, int W,
+                                      int radius, int add_grid, int* nt_list, int* nt_count, int nt_stride, unsigned* tn_bits,
+                                      int* tn_list, int* tn_count, int tn_stride, unsigned* wmask, hipStream_t stream) {
+  VolLayout L;
+  if (!coords || !coords_str || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) || !nt_list || !nt_count ||
+      !tn_bits || !tn_list || !tn_count || (radius != 3 && radius != 4))
+    return FS_ERR_ARG;
+  const int HW = H * W, nrec = L.P / 32, mtiles = (L.P + KT_MC - 1) / KT_MC, ktq = (HW + 31) / 32, mw = (mtiles + 31) / 32;
+  if (nrec > KT_MAXW * 32 || mw > KT_MAXM || nt_stride < nrec || tn_stride < ktq) return FS_ERR_ARG;
+  KtArgs a;
+  a.n = n;
+  for (int t = 0; t < n; ++t) {
+    if (!coords[t]) return FS_ERR_ARG;
+    a.co[t] = Coords{coords[t], coords_str[3 * t], coords_str[3 * t + 1], coords_str[3 * t + 2]};
+  }
+  for (int t = n; t < DV_MAXN; ++t) a.co[t] = Coords{nullptr, 0, 0, 0};
+#define KT_MARK(E) hipLaunchKernelGGL(corr_ktiles_mark_kernel<E>, dim3((HW + KT_NQ - 1) / KT_NQ, B), dim3(KT_NQ), 0, stream, a, L, HW, radius, \
+                                      add_grid ? W : 0, nt_list, nt_count, nt_stride, tn_bits, mw, wmask)
+  if (g_ktile_exact >= 2) KT_MARK(2);
+  else if (g_ktile_exact == 1) KT_MARK(1);
+  else KT_MARK(0);
+#undef KT_MARK
+  hipLaunchKernelGGL(corr_ktiles_tn_kernel, dim3(mtiles, B), dim3(256), 0, stream, tn_bits, mw, ktq, tn_list, tn_count, tn_stride);
   return fs_launch_status();
 }
 

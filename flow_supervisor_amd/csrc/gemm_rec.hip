@@ -13,18 +13,29 @@ struct RecGemmArgs {
   float* C; int64_t ldc, sC;
   int M, N, KT, ksplit;
   float alpha; int atomic;
+  // sparse k (fsraft_gemm_rec_*_list): per (batch entry, tile of the sparse operand) `kcount` k-tile numbers in `klist`
+  // (kl_stride ints apart); kl_by_n: the lists belong to the N tiles (B operand rows), else to the M tiles
+  const int* klist; const int* kcount; int kl_stride, kl_by_n;
 };
 
 int g_rec_mfma16 = 0;      // fsraft_set_tuning-style switch (fsraft_set_rec_mfma16): the NT kernel on v_mfma_f32_16x16x32_bf16
 
-template <bool M16>
+template <bool M16, bool LIST = false>
 __global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
   __shared__ __attribute__((aligned(1024))) char lds[G::LDS_BYTES];
   const int ntn = (g.N + G::BN - 1) / G::BN;
   const int tile = blockIdx.x, ks = blockIdx.y, b = blockIdx.z;
   const int n0 = (tile % ntn) * G::BN, m0 = (tile / ntn) * G::BM;
-  const int per = (g.KT + g.ksplit - 1) / g.ksplit;
-  const int kt0 = ks * per, kt = min(per, g.KT - kt0);
+  int KTall = g.KT;
+  const int* list = nullptr;
+  if constexpr (LIST) {
+    const int ntm = (g.M + G::BM - 1) / G::BM;
+    const int lt = g.kl_by_n ? b * ntn + tile % ntn : b * ntm + tile / ntn;
+    KTall = g.kcount[lt];
+    list = g.klist + (int64_t)lt * g.kl_stride;
+  }
+  const int per = (KTall + g.ksplit - 1) / g.ksplit;
+  const int kt0 = ks * per, kt = min(per, KTall - kt0);
   const char* A = g.A + b * g.sA + (int64_t)m0 * g.pitchA;
   const char* Bm = g.Bm + b * g.sB + (int64_t)n0 * g.pitchB;
   const int ar = min(G::BM, g.M - m0), br = min(G::BN, g.N - n0);
@@ -38,12 +49,23 @@ __global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
     for (int j = 0; j < G::TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  RecPlainA<G> pa;
+  if constexpr (LIST) {
+    __shared__ int klds[REC_LIST_MAX];
+    for (int i = threadIdx.x; i < kt; i += G::NT) klds[i] = list[kt0 + i];
+    __syncthreads();
+    RecListA<G> pa;
 #pragma unroll
-  for (int j = 0; j < G::NPA; ++j) pa.va[j] = o.va[j];
-  pa.kt0 = kt0; pa.step = 128u;
-  if constexpr (M16) rec_mainloop16<G>(lds, o, pa, kt0, kt, acc);
-  else rec_mainloop<G>(lds, o, pa, kt0, kt, acc);
+    for (int j = 0; j < G::NPA; ++j) pa.va[j] = o.va[j];
+    pa.list = (const int __attribute__((address_space(3)))*)klds; pa.cnt = kt > 0 ? kt : 1; pa.step = 128u;
+    rec_mainloop<G>(lds, o, pa, 0, kt, acc);
+  } else {
+    RecPlainA<G> pa;
+#pragma unroll
+    for (int j = 0; j < G::NPA; ++j) pa.va[j] = o.va[j];
+    pa.kt0 = kt0; pa.step = 128u;
+    if constexpr (M16) rec_mainloop16<G>(lds, o, pa, kt0, kt, acc);
+    else rec_mainloop<G>(lds, o, pa, kt0, kt, acc);
+  }
   float* C = g.C + b * g.sC;
 #pragma unroll
   for (int nt = 0; nt < G::TN; ++nt) {
@@ -65,13 +87,22 @@ __global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
 // C[b][m][n] (+)= alpha * sum_k A[b][k][m] * B[b][k][n], both operands k-major rows of records (along m resp. n)
 using GT = RecCfg<256, 128, 4, 2, 3, true>;
 
+template <bool LIST = false>
 __global__ __launch_bounds__(512) void gemm_rec_tn_kernel(RecGemmArgs g, int K) {
   __shared__ __attribute__((aligned(1024))) char lds[GT::LDS_BYTES];
   const int ntn = (g.N + GT::BN - 1) / GT::BN;
   const int tile = blockIdx.x, ks = blockIdx.y, b = blockIdx.z;
   const int n0 = (tile % ntn) * GT::BN, m0 = (tile / ntn) * GT::BM;
-  const int per = (g.KT + g.ksplit - 1) / g.ksplit;
-  const int kt0 = ks * per, kt = min(per, g.KT - kt0);
+  int KTall = g.KT;
+  const int* list = nullptr;
+  if constexpr (LIST) {
+    const int ntm = (g.M + GT::BM - 1) / GT::BM;
+    const int lt = g.kl_by_n ? b * ntn + tile % ntn : b * ntm + tile / ntn;
+    KTall = g.kcount[lt];
+    list = g.klist + (int64_t)lt * g.kl_stride;
+  }
+  const int per = (KTall + g.ksplit - 1) / g.ksplit;
+  const int kt0 = ks * per, kt = min(per, KTall - kt0);
   const char* A = g.A + b * g.sA + (int64_t)m0 * 4;
   const char* Bm = g.Bm + b * g.sB + (int64_t)n0 * 4;
   RecOperands<GT> o;
@@ -84,11 +115,22 @@ __global__ __launch_bounds__(512) void gemm_rec_tn_kernel(RecGemmArgs g, int K) 
     for (int j = 0; j < GT::TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  RecPlainA<GT> pa;
+  if constexpr (LIST) {
+    __shared__ int klds[REC_LIST_MAX];
+    for (int i = threadIdx.x; i < kt; i += GT::NT) klds[i] = list[kt0 + i];
+    __syncthreads();
+    RecListA<GT> pa;
 #pragma unroll
-  for (int j = 0; j < GT::NPA; ++j) pa.va[j] = o.va[j];
-  pa.kt0 = kt0; pa.step = 32u * g.pitchA;
-  rec_mainloop<GT>(lds, o, pa, kt0, kt, acc);
+    for (int j = 0; j < GT::NPA; ++j) pa.va[j] = o.va[j];
+    pa.list = (const int __attribute__((address_space(3)))*)klds; pa.cnt = kt > 0 ? kt : 1; pa.step = 32u * g.pitchA;
+    rec_mainloop<GT>(lds, o, pa, 0, kt, acc);
+  } else {
+    RecPlainA<GT> pa;
+#pragma unroll
+    for (int j = 0; j < GT::NPA; ++j) pa.va[j] = o.va[j];
+    pa.kt0 = kt0; pa.step = 32u * g.pitchA;
+    rec_mainloop<GT>(lds, o, pa, kt0, kt, acc);
+  }
   float* C = g.C + b * g.sC;
 #pragma unroll
   for (int nt = 0; nt < GT::TN; ++nt) {
@@ -178,9 +220,10 @@ extern "C" int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_
 // floats, B [batch][N] rows with pitch ldb (lda, ldb multiples of 32, >= K; 0 = K: dense), K % 32 == 0; sA / sB: batch
 // strides in BYTES.  ksplit > 1 splits K over workgroups that add their partial tiles with fp32 atomics (C is zeroed first
 // unless accumulate != 0); ksplit == 1 and accumulate == 0: plain stores.
-extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
-                                  int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
-                                  hipStream_t stream) {
+namespace {
+int gemm_rec_nt_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc, int64_t sC,
+                     int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist, const int* kcount,
+                     int kl_stride, int kl_by_n, hipStream_t stream) {
   if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 32 || (K % 32) || ksplit < 1 || ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16))
     return FS_ERR_ARG;
   if (lda == 0) lda = K;
@@ -193,19 +236,40 @@ extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const 
     const int rc = zero_matrices(C, ldc, sC, batch, M, N, stream);
     if (rc) return rc;
   }
-  RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
+  RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0,
+                klist, kcount, kl_stride, kl_by_n};
   dim3 grid(ceil_div(N, G::BN) * ceil_div(M, G::BM), ksplit, batch);
-  if (g_rec_mfma16) hipLaunchKernelGGL(gemm_rec_nt_kernel<true>, grid, dim3(512), 0, stream, g);
-  else hipLaunchKernelGGL(gemm_rec_nt_kernel<false>, grid, dim3(512), 0, stream, g);
+  if (klist) hipLaunchKernelGGL((gemm_rec_nt_kernel<false, true>), grid, dim3(512), 0, stream, g);
+  else if (g_rec_mfma16) hipLaunchKernelGGL((gemm_rec_nt_kernel<true, false>), grid, dim3(512), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_rec_nt_kernel<false, false>), grid, dim3(512), 0, stream, g);
   return fs_launch_status();
+}
+}  // namespace
+
+extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
+                                  int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
+                                  hipStream_t stream) {
+  return gemm_rec_nt_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, nullptr, nullptr, 0, 0, stream);
+}
+// The same contraction over LISTED k-tiles only: klist[(b * tiles + tile) * kl_stride + i], i < kcount[b * tiles + tile], ascending
+// k-tile numbers (32 k each) for every tile of the sparse operand -- the 128-row tiles of B (kl_by_n != 0) or the 256-row tiles
+// of A; everything the lists leave out must be zero records (fsraft_corr_bwd_ktiles builds such lists for the gradient volume).
+extern "C" int fsraft_gemm_rec_nt_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
+                                       int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit,
+                                       int accumulate, const int* klist, const int* kcount, int kl_stride, int kl_by_n,
+                                       hipStream_t stream) {
+  if (!klist || !kcount || kl_stride < 1 || K / 32 > REC_LIST_MAX) return FS_ERR_ARG;
+  return gemm_rec_nt_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, klist, kcount, kl_stride,
+                          kl_by_n, stream);
 }
 
 // C[b][m][n] = alpha * sum_k A[b][k][m] B[b][k][n]: A [batch][K][lda floats] with the records along m, B [batch][K][ldb
 // floats] with the records along n (lda, ldb multiples of 32 covering M resp. N; sA / sB batch strides in BYTES).  K need not
 // be a multiple of 32 (rows beyond K read as zeros).  ksplit / accumulate as fsraft_gemm_rec_nt.
-extern "C" int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
-                                  int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
-                                  hipStream_t stream) {
+namespace {
+int gemm_rec_tn_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc, int64_t sC,
+                     int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist, const int* kcount,
+                     int kl_stride, int kl_by_n, hipStream_t stream) {
   if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 1 || ksplit < 1 || (lda % 32) || (ldb % 32) || lda < M || ldb < N ||
       ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16))
     return FS_ERR_ARG;
@@ -216,10 +280,29 @@ extern "C" int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const 
     const int rc = zero_matrices(C, ldc, sC, batch, M, N, stream);
     if (rc) return rc;
   }
-  RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0};
+  RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0,
+                klist, kcount, kl_stride, kl_by_n};
   dim3 grid(ceil_div(N, GT::BN) * ceil_div(M, GT::BM), ksplit, batch);
-  hipLaunchKernelGGL(gemm_rec_tn_kernel, grid, dim3(512), 0, stream, g, K);
+  if (klist) hipLaunchKernelGGL(gemm_rec_tn_kernel<true>, grid, dim3(512), 0, stream, g, K);
+  else hipLaunchKernelGGL(gemm_rec_tn_kernel<false>, grid, dim3(512), 0, stream, g, K);
   return fs_launch_status();
+}
+}  // namespace
+
+extern "C" int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
+                                  int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
+                                  hipStream_t stream) {
+  return gemm_rec_tn_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, nullptr, nullptr, 0, 0, stream);
+}
+// k-major twin of fsraft_gemm_rec_nt_list: the lists belong to the 256-column tiles of A (M tiles; kl_by_n == 0) or the
+// 128-column tiles of B, a k-tile is 32 consecutive k-rows.
+extern "C" int fsraft_gemm_rec_tn_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
+                                       int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit,
+                                       int accumulate, const int* klist, const int* kcount, int kl_stride, int kl_by_n,
+                                       hipStream_t stream) {
+  if (!klist || !kcount || kl_stride < 1 || (K + 31) / 32 > REC_LIST_MAX) return FS_ERR_ARG;
+  return gemm_rec_tn_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, klist, kcount, kl_stride,
+                          kl_by_n, stream);
 }
 
 extern "C" int fsraft_set_rec_mfma16(int on) {

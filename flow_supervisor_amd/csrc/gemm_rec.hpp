@@ -129,6 +129,31 @@ struct RecPlainA {
   __device__ __forceinline__ unsigned voff(const Tile&, int j) const { return va[j]; }
 };
 
+// Sparse k: the k-tiles a workgroup visits come from a LIST (ascending k-tile numbers, `cnt` of them) instead of a range --
+// the volume-backward GEMMs contract over gradient rows of which the step's lookups touched a fraction, and a pre-pass
+// (fsraft_corr_bwd_ktiles) lists, per tile of the sparse operand, the k-tiles that can hold anything but zero records.
+// Both operands take their k-tile from the list (`kidx`), so A and B stay aligned; skipped tiles would have added +-0.
+template <class Cfg>
+struct RecListA {
+  unsigned va[Cfg::NPA];
+  // The list sits in LDS (the kernel copies its slice there first): LDS reads return in order, so the compiler keeps its counted
+  // lgkmcnt waits in the k-loop.  (Scalar loads from global memory return out of order -- with one in flight every wait for a
+  // fragment read becomes lgkmcnt(0) -- and a vector load would join the in-order vmcnt queue of the DMA ring.)
+  const int __attribute__((address_space(3))) * list;
+  int cnt;                               // >= 1
+  unsigned step;
+  struct Tile { unsigned soff; };
+  __device__ __forceinline__ unsigned kidx(int t) const { return (unsigned)list[t < cnt ? t : cnt - 1]; }
+  __device__ __forceinline__ Tile tile_k(unsigned k) const { return Tile{(unsigned)__builtin_amdgcn_readfirstlane((int)k) * step}; }
+  __device__ __forceinline__ Tile tile(int t) const { return tile_k(kidx(t)); }
+  __device__ __forceinline__ unsigned voff(const Tile&, int j) const { return va[j]; }
+};
+constexpr int REC_LIST_MAX = 2048;       // k-tiles per list the kernels hold in LDS
+template <class T, class = void>
+struct rec_has_kidx : std::false_type {};
+template <class T>
+struct rec_has_kidx<T, std::void_t<decltype(std::declval<const T&>().kidx(0))>> : std::true_type {};
+
 // acc += A(k-tiles 0 .. KT-1 as described by asrc) . B[rows][kt0 .. kt0+KT)^T
 //
 // Schedule: three ring slots, two k-tiles in flight, ONE barrier per k-tile placed in the MIDDLE of a tile's MFMAs:
@@ -154,16 +179,26 @@ __device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOp
   auto issue_a = [&](int t, int SL, int j, const typename ASrc::Tile& ts) {
     rec_dma16(asrc.voff(ts, j), o.da, t < KT ? ts.soff : 0x80000000u, wbase + (unsigned)(SL * Cfg::SLOT + Cfg::NWAVE * j * 1024));
   };
-  auto issue_b = [&](int t, int SL, int j) {
-    rec_dma16(o.vb[j], o.db, t < KT ? (unsigned)(kt0 + t) * o.b_step : 0x80000000u,
+  // k-tile number of step t for the B operand: the range kt0 + t, or the ASrc's list entry
+  auto kof = [&](int t) -> unsigned {
+    if constexpr (rec_has_kidx<ASrc>::value) return asrc.kidx(t);
+    else return (unsigned)(kt0 + t);
+  };
+  auto tile_of = [&](int t, unsigned k) -> typename ASrc::Tile {
+    if constexpr (rec_has_kidx<ASrc>::value) return asrc.tile_k(k);
+    else return asrc.tile(t);
+  };
+  auto issue_b = [&](int t, int SL, int j, unsigned k) {
+    rec_dma16(o.vb[j], o.db, t < KT ? (unsigned)__builtin_amdgcn_readfirstlane((int)k) * o.b_step : 0x80000000u,
               wbase + (unsigned)(SL * Cfg::SLOT + Cfg::A_BYTES + Cfg::NWAVE * j * 1024));
   };
   auto issue_all = [&](int t, int SL) {
-    const typename ASrc::Tile ts = asrc.tile(t);
+    const unsigned k = kof(t);
+    const typename ASrc::Tile ts = tile_of(t, k);
 #pragma unroll
     for (int j = 0; j < NPA; ++j) issue_a(t, SL, j, ts);
 #pragma unroll
-    for (int j = 0; j < NPB; ++j) issue_b(t, SL, j);
+    for (int j = 0; j < NPB; ++j) issue_b(t, SL, j, k);
   };
 
   struct Frag { bf16x8r ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN]; };
@@ -236,8 +271,9 @@ __device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOp
   if (KT <= 0) return;
   issue_all(0, 0);
   issue_all(1, 1);
+  unsigned kc = kof(2);                          // k-tile number of tile t + 2 at the top of step t
   {                                              // tile 2: A pieces now, B pieces inside the first MFMA group (as in steady state)
-    const typename ASrc::Tile ts = asrc.tile(2);
+    const typename ASrc::Tile ts = tile_of(2, kc);
 #pragma unroll
     for (int j = 0; j < NPA; ++j) issue_a(2, 2, j, ts);
   }
@@ -249,18 +285,20 @@ __device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOp
   // one k-tile: tile t lives in slot SL, tile t+1 in slot (SL + 1) % 3
   auto step = [&](int t, auto SLc) {
     constexpr int SL = decltype(SLc)::value, SN = (SL + 1) % 3, SP = (SL + 2) % 3;
+    const unsigned k3 = kof(t + 3);              // (list variant: an LDS read with the first MFMA group to land behind)
     read_frag(SL, 1, f1);
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(f0, [&](int k) { issue_b(t + 2, SP, k); }, NPB);            // B pieces of tile t+2 (its A pieces went last step)
+    mfmas(f0, [&](int k) { issue_b(t + 2, SP, k, kc); }, NPB);        // B pieces of tile t+2 (its A pieces went last step)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     rec_wait_vm<NPA + NPB>();                    // outstanding: tile t+1, tile t+2 -> leave tile t+2 in flight
     __builtin_amdgcn_s_barrier();
     read_frag(SN, 0, f0);
     __builtin_amdgcn_sched_barrier(0);
-    const typename ASrc::Tile ts = asrc.tile(t + 3);
+    const typename ASrc::Tile ts = tile_of(t + 3, k3);
     mfmas(f1, [&](int k) { issue_a(t + 3, SL, k, ts); }, NPA);        // A pieces of tile t+3 into the slot tile t leaves
     __builtin_amdgcn_sched_barrier(0);
+    kc = k3;
   };
   for (int t = 0; t < KT; t += 3) {
     step(t, std::integral_constant<int, 0>{});

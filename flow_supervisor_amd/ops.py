@@ -6,6 +6,7 @@ see core/corr.py, core/update.py and core/raft.py for the autograd.Function wrap
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.optim.optimizer as _optimizer_module
@@ -247,13 +248,17 @@ def corr_lookup_tiled_fwd(vol, lay, coords, radius, is_flow=False):
     return out
 
 
-def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False, q0=0, nq=0):
+def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False, q0=0, nq=0, wmask=None, out=None):
     """Gradient volume [B*H*W, P] of all stashed lookups (douts[t]: [B,H,W,CH] channels-last, coords[t]: [B,2,H,W]);
     records=True: rows of [32 hi | 32 lo] bf16 records (the operand format of gemm_rec_nt / gemm_rec_tn).
-    q0 / nq: build only queries [q0, q0 + nq) (into rows 0 .. nq-1)."""
+    q0 / nq: build only queries [q0, q0 + nq) (into rows 0 .. nq-1).  wmask (KTileLists.wmask): write only the records the two
+    list GEMMs of corr_build_bwd_tiled(ktiles=...) read -- the rest of the returned tensor is then UNINITIALISED.
+    out: optional preallocated [rows, P] tensor."""
     H, W = lay.H, lay.W
     rows = nq if nq else B * H * W - q0
-    dvol = torch.empty(rows, lay.P, device=douts[0].device, dtype=torch.float32)
+    dvol = torch.empty(rows, lay.P, device=douts[0].device, dtype=torch.float32) if out is None else out
+    if wmask is not None and not (records and len(douts) <= 16 and q0 == 0 and not nq):
+        wmask = None
     # scratch for the work list of queries whose lookups spread beyond the bounding-box kernel's box (1 + rows unsigned)
     qlist = torch.empty(rows + 1, device=douts[0].device, dtype=torch.int32) if len(douts) <= 16 else None
     t = TIMER
@@ -269,13 +274,61 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
             st += list(_planar2_strides(c))
         a_s = (ctypes.c_int64 * (3 * n))(*st)
         L.check(_lib().fsraft_corr_dvol_build(ctypes.cast(a_d, L._PP), ctypes.cast(a_c, L._PP), a_s, n, L.ptr(dvol), lay.nlev, B, H,
-                                              W, radius, int(g0 > 0), int(records), int(is_flow), q0, rows, L.ptr(qlist), L.stream()),
+                                              W, radius, int(g0 > 0), int(records), int(is_flow), q0, rows, L.ptr(qlist), L.ptr(wmask),
+                                              L.stream()),
                 "corr_dvol_build")
     if t:   # per lookup read dOut + read-modify-write the window taps; plus the zero fill of the dense gradient
         nl = lay.nlev
         t.end("corr_lookup_bwd", e0, 0.0, 4.0 * rows * (len(douts) * (nl * (2 * radius + 1) ** 2 + 2 + 2 * nl * (2 * radius + 2) ** 2)
                                                          + sum(h * w for h, w in zip(lay.h, lay.w))))
     return dvol
+
+
+BWD_KSKIP = os.environ.get("FSRAFT_BWD_KSKIP", "1") != "0"     # volume-backward GEMMs over the k-tiles the lookups reached only
+TN_LIST_KSPLIT = int(os.environ.get("FSRAFT_TN_LIST_KSPLIT", "2"))   # k-slices of the listed d2cat GEMM (one slice with plain stores measured slower: 270 vs 210 us)
+DVOL_WMASK = os.environ.get("FSRAFT_DVOL_WMASK", "1") != "0"   # ... and the gradient volume written only where they read
+
+
+class KTileLists:
+    """k-tile lists of the two volume-backward GEMMs (fsraft_corr_bwd_ktiles) for one step's lookups."""
+    __slots__ = ("nt_list", "nt_count", "nt_stride", "tn_list", "tn_count", "tn_stride", "wmask")
+
+
+def corr_bwd_ktiles(coords, lay, B, radius, is_flow=False):
+    """coords: the step's lookup coordinates ([B,2,H,W] each, at most 16) -> KTileLists, or None where the lists do not apply
+    (more than 16 lookups, rows beyond the kernels' bitmaps): the caller then contracts densely."""
+    n = len(coords)
+    H, W, P = lay.H, lay.W, lay.P
+    if n < 1 or n > 16 or P // 32 > 2048 or -(-H * W // 32) > 2048:        # (the GEMMs hold a list of <= 2048 k-tiles in LDS)
+        return None
+    L.require_cuda_f32(*coords)
+    dev = coords[0].device
+    HW = H * W
+    k = KTileLists()
+    ntiles, mtiles, ktq = -(-HW // 128), -(-P // 256), -(-HW // 32)
+    k.nt_stride, k.tn_stride = P // 32, ktq
+    k.nt_list = torch.empty(B * ntiles * k.nt_stride, device=dev, dtype=torch.int32)
+    k.nt_count = torch.empty(B * ntiles, device=dev, dtype=torch.int32)
+    k.tn_list = torch.empty(B * mtiles * k.tn_stride, device=dev, dtype=torch.int32)
+    k.tn_count = torch.empty(B * mtiles, device=dev, dtype=torch.int32)
+    bits = torch.empty(B * ktq * (-(-mtiles // 32)), device=dev, dtype=torch.int32)
+    k.wmask = torch.empty(B * ktq * (-(-(P // 32) // 32)), device=dev, dtype=torch.int32)     # records per 32-query block the GEMMs read
+    a_c = (ctypes.c_void_p * n)(*[c.data_ptr() for c in coords])
+    st = []
+    for c in coords:
+        st += list(_planar2_strides(c))
+    a_s = (ctypes.c_int64 * (3 * n))(*st)
+    tm = TIMER
+    e0 = tm.begin() if tm else None
+    L.check(_lib().fsraft_corr_bwd_ktiles(ctypes.cast(a_c, L._PP), a_s, n, lay.nlev, B, H, W, radius, int(is_flow), L.ptr(k.nt_list),
+                                          L.ptr(k.nt_count), k.nt_stride, L.ptr(bits), L.ptr(k.tn_list), L.ptr(k.tn_count), k.tn_stride,
+                                          L.ptr(k.wmask), L.stream()), "corr_bwd_ktiles")
+    if tm:      # (its time belongs to the volume backward it shortens; no algorithmic bytes of its own)
+        tm.end("corr_build_bwd", e0, 0.0, 0.0)
+    if os.environ.get("FSRAFT_KTILE_STATS"):      # debugging aid (synchronises): how much of the contraction the lists keep
+        print(f"k-tiles kept: NT {k.nt_count.sum().item() / (B * ntiles * (P // 32)):.3f}  TN {k.tn_count.sum().item() / (B * mtiles * ktq):.3f}  "
+              f"records written {sum(bin(v & 0xffffffff).count('1') for v in k.wmask.tolist()) / (B * ktq * (P // 32)):.3f}", flush=True)
+    return k
 
 
 def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, chunk=2048, f1r=None):
@@ -347,7 +400,7 @@ def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None
     return out
 
 
-def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None):
+def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None, ktiles=None):
     """(dfmap1, dfmap2) NCHW from the gradient volume in the tiled-row layout: two GEMMs that contract over whole rows
     (K = P resp. M = P), the pooling chain folded into the pooled operand f2cat and the un-pool of the feature gradient.
     records=True: dvol holds records; both GEMMs run on the LDS-DMA record core (gemm_rec.hpp)."""
@@ -362,8 +415,27 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None):
     if records:
         if f1r is None:
             f1r = fmap_records(fmap1)
-        d1 = gemm_rec_nt(to_records(f2cat), dV, s)                # [B,C,N] = s * f2cat . dV^T
-        d2cat = gemm_rec_tn(dV, f1r, P, C, s, ksplit=2)           # [B,P,C] = s * dV^T . f1^T
+        if ktiles is not None:      # only the k-tiles the step's lookups reached (the rest of the gradient rows is zero records)
+            f2r = to_records(f2cat)
+            Cr = f1r.shape[-1]
+            d1 = torch.empty(B, C, N, device=fmap1.device, dtype=torch.float32)
+            d2cat = torch.empty(B, P, C, device=fmap1.device, dtype=torch.float32)
+            lib = _lib()
+            e1 = tm.begin() if tm else None
+            L.check(lib.fsraft_gemm_rec_nt_list(L.ptr(f2r), P, C * P * 4, L.ptr(dV), P, N * P * 4, L.ptr(d1), N, C * N, B, C, N, P, s, 1, 0,
+                                                L.ptr(ktiles.nt_list), L.ptr(ktiles.nt_count), ktiles.nt_stride, 1, L.stream()),
+                    "gemm_rec_nt_list")
+            if tm:      # (the family's FLOPs stay the dense contraction's: what is skipped multiplies zeros)
+                tm.end("gemm_f32", e1, 2.0 * B * C * N * P, 4.0 * B * (C * P + N * P + C * N))
+                e1 = tm.begin()
+            L.check(lib.fsraft_gemm_rec_tn_list(L.ptr(dV), P, N * P * 4, L.ptr(f1r), Cr, N * Cr * 4, L.ptr(d2cat), C, P * C, B, P, C, N, s,
+                                                TN_LIST_KSPLIT, 0, L.ptr(ktiles.tn_list), L.ptr(ktiles.tn_count), ktiles.tn_stride, 0, L.stream()),
+                    "gemm_rec_tn_list")
+            if tm:
+                tm.end("gemm_f32", e1, 2.0 * B * P * C * N, 4.0 * B * (N * P + N * C + P * C))
+        else:
+            d1 = gemm_rec_nt(to_records(f2cat), dV, s)                # [B,C,N] = s * f2cat . dV^T
+            d2cat = gemm_rec_tn(dV, f1r, P, C, s, ksplit=2)           # [B,P,C] = s * dV^T . f1^T
     else:
         f1t = nchw_to_nhwc(fmap1).view(B, N, C)
         d1 = gemm(f2cat, dV, True, s)

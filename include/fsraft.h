@@ -77,10 +77,13 @@ int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* 
  * (nq == 0: all from q0) are built, into dvol rows 0 .. nq-1 -- AlternateCorrBlock's backward walks the queries in chunks so
  * that no O(N^2) buffer exists.  qlist (nullable): caller-owned scratch of 1 + rows unsigned.  With it, one wave per query
  * builds the row from the bounding boxes of its lookups' windows (a few KB of LDS instead of the whole row) and queries whose
- * lookups spread beyond the box are listed there for the row-at-a-time kernel; without it every query takes that kernel. */
+ * lookups spread beyond the box are listed there for the row-at-a-time kernel; without it every query takes that kernel.
+ * wmask (nullable; needs qlist, records, all queries, no accumulate): the record bitmap of fsraft_corr_bwd_ktiles -- only the
+ * records either list GEMM reads are written, the rest of dvol stays untouched (it would be zero records nobody reads). */
 int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
                            int num_levels, int B, int H, int W, int radius, int accumulate, int records, int add_grid,
-                           int64_t q0, int64_t nq, unsigned* qlist, hipStream_t stream);
+                           int64_t q0, int64_t nq, unsigned* qlist, const unsigned* wmask,
+                           hipStream_t stream);
 /* Backward of matmul + avg_pool2d chain (pytorch/core/corr.py:21-27, 52-60) without un-pooling the volume gradient:
  *   f2cat [B][C][P]: level-l cell = mean of fmap2 over its 2^l x 2^l pixels (0 in pad cells), so that
  *   dF1[b][c][i] = s * sum_p f2cat[b][c][p] * dvol[b][i][p]   (one NT GEMM, K = P)  and
@@ -268,6 +271,28 @@ int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const void* Bm, i
  * transposed LDS read (ds_read_b64_tr_b16). */
 int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
                        int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream);
+
+/* The two contractions above over LISTED k-tiles only (32 k each, ascending): klist[(b * tiles + tile) * kl_stride + i],
+ * i < kcount[b * tiles + tile], one list per tile of the sparse operand -- the 128-row tiles of B resp. 128-column tiles of B
+ * (kl_by_n != 0) or the 256-row / 256-column tiles of A.  Everything the lists leave out must be zero records: the skipped
+ * products would have added +-0.  Replaces nothing in the reference (its autograd contracts the dense gradient volume,
+ * pytorch/core/corr.py:52-60); the lists come from fsraft_corr_bwd_ktiles. */
+int fsraft_gemm_rec_nt_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
+                            int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist,
+                            const int* kcount, int kl_stride, int kl_by_n, hipStream_t stream);
+int fsraft_gemm_rec_tn_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
+                            int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist,
+                            const int* kcount, int kl_stride, int kl_by_n, hipStream_t stream);
+/* Which k-tiles of the volume-backward GEMMs the step's lookups can reach, from their coordinates alone (arguments as
+ * fsraft_corr_dvol_build; n <= 16): nt_list [B][ceil(H*W / 128)][nt_stride >= P / 32] + nt_count = records per 128-query tile
+ * (dF1 = s * F2cat . dV^T with dV as the B operand, kl_by_n = 1); tn_list [B][ceil(P / 256)][tn_stride >= ceil(H*W / 32)] +
+ * tn_count = 32-query blocks per 256-cell tile (d2cat = s * dV^T . f1 with dV as the A operand); tn_bits: scratch of
+ * B * ceil(H*W / 32) * ceil(ceil(P / 256) / 32) unsigned.  wmask (nullable): [B][ceil(H*W / 32)][ceil(P / 1024)] unsigned, bit r of
+ * a 32-query block = record r of its rows is read by one of the two list GEMMs; handed to fsraft_corr_dvol_build, the gradient
+ * volume is then written there and nowhere else.  P = the row length of fsraft_vol_layout. */
+int fsraft_corr_bwd_ktiles(const float* const* coords, const int64_t* coords_str, int n, int num_levels, int B, int H, int W,
+                           int radius, int add_grid, int* nt_list, int* nt_count, int nt_stride, unsigned* tn_bits, int* tn_list,
+                           int* tn_count, int tn_stride, unsigned* wmask, hipStream_t stream);
 
 /* ---- GMA variant (config 5) --------------------------------------------------------------
  * Attention.forward, pytorch/core/gma.py:54-76: sim = scale * q k^T runs on fsraft_gemm_f32 (trans_b), then this

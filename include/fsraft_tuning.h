@@ -30,6 +30,9 @@ int fsraft_set_tuning(int key, int value);
 int fsraft_get_tuning(int key);   /* keys 3 / 4 */
 int fsraft_set_build_split(int on);   /* volume build: 1 bf16x3 (default), 0 exact fp32 MFMA */
 int fsraft_set_build_kernel(int which); /* record build: 1 stores from the accumulators (default), 0 round 2's LDS-parked epilogue */
+/* fsraft_corr_bwd_ktiles: 0 = per query and level the bounding rectangle of its lookups' windows is marked; 1 / 2 = on the
+ * first one / two levels every lookup's window is marked on its own (tighter lists, a longer pre-pass). */
+int fsraft_set_ktile_exact(int levels);
 int fsraft_set_dvol_box(int on);        /* gradient volume: 1 (default) bounding-box kernel + work list, 0 row-segment kernel only */
 int fsraft_set_dvol_policy(int policy); /* cache policy of the gradient-volume stores: 0 plain, 1 sc1, 2 nt */
 int fsraft_set_gemm_split(int on);    /* fsraft_gemm_f32 with trans_b: 1 bf16x3 when operands are 16-byte aligned */

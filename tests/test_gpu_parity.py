@@ -166,6 +166,64 @@ def test_alt_lookup_on_the_matrix_pipe(B, C, H, W, nlev):
         close(got, fp32, 1e-4, what=f"matrix-pipe alt lookup vs fp32 tile kernel, {name}")
 
 
+@pytest.mark.parametrize("B,H,W,n,spread", [(2, 40, 48, 5, 2.0), (1, 37, 53, 12, 1.0), (1, 55, 128, 12, 3.0), (2, 24, 40, 3, 40.0)])
+def test_volume_backward_over_listed_k_tiles_equals_the_dense_contraction(B, H, W, n, spread):
+    """fsraft_corr_bwd_ktiles + fsraft_gemm_rec_nt_list / _tn_list against the dense record GEMMs on the same gradient volume:
+    the lists must cover every non-zero record (checked on the raw records), dF1 -- one workgroup per tile walks its list in
+    ascending order, the skipped k-tiles would have added +-0 -- is bit-equal, d2cat (two k-slices meeting in atomics, the slices
+    cut differently) to summation-order noise.  Small flows, a ragged grid, the bench grid, and flows far beyond the image."""
+    from flow_supervisor_amd import ops
+    C, r = 64, 4
+    lay = ops.VolLayout.get(H, W, 4)
+    f1 = rand_tensor((B, C, H, W), 71, 1.0).to(DEV)
+    f2 = rand_tensor((B, C, H, W), 72, 1.0).to(DEV)
+    base = rand_tensor((B, 2, H, W), 73, spread).to(DEV)
+    flows = [(base + rand_tensor((B, 2, H, W), 80 + t, 0.7).to(DEV)).contiguous() for t in range(n)]
+    douts = [rand_tensor((B, H, W, 4 * (2 * r + 1) ** 2), 90 + t, 1.0).to(DEV) for t in range(n)]
+    dvol = ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True)
+    kt = ops.corr_bwd_ktiles(flows, lay, B, r, True)
+    assert kt is not None
+    # coverage: any record of a 128-query tile that holds a non-zero word must be listed
+    N, P = H * W, lay.P
+    nrec, ntiles = P // 32, -(-N // 128)
+    nz = (dvol.view(torch.int32).view(B, N, nrec, 32) != 0).any(-1)                       # [B, N, nrec]
+    pad = ntiles * 128 - N
+    nzt = torch.nn.functional.pad(nz, (0, 0, 0, pad)).view(B, ntiles, 128, nrec).any(2).cpu()
+    lists, counts = kt.nt_list.view(B, ntiles, kt.nt_stride).cpu(), kt.nt_count.view(B, ntiles).cpu()
+    listed = torch.zeros(B, ntiles, nrec, dtype=torch.bool)
+    for b in range(B):
+        for t in range(ntiles):
+            e = lists[b, t, :counts[b, t]].long()
+            assert (e[1:] > e[:-1]).all(), "k-tile lists must ascend"
+            listed[b, t, e] = True
+    assert not (nzt & ~listed).any(), "a non-zero record is missing from the NT lists"
+    # ... and every (256-cell tile, 32-query block) with a non-zero word from the TN lists
+    mtiles, ktq = -(-P // 256), -(-N // 32)
+    nzq = torch.nn.functional.pad(nz, (0, mtiles * 8 - nrec, 0, ktq * 32 - N)).view(B, ktq, 32, mtiles, 8).any(4).any(2).cpu()   # [B, ktq, mtiles]
+    tl, tc = kt.tn_list.view(B, mtiles, kt.tn_stride).cpu(), kt.tn_count.view(B, mtiles).cpu()
+    listed2 = torch.zeros(B, ktq, mtiles, dtype=torch.bool)
+    for b in range(B):
+        for m_ in range(mtiles):
+            e = tl[b, m_, :tc[b, m_]].long()
+            assert (e[1:] > e[:-1]).all()
+            listed2[b, e, m_] = True
+    assert not (nzq & ~listed2).any(), "a non-zero (query block, cell tile) pair is missing from the TN lists"
+    f1r = ops.fmap_records(f1)
+    a1, a2 = ops.corr_build_bwd_tiled(f1, f2, dvol, lay, records=True, f1r=f1r, ktiles=None)
+    b1, b2 = ops.corr_build_bwd_tiled(f1, f2, dvol, lay, records=True, f1r=f1r, ktiles=kt)
+    assert torch.equal(a1, b1)
+    close(b2, a2, 1e-6, 1e-5, what="dfmap2 over listed k-tiles vs dense")
+    # the gradient volume written only where the list GEMMs read (wmask), into a buffer poisoned with NaN bit patterns
+    poison = torch.full((B * N, P), float("nan"), device=DEV)
+    dv2 = ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True, wmask=kt.wmask, out=poison)
+    c1, c2 = ops.corr_build_bwd_tiled(f1, f2, dv2, lay, records=True, f1r=f1r, ktiles=kt)
+    assert torch.equal(c1, b1) and torch.equal(c2, b2)
+    written = ~torch.isnan(dv2.view(B, N, nrec, 32)).all(-1)
+    print(f"records written {written.float().mean().item():.2f}")
+    frac = counts.sum().item() / (B * ntiles * nrec)
+    print(f"k-tile fraction NT {frac:.2f}, TN {tc.sum().item() / (B * mtiles * ktq):.2f}")
+
+
 @pytest.mark.parametrize("B,H,W,nlev,n", [(2, 55, 128, 4, 12), (1, 17, 19, 4, 3), (2, 16, 24, 3, 16), (1, 46, 62, 4, 12)])
 def test_gradient_volume_bounding_box_kernel_matches_the_row_kernel(B, H, W, nlev, n):
     """corr_dvol_box_kernel (one wave per query, only the bounding boxes of the lookups' windows in LDS, a work list for
