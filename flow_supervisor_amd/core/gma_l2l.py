@@ -40,6 +40,9 @@ class GMAL2L(RAFTGMA):
         half = iters // 2
         crop = None
         grad_mode = torch.is_grad_enabled()
+        # training: mask head + upsampler of a phase's iterations as one launch each after the loop (update.HeadBatch)
+        hb = self.update_block.head_batch(half, net) if not test_mode else None
+        hb2, flows, flows2 = None, [], []
         try:
             for itr in range(iters):
                 if itr == half and not supervisor_grad and not test_mode:
@@ -59,10 +62,15 @@ class GMAL2L(RAFTGMA):
                         _, inp, attention = self._context(ci1)
                     net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                     attention = attention.detach()
+                    hb2 = self.update_block.head_batch(iters - half, net)
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_l2l.py:126-127)
-                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up)
+                cur = None if test_mode else (hb if itr < half else hb2)
+                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up, head_batch=cur)
 
                 flow = flow + delta_flow
+                if cur is not None:
+                    (flows if itr < half else flows2).append(flow)
+                    continue
                 if not want_up:
                     continue
                 if up_mask is None:
@@ -74,6 +82,13 @@ class GMAL2L(RAFTGMA):
                 flow_predictions.append(flow_up)
         finally:
             torch.set_grad_enabled(grad_mode)
+        # the deferred mask head + upsampler of each phase (after the caller's gradient mode is back: the unlabelled pass of the
+        # flow-supervisor step switches it off for the supervisor's half).  A phase that ran without a batch has its predictions in
+        # the list already; the student's come first.
+        if hb is not None and flows:
+            flow_predictions = hb.finish(flows) + flow_predictions
+        if hb2 is not None and flows2:
+            flow_predictions = flow_predictions + [_crop_back(p, *crop) for p in hb2.finish(flows2)]
 
         if test_mode:
             return flow, flow_up

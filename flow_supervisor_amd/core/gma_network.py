@@ -63,27 +63,34 @@ class RAFTGMA(nn.Module):
         corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
         net, inp, attention = self._context(image1)
 
-        coords0, coords1 = self.initialize_flow(image1)
-        if flow_init is not None:
-            coords1 = coords1 + flow_init
+        # as in RAFT.forward the loop carries the flow (the lookups add the pixel grid themselves), and in training the mask head
+        # and the upsampler of all iterations run as one launch each after the loop (update.HeadBatch)
+        B, _, Hi, Wi = image1.shape
+        flow = flow_init.float() if flow_init is not None else torch.zeros(B, 2, Hi // 8, Wi // 8, device=image1.device)
 
         flow_predictions = []
         flow_up = None
+        hb = self.update_block.head_batch(iters, net) if not test_mode else None
+        flows = []
         for itr in range(iters):
-            coords1 = coords1.detach()
-            corr = corr_fn(coords1, channels_last=True)
-            flow = coords1 - coords0
+            flow = flow.detach()
+            corr = corr_fn(flow, channels_last=True, is_flow=True)
             want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_network.py:127-128)
-            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up)
-            coords1 = coords1 + delta_flow
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up, head_batch=hb)
+            flow = flow + delta_flow
+            if hb is not None:
+                flows.append(flow)
+                continue
             if not want_up:
                 continue
             if up_mask is None:
-                flow_up = upflow8(coords1 - coords0)
+                flow_up = upflow8(flow)
             else:
-                flow_up = convex_upsample(coords1 - coords0, up_mask, channels_last=True)
+                flow_up = convex_upsample(flow, up_mask, channels_last=True)
             flow_predictions.append(flow_up)
+        if hb is not None:
+            flow_predictions = hb.finish(flows)
 
         if test_mode:
-            return coords1 - coords0, flow_up
+            return flow, flow_up
         return flow_predictions

@@ -123,6 +123,10 @@ class L2L(RAFT):
         half = iters // 2
         crop = None
         grad_mode = torch.is_grad_enabled()
+        # training: mask head + upsampler of a phase's iterations as one launch each after the loop (update.HeadBatch), one batch
+        # per phase (the two phases run different blocks on different grids)
+        hb = self.update_block.head_batch(half, net) if not test_mode else None
+        hb2, flows, flows2 = None, [], []
         try:
             for itr in range(iters):
                 if itr == half and not supervisor_grad and not test_mode:
@@ -134,7 +138,7 @@ class L2L(RAFT):
                     corr = corr_fn(flow, channels_last=True, is_flow=True)
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (l2l.py:130-131)
                 if test_mode or itr < half:
-                    net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up)
+                    net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up, head_batch=hb)
                 else:
                     if itr == half:
                         if ci1 is not None:
@@ -146,9 +150,13 @@ class L2L(RAFT):
                             _, inp = context(ci1)
                             inp = to_channels_last(torch.relu(inp))
                         net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
-                    net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow)
+                        hb2 = self.grad_update_block.head_batch(iters - half, net)
+                    net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow, head_batch=hb2)
 
                 flow = flow + delta_flow
+                if not test_mode and (hb if itr < half else hb2) is not None:
+                    (flows if itr < half else flows2).append(flow)
+                    continue
                 if not want_up:
                     continue
                 if up_mask is None:
@@ -160,6 +168,13 @@ class L2L(RAFT):
                 flow_predictions.append(flow_up)
         finally:
             torch.set_grad_enabled(grad_mode)
+        # the deferred mask head + upsampler of each phase (after the caller's gradient mode is back: the unlabelled pass of the
+        # flow-supervisor step switches it off for the supervisor's half).  A phase that ran without a batch has its predictions in
+        # the list already; the student's come first.
+        if hb is not None and flows:
+            flow_predictions = hb.finish(flows) + flow_predictions
+        if hb2 is not None and flows2:
+            flow_predictions = flow_predictions + [_crop_back(p, *crop) for p in hb2.finish(flows2)]
 
         if test_mode:
             return flow, flow_up

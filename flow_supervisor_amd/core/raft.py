@@ -113,14 +113,20 @@ class RAFT(nn.Module):
 
         flow_predictions = []
         flow_up = None
+        # training: the mask head and the upsampler of all iterations run as one launch each after the loop (update.HeadBatch)
+        hb = self.update_block.head_batch(iters, net) if not test_mode else None
+        flows = []
         for itr in range(iters):
             flow = flow.detach()
             corr = corr_fn(flow, channels_last=True, is_flow=True)
             # test_mode returns only the last upsampled flow (raft.py:141-142): the mask convolution and the upsampler of
             # the other iterations are skipped -- same outputs, the reference computes them and drops them (raft.py:134-139)
             want_up = not test_mode or itr == iters - 1
-            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up)
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up, head_batch=hb)
             flow = flow + delta_flow
+            if hb is not None:
+                flows.append(flow)
+                continue
             if not want_up:
                 continue
             if up_mask is None:
@@ -129,6 +135,8 @@ class RAFT(nn.Module):
                 flow_up = convex_upsample(flow, up_mask, channels_last=True)
             flow_predictions.append(flow_up)
 
+        if hb is not None:
+            flow_predictions = hb.finish(flows)
         if test_mode:
             return flow, flow_up
         return flow_predictions

@@ -336,7 +336,7 @@ class _Engine:
         cst.dsum = {}
         return dinp
 
-    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True):
+    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True, head_out=None):
         """net/corr: channels-last [B,H,W,C]; ctxb: context() of the context features; flow: [B,2,H,W] (any pixel stride).
         Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
         a dict of the intermediates backward needs.  need_mask=False (inference, every iteration but the last: the
@@ -407,7 +407,9 @@ class _Engine:
             gates.append((h, z, r, rh, q))
             h = hn
         nhead = self.head_c * (2 if self.has_mask else 1)
-        head = buf(nhead)
+        # head_out: a slot of a HeadBatch -- the mask convolution (and the upsampler) of all iterations then run as one launch
+        # after the loop, on the slots
+        head = buf(nhead) if head_out is None else head_out
         conv("hd", [V(h, hid)], [Dst.nhwc(head)], relu=True)
         delta = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
         if self.head_c % 4 == 0 and self.head_c <= 512:
@@ -415,7 +417,7 @@ class _Engine:
         else:
             conv("fh2", [V(head, self.head_c)], [Dst.nchw(delta)])
         mask = None
-        if self.has_mask and (need_mask or save):
+        if self.has_mask and (need_mask or save) and head_out is None:
             mask = buf(576)
             conv("m2", [V(head, self.head_c, self.head_c)], [Dst.nhwc(mask)], alpha=0.25)
         saved = None
@@ -478,9 +480,15 @@ class _Engine:
             ops.conv_forward([dy], P[k][1], None, B, H, W, l.kh, l.kw, n_in, dsts, alpha=alpha, wpk_split=P[k][6])
 
         # ---- heads
-        dhead = buf(self.head_c * (2 if self.has_mask else 1))
+        hb = S.get("hb")
         head = S["head"]
-        if self.has_mask:
+        if hb is not None:
+            # the mask half of dhead was written by the batched backward of the mask head (HeadBatch / _MaskUpFn), which autograd
+            # runs before this node: this iteration's delta gradient comes out of it
+            dhead = hb[0].dhead_slot(hb[1])
+        else:
+            dhead = buf(self.head_c * (2 if self.has_mask else 1))
+        if self.has_mask and hb is None:
             if dmask is not None:
                 # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask: the data gradient applies the factor in its
                 # epilogue, the weight / bias gradients once per step when the arena is unpacked
@@ -708,9 +716,13 @@ class _UpdateFn(torch.autograd.Function):
     """(anchor; net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
 
     @staticmethod
-    def forward(ctx, engine, st, params, anchor, net, cst, canchor, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None):
+    def forward(ctx, engine, st, params, anchor, net, cst, canchor, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None, hb=None):
         need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
-        h, mask, delta, saved = engine.forward(net, cst.bufs, corr, flow, params, save=need, attn=attn, attn_t=attn_t)
+        slot = hb.next_slot() if hb is not None else None
+        h, mask, delta, saved = engine.forward(net, cst.bufs, corr, flow, params, save=need, attn=attn, attn_t=attn_t,
+                                               head_out=None if slot is None else hb.head[slot])
+        if saved is not None and slot is not None:
+            saved["hb"] = (hb, slot)
         ctx.engine, ctx.st, ctx.saved = engine, st, saved
         ctx.ast, ctx.cst = ast, cst
         ctx.P = engine._packed(params) if need else None
@@ -733,7 +745,122 @@ class _UpdateFn(torch.autograd.Function):
                                           cst=cst if cst.anchor is not None else None, need_dflow=ctx.needs_input_grad[8])
         # the three anchors get no gradient tensor: autograd still runs their producers (_ParamFn, _CtxFn, _AttnFn) once
         # every consumer is done -- that ordering is all they are for -- and skips 3 x 12 one-element accumulation kernels
-        return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None)
+        return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None, None)
+
+
+HEAD_BATCH = os.environ.get("FSRAFT_HEAD_BATCH", "1") != "0"
+
+
+class HeadBatch:
+    """The mask head and the convex upsampler of ALL iterations of a step as one launch each (and their backward likewise).
+    Neither feeds the recurrence -- an iteration hands on the hidden state and the flow; the mask only shapes that iteration's
+    full-resolution prediction (raft.py:134-139) -- so the loop writes each iteration's head activations into a slot of one
+    buffer and `finish(flows)` runs the 1x1 mask convolution over T x B x H x W pixels and the upsampler over T x B images:
+    4 x T launches per step become 4, and at one or two pairs per GPU they fill the chip instead of a fifth of it.
+    Same values as T separate calls (the kernels are per-pixel / per-image); gradients reach the iterations through the
+    flows (delta_t) and through `dhead_slot` (the mask half of each iteration's head gradient)."""
+
+    def __init__(self, eng, params, st, anchor, T, B, H, W, device):
+        self.eng, self.params, self.st, self.anchor = eng, params, st, anchor
+        self.T, self.B, self.H, self.W = T, B, H, W
+        self.head = torch.empty(T, B, H, W, 2 * eng.head_c, device=device, dtype=torch.float32)
+        self.dhead = None
+        self.n = 0
+
+    @staticmethod
+    def fits(T, B, H, W):
+        return T * B * H * W * 576 * 4 < 0x7fffffff          # (buffer-addressed kernels: 32-bit byte offsets)
+
+    def next_slot(self):
+        if self.n >= self.T:
+            raise RuntimeError("HeadBatch: more update-block calls than slots")
+        self.n += 1
+        return self.n - 1
+
+    def dhead_slot(self, t):
+        if self.dhead is None:      # (no prediction of this batch reached the loss: the mask head gets no gradient)
+            self.dhead = torch.zeros_like(self.head)
+        return self.dhead[t]
+
+    def finish(self, flows):
+        """flows: the T flow fields [B,2,H,W] after each iteration -> the T upsampled predictions [B,2,8H,8W]."""
+        if len(flows) != self.n:
+            raise RuntimeError(f"HeadBatch: {self.n} update-block calls but {len(flows)} flows")
+        return list(_MaskUpFn.apply(self, self.anchor, *flows))
+
+
+def _one_tensor(ts):
+    """The tensors of `ts` as ONE tensor [len(ts) * n0, ...] without a copy when they are equal-shaped contiguous pieces lying
+    back to back in one storage (the loss kernel hands out its gradients that way); None otherwise."""
+    g0 = ts[0]
+    if g0 is None or not g0.is_contiguous():
+        return None
+    nb = g0.numel() * g0.element_size()
+    base = g0.untyped_storage().data_ptr()
+    for i, g in enumerate(ts):
+        if (g is None or g.shape != g0.shape or g.dtype != g0.dtype or not g.is_contiguous() or g.untyped_storage().data_ptr() != base
+                or g.data_ptr() != g0.data_ptr() + i * nb):
+            return None
+    shape = (len(ts) * g0.shape[0],) + tuple(g0.shape[1:])
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= d
+    return torch.as_strided(g0, shape, tuple(reversed(st)))
+
+
+class _MaskUpFn(torch.autograd.Function):
+    """(HeadBatch, parameter anchor, flow_0 .. flow_{T-1}) -> T upsampled predictions: mask = 0.25 * conv1x1(head_mask) over
+    all slots, then upsample_flow (raft.py:72-83) over T x B images."""
+
+    @staticmethod
+    def forward(ctx, hb, anchor, *flows):
+        eng = hb.eng
+        T, B, H, W = hb.n, hb.B, hb.H, hb.W
+        P = eng._packed(hb.params)
+        head = hb.head[:T].view(T * B, H, W, 2 * eng.head_c)
+        fl = torch.stack([f.float() for f in flows]).view(T * B, 2, H, W)
+        mask = torch.empty(T * B, H, W, 576, device=head.device, dtype=torch.float32)
+        l = eng.layers["m2"]
+        ops.conv_forward([V(head, eng.head_c, eng.head_c)], P["m2"][0], P["m2"][2], T * B, H, W, l.kh, l.kw, 576, [Dst.nhwc(mask)],
+                         alpha=0.25, wpk_split=P["m2"][5])
+        up = ops.upsample_fwd(fl, mask)
+        ctx.hb, ctx.P = hb, P
+        ctx.save_for_backward(fl, mask)
+        ctx.set_materialize_grads(False)
+        return tuple(up[t * B:(t + 1) * B] for t in range(T))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        hb, P = ctx.hb, ctx.P
+        eng = hb.eng
+        fl, mask = ctx.saved_tensors
+        T, B, H, W = hb.n, hb.B, hb.H, hb.W
+        if all(g is None for g in gs):
+            return (None, None) + (None,) * T
+        dup = _one_tensor(gs)
+        if dup is None:
+            z = next(g for g in gs if g is not None)
+            dup = torch.cat([g if g is not None else torch.zeros_like(z) for g in gs])
+        dflow, dmask = ops.upsample_bwd(fl, mask, dup)
+        ctx.hb = None
+        head = hb.head[:T].view(T * B, H, W, 2 * eng.head_c)
+        hb.dhead = torch.empty_like(hb.head)
+        dhead = hb.dhead[:T].view(T * B, H, W, 2 * eng.head_c)
+        hc = eng.head_c
+        st = hb.st
+        # y = 0.25 * (W x + b): the data gradient applies the factor in its epilogue, the weight / bias gradients once per step
+        # when the arena is unpacked (unpack_param_grads)
+        gv, xv = V(dmask, 576), V(head, hc, hc)
+        if st is not None and st.key is not None:
+            dW, dB = eng._grad_arena(st, P, head.device)
+            if st.pending is not None:
+                st.pending.setdefault(("m2", T * B, H, W), []).append((gv, [xv]))
+            else:
+                ops.conv_wgrad(gv, [xv], dW["m2"], T * B, H, W, 1, 1, dbias=dB["m2"])
+        ops.conv_forward([gv], P["m2"][1], None, T * B, H, W, 1, 1, hc, [Dst.nhwc(dhead, hc).masked(xv)], alpha=0.25,
+                         wpk_split=P["m2"][6])
+        return (None, None) + tuple(dflow[t * B:(t + 1) * B] for t in range(T))
 
 
 class _ToCL(torch.autograd.Function):
@@ -823,7 +950,7 @@ class _UpdateBlockBase(nn.Module):
             self.__dict__["_cst"] = cst
         return cst
 
-    def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True):
+    def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True, head_batch=None):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
         Returns (net', mask_cl or None, delta).  need_mask=False: the caller will not upsample this iteration's flow
@@ -849,8 +976,21 @@ class _UpdateBlockBase(nn.Module):
         cst = self._ctx_state(eng, st, params, anchor, inp, track)
         attn = attention.detach() if attention is not None else None
         h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, cst, cst.anchor, corr, flow, ast, attn, aanchor,
-                                         self._attn_transposed(attention))
-        return h, (mask if eng.has_mask else None), delta
+                                         self._attn_transposed(attention), head_batch)
+        return h, (mask if (eng.has_mask and head_batch is None) else None), delta
+
+    def head_batch(self, iters, net):
+        """A HeadBatch for `iters` calls of forward_cl(..., head_batch=...) on states shaped like `net` ([B,H,W,hid]), or None
+        where it does not apply (no mask head, no gradient being recorded, frozen parameters, switched off, too large)."""
+        eng = self._engine()
+        if not (HEAD_BATCH and eng.has_mask and torch.is_grad_enabled() and net.is_cuda):
+            return None
+        params = tuple(eng.params())
+        st, anchor = eng.param_state(params)
+        B, H, W, _ = net.shape
+        if anchor is None or not HeadBatch.fits(iters, B, H, W):
+            return None
+        return HeadBatch(eng, params, st, anchor, iters, B, H, W, net.device)
 
     def _forward_nchw(self, net, inp, corr, flow, attention=None):
         # The channels-last copy of `inp` is reused while the caller passes the SAME tensor object at the same version

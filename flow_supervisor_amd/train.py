@@ -22,7 +22,12 @@ class _SeqLossFn(torch.autograd.Function):
         B, _, H, W = preds[0].shape
         n = len(preds)
         need = [ctx.needs_input_grad[6 + i] for i in range(n)]
-        dps = [torch.empty_like(p) if nd else None for p, nd in zip(preds, need)]
+        if all(need) and all(p.shape == preds[0].shape for p in preds):
+            # one buffer, the gradients back to back: a producer that made the predictions in one launch (update.HeadBatch) takes
+            # them back as one tensor
+            dps = list(torch.empty((n,) + tuple(preds[0].shape), device=preds[0].device, dtype=torch.float32).unbind(0))
+        else:
+            dps = [torch.empty_like(p) if nd else None for p, nd in zip(preds, need)]
         out = torch.zeros(6, device=preds[0].device, dtype=torch.float32)
         a_p = (ctypes.c_void_p * n)(*[p.data_ptr() for p in preds])
         a_d = (ctypes.c_void_p * n)(*[d.data_ptr() if d is not None else None for d in dps])
@@ -61,7 +66,8 @@ class _SemiLossFn(torch.autograd.Function):
         n = len(preds)
         if B2 != 2 * bs or len(w_sup) != n or len(w_unsup) != n:
             raise ValueError("batched flow-supervisor loss: predictions must hold bs labelled then bs unlabelled samples")
-        dps = [torch.empty_like(p) for p in preds]
+        # (one buffer, the gradients back to back: update.HeadBatch takes a phase's gradients back as one tensor)
+        dps = list(torch.empty((n,) + tuple(preds[0].shape), device=preds[0].device, dtype=torch.float32).unbind(0))
         out = torch.zeros(12, device=preds[0].device, dtype=torch.float32)
         gt = gt.contiguous().float()
         valid = valid.contiguous().float() if valid is not None else None

@@ -669,6 +669,36 @@ def test_batched_flow_supervisor_losses_equal_the_two_functions_on_slices(bs):
     assert float(a[-1].grad[bs:].abs().max()) == 0.0          # the supervisor's half of the unlabelled samples: no gradient
 
 
+def test_mask_head_and_upsampler_of_all_iterations_as_one_launch():
+    """update.HeadBatch (the mask convolution and the convex upsampler of every iteration deferred to one launch each, their
+    backward likewise) against the per-iteration path on the same weights and inputs: predictions bit-equal (per-pixel /
+    per-image kernels: the batch only changes how many rows a launch sees), every parameter gradient equal to summation-order
+    noise (the mask head's weight gradient becomes one 12x longer segment, the encoders' statistics meet in atomics)."""
+    from flow_supervisor_amd.core import update as U
+    from flow_supervisor_amd.train import raft_sequence_loss
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(2, 128, 192, 91))
+    out = {}
+    was = U.HEAD_BATCH
+    try:
+        for on in (True, False):
+            U.HEAD_BATCH = on
+            torch.manual_seed(3)
+            m = _model(False, 92).train()
+            m.freeze_bn()
+            preds = m(im1, im2, iters=5)
+            raft_sequence_loss(preds).backward()
+            out[on] = ([p.detach().clone() for p in preds], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        U.HEAD_BATCH = was
+    for a, b in zip(out[True][0], out[False][0]):
+        close(a, b, 2e-5, rtol=0.0, what="prediction with / without the head batch")      # (run-to-run noise of the InstanceNorm atomics)
+    assert out[True][1].keys() == out[False][1].keys()
+    for n, ga in out[True][1].items():
+        gb = out[False][1][n]
+        tol = 2e-2 if n.startswith("fnet.") else 2e-3
+        assert (ga - gb).norm().item() <= tol * gb.norm().item() + 1e-6, (n, (ga - gb).norm().item(), gb.norm().item())
+
+
 def test_test_mode_skips_the_dropped_upsamples_with_identical_outputs():
     """test_mode returns only the last flow_up (raft.py:141-142); the mask convolution and the upsampler of
     the other iterations are skipped.  Outputs must equal the last training-mode prediction of the same weights (same kernels,
