@@ -28,11 +28,12 @@ from .utils.utils import coords_grid
 class _GradState:
     """Backward state of one CorrBlock: the (coords, dOut) pairs of every lookup whose gradient has arrived.  The window
     gradients are a pure function of those, so nothing else is done until autograd reaches the volume build."""
-    __slots__ = ("stash", "is_flow")
+    __slots__ = ("stash", "is_flow", "gs")
 
     def __init__(self, device):
         self.stash = []
         self.is_flow = False                    # stash entries hold flows (pixel grid added by the kernel), not coordinates
+        self.gs = None                          # CorrBlock(grad_samples=k): only the first k samples' lookups receive gradient
 
 
 def _build_records(fmap1, fmap2):
@@ -65,6 +66,14 @@ class _BuildFn(torch.autograd.Function):
         if not st.stash:                            # no lookup contributed a gradient
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None, None
         stash, st.stash = st.stash, []
+        Bf, f1r = fmap1.shape[0], ctx.f1r
+        sliced = st.gs is not None and 0 < st.gs < Bf
+        if sliced:       # the other samples' window gradients are zeros by the caller's word: build and contract the first k only
+            k = st.gs
+            full1, full2 = fmap1, fmap2
+            fmap1, fmap2 = fmap1[:k], fmap2[:k]
+            stash = [(c[:k], d[:k]) for c, d in stash]
+            f1r = f1r[:k] if f1r is not None else None
         rec = ops.SPLIT_VOLUME_BWD             # (off = the exact-fp32 test mode: fp32 gradient volume, exact GEMMs)
         # which k-tiles of the two volume-backward GEMMs the step's lookups can reach: the GEMMs walk those only, and the gradient
         # volume is only written where they will read (the rest would be zero records)
@@ -72,8 +81,13 @@ class _BuildFn(torch.autograd.Function):
         dvol = ops.corr_dvol_build([d for _, d in stash], [c for c, _ in stash], ctx.lay, fmap1.shape[0], ctx.radius, records=rec,
                                    is_flow=st.is_flow, wmask=kt.wmask if kt is not None and ops.DVOL_WMASK else None)
         del stash
-        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay, records=rec, f1r=ctx.f1r if rec else None, ktiles=kt)
+        d1, d2 = ops.corr_build_bwd_tiled(fmap1, fmap2, dvol, ctx.lay, records=rec, f1r=f1r if rec else None, ktiles=kt)
         ctx.f1r = None
+        if sliced:
+            z1, z2 = torch.zeros_like(full1), torch.zeros_like(full2)
+            z1[:k].copy_(d1)
+            z2[:k].copy_(d2)
+            d1, d2 = z1, z2
         return d1, d2, None, None, None
 
 
@@ -101,9 +115,12 @@ class _LookupFn(torch.autograd.Function):
 class CorrBlock:
     """All-pairs volume + pyramid + lookup (pytorch/core/corr.py:13-60).  The volume lives in the tiled-row layout of
     csrc/corr_layout.hpp (one row per query, all levels, 4x4-cell tiles); `corr_pyramid` -- the reference's list of
-    [B*H*W, 1, h_l, w_l] tensors -- is materialised from it on first access (API edge; nothing on the path reads it)."""
+    [B*H*W, 1, h_l, w_l] tensors -- is materialised from it on first access (API edge; nothing on the path reads it).
+    grad_samples (extension, default None): the caller vouches that only the lookups of the first k samples receive gradient
+    (core/l2l.py: the supervisor phase of a batched flow-supervisor step); the backward then builds and contracts the gradient
+    volume of those samples only."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, grad_samples=None):
         if not 1 <= num_levels <= 4:
             raise NotImplementedError("the HIP correlation kernels are built for 1..4 pyramid levels (all RAFT variants use 4)")
         if radius not in (3, 4):
@@ -118,6 +135,7 @@ class CorrBlock:
             holder = []
             self._anchor, self._vol = _BuildFn.apply(fmap1, fmap2, num_levels, radius, holder)
             self._state, self._lay = holder[0]
+            self._state.gs = grad_samples
         else:
             self._vol, self._lay = ops.corr_build_tiled(fmap1, fmap2, num_levels, recs=_build_records(fmap1, fmap2))
             self._anchor, self._state = None, None

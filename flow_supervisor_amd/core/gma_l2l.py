@@ -20,7 +20,7 @@ class GMAL2L(RAFTGMA):
         self.grad_update_block = GMAUpdateBlock(self.args, hidden_dim=self.hidden_dim)
 
     def forward(self, image1, image2, ci1=None, ci2=None, ox=None, oy=None, iters=12, flow_init=None,
-                upsample=True, test_mode=False, supervisor_grad=True):
+                upsample=True, test_mode=False, supervisor_grad=True, sup_grad_samples=None):
         norm = lambda im: (2 * (im / 255.0) - 1.0).contiguous()
         image1, image2 = norm(image1), norm(image2)
         if ci1 is not None:
@@ -56,16 +56,28 @@ class GMAL2L(RAFTGMA):
                     if ci1 is not None:
                         crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
                         net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))
-                        tfmap1, tfmap2 = self._features(ci1, ci2)
-                        corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)
+                        k = sup_grad_samples
+                        k = k if (k is not None and 0 < k < net.shape[0] and torch.is_grad_enabled()) else None
+                        if k is not None:
+                            # (extension, see core/l2l.py) only the first k samples' supervisor predictions receive gradient: the
+                            # uncropped frames of the others are encoded without a graph
+                            ta1, ta2 = self._features(ci1[:k], ci2[:k])
+                            with torch.no_grad():
+                                tb1, tb2 = self._features(ci1[k:], ci2[k:])
+                            tfmap1, tfmap2 = torch.cat([ta1, tb1]), torch.cat([ta2, tb2])
+                        else:
+                            tfmap1, tfmap2 = self._features(ci1, ci2)
+                        corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius, grad_samples=k)
                         corr = corr_fn(flow, channels_last=True, is_flow=True)
-                        _, inp, attention = self._context(ci1)
+                        with torch.no_grad():             # (detached below, as in the reference: no graph, no saved activations)
+                            _, inp, attention = self._context(ci1)
                     net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                     attention = attention.detach()
                     hb2 = self.update_block.head_batch(iters - half, net)
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_l2l.py:126-127)
                 cur = None if test_mode else (hb if itr < half else hb2)
-                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up, head_batch=cur)
+                net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up, head_batch=cur,
+                                                                        grad_samples=sup_grad_samples if itr >= half else None)
 
                 flow = flow + delta_flow
                 if cur is not None:

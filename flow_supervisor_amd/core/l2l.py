@@ -82,7 +82,7 @@ class L2L(RAFT):
         self.grad_update_block = BasicUpdateBlock(self.args, hidden_dim=self.hidden_dim)   # l2l.py:27
 
     def forward(self, image1, image2, ci1=None, ci2=None, ox=None, oy=None, iters=24, flow_init=None,
-                upsample=True, test_mode=False, supervisor_grad=True):
+                upsample=True, test_mode=False, supervisor_grad=True, sup_grad_samples=None):
         norm = lambda im: (2 * (im / 255.0) - 1.0).contiguous()
         image1, image2 = norm(image1), norm(image2)
         if ci1 is not None:
@@ -144,14 +144,27 @@ class L2L(RAFT):
                         if ci1 is not None:
                             crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
                             net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))   # (l2l.py:90-93)
-                            tfmap1, tfmap2 = features(ci1, ci2)
-                            corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius)   # second volume (l2l.py:101)
+                            k = sup_grad_samples
+                            if k is not None and 0 < k < net.shape[0] and torch.is_grad_enabled():
+                                # (extension) the caller's loss reaches the supervisor's predictions of the first k samples only
+                                # (the flow-supervisor step batches its labelled and its unlabelled sample: train.SemiTrainStep): the
+                                # uncropped frames of the others are encoded without a graph -- their gradient would be zeros
+                                # pushed through the whole feature encoder
+                                ta1, ta2 = features(ci1[:k], ci2[:k])
+                                with torch.no_grad():
+                                    tb1, tb2 = features(ci1[k:], ci2[k:])
+                                tfmap1, tfmap2 = torch.cat([ta1, tb1]), torch.cat([ta2, tb2])
+                            else:
+                                tfmap1, tfmap2 = features(ci1, ci2)
+                            corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius,     # second volume (l2l.py:101)
+                                                grad_samples=k if (k is not None and 0 < k < net.shape[0]) else None)
                             corr = corr_fn(flow, channels_last=True, is_flow=True)
-                            _, inp = context(ci1)
-                            inp = to_channels_last(torch.relu(inp))
+                            with torch.no_grad():         # (detached below, as in the reference: no graph, no saved activations)
+                                _, inp = context(ci1)
+                                inp = to_channels_last(torch.relu(inp))
                         net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                         hb2 = self.grad_update_block.head_batch(iters - half, net)
-                    net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow, head_batch=hb2)
+                    net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow, head_batch=hb2, grad_samples=sup_grad_samples)
 
                 flow = flow + delta_flow
                 if not test_mode and (hb if itr < half else hb2) is not None:

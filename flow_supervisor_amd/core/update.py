@@ -433,6 +433,18 @@ class _Engine:
         B, H, W = S["B"], S["H"], S["W"]
         dev = S["corr"].device
         lib = L.load()
+        # grad_samples (forward_cl): the caller vouches that only the first k samples of the batch receive gradient from its
+        # loss (the flow-supervisor step batches a labelled and an unlabelled sample; the supervisor's predictions of the
+        # unlabelled one carry none).  Every buffer is sample-major, so the whole backward simply runs on B = k: the kernels read
+        # the first k samples of the saved activations and of the incoming gradients; what goes back to autograd (dnet, dcorr)
+        # and the context part's running sums are full-size with zeros behind sample k.
+        Bf = B
+        gs = S.get("gs")
+        if gs is not None and 0 < gs < Bf and (not self.gma or ast is None) and not need_dflow:
+            B = gs
+            dnet_out = dnet_out[:B] if dnet_out is not None else None
+            ddelta = ddelta[:B] if ddelta is not None else None
+            dmask = dmask[:B] if dmask is not None else None
         M = B * H * W
         hid = self.hid
 
@@ -485,7 +497,7 @@ class _Engine:
         if hb is not None:
             # the mask half of dhead was written by the batched backward of the mask head (HeadBatch / _MaskUpFn), which autograd
             # runs before this node: this iteration's delta gradient comes out of it
-            dhead = hb[0].dhead_slot(hb[1])
+            dhead = hb[0].dhead_slot(hb[1])[:B]
         else:
             dhead = buf(self.head_c * (2 if self.has_mask else 1))
         if self.has_mask and hb is None:
@@ -530,14 +542,18 @@ class _Engine:
             if cst is None:
                 return None
             if k not in cst.dsum:
-                cst.dsum[k] = ops.zeros(tuple(like.shape), device=like.device)
+                cst.dsum[k] = ops.zeros((Bf,) + tuple(like.shape[1:]), device=like.device)
             return cst.dsum[k]
 
         first_pass = self.passes[0][0]
         for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
             dzr = buf(2 * hid)
             dq = buf(hid)
-            dhp = buf(hid)
+            if B != Bf and sfx == first_pass:          # the buffer that goes back to autograd as dnet: full size, zeros behind sample B
+                dh_full = ops.zeros(Bf, H, W, _pad4(hid), device=dev)
+                dhp = dh_full[:B]
+            else:
+                dhp = buf(hid)
             zsum, qsum = ctx_sum("zi" + sfx, dzr), ctx_sum("qi" + sfx, dq)
             ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid, zsum, qsum)
             xs = [V(motion, self.x_c)]
@@ -601,7 +617,10 @@ class _Engine:
             dgrad("f1", V(dflo1, self.f1), [Dst.nhwc(dcols)])
             ops.col2im7(dcols, dflow, True)
         corr = S["corr"]
-        dcorr = buf(self.corr_c) if need_input_grads else None
+        dcorr = dcorr_full = None
+        if need_input_grads:
+            dcorr_full = ops.zeros(Bf, H, W, _pad4(self.corr_c), device=dev) if B != Bf else buf(self.corr_c)
+            dcorr = dcorr_full[:B]
         if self.c2:
             cor1 = S["cor1"]
             wgrad("c2", V(dcorflo, self.c2, 0), [V(cor1, self.c1)])
@@ -615,7 +634,7 @@ class _Engine:
             if need_input_grads:
                 dgrad("c1", V(dcorflo, self.c1, 0), [Dst.nhwc(dcorr)])
 
-        return dh, dcorr, dflow
+        return (dh_full if B != Bf else dh), dcorr_full, dflow
 
 
 class _CtxState:
@@ -716,13 +735,16 @@ class _UpdateFn(torch.autograd.Function):
     """(anchor; net, inp, corr: channels-last; flow: NCHW) -> (net', mask channels-last or empty, delta NCHW)."""
 
     @staticmethod
-    def forward(ctx, engine, st, params, anchor, net, cst, canchor, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None, hb=None):
+    def forward(ctx, engine, st, params, anchor, net, cst, canchor, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None, hb=None,
+                grad_samples=None):
         need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
         slot = hb.next_slot() if hb is not None else None
         h, mask, delta, saved = engine.forward(net, cst.bufs, corr, flow, params, save=need, attn=attn, attn_t=attn_t,
                                                head_out=None if slot is None else hb.head[slot])
         if saved is not None and slot is not None:
             saved["hb"] = (hb, slot)
+        if saved is not None and grad_samples is not None:
+            saved["gs"] = int(grad_samples)
         ctx.engine, ctx.st, ctx.saved = engine, st, saved
         ctx.ast, ctx.cst = ast, cst
         ctx.P = engine._packed(params) if need else None
@@ -745,7 +767,7 @@ class _UpdateFn(torch.autograd.Function):
                                           cst=cst if cst.anchor is not None else None, need_dflow=ctx.needs_input_grad[8])
         # the three anchors get no gradient tensor: autograd still runs their producers (_ParamFn, _CtxFn, _AttnFn) once
         # every consumer is done -- that ordering is all they are for -- and skips 3 x 12 one-element accumulation kernels
-        return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None, None)
+        return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None, None, None)
 
 
 HEAD_BATCH = os.environ.get("FSRAFT_HEAD_BATCH", "1") != "0"
@@ -950,7 +972,7 @@ class _UpdateBlockBase(nn.Module):
             self.__dict__["_cst"] = cst
         return cst
 
-    def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True, head_batch=None):
+    def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True, head_batch=None, grad_samples=None):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
         Returns (net', mask_cl or None, delta).  need_mask=False: the caller will not upsample this iteration's flow
@@ -976,7 +998,7 @@ class _UpdateBlockBase(nn.Module):
         cst = self._ctx_state(eng, st, params, anchor, inp, track)
         attn = attention.detach() if attention is not None else None
         h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, cst, cst.anchor, corr, flow, ast, attn, aanchor,
-                                         self._attn_transposed(attention), head_batch)
+                                         self._attn_transposed(attention), head_batch, grad_samples)
         return h, (mask if (eng.has_mask and head_batch is None) else None), delta
 
     def head_batch(self, iters, net):

@@ -104,13 +104,15 @@ class _SemiLossFn(torch.autograd.Function):
         return (None,) * 7 + tuple(dps)
 
 
-def semi_sequence_losses(flow_preds, bs, flow_gt, valid, gamma=0.8, gamma2=1.0, unsup_weight=1.0, max_flow=MAX_FLOW):
+def semi_sequence_losses(flow_preds, bs, flow_gt, valid, gamma=0.8, gamma2=1.0, unsup_weight=1.0, max_flow=MAX_FLOW, gamma_unsup=0.8):
     """(sequence_loss of samples [0, bs), sequence_loss_unsup of samples [bs, 2*bs)) of batched flow-supervisor predictions:
-    same values and gradients as the two functions on the two slices (pytorch/train.py:60-129), without the slices."""
+    same values and gradients as the two functions on the two slices (pytorch/train.py:60-129), without the slices.
+    gamma_unsup: the unlabelled loss has its OWN decay -- the reference's step calls sequence_loss_unsup without a gamma
+    (train.py:276: always the default 0.8) while sequence_loss gets args.gamma (0.85 in the GMA recipe)."""
     nm = len(flow_preds)
     n = nm // 2
     w_sup = [gamma ** (n - i - 1) for i in range(n)] + [gamma2 ** (n - i - 1) for i in range(nm - n)]
-    w_unsup = [unsup_weight * gamma ** (n - i - 1) for i in range(n)] + [0.0] * (nm - n)
+    w_unsup = [unsup_weight * gamma_unsup ** (n - i - 1) for i in range(n)] + [0.0] * (nm - n)
     return _SemiLossFn.apply(bs, w_sup, w_unsup, flow_gt, valid, max_flow, 1e-3, *flow_preds)
 
 
@@ -232,6 +234,8 @@ class SemiTrainStep(TrainStep):
         # kernels that see twice the pixels (at the recipe's batch size of 1 a launch fills a fifth of the chip).
         self.batched = (os.environ.get("FSRAFT_SEMI_BATCHED", "1") != "0") if batched is None else bool(batched)
         self._cat = None
+        import inspect
+        self._sup_kw = "sup_grad_samples" in inspect.signature(model.forward).parameters and os.environ.get("FSRAFT_SUP_GRAD_SAMPLES", "1") != "0"
 
     def _batched_inputs(self, sup, unsup):
         """cat of the two samples, cached while the caller passes the same tensors (the benchmark's resident inputs)."""
@@ -252,7 +256,8 @@ class SemiTrainStep(TrainStep):
         im1, im2, ci1, ci2 = self._batched_inputs(sup, unsup)
         ox = _offsets(sup[4], bs) + _offsets(unsup[4], unsup[0].shape[0])
         oy = _offsets(sup[5], bs) + _offsets(unsup[5], unsup[0].shape[0])
-        preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters)
+        kw = {"sup_grad_samples": bs} if self._sup_kw else {}        # the unlabelled samples' supervisor predictions carry no gradient
+        preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters, **kw)
         if preds[0].is_cuda and unsup[0].shape[0] == bs:
             loss, loss_u = semi_sequence_losses(preds, bs, sup[6], sup[7], self.gamma, unsup_weight=self.unsup_lambda)
         else:
