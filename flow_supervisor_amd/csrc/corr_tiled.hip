@@ -90,7 +90,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* row, uns
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uint64_t)hi << 32 | lo), 0, bytes, 0x00020000);
 }
 
-template <int R>
+template <int R, int AUX = 0>      // AUX: cache policy of the window loads (0 plain, 2 nt, 16 sc1, 18 both: fsraft_set_lookup_policy)
 __device__ __forceinline__ void lookup_issue(LookupLoad<R>& ld, const float* __restrict__ row, unsigned row_bytes, const LevelGeo (&g)[4],
                                              int nlev, float cx, float cy, int tsx, int tsy, int r) {
   using S = TL<R>;
@@ -103,12 +103,12 @@ __device__ __forceinline__ void lookup_issue(LookupLoad<R>& ld, const float* __r
     const bool need = l < nlev && tx >= 0 && tx < g[l].tw && ty >= 0 && y < g[l].h && y >= ld.lq[l].wy0 && y < ld.lq[l].wy0 + S::WIN &&
                       x + 3 >= ld.lq[l].wx0 && x < ld.lq[l].wx0 + S::WIN;
     const unsigned voff = need ? (unsigned)(g[l].off + (ty * g[l].tw + tx) * 16 + r * 4) * 4u : 0x80000000u;
-    ld.v[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    ld.v[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, AUX));
     ld.xr[l] = g[l].w - x;
   }
 }
 
-template <int R, int QW>
+template <int R, int QW, int AUX = 0>
 __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __restrict__ vol, VolLayout L, Coords co,
                                                                float* __restrict__ out, int64_t nq, int HW, int grid_w) {
   using S = TL<R>;
@@ -137,14 +137,14 @@ __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __re
     query_xy(co, (int)(q / (unsigned)HW), (int)(q % (unsigned)HW), grid_w, cxs[qq], cys[qq]);
   }
   LookupLoad<R> cur, nxt;
-  lookup_issue<R>(cur, vol + (int64_t)q0 * L.P, row_bytes, g, nlev, cxs[0], cys[0], tsx, tsy, r);
+  lookup_issue<R, AUX>(cur, vol + (int64_t)q0 * L.P, row_bytes, g, nlev, cxs[0], cys[0], tsx, tsy, r);
 #pragma unroll
   for (int qq = 0; qq < QW; ++qq) {
     if (qq >= nqw) break;
     const unsigned q = q0 + qq;
     // the next query's regions are requested before this one's are consumed (the last valid query is simply requested again)
     const int qn = qq + 1 < nqw ? qq + 1 : qq;
-    if (qq + 1 < QW) lookup_issue<R>(nxt, vol + (int64_t)(q0 + qn) * L.P, row_bytes, g, nlev, cxs[qn], cys[qn], tsx, tsy, r);
+    if (qq + 1 < QW) lookup_issue<R, AUX>(nxt, vol + (int64_t)(q0 + qn) * L.P, row_bytes, g, nlev, cxs[qn], cys[qn], tsx, tsy, r);
 #pragma unroll
     for (int l = 0; l < 4; ++l)
       if (l < nlev) {
@@ -516,6 +516,7 @@ __global__ void dvol_list_reset_kernel(unsigned* qlist) { qlist[0] = 0u; }
 // marks, from the lookups' coordinates alone, every (128-query tile, record) and every (256-cell tile, 32-query block) that a
 // window can reach -- per query and level the bounding rectangle of its lookups' windows, a superset of what the gradient
 // kernel writes -- and compacts the marks into ascending k-tile lists for fsraft_gemm_rec_nt_list / _tn_list.
+int g_lookup_policy = -1;         // cache policy of the tiled lookup's window loads (fsraft_set_lookup_policy); -1: nt for volumes beyond the Infinity Cache
 int g_ktile_exact = 0;            // levels whose windows are marked lookup by lookup instead of by bounding rectangle (fsraft_set_ktile_exact)
 constexpr int KT_NQ = 128;        // queries per NT list
 constexpr int KT_MC = 256;        // cells per TN list
@@ -716,8 +717,15 @@ __global__ __launch_bounds__(256) void corr_dfmap2_kernel(const float* __restric
 template <int R>
 int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float* out, int64_t nq, int HW, int grid_w, hipStream_t s) {
   constexpr int QW = 4;
-  hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW>), dim3((unsigned)((nq + 4 * QW - 1) / (4 * QW))), dim3(256), 0, s, vol, L, co,
-                     out, nq, HW, grid_w);
+  const dim3 grid((unsigned)((nq + 4 * QW - 1) / (4 * QW)));
+  // Non-temporal window loads once the volume is larger than the 256 MB Infinity Cache (every lookup then streams ~110 MB of a
+  // 1 GB volume that will not be there next time anyway): 12 lookups 0.39 -> 0.367 ms in the step (same-box A/B,
+  // scripts/lookup_policy_ab.sh; sc1 alone: no change).
+  const int pol = g_lookup_policy >= 0 ? g_lookup_policy : ((int64_t)nq * L.P * 4 > ((int64_t)300 << 20) ? 2 : 0);
+  if (pol == 2) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 2>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
+  else if (pol == 16) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 16>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
+  else if (pol == 18) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 18>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
+  else hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 0>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
   return fs_launch_status();
 }
 
@@ -749,6 +757,11 @@ extern "C" int fsraft_set_dvol_policy(int policy) {
 }
 
 int g_dvol_box = 1;       // 1: corr_dvol_box_kernel + work list where a scratch list is supplied, 0: corr_dvol_kernel for every query
+extern "C" int fsraft_set_lookup_policy(int aux) {
+  if (aux != -1 && aux != 0 && aux != 2 && aux != 16 && aux != 18) return FS_ERR_ARG;
+  g_lookup_policy = aux;
+  return FS_OK;
+}
 extern "C" int fsraft_set_ktile_exact(int levels) {
   if (levels < 0 || levels > 2) return FS_ERR_ARG;
   g_ktile_exact = levels;
