@@ -261,9 +261,18 @@ def main():
                 step(im1, im2)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        cap_kw = {}
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # The process group's watchdog thread polls the events of finished collectives (hipEventQuery).  Under the default
+            # GLOBAL capture mode such a call from another thread while this one captures is an error -- it invalidates the
+            # capture and the watchdog aborts the process (seen once in ~10 runs of tests/_rccl_worker.py: hipErrorStreamCapture-
+            # Unsupported).  Thread-local mode confines the check to the capturing thread; the pause lets the watchdog reap
+            # the warm-up steps' work objects first.
+            time.sleep(0.5)
+            cap_kw["capture_error_mode"] = "thread_local"
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):   # same stream as the warm-up: autograd pins each AccumulateGrad node to the stream it was created on
+            with torch.cuda.graph(graph, stream=side, **cap_kw):   # same stream as the warm-up: autograd pins each AccumulateGrad node to the stream it was created on
                 loss = step(im1, im2)
             run = graph.replay
         except Exception as e:                       # (never seen; the eager path below is the same step)

@@ -93,8 +93,8 @@ class _BuildFn(torch.autograd.Function):
 
 class _LookupFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, coords, block, channels_last, is_flow):
-        out = ops.corr_lookup_tiled_fwd(block._vol, block._lay, coords, block.radius, is_flow)
+    def forward(ctx, anchor, coords, block, channels_last, is_flow, out_buf=None):
+        out = ops.corr_lookup_tiled_fwd(block._vol, block._lay, coords, block.radius, is_flow, out=out_buf)
         ctx.state = block._state
         ctx.cl, ctx.is_flow = channels_last, is_flow
         ctx.save_for_backward(coords)
@@ -109,7 +109,7 @@ class _LookupFn(torch.autograd.Function):
             g = coords_grid(B, H, W, device=coords.device)
             coords = coords - g if ctx.state.is_flow else coords + g
         ctx.state.stash.append((coords, dout))
-        return None, None, None, None, None   # (no gradient tensor for the anchor: the build node still runs after every lookup)
+        return None, None, None, None, None, None   # (no gradient tensor for the anchor: the build node still runs after every lookup)
 
 
 class CorrBlock:
@@ -147,17 +147,20 @@ class CorrBlock:
             self._pyr = [self._lay.level_view(self._vol, l) for l in range(self.num_levels)]
         return self._pyr
 
-    def __call__(self, coords, channels_last=False, is_flow=False):
+    def __call__(self, coords, channels_last=False, is_flow=False, out=None):
         """coords [B,2,H,W] (x,y).  Returns [B, L*(2r+1)^2, H, W] contiguous (or [B,H,W,C] when
         channels_last=True, the layout our update block consumes directly).  is_flow=True: the tensor holds the flow and
-        the lookup is centred on pixel grid + flow (what the RAFT loop passes: it never forms coords1)."""
+        the lookup is centred on pixel grid + flow (what the RAFT loop passes: it never forms coords1).  out (channels_last
+        only): a preallocated [B,H,W,C] buffer the lookup writes into (update.MotionBatch's slots)."""
         coords = coords.float()
+        if out is not None and not channels_last:
+            raise ValueError("out= is for channels_last lookups")
         if self._tracks_grad and torch.is_grad_enabled():
             if not self._state.stash:
                 self._state.is_flow = is_flow
-            return _LookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow)
-        out = ops.corr_lookup_tiled_fwd(self._vol, self._lay, coords, self.radius, is_flow)
-        return out if channels_last else ops.nhwc_to_nchw(out)
+            return _LookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow, out)
+        res = ops.corr_lookup_tiled_fwd(self._vol, self._lay, coords, self.radius, is_flow, out=out)
+        return res if channels_last else ops.nhwc_to_nchw(res)
 
     @staticmethod
     def corr(fmap1, fmap2):
@@ -194,8 +197,8 @@ class _AltBuildFn(torch.autograd.Function):
 
 class _AltLookupFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, coords, block, channels_last, is_flow):
-        out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow, recs=block._recs)
+    def forward(ctx, anchor, coords, block, channels_last, is_flow, out_buf=None):
+        out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow, recs=block._recs, out=out_buf)
         ctx.block, ctx.cl, ctx.is_flow = block, channels_last, is_flow
         ctx.save_for_backward(coords)
         return out if channels_last else ops.nhwc_to_nchw(out)
@@ -210,7 +213,7 @@ class _AltLookupFn(torch.autograd.Function):
             g = coords_grid(B, H, W, device=coords.device)
             coords = coords - g if blk._stash_is_flow else coords + g
         blk._stash.append((coords, dout))
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class AlternateCorrBlock:
@@ -249,11 +252,13 @@ class AlternateCorrBlock:
                 B = fmap1.shape[0]
                 self._recs = (ops.to_records(self._f1.view(B, -1, C)), [ops.to_records(f.view(B, -1, C)) for f in self._f2])
 
-    def __call__(self, coords, channels_last=False, is_flow=False):
+    def __call__(self, coords, channels_last=False, is_flow=False, out=None):
         coords = coords.float()
+        if out is not None and not channels_last:
+            raise ValueError("out= is for channels_last lookups")
         if self._tracks_grad and torch.is_grad_enabled():
             if not self._stash:
                 self._stash_is_flow = is_flow
-            return _AltLookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow)
-        out = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs)
-        return out if channels_last else ops.nhwc_to_nchw(out)
+            return _AltLookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow, out)
+        res = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs, out=out)
+        return res if channels_last else ops.nhwc_to_nchw(res)

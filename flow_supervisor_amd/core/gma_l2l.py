@@ -42,6 +42,7 @@ class GMAL2L(RAFTGMA):
         grad_mode = torch.is_grad_enabled()
         # training: mask head + upsampler of a phase's iterations as one launch each after the loop (update.HeadBatch)
         hb = self.update_block.head_batch(half, net) if not test_mode else None
+        mb = self.update_block.motion_batch(half, net) if not test_mode else None      # (update.MotionBatch; the student's phase)
         hb2, flows, flows2 = None, [], []
         try:
             for itr in range(iters):
@@ -51,7 +52,8 @@ class GMAL2L(RAFTGMA):
                     torch.set_grad_enabled(False)
                 flow = flow.detach()
                 if test_mode or itr != half:          # (at the switch the reference looks up the crop's volume and drops it)
-                    corr = corr_fn(flow, channels_last=True, is_flow=True)
+                    slot = {"out": mb.corr[mb.n]} if (mb is not None and itr < half and not test_mode) else {}
+                    corr = corr_fn(flow, channels_last=True, is_flow=True, **slot)
                 if not (test_mode or itr < half) and itr == half:
                     if ci1 is not None:
                         crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
@@ -77,7 +79,8 @@ class GMAL2L(RAFTGMA):
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_l2l.py:126-127)
                 cur = None if test_mode else (hb if itr < half else hb2)
                 net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up, head_batch=cur,
-                                                                        grad_samples=sup_grad_samples if itr >= half else None)
+                                                                        grad_samples=sup_grad_samples if itr >= half else None,
+                                                                        motion_batch=mb if (itr < half and not test_mode) else None)
 
                 flow = flow + delta_flow
                 if cur is not None:

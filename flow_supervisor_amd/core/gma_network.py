@@ -71,12 +71,14 @@ class RAFTGMA(nn.Module):
         flow_predictions = []
         flow_up = None
         hb = self.update_block.head_batch(iters, net) if not test_mode else None
+        mb = self.update_block.motion_batch(iters, net) if not test_mode else None        # (update.MotionBatch)
         flows = []
         for itr in range(iters):
             flow = flow.detach()
-            corr = corr_fn(flow, channels_last=True, is_flow=True)
+            corr = corr_fn(flow, channels_last=True, is_flow=True, **({"out": mb.corr[mb.n]} if mb is not None else {}))
             want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_network.py:127-128)
-            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up, head_batch=hb)
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, attention, need_mask=want_up, head_batch=hb,
+                                                                    motion_batch=mb)
             flow = flow + delta_flow
             if hb is not None:
                 flows.append(flow)

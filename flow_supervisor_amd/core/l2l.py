@@ -126,7 +126,8 @@ class L2L(RAFT):
         # training: mask head + upsampler of a phase's iterations as one launch each after the loop (update.HeadBatch), one batch
         # per phase (the two phases run different blocks on different grids)
         hb = self.update_block.head_batch(half, net) if not test_mode else None
-        hb2, flows, flows2 = None, [], []
+        mb = self.update_block.motion_batch(half, net) if not test_mode else None      # (update.MotionBatch; the student's phase)
+        hb2, mb2, flows, flows2 = None, None, [], []
         try:
             for itr in range(iters):
                 if itr == half and not supervisor_grad and not test_mode:
@@ -135,10 +136,13 @@ class L2L(RAFT):
                     torch.set_grad_enabled(False)
                 flow = flow.detach()
                 if test_mode or itr != half:          # (at the switch the reference looks up the crop's volume and drops it, l2l.py:73/102)
-                    corr = corr_fn(flow, channels_last=True, is_flow=True)
+                    cur_mb = None if test_mode else (mb if itr < half else mb2)
+                    slot = {"out": cur_mb.corr[cur_mb.n]} if cur_mb is not None else {}
+                    corr = corr_fn(flow, channels_last=True, is_flow=True, **slot)
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (l2l.py:130-131)
                 if test_mode or itr < half:
-                    net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up, head_batch=hb)
+                    net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up, head_batch=hb,
+                                                                            motion_batch=None if test_mode else mb)
                 else:
                     if itr == half:
                         if ci1 is not None:
@@ -164,7 +168,10 @@ class L2L(RAFT):
                                 inp = to_channels_last(torch.relu(inp))
                         net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                         hb2 = self.grad_update_block.head_batch(iters - half, net)
-                    net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow, head_batch=hb2, grad_samples=sup_grad_samples)
+                        # (the switch iteration's own correlation features are detached: it runs outside the batch)
+                        mb2 = self.grad_update_block.motion_batch(iters - half - 1, net, grad_samples=sup_grad_samples)
+                    net, up_mask, delta_flow = self.grad_update_block.forward_cl(net, inp, corr, flow, head_batch=hb2, grad_samples=sup_grad_samples,
+                                                                                 motion_batch=mb2 if itr > half else None)
 
                 flow = flow + delta_flow
                 if not test_mode and (hb if itr < half else hb2) is not None:

@@ -115,14 +115,16 @@ class RAFT(nn.Module):
         flow_up = None
         # training: the mask head and the upsampler of all iterations run as one launch each after the loop (update.HeadBatch)
         hb = self.update_block.head_batch(iters, net) if not test_mode else None
+        # ... and the motion encoder's backward of all iterations likewise (update.MotionBatch: the lookups write into its slots)
+        mb = self.update_block.motion_batch(iters, net) if not test_mode else None
         flows = []
         for itr in range(iters):
             flow = flow.detach()
-            corr = corr_fn(flow, channels_last=True, is_flow=True)
+            corr = corr_fn(flow, channels_last=True, is_flow=True, **({"out": mb.corr[mb.n]} if mb is not None else {}))
             # test_mode returns only the last upsampled flow (raft.py:141-142): the mask convolution and the upsampler of
             # the other iterations are skipped -- same outputs, the reference computes them and drops them (raft.py:134-139)
             want_up = not test_mode or itr == iters - 1
-            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up, head_batch=hb)
+            net, up_mask, delta_flow = self.update_block.forward_cl(net, inp, corr, flow, need_mask=want_up, head_batch=hb, motion_batch=mb)
             flow = flow + delta_flow
             if hb is not None:
                 flows.append(flow)

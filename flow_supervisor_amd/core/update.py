@@ -336,7 +336,7 @@ class _Engine:
         cst.dsum = {}
         return dinp
 
-    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True, head_out=None):
+    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True, head_out=None, mslot=None):
         """net/corr: channels-last [B,H,W,C]; ctxb: context() of the context features; flow: [B,2,H,W] (any pixel stride).
         Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
         a dict of the intermediates backward needs.  need_mask=False (inference, every iteration but the last: the
@@ -359,11 +359,21 @@ class _Engine:
                              wpk_split=P[k][5], **kw)
 
         hid = self.hid
-        cor1 = buf(self.c1) if self.c2 else None
-        corflo = buf(self.cf_c)
-        cols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)      # (im2col7 writes the two pad columns itself)
-        flo1 = buf(self.f1)
-        motion = buf(self.x_c)           # GMA: channels [mot_c, 2 mot_c) hold motion_global
+        if mslot is not None:
+            # slots of a MotionBatch: the motion encoder's activations of all iterations back to back, so that its backward can
+            # run once per step over T x B x H x W pixels
+            mb, t = mslot
+            if corr.data_ptr() != mb.corr[t].data_ptr():
+                mb.corr[t].copy_(corr)
+            corr = mb.corr[t]
+            cor1 = mb.cor1[t] if self.c2 else None
+            corflo, cols, flo1, motion = mb.corflo[t], mb.cols[t], mb.flo1[t], mb.motion[t]
+        else:
+            cor1 = buf(self.c1) if self.c2 else None
+            corflo = buf(self.cf_c)
+            cols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)      # (im2col7 writes the two pad columns itself)
+            flo1 = buf(self.f1)
+            motion = buf(self.x_c)           # GMA: channels [mot_c, 2 mot_c) hold motion_global
         if self.c2:
             conv("c1", [V(corr, self.corr_c)], [Dst.nhwc(cor1)], relu=True)
             conv("c2", [V(cor1, self.c1)], [Dst.nhwc(corflo)], relu=True)
@@ -427,7 +437,7 @@ class _Engine:
         return h, mask, delta, saved
 
     # ---- backward -----------------------------------------------------------------
-    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None, cst=None, need_dflow=True):
+    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None, cst=None, need_dflow=True, motion_only=None):
         """Accumulates parameter gradients into the packed arena of `st` and the gate gradients into `cst.dsum`
         (the context part's backward runs once per step, context_backward); returns (dnet, dcorr, dflow)."""
         B, H, W = S["B"], S["H"], S["W"]
@@ -440,7 +450,7 @@ class _Engine:
         # and the context part's running sums are full-size with zeros behind sample k.
         Bf = B
         gs = S.get("gs")
-        if gs is not None and 0 < gs < Bf and (not self.gma or ast is None) and not need_dflow:
+        if gs is not None and 0 < gs < Bf and (not self.gma or ast is None) and not need_dflow and motion_only is None:
             B = gs
             dnet_out = dnet_out[:B] if dnet_out is not None else None
             ddelta = ddelta[:B] if ddelta is not None else None
@@ -491,107 +501,121 @@ class _Engine:
             n_in = sum(l.src_c)
             ops.conv_forward([dy], P[k][1], None, B, H, W, l.kh, l.kw, n_in, dsts, alpha=alpha, wpk_split=P[k][6])
 
-        # ---- heads
-        hb = S.get("hb")
-        head = S["head"]
-        if hb is not None:
-            # the mask half of dhead was written by the batched backward of the mask head (HeadBatch / _MaskUpFn), which autograd
-            # runs before this node: this iteration's delta gradient comes out of it
-            dhead = hb[0].dhead_slot(hb[1])[:B]
-        else:
-            dhead = buf(self.head_c * (2 if self.has_mask else 1))
-        if self.has_mask and hb is None:
-            if dmask is not None:
-                # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask: the data gradient applies the factor in its
-                # epilogue, the weight / bias gradients once per step when the arena is unpacked
-                g = dmask.contiguous()
-                wgrad("m2", V(g, 576), [V(head, self.head_c, self.head_c)])
-                dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))], alpha=0.25)
+        dh = dh_full = None
+        mbs = S.get("mb")             # (MotionBatch, slot): the motion encoder's backward of all iterations runs once, after slot 0's
+        if motion_only is not None:
+            dmotion, motion = motion_only, S["motion"]
+        if motion_only is None:
+            # ---- heads
+            hb = S.get("hb")
+            head = S["head"]
+            if hb is not None:
+                # the mask half of dhead was written by the batched backward of the mask head (HeadBatch / _MaskUpFn), which autograd
+                # runs before this node: this iteration's delta gradient comes out of it
+                dhead = hb[0].dhead_slot(hb[1])[:B]
             else:
-                dhead[..., self.head_c:].zero_()
-        dd = ops.zeros(B, H, W, 4, device=dev)
-        if ddelta is not None:
-            ops.flow_to_nhwc(ddelta, dd, 0)
-            wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
-            dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0).masked(V(head, self.head_c, 0))])
-        else:
-            dhead[..., : self.head_c].zero_()
-        # (no separate ReLU-backward pass: the two data-gradient epilogues above wrote dhead already masked by head > 0)
-        hlast = S["hlast"]
-        wgrad("hd", V(dhead), [V(hlast, hid)])
-        dh = buf(hid)
-        if dnet_out is not None:
-            dh.copy_(dnet_out)
-            dgrad("hd", V(dhead), [Dst.nhwc(dh, 0, 0, True)])
-        else:
-            dgrad("hd", V(dhead), [Dst.nhwc(dh)])
-
-        # ---- GRU passes, last to first
-        motion = S["motion"]
-        # every GRU data gradient adds its motion part; the first one (the q convolution of the last pass covers all x_c
-        # channels) overwrites instead, so the buffer needs no zero fill -- only its padding channels, if any, do
-        dmotion = buf(self.x_c)
-        dm_first = [True]
-
-        def dm_acc():
-            first, dm_first[0] = dm_first[0], False
-            return not first
-
-        def ctx_sum(k, like):
-            """Running sum of the gate gradients over the iterations of the step (filled by the gru_bwd kernels)."""
-            if cst is None:
-                return None
-            if k not in cst.dsum:
-                cst.dsum[k] = ops.zeros((Bf,) + tuple(like.shape[1:]), device=like.device)
-            return cst.dsum[k]
-
-        first_pass = self.passes[0][0]
-        for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
-            dzr = buf(2 * hid)
-            dq = buf(hid)
-            if B != Bf and sfx == first_pass:          # the buffer that goes back to autograd as dnet: full size, zeros behind sample B
-                dh_full = ops.zeros(Bf, H, W, _pad4(hid), device=dev)
-                dhp = dh_full[:B]
+                dhead = buf(self.head_c * (2 if self.has_mask else 1))
+            if self.has_mask and hb is None:
+                if dmask is not None:
+                    # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask: the data gradient applies the factor in its
+                    # epilogue, the weight / bias gradients once per step when the arena is unpacked
+                    g = dmask.contiguous()
+                    wgrad("m2", V(g, 576), [V(head, self.head_c, self.head_c)])
+                    dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))], alpha=0.25)
+                else:
+                    dhead[..., self.head_c:].zero_()
+            dd = ops.zeros(B, H, W, 4, device=dev)
+            if ddelta is not None:
+                ops.flow_to_nhwc(ddelta, dd, 0)
+                wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
+                dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0).masked(V(head, self.head_c, 0))])
             else:
-                dhp = buf(hid)
-            zsum, qsum = ctx_sum("zi" + sfx, dzr), ctx_sum("qi" + sfx, dq)
-            ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid, zsum, qsum)
-            xs = [V(motion, self.x_c)]
-            wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
-            drh = buf(hid)
-            dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dmotion, 0, hid, dm_acc())])
-            ops.gru_bwd2(drh, r, h, dzr, dhp, hid, zsum)
-            wgrad("zr" + sfx, V(dzr, 2 * hid), [V(h, hid)] + xs)
-            dm = Dst.nhwc(dmotion, 0, hid, True)
-            if sfx == first_pass and not self.gma:
-                # last accumulation into dmotion: its epilogue applies the motion encoder's ReLU backward to the conv
-                # channels [0, cv) (the two flow channels behind them pass through)
-                dm = dm.masked(V(motion, self.cv))
-            dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), dm])
-            dh = dhp
-
-        # ---- Aggregate (GMA): motion_global = motion + gamma * (attn @ to_v(motion))
-        if self.gma:
-            N, mc = H * W, self.mot_c
-            attn, v, agg = S["attn"], S["v"], S["agg"]
-            dagg, dv = buf(mc), buf(mc)
-            ops.gma_mix_bwd(V(dmotion, mc, mc), V(agg), P["aggregator.gamma"], V(dmotion, mc, 0), V(dagg),
-                            dB["aggregator.gamma"])
-            attn_r = S.get("attn_r")
-            if attn_r is not None:   # dv = attn^T dagg: both operands k-major records -> transposed-read record GEMM
-                Nr = attn_r.shape[-1]
-                dr = ops.to_records(dagg.view(B, N, mc))
-                ops.gemm_rec_tn_raw(attn_r.data_ptr(), Nr, N * Nr, dr.data_ptr(), dr.shape[-1], N * dr.shape[-1], dv.data_ptr(), mc,
-                                    N * mc, B, N, mc, N, ksplit=2)
-            elif N % 4 == 0:     # (exact-fp32 test mode) both operands k-major -> transposed-read split GEMM
-                ops.gemm_tn_raw(attn.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N)
+                dhead[..., : self.head_c].zero_()
+            # (no separate ReLU-backward pass: the two data-gradient epilogues above wrote dhead already masked by head > 0)
+            hlast = S["hlast"]
+            wgrad("hd", V(dhead), [V(hlast, hid)])
+            dh = buf(hid)
+            if dnet_out is not None:
+                dh.copy_(dnet_out)
+                dgrad("hd", V(dhead), [Dst.nhwc(dh, 0, 0, True)])
             else:
-                at = attn.view(B, N, N).transpose(1, 2).contiguous()
-                ops.gemm_raw(at.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N, False)
-            if ast is not None:  # dattn = sum_t dagg_t v_t^T is formed once per step from the stashed factors
-                ast.stash.append((dagg.view(B, N, mc), v.view(B, N, mc)))
-            wgrad("av", V(dv, mc), [V(motion, mc, 0)])
-            dgrad("av", V(dv, mc), [Dst.nhwc(dmotion, 0, 0, True)])
+                dgrad("hd", V(dhead), [Dst.nhwc(dh)])
+
+            # ---- GRU passes, last to first
+            motion = S["motion"]
+            # every GRU data gradient adds its motion part; the first one (the q convolution of the last pass covers all x_c
+            # channels) overwrites instead, so the buffer needs no zero fill -- only its padding channels, if any, do
+            dmotion = mbs[0].dmotion[mbs[1]][:B] if mbs is not None else buf(self.x_c)
+            dm_first = [True]
+
+            def dm_acc():
+                first, dm_first[0] = dm_first[0], False
+                return not first
+
+            def ctx_sum(k, like):
+                """Running sum of the gate gradients over the iterations of the step (filled by the gru_bwd kernels)."""
+                if cst is None:
+                    return None
+                if k not in cst.dsum:
+                    cst.dsum[k] = ops.zeros((Bf,) + tuple(like.shape[1:]), device=like.device)
+                return cst.dsum[k]
+
+            first_pass = self.passes[0][0]
+            for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
+                dzr = buf(2 * hid)
+                dq = buf(hid)
+                if B != Bf and sfx == first_pass:          # the buffer that goes back to autograd as dnet: full size, zeros behind sample B
+                    dh_full = ops.zeros(Bf, H, W, _pad4(hid), device=dev)
+                    dhp = dh_full[:B]
+                else:
+                    dhp = buf(hid)
+                zsum, qsum = ctx_sum("zi" + sfx, dzr), ctx_sum("qi" + sfx, dq)
+                ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid, zsum, qsum)
+                xs = [V(motion, self.x_c)]
+                wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
+                drh = buf(hid)
+                dgrad("q" + sfx, V(dq, hid), [Dst.nhwc(drh, 0, 0), Dst.nhwc(dmotion, 0, hid, dm_acc())])
+                ops.gru_bwd2(drh, r, h, dzr, dhp, hid, zsum)
+                wgrad("zr" + sfx, V(dzr, 2 * hid), [V(h, hid)] + xs)
+                dm = Dst.nhwc(dmotion, 0, hid, True)
+                if sfx == first_pass and not self.gma:
+                    # last accumulation into dmotion: its epilogue applies the motion encoder's ReLU backward to the conv
+                    # channels [0, cv) (the two flow channels behind them pass through)
+                    dm = dm.masked(V(motion, self.cv))
+                dgrad("zr" + sfx, V(dzr, 2 * hid), [Dst.nhwc(dhp, 0, 0, True), dm])
+                dh = dhp
+
+            # ---- Aggregate (GMA): motion_global = motion + gamma * (attn @ to_v(motion))
+            if self.gma:
+                N, mc = H * W, self.mot_c
+                attn, v, agg = S["attn"], S["v"], S["agg"]
+                dagg, dv = buf(mc), buf(mc)
+                ops.gma_mix_bwd(V(dmotion, mc, mc), V(agg), P["aggregator.gamma"], V(dmotion, mc, 0), V(dagg),
+                                dB["aggregator.gamma"])
+                attn_r = S.get("attn_r")
+                if attn_r is not None:   # dv = attn^T dagg: both operands k-major records -> transposed-read record GEMM
+                    Nr = attn_r.shape[-1]
+                    dr = ops.to_records(dagg.view(B, N, mc))
+                    ops.gemm_rec_tn_raw(attn_r.data_ptr(), Nr, N * Nr, dr.data_ptr(), dr.shape[-1], N * dr.shape[-1], dv.data_ptr(), mc,
+                                        N * mc, B, N, mc, N, ksplit=2)
+                elif N % 4 == 0:     # (exact-fp32 test mode) both operands k-major -> transposed-read split GEMM
+                    ops.gemm_tn_raw(attn.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N)
+                else:
+                    at = attn.view(B, N, N).transpose(1, 2).contiguous()
+                    ops.gemm_raw(at.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N, False)
+                if ast is not None:  # dattn = sum_t dagg_t v_t^T is formed once per step from the stashed factors
+                    ast.stash.append((dagg.view(B, N, mc), v.view(B, N, mc)))
+                wgrad("av", V(dv, mc), [V(motion, mc, 0)])
+                dgrad("av", V(dv, mc), [Dst.nhwc(dmotion, 0, 0, True)])
+
+        if mbs is not None:
+            # deferred: this iteration's dmotion sits in its slot; the motion encoder's backward (four data gradients, five weight
+            # gradients) runs for all slots at once when slot 0 -- the first iteration, the last to run backward -- has handed in
+            # its own.  The correlation gradient returned here is the slot's view of the batch's output, filled by then.
+            mb, t = mbs
+            if t == 0:
+                mb.run(self, P, st)
+            return (dh_full if B != Bf else dh), mb.dcorr[t], None
 
         # ---- motion encoder
         # (the loops detach the flow that enters an iteration, raft.py:123: its gradient -- the pass-through channels of the
@@ -619,7 +643,10 @@ class _Engine:
         corr = S["corr"]
         dcorr = dcorr_full = None
         if need_input_grads:
-            dcorr_full = ops.zeros(Bf, H, W, _pad4(self.corr_c), device=dev) if B != Bf else buf(self.corr_c)
+            if motion_only is not None:
+                dcorr_full = S["dcorr_out"]
+            else:
+                dcorr_full = ops.zeros(Bf, H, W, _pad4(self.corr_c), device=dev) if B != Bf else buf(self.corr_c)
             dcorr = dcorr_full[:B]
         if self.c2:
             cor1 = S["cor1"]
@@ -736,11 +763,19 @@ class _UpdateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, st, params, anchor, net, cst, canchor, corr, flow, ast=None, attn=None, aanchor=None, attn_t=None, hb=None,
-                grad_samples=None):
+                grad_samples=None, mb=None):
         need = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the reliable signal)
         slot = hb.next_slot() if hb is not None else None
+        if mb is not None and (not need or ctx.needs_input_grad[8]):
+            # (the caller's lookup already wrote into the batch's next slot: dropping the batch here would leave the saved
+            #  correlation features in a slot the next iteration overwrites)
+            raise RuntimeError("motion_batch needs a recorded call whose flow input carries no gradient")
+        mt = mb.next_slot() if mb is not None else None
         h, mask, delta, saved = engine.forward(net, cst.bufs, corr, flow, params, save=need, attn=attn, attn_t=attn_t,
-                                               head_out=None if slot is None else hb.head[slot])
+                                               head_out=None if slot is None else hb.head[slot],
+                                               mslot=None if mt is None else (mb, mt))
+        if saved is not None and mt is not None:
+            saved["mb"] = (mb, mt)
         if saved is not None and slot is not None:
             saved["hb"] = (hb, slot)
         if saved is not None and grad_samples is not None:
@@ -767,10 +802,11 @@ class _UpdateFn(torch.autograd.Function):
                                           cst=cst if cst.anchor is not None else None, need_dflow=ctx.needs_input_grad[8])
         # the three anchors get no gradient tensor: autograd still runs their producers (_ParamFn, _CtxFn, _AttnFn) once
         # every consumer is done -- that ordering is all they are for -- and skips 3 x 12 one-element accumulation kernels
-        return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None, None, None)
+        return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None, None, None, None)
 
 
 HEAD_BATCH = os.environ.get("FSRAFT_HEAD_BATCH", "1") != "0"
+MOTION_BATCH = os.environ.get("FSRAFT_MOTION_BATCH", "1") != "0"
 
 
 class HeadBatch:
@@ -809,6 +845,49 @@ class HeadBatch:
         if len(flows) != self.n:
             raise RuntimeError(f"HeadBatch: {self.n} update-block calls but {len(flows)} flows")
         return list(_MaskUpFn.apply(self, self.anchor, *flows))
+
+
+class MotionBatch:
+    """The motion encoder's backward of ALL iterations of a step as one launch per layer.  In backward only the GRU chain is
+    sequential: the gradient of an iteration's motion features leaves it (towards the correlation lookup, whose own backward
+    is deferred to the volume's build node anyway, and into weight gradients, which are deferred to the end of the step), so
+    nothing waits for it.  The forward writes each iteration's motion-encoder activations (and the lookup writes its output)
+    into slots of [T,B,H,W,C] buffers; an iteration's backward parks its dmotion in a slot and returns its slot of `dcorr`;
+    when slot 0 -- the first iteration, the last to run backward -- has parked its own, `run` executes the four data
+    gradients and queues the five weight gradients over T x B x H x W pixels.  4 x T launches become 4, on grids that fill the
+    chip at one pair per GPU (per layer -10..-35 % at four pairs, -50..-75 % at one or two: scripts/batch_gain.sh)."""
+
+    def __init__(self, eng, T, B, H, W, device, zero=False):
+        def e(c):
+            return torch.empty(T, B, H, W, _pad4(c), device=device, dtype=torch.float32)
+        self.T, self.B, self.H, self.W, self.n = T, B, H, W, 0
+        self.corr = e(eng.corr_c)
+        self.cor1 = e(eng.c1) if eng.c2 else None
+        self.corflo, self.cols, self.flo1, self.motion = e(eng.cf_c), e(98), e(eng.f1), e(eng.x_c)
+        # zero: the iterations run their backward on the first k samples only (grad_samples) and park dmotion for those; the
+        # batch then multiplies zeros for the others
+        self.dmotion = torch.zeros(T, B, H, W, _pad4(eng.x_c), device=device, dtype=torch.float32) if zero else e(eng.x_c)
+        self.dcorr = e(eng.corr_c)
+
+    @staticmethod
+    def fits(eng, T, B, H, W):
+        cs = (eng.corr_c, eng.c1, eng.cf_c, eng.f1, eng.x_c)
+        return all(c % 4 == 0 for c in cs) and T * B * H * W * max(cs) * 4 < 0x7fffffff      # no pad channels; 32-bit byte offsets
+
+    def next_slot(self):
+        if self.n >= self.T:
+            raise RuntimeError("MotionBatch: more update-block calls than slots")
+        self.n += 1
+        return self.n - 1
+
+    def run(self, eng, P, st):
+        n, B, H, W = self.n, self.B, self.H, self.W
+
+        def v(t):
+            return None if t is None else t[:n].view(n * B, H, W, t.shape[-1])
+        S = dict(B=n * B, H=H, W=W, corr=v(self.corr), cor1=v(self.cor1), corflo=v(self.corflo), cols=v(self.cols), flo1=v(self.flo1),
+                 motion=v(self.motion), dcorr_out=v(self.dcorr))
+        eng.backward(S, P, st, None, None, None, need_input_grads=True, need_dflow=False, motion_only=v(self.dmotion))
 
 
 def _one_tensor(ts):
@@ -972,7 +1051,7 @@ class _UpdateBlockBase(nn.Module):
             self.__dict__["_cst"] = cst
         return cst
 
-    def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True, head_batch=None, grad_samples=None):
+    def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True, head_batch=None, grad_samples=None, motion_batch=None):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
         Returns (net', mask_cl or None, delta).  need_mask=False: the caller will not upsample this iteration's flow
@@ -998,8 +1077,22 @@ class _UpdateBlockBase(nn.Module):
         cst = self._ctx_state(eng, st, params, anchor, inp, track)
         attn = attention.detach() if attention is not None else None
         h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, cst, cst.anchor, corr, flow, ast, attn, aanchor,
-                                         self._attn_transposed(attention), head_batch, grad_samples)
+                                         self._attn_transposed(attention), head_batch, grad_samples, motion_batch)
         return h, (mask if (eng.has_mask and head_batch is None) else None), delta
+
+    def motion_batch(self, iters, net, grad_samples=None):
+        """A MotionBatch for `iters` calls of forward_cl(..., motion_batch=...) on states shaped like `net`, or None where it does
+        not apply (see head_batch).  The caller has the lookup write into `mb.corr[mb.n]` (CorrBlock(..., out=)).
+        grad_samples: what the calls will pass as grad_samples (the batch then starts from zeroed slots)."""
+        eng = self._engine()
+        if not (MOTION_BATCH and torch.is_grad_enabled() and net.is_cuda):
+            return None
+        params = tuple(eng.params())
+        st, anchor = eng.param_state(params)
+        B, H, W, _ = net.shape
+        if anchor is None or st.pending is None or not MotionBatch.fits(eng, iters, B, H, W):
+            return None
+        return MotionBatch(eng, iters, B, H, W, net.device, zero=grad_samples is not None)
 
     def head_batch(self, iters, net):
         """A HeadBatch for `iters` calls of forward_cl(..., head_batch=...) on states shaped like `net` ([B,H,W,hid]), or None

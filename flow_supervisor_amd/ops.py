@@ -232,13 +232,17 @@ def corr_build_tiled(fmap1, fmap2, num_levels=4, recs=None):
     return vol, lay
 
 
-def corr_lookup_tiled_fwd(vol, lay, coords, radius, is_flow=False):
-    """-> [B,H,W,L*(2r+1)^2] channels-last.  is_flow: `coords` holds the flow, the query position is pixel grid + flow."""
+def corr_lookup_tiled_fwd(vol, lay, coords, radius, is_flow=False, out=None):
+    """-> [B,H,W,L*(2r+1)^2] channels-last (into `out` if given).  is_flow: `coords` holds the flow, the query position is pixel
+    grid + flow."""
     L.require_cuda_f32(vol, coords)
     B, _, H, W = coords.shape
     bs, cs, ps = _planar2_strides(coords)
     ch = lay.nlev * (2 * radius + 1) ** 2
-    out = torch.empty(B, H, W, ch, device=coords.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, H, W, ch, device=coords.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, H, W, ch) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError(f"lookup out= must be a contiguous fp32 [{B},{H},{W},{ch}] tensor")
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_corr_lookup_tiled_fwd(L.ptr(vol), lay.nlev, L.ptr(coords), bs, cs, ps, L.ptr(out), B, H, W, radius,
@@ -375,7 +379,7 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
 ALT_MFMA = True      # AlternateCorrBlock lookups on the matrix pipe (fsraft_altcorr_mfma_fwd) when the records are supplied
 
 
-def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None):
+def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None, out=None):
     """f1_cl [B,H,W,C], f2_levels[l] [B,H>>l,W>>l,C] channels-last -> [B,H,W,L*(2r+1)^2] (scaled by 1/sqrt(C)).
     recs = (f1r, [f2r per level]): the same maps as records -> the tile GEMM kernel (bf16x3); without them, or with the
     exact-fp32 arithmetic selected, the fp32 dot-product kernels."""
@@ -383,7 +387,11 @@ def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None
     B, H, W, C = f1_cl.shape
     bs, cs, ps = _planar2_strides(coords)
     nl = len(f2_levels)
-    out = torch.empty(B, H, W, nl * (2 * radius + 1) ** 2, device=f1_cl.device, dtype=torch.float32)
+    ch = nl * (2 * radius + 1) ** 2
+    if out is None:
+        out = torch.empty(B, H, W, ch, device=f1_cl.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, H, W, ch) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError(f"lookup out= must be a contiguous fp32 [{B},{H},{W},{ch}] tensor")
     pp, keep = L.ptr_array(f2_levels)
     t = TIMER
     e0 = t.begin() if t else None

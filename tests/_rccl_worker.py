@@ -7,6 +7,7 @@ The sum over one rank is the identity, so every result must equal the no-collect
 usage: _rccl_worker.py port out.json [H W iters batch]"""
 import json
 import os
+import time
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,8 +59,10 @@ def main():
                 losses.append(float(step(im1, im2)))            # eager warm-up step on the capture stream
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            # (as bench.py: the watchdog thread's event queries must not meet a GLOBAL-mode capture)
+            time.sleep(0.5)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 loss = step(im1, im2)
             for _ in range(nsteps - 1):
                 g.replay()
