@@ -336,7 +336,7 @@ class _Engine:
         cst.dsum = {}
         return dinp
 
-    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True, head_out=None, mslot=None):
+    def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True, head_out=None, mslot=None, hlast_out=None):
         """net/corr: channels-last [B,H,W,C]; ctxb: context() of the context features; flow: [B,2,H,W] (any pixel stride).
         Returns (net_out [B,H,W,hid], mask [B,H,W,576] or None, delta [B,2,H,W]) and, if `save`,
         a dict of the intermediates backward needs.  need_mask=False (inference, every iteration but the last: the
@@ -409,8 +409,10 @@ class _Engine:
 
         h = net
         gates = []
-        for sfx, _, _ in self.passes:
-            z, r, rh, q, hn = buf(hid), buf(hid), buf(hid), buf(hid), buf(hid)
+        for pi, (sfx, _, _) in enumerate(self.passes):
+            z, r, rh, q = buf(hid), buf(hid), buf(hid), buf(hid)
+            # (the block's output state: into its HeadBatch slot when there is one -- the batched head backward reads all of them)
+            hn = hlast_out if (hlast_out is not None and pi == len(self.passes) - 1) else buf(hid)
             xs = [V(motion, self.x_c)]
             conv("zr" + sfx, [V(h, hid)] + xs, [Dst.nhwc(z)], epi=2, h=h, aux1=rh, aux2=r, hid=hid, pre=ctxb["zi" + sfx])
             conv("q" + sfx, [V(rh, hid)] + xs, [Dst.nhwc(hn)], epi=3, h=h, z=z, aux1=q, pre=ctxb["qi" + sfx])
@@ -437,7 +439,7 @@ class _Engine:
         return h, mask, delta, saved
 
     # ---- backward -----------------------------------------------------------------
-    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None, cst=None, need_dflow=True, motion_only=None):
+    def backward(self, S, P, st, dnet_out, dmask, ddelta, need_input_grads=True, ast=None, cst=None, need_dflow=True, motion_only=None, heads_only=False):
         """Accumulates parameter gradients into the packed arena of `st` and the gate gradients into `cst.dsum`
         (the context part's backward runs once per step, context_backward); returns (dnet, dcorr, dflow)."""
         B, H, W = S["B"], S["H"], S["W"]
@@ -450,7 +452,7 @@ class _Engine:
         # and the context part's running sums are full-size with zeros behind sample k.
         Bf = B
         gs = S.get("gs")
-        if gs is not None and 0 < gs < Bf and (not self.gma or ast is None) and not need_dflow and motion_only is None:
+        if gs is not None and 0 < gs < Bf and (not self.gma or ast is None) and not need_dflow and motion_only is None and not heads_only:
             B = gs
             dnet_out = dnet_out[:B] if dnet_out is not None else None
             ddelta = ddelta[:B] if ddelta is not None else None
@@ -508,38 +510,52 @@ class _Engine:
         if motion_only is None:
             # ---- heads
             hb = S.get("hb")
-            head = S["head"]
-            if hb is not None:
-                # the mask half of dhead was written by the batched backward of the mask head (HeadBatch / _MaskUpFn), which autograd
-                # runs before this node: this iteration's delta gradient comes out of it
-                dhead = hb[0].dhead_slot(hb[1])[:B]
+            if hb is not None and hb[0].heads_done:
+                # the whole head backward of this iteration (flow head, mask head, the 3x3 convolution under both) already ran, for
+                # all iterations at once, inside the batched backward of the mask head + upsampler (_MaskUpFn): it depends on the
+                # loss alone, not on the recurrence.  What is left is to add the hidden-state gradient arriving from iteration t + 1.
+                dh = hb[0].dh_heads[hb[1]][:B]
+                if ddelta is not None and ddelta.data_ptr() != hb[0].dflow[hb[1]].data_ptr():
+                    raise RuntimeError("HeadBatch: an iteration's delta_flow received a gradient from somewhere other than its prediction")
+                if dnet_out is not None:
+                    dh.add_(dnet_out)
             else:
-                dhead = buf(self.head_c * (2 if self.has_mask else 1))
-            if self.has_mask and hb is None:
-                if dmask is not None:
-                    # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask: the data gradient applies the factor in its
-                    # epilogue, the weight / bias gradients once per step when the arena is unpacked
-                    g = dmask.contiguous()
-                    wgrad("m2", V(g, 576), [V(head, self.head_c, self.head_c)])
-                    dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))], alpha=0.25)
+                head = S["head"]
+                if heads_only:
+                    dhead = S["dhead"]
+                elif hb is not None:
+                    # the mask half of dhead was written by the batched backward of the mask head (HeadBatch / _MaskUpFn), which
+                    # autograd runs before this node: this iteration's delta gradient comes out of it
+                    dhead = hb[0].dhead_slot(hb[1])[:B]
                 else:
-                    dhead[..., self.head_c:].zero_()
-            dd = ops.zeros(B, H, W, 4, device=dev)
-            if ddelta is not None:
-                ops.flow_to_nhwc(ddelta, dd, 0)
-                wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
-                dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0).masked(V(head, self.head_c, 0))])
-            else:
-                dhead[..., : self.head_c].zero_()
-            # (no separate ReLU-backward pass: the two data-gradient epilogues above wrote dhead already masked by head > 0)
-            hlast = S["hlast"]
-            wgrad("hd", V(dhead), [V(hlast, hid)])
-            dh = buf(hid)
-            if dnet_out is not None:
-                dh.copy_(dnet_out)
-                dgrad("hd", V(dhead), [Dst.nhwc(dh, 0, 0, True)])
-            else:
-                dgrad("hd", V(dhead), [Dst.nhwc(dh)])
+                    dhead = buf(self.head_c * (2 if self.has_mask else 1))
+                if self.has_mask and hb is None and not heads_only:
+                    if dmask is not None:
+                        # y = 0.25*(Wx+b)  =>  everything upstream sees 0.25*dmask: the data gradient applies the factor in its
+                        # epilogue, the weight / bias gradients once per step when the arena is unpacked
+                        g = dmask.contiguous()
+                        wgrad("m2", V(g, 576), [V(head, self.head_c, self.head_c)])
+                        dgrad("m2", V(g, 576), [Dst.nhwc(dhead, self.head_c).masked(V(head, self.head_c, self.head_c))], alpha=0.25)
+                    else:
+                        dhead[..., self.head_c:].zero_()
+                dd = ops.zeros(B, H, W, 4, device=dev)
+                if ddelta is not None:
+                    ops.flow_to_nhwc(ddelta, dd, 0)
+                    wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
+                    dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0).masked(V(head, self.head_c, 0))])
+                else:
+                    dhead[..., : self.head_c].zero_()
+                # (no separate ReLU-backward pass: the two data-gradient epilogues above wrote dhead already masked by head > 0)
+                hlast = S["hlast"]
+                wgrad("hd", V(dhead), [V(hlast, hid)])
+                dh = S["dh_out"] if heads_only else buf(hid)
+                if dnet_out is not None:
+                    dh.copy_(dnet_out)
+                    dgrad("hd", V(dhead), [Dst.nhwc(dh, 0, 0, True)])
+                else:
+                    dgrad("hd", V(dhead), [Dst.nhwc(dh)])
+                if heads_only:
+                    return None, None, None
 
             # ---- GRU passes, last to first
             motion = S["motion"]
@@ -773,7 +789,8 @@ class _UpdateFn(torch.autograd.Function):
         mt = mb.next_slot() if mb is not None else None
         h, mask, delta, saved = engine.forward(net, cst.bufs, corr, flow, params, save=need, attn=attn, attn_t=attn_t,
                                                head_out=None if slot is None else hb.head[slot],
-                                               mslot=None if mt is None else (mb, mt))
+                                               mslot=None if mt is None else (mb, mt),
+                                               hlast_out=None if (slot is None or hb.hlast is None) else hb.hlast[slot])
         if saved is not None and mt is not None:
             saved["mb"] = (mb, mt)
         if saved is not None and slot is not None:
@@ -807,6 +824,7 @@ class _UpdateFn(torch.autograd.Function):
 
 HEAD_BATCH = os.environ.get("FSRAFT_HEAD_BATCH", "1") != "0"
 MOTION_BATCH = os.environ.get("FSRAFT_MOTION_BATCH", "1") != "0"
+HEADS_BWD_BATCH = os.environ.get("FSRAFT_HEADS_BWD_BATCH", "1") != "0"
 
 
 class HeadBatch:
@@ -822,7 +840,10 @@ class HeadBatch:
         self.eng, self.params, self.st, self.anchor = eng, params, st, anchor
         self.T, self.B, self.H, self.W = T, B, H, W
         self.head = torch.empty(T, B, H, W, 2 * eng.head_c, device=device, dtype=torch.float32)
+        self.hlast = torch.empty(T, B, H, W, _pad4(eng.hid), device=device, dtype=torch.float32) if _pad4(eng.hid) == eng.hid else None
         self.dhead = None
+        self.dh_heads = self.dflow = None
+        self.heads_done = False
         self.n = 0
 
     @staticmethod
@@ -961,7 +982,18 @@ class _MaskUpFn(torch.autograd.Function):
                 ops.conv_wgrad(gv, [xv], dW["m2"], T * B, H, W, 1, 1, dbias=dB["m2"])
         ops.conv_forward([gv], P["m2"][1], None, T * B, H, W, 1, 1, hc, [Dst.nhwc(dhead, hc).masked(xv)], alpha=0.25,
                          wpk_split=P["m2"][6])
-        return (None, None) + tuple(dflow[t * B:(t + 1) * B] for t in range(T))
+        dfl = dflow.view(T, B, 2, H, W)
+        if HEADS_BWD_BATCH and hb.hlast is not None and st is not None and st.key is not None:
+            # the rest of the heads' backward depends on nothing but what this node just produced: the flow head (from dflow), then
+            # the 3x3 convolution under both heads -- for all iterations at once; each iteration's backward starts from its slot
+            # of dh_heads
+            hb.dflow = dfl
+            hb.dh_heads = torch.empty_like(hb.hlast)
+            Sb = dict(B=T * B, H=H, W=W, corr=head, head=head, hlast=hb.hlast[:T].view(T * B, H, W, hb.hlast.shape[-1]), dhead=dhead,
+                      dh_out=hb.dh_heads[:T].view(T * B, H, W, hb.hlast.shape[-1]))
+            eng.backward(Sb, P, st, None, None, dflow, need_input_grads=False, need_dflow=False, heads_only=True)
+            hb.heads_done = True
+        return (None, None) + tuple(dfl[t] for t in range(T))
 
 
 class _ToCL(torch.autograd.Function):
