@@ -147,8 +147,8 @@ SIGNATURES = {
                                 c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, _S],
     "fsraft_gemm_rec_tn_list": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                 c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, _S],
-    "fsraft_corr_bwd_ktiles": [_PP, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                               c_void_p, c_void_p, c_int, c_void_p, _S],
+    "fsraft_corr_bwd_ktiles": [_PP, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                               c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, _S],
 }
 
 

@@ -337,7 +337,7 @@ constexpr int DVB = 24;
 template <int R, bool REC>
 __global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int grid_w, int64_t q0,
                                                             unsigned nq, unsigned* __restrict__ qlist, int policy,
-                                                            const unsigned* __restrict__ wmask) {
+                                                            const unsigned* __restrict__ wmask, int wm_hw) {
   using S = TL<R>;
   __shared__ float box_s[4][DVB * DVB];
   __shared__ float g_s[4][DV_MAXN * S::N2];
@@ -400,7 +400,9 @@ __global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayou
   char* rowb = reinterpret_cast<char*>(dvol + (int64_t)qrel * L.P);
   // wmask (nullable, records only): bit r of this query's 32-query block = record r of the row will be read by a list GEMM
   // (fsraft_corr_bwd_ktiles); the others are not written at all -- most of a row is zero records outside every list
-  const unsigned* wm = wmask ? wmask + ((int64_t)b * ((HW + 31) >> 5) + (pix >> 5)) * (((L.P >> 5) + 31) >> 5) : nullptr;
+  // (rows of wmask: per list set -- image, or chunk of wm_hw queries starting at q0 -- and 32-query block)
+  const unsigned* wm = wmask ? wmask + ((int64_t)(qrel / (unsigned)wm_hw) * ((wm_hw + 31) >> 5) + ((qrel % (unsigned)wm_hw) >> 5)) *
+                                            (((L.P >> 5) + 31) >> 5) : nullptr;
   // this lane's window cells (wy, wx): window cell (wy, wx) is tap (ay, ax) of output (j = wy - ay, i = wx - ax), channel i * N1 + j;
   // a tap that does not exist gets weight 0 and re-reads the other one
   constexpr int KC = (S::WIN * S::WIN + 63) / 64;
@@ -535,17 +537,19 @@ __device__ __forceinline__ void kt_mark(unsigned* bits, int i) {
 template <int EXACT>      // levels below EXACT: every lookup's window marked on its own; from EXACT on: the bounding rectangle of all
 __global__ __launch_bounds__(KT_NQ) void corr_ktiles_mark_kernel(KtArgs a, VolLayout L, int HW, int R, int grid_w, int* __restrict__ nt_list,
                                                                  int* __restrict__ nt_count, int nt_stride, unsigned* __restrict__ tn_bits,
-                                                                 int mw, unsigned* __restrict__ wmask) {
+                                                                 int mw, unsigned* __restrict__ wmask, int b0, int pix0) {
+  // HW: queries per list set (a whole image, or the chunk [pix0, pix0 + HW) of image b0: AlternateCorrBlock's chunked backward)
   __shared__ unsigned rb[KT_MAXW];
   __shared__ unsigned mb[KT_NQ / 32][KT_MAXM];
   __shared__ int wpre[KT_MAXW + 1];
   const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int bq = b0 + b;                                  // the image the queries belong to
   const int nrec = L.P >> 5, nw = (nrec + 31) >> 5, nlev = L.nlev;
   for (int i = tid; i < nw; i += KT_NQ) rb[i] = 0u;
   for (int i = tid; i < (KT_NQ / 32) * KT_MAXM; i += KT_NQ) mb[i / KT_MAXM][i % KT_MAXM] = 0u;
   __syncthreads();
-  const int pix = tile * KT_NQ + tid;
-  if (pix < HW) {
+  const int pixr = tile * KT_NQ + tid, pix = pix0 + pixr;
+  if (pixr < HW) {
     int mnx[4], mny[4], mxx[4], mxy[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) { mnx[l] = mny[l] = 0x7fffffff; mxx[l] = mxy[l] = -0x7fffffff; }
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(KT_NQ) void corr_ktiles_mark_kernel(KtArgs a, VolLa
     for (int t = 0; t < DV_MAXN; ++t)
       if (t < a.n) {
         float cx, cy;
-        query_xy(a.co[t], b, pix, grid_w, cx, cy);
+        query_xy(a.co[t], bq, pix, grid_w, cx, cy);
 #pragma unroll
         for (int l = 0; l < 4; ++l)
           if (l < nlev) {
@@ -794,11 +798,14 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   // fast route: one wave per query with only the lookups' bounding boxes in LDS; queries that do not fit go to `qlist`
   // (caller-owned scratch of 1 + rows unsigned), which the row-segment kernel below then walks
   const unsigned* list = nullptr;
-  if (wmask && !(g_dvol_box && qlist && !accumulate && records && q0 == 0 && grid == (unsigned)((int64_t)B * H * W))) return FS_ERR_ARG;
+  const bool whole = q0 == 0 && grid == (unsigned)((int64_t)B * H * W);
+  const bool chunk = !whole && q0 / (H * W) == (q0 + grid - 1) / (H * W);                // a chunk inside one image
+  if (wmask && !(g_dvol_box && qlist && !accumulate && records && (whole || chunk))) return FS_ERR_ARG;
+  const int wm_hw = whole ? H * W : (int)grid;
   if (g_dvol_box && qlist && !accumulate && (L.P % 8) == 0) {
     hipLaunchKernelGGL(dvol_list_reset_kernel, dim3(1), dim3(1), 0, stream, qlist);
 #define DVBOX(RR, REC) hipLaunchKernelGGL((corr_dvol_box_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, \
-                                          add_grid ? W : 0, q0, grid, qlist, g_dvol_policy, wmask)
+                                          add_grid ? W : 0, q0, grid, qlist, g_dvol_policy, wmask, wm_hw)
     if (radius == 4) { if (records) DVBOX(4, true); else DVBOX(4, false); }
     else { if (records) DVBOX(3, true); else DVBOX(3, false); }
 #undef DVBOX
@@ -831,20 +838,28 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
 }
 
 // k-tile lists of the two volume-backward GEMMs from the coordinates of the step's n <= 16 lookups (same arguments as
-// fsraft_corr_dvol_build).  nt_list [B][ceil(HW / 128)][nt_stride >= P / 32] + nt_count: records per 128-query tile, for
+// fsraft_corr_dvol_build; nq > 0: ONE list set for the chunk of queries [q0, q0 + nq) of one image, B / H*W below then read
+// 1 / nq).  nt_list [B][ceil(HW / 128)][nt_stride >= P / 32] + nt_count: records per 128-query tile, for
 // fsraft_gemm_rec_nt_list(..., kl_by_n = 1) with dV as the B operand; tn_list [B][ceil(P / 256)][tn_stride >= ceil(HW / 32)] +
 // tn_count: 32-query blocks per 256-cell tile, for fsraft_gemm_rec_tn_list(..., kl_by_n = 0) with dV as the A operand;
 // tn_bits: scratch of B * ceil(HW / 32) * ceil(ceil(P / 256) / 32) unsigned; wmask (nullable): [B][ceil(HW / 32)][ceil(P / 1024)]
 // unsigned, the records of each 32-query block's rows that the two list GEMMs read (for fsraft_corr_dvol_build).  Returns
 // FS_ERR_ARG for shapes beyond the kernels' bitmaps (P > 262144 floats): the caller then runs the dense GEMMs.
 extern "C" int fsraft_corr_bwd_ktiles(const float* const* coords, const int64_t* coords_str, int n, int num_levels, int B, int H, int W,
-                                      int radius, int add_grid, int* nt_list, int* nt_count, int nt_stride, unsigned* tn_bits,
-                                      int* tn_list, int* tn_count, int tn_stride, unsigned* wmask, hipStream_t stream) {
+                                      int radius, int add_grid, int64_t q0, int64_t nq, int* nt_list, int* nt_count, int nt_stride,
+                                      unsigned* tn_bits, int* tn_list, int* tn_count, int tn_stride, unsigned* wmask, hipStream_t stream) {
   VolLayout L;
   if (!coords || !coords_str || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) || !nt_list || !nt_count ||
       !tn_bits || !tn_list || !tn_count || (radius != 3 && radius != 4))
     return FS_ERR_ARG;
-  const int HW = H * W, nrec = L.P / 32, mtiles = (L.P + KT_MC - 1) / KT_MC, ktq = (HW + 31) / 32, mw = (mtiles + 31) / 32;
+  // nq > 0: one list set for the queries [q0, q0 + nq) of one image (a chunk of the chunked backward), else one per image
+  int HW = H * W, Bl = B, b0 = 0, pix0 = 0;
+  if (nq > 0) {
+    if (q0 < 0 || q0 + nq > (int64_t)B * HW || q0 / HW != (q0 + nq - 1) / HW) return FS_ERR_ARG;
+    b0 = (int)(q0 / HW); pix0 = (int)(q0 % HW); HW = (int)nq; Bl = 1;
+  }
+  B = Bl;
+  const int nrec = L.P / 32, mtiles = (L.P + KT_MC - 1) / KT_MC, ktq = (HW + 31) / 32, mw = (mtiles + 31) / 32;
   if (nrec > KT_MAXW * 32 || mw > KT_MAXM || nt_stride < nrec || tn_stride < ktq) return FS_ERR_ARG;
   KtArgs a;
   a.n = n;
@@ -854,7 +869,7 @@ extern "C" int fsraft_corr_bwd_ktiles(const float* const* coords, const int64_t*
   }
   for (int t = n; t < DV_MAXN; ++t) a.co[t] = Coords{nullptr, 0, 0, 0};
 #define KT_MARK(E) hipLaunchKernelGGL(corr_ktiles_mark_kernel<E>, dim3((HW + KT_NQ - 1) / KT_NQ, B), dim3(KT_NQ), 0, stream, a, L, HW, radius, \
-                                      add_grid ? W : 0, nt_list, nt_count, nt_stride, tn_bits, mw, wmask)
+                                      add_grid ? W : 0, nt_list, nt_count, nt_stride, tn_bits, mw, wmask, b0, pix0)
   if (g_ktile_exact >= 2) KT_MARK(2);
   else if (g_ktile_exact == 1) KT_MARK(1);
   else KT_MARK(0);

@@ -261,7 +261,7 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
     H, W = lay.H, lay.W
     rows = nq if nq else B * H * W - q0
     dvol = torch.empty(rows, lay.P, device=douts[0].device, dtype=torch.float32) if out is None else out
-    if wmask is not None and not (records and len(douts) <= 16 and q0 == 0 and not nq):
+    if wmask is not None and not (records and len(douts) <= 16):
         wmask = None
     # scratch for the work list of queries whose lookups spread beyond the bounding-box kernel's box (1 + rows unsigned)
     qlist = torch.empty(rows + 1, device=douts[0].device, dtype=torch.int32) if len(douts) <= 16 else None
@@ -289,6 +289,7 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
 
 
 BWD_KSKIP = os.environ.get("FSRAFT_BWD_KSKIP", "1") != "0"     # volume-backward GEMMs over the k-tiles the lookups reached only
+CHUNK_KSKIP = os.environ.get("FSRAFT_BWD_KSKIP_CHUNKS", "0") != "0"    # ... also in the chunked backward of AlternateCorrBlock (measured slower)
 TN_LIST_KSPLIT = int(os.environ.get("FSRAFT_TN_LIST_KSPLIT", "2"))   # k-slices of the listed d2cat GEMM (one slice with plain stores measured slower: 270 vs 210 us)
 DVOL_WMASK = os.environ.get("FSRAFT_DVOL_WMASK", "1") != "0"   # ... and the gradient volume written only where they read
 
@@ -298,16 +299,22 @@ class KTileLists:
     __slots__ = ("nt_list", "nt_count", "nt_stride", "tn_list", "tn_count", "tn_stride", "wmask")
 
 
-def corr_bwd_ktiles(coords, lay, B, radius, is_flow=False):
+def corr_bwd_ktiles(coords, lay, B, radius, is_flow=False, q0=0, nq=0):
     """coords: the step's lookup coordinates ([B,2,H,W] each, at most 16) -> KTileLists, or None where the lists do not apply
-    (more than 16 lookups, rows beyond the kernels' bitmaps): the caller then contracts densely."""
+    (more than 16 lookups, rows beyond the kernels' bitmaps): the caller then contracts densely.  nq > 0: the lists of the chunk
+    of queries [q0, q0 + nq) of one image (one list set, as for B = 1 and H*W = nq)."""
     n = len(coords)
+    Bfull = B
     H, W, P = lay.H, lay.W, lay.P
     if n < 1 or n > 16 or P // 32 > 2048 or -(-H * W // 32) > 2048:        # (the GEMMs hold a list of <= 2048 k-tiles in LDS)
         return None
     L.require_cuda_f32(*coords)
     dev = coords[0].device
     HW = H * W
+    if nq:
+        if q0 // HW != (q0 + nq - 1) // HW:
+            return None
+        B, HW = 1, nq
     k = KTileLists()
     ntiles, mtiles, ktq = -(-HW // 128), -(-P // 256), -(-HW // 32)
     k.nt_stride, k.tn_stride = P // 32, ktq
@@ -324,7 +331,7 @@ def corr_bwd_ktiles(coords, lay, B, radius, is_flow=False):
     a_s = (ctypes.c_int64 * (3 * n))(*st)
     tm = TIMER
     e0 = tm.begin() if tm else None
-    L.check(_lib().fsraft_corr_bwd_ktiles(ctypes.cast(a_c, L._PP), a_s, n, lay.nlev, B, H, W, radius, int(is_flow), L.ptr(k.nt_list),
+    L.check(_lib().fsraft_corr_bwd_ktiles(ctypes.cast(a_c, L._PP), a_s, n, lay.nlev, Bfull, H, W, radius, int(is_flow), q0, nq, L.ptr(k.nt_list),
                                           L.ptr(k.nt_count), k.nt_stride, L.ptr(bits), L.ptr(k.tn_list), L.ptr(k.tn_count), k.tn_stride,
                                           L.ptr(k.wmask), L.stream()), "corr_bwd_ktiles")
     if tm:      # (its time belongs to the volume backward it shortens; no algorithmic bytes of its own)
@@ -356,15 +363,24 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
     for b in range(B):
         for i0 in range(0, N, chunk):
             n = min(chunk, N - i0)
-            dV = corr_dvol_build(douts, coords, lay, B, radius, records=True, is_flow=is_flow, q0=b * N + i0, nq=n)
-            # d1[b][:, i0:i0+n] = s * f2cat[b] [C x P] . dV [n x P]^T
-            L.check(lib.fsraft_gemm_rec_nt(ctypes.c_void_p(f2r.data_ptr() + b * C * P * 4), P, 0, L.ptr(dV), P, 0,
-                                           ctypes.c_void_p(d1.data_ptr() + (b * C * N + i0) * 4), N, 0, 1, C, n, P, s, 8, 0, L.stream()),
-                    "gemm_rec_nt")
-            # d2cat[b] [P x C] += s * dV [n x P]^T . f1[b][i0:i0+n] [n x C]
-            L.check(lib.fsraft_gemm_rec_tn(L.ptr(dV), P, 0, ctypes.c_void_p(f1r.data_ptr() + (b * N + i0) * Cr * 4), Cr, 0,
-                                           ctypes.c_void_p(d2cat.data_ptr() + b * P * C * 4), C, 0, 1, P, C, n, s, 3, 1, L.stream()),
-                    "gemm_rec_tn")
+            # (CHUNK_KSKIP, off: as in the dense path the two GEMMs can visit only the k-tiles the chunk's lookups reached -- measured
+            #  at 1 x 47x156 in 2048-query chunks: the gradient rows 0.263 -> 0.227 ms, but the per-chunk pre-pass and the short GEMMs'
+            #  fixed costs take more than the skipped k-tiles give back, 0.784 -> 0.889 ms)
+            kt = corr_bwd_ktiles(coords, lay, B, radius, is_flow, q0=b * N + i0, nq=n) if (BWD_KSKIP and CHUNK_KSKIP) else None
+            dV = corr_dvol_build(douts, coords, lay, B, radius, records=True, is_flow=is_flow, q0=b * N + i0, nq=n,
+                                 wmask=kt.wmask if (kt is not None and DVOL_WMASK) else None)
+            a_nt = (ctypes.c_void_p(f2r.data_ptr() + b * C * P * 4), P, 0, L.ptr(dV), P, 0,
+                    ctypes.c_void_p(d1.data_ptr() + (b * C * N + i0) * 4), N, 0, 1, C, n, P, s)
+            a_tn = (L.ptr(dV), P, 0, ctypes.c_void_p(f1r.data_ptr() + (b * N + i0) * Cr * 4), Cr, 0,
+                    ctypes.c_void_p(d2cat.data_ptr() + b * P * C * 4), C, 0, 1, P, C, n, s)
+            if kt is not None:
+                L.check(lib.fsraft_gemm_rec_nt_list(*a_nt, 2, 0, L.ptr(kt.nt_list), L.ptr(kt.nt_count), kt.nt_stride, 1, L.stream()), "gemm_rec_nt_list")
+                L.check(lib.fsraft_gemm_rec_tn_list(*a_tn, 3, 1, L.ptr(kt.tn_list), L.ptr(kt.tn_count), kt.tn_stride, 0, L.stream()), "gemm_rec_tn_list")
+            else:
+                # d1[b][:, i0:i0+n] = s * f2cat[b] [C x P] . dV [n x P]^T
+                L.check(lib.fsraft_gemm_rec_nt(*a_nt, 8, 0, L.stream()), "gemm_rec_nt")
+                # d2cat[b] [P x C] += s * dV [n x P]^T . f1[b][i0:i0+n] [n x C]
+                L.check(lib.fsraft_gemm_rec_tn(*a_tn, 3, 1, L.stream()), "gemm_rec_tn")
     d2 = torch.empty(B, H, W, C, device=fmap1.device, dtype=torch.float32)
     L.check(lib.fsraft_corr_dfmap2(L.ptr(d2cat), L.ptr(d2), lay.nlev, B, C, H, W, L.stream()), "corr_dfmap2")
     out = d1.view(B, C, H, W), nhwc_to_nchw(d2, C)

@@ -78,7 +78,8 @@ int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* 
  * that no O(N^2) buffer exists.  qlist (nullable): caller-owned scratch of 1 + rows unsigned.  With it, one wave per query
  * builds the row from the bounding boxes of its lookups' windows (a few KB of LDS instead of the whole row) and queries whose
  * lookups spread beyond the box are listed there for the row-at-a-time kernel; without it every query takes that kernel.
- * wmask (nullable; needs qlist, records, all queries, no accumulate): the record bitmap of fsraft_corr_bwd_ktiles -- only the
+ * wmask (nullable; needs qlist, records, no accumulate, all queries or a chunk inside one image): the record bitmap of
+ * fsraft_corr_bwd_ktiles for the same queries -- only the
  * records either list GEMM reads are written, the rest of dvol stays untouched (it would be zero records nobody reads). */
 int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
                            int num_levels, int B, int H, int W, int radius, int accumulate, int records, int add_grid,
@@ -289,10 +290,11 @@ int fsraft_gemm_rec_tn_list(const void* A, int64_t lda, int64_t sA, const void* 
  * tn_count = 32-query blocks per 256-cell tile (d2cat = s * dV^T . f1 with dV as the A operand); tn_bits: scratch of
  * B * ceil(H*W / 32) * ceil(ceil(P / 256) / 32) unsigned.  wmask (nullable): [B][ceil(H*W / 32)][ceil(P / 1024)] unsigned, bit r of
  * a 32-query block = record r of its rows is read by one of the two list GEMMs; handed to fsraft_corr_dvol_build, the gradient
- * volume is then written there and nowhere else.  P = the row length of fsraft_vol_layout. */
+ * volume is then written there and nowhere else.  P = the row length of fsraft_vol_layout.  nq > 0: one list set for the chunk
+ * of queries [q0, q0 + nq) of one image (the chunked backward of AlternateCorrBlock): read B = 1 and H*W = nq above. */
 int fsraft_corr_bwd_ktiles(const float* const* coords, const int64_t* coords_str, int n, int num_levels, int B, int H, int W,
-                           int radius, int add_grid, int* nt_list, int* nt_count, int nt_stride, unsigned* tn_bits, int* tn_list,
-                           int* tn_count, int tn_stride, unsigned* wmask, hipStream_t stream);
+                           int radius, int add_grid, int64_t q0, int64_t nq, int* nt_list, int* nt_count, int nt_stride, unsigned* tn_bits,
+                           int* tn_list, int* tn_count, int tn_stride, unsigned* wmask, hipStream_t stream);
 
 /* ---- GMA variant (config 5) --------------------------------------------------------------
  * Attention.forward, pytorch/core/gma.py:54-76: sim = scale * q k^T runs on fsraft_gemm_f32 (trans_b), then this

@@ -224,6 +224,29 @@ def test_volume_backward_over_listed_k_tiles_equals_the_dense_contraction(B, H, 
     print(f"k-tile fraction NT {frac:.2f}, TN {tc.sum().item() / (B * mtiles * ktq):.2f}")
 
 
+def test_chunked_volume_backward_with_k_tile_lists_equals_without():
+    """ops.corr_bwd_chunked (AlternateCorrBlock's backward: the gradient volume 2048 queries at a time) with the per-chunk k-tile
+    lists and write masks (fsraft_corr_bwd_ktiles with q0 / nq; off by default: measured slower at the KITTI shape) against the
+    dense chunks, on a grid whose last chunk is ragged."""
+    from flow_supervisor_amd import ops
+    B, C, H, W, r, n = 2, 64, 47, 61, 4, 4
+    lay = ops.VolLayout.get(H, W, 4)
+    f1 = rand_tensor((B, C, H, W), 171, 1.0).to(DEV)
+    f2 = rand_tensor((B, C, H, W), 172, 1.0).to(DEV)
+    flows = [(rand_tensor((B, 2, H, W), 173, 2.0) + rand_tensor((B, 2, H, W), 180 + t, 0.5)).to(DEV).contiguous() for t in range(n)]
+    douts = [rand_tensor((B, H, W, 4 * (2 * r + 1) ** 2), 190 + t, 1.0).to(DEV) for t in range(n)]
+    was = ops.CHUNK_KSKIP
+    try:
+        ops.CHUNK_KSKIP = False
+        a1, a2 = ops.corr_bwd_chunked(f1, f2, douts, flows, lay, r, is_flow=True, chunk=1024)
+        ops.CHUNK_KSKIP = True
+        b1, b2 = ops.corr_bwd_chunked(f1, f2, douts, flows, lay, r, is_flow=True, chunk=1024)
+    finally:
+        ops.CHUNK_KSKIP = was
+    close(b1, a1, 1e-6, 1e-5, what="dfmap1, chunked, with k-tile lists")          # (k-slices meet in atomics: summation order)
+    close(b2, a2, 1e-6, 1e-5, what="dfmap2, chunked, with k-tile lists")
+
+
 @pytest.mark.parametrize("B,H,W,nlev,n", [(2, 55, 128, 4, 12), (1, 17, 19, 4, 3), (2, 16, 24, 3, 16), (1, 46, 62, 4, 12)])
 def test_gradient_volume_bounding_box_kernel_matches_the_row_kernel(B, H, W, nlev, n):
     """corr_dvol_box_kernel (one wave per query, only the bounding boxes of the lookups' windows in LDS, a work list for
