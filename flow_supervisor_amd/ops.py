@@ -290,6 +290,7 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
 
 BWD_KSKIP = os.environ.get("FSRAFT_BWD_KSKIP", "1") != "0"     # volume-backward GEMMs over the k-tiles the lookups reached only
 CHUNK_KSKIP = os.environ.get("FSRAFT_BWD_KSKIP_CHUNKS", "0") != "0"    # ... also in the chunked backward of AlternateCorrBlock (measured slower)
+NT_LIST_KSPLIT = int(os.environ.get("FSRAFT_NT_LIST_KSPLIT", "1"))   # k-slices of the listed dF1 GEMM
 TN_LIST_KSPLIT = int(os.environ.get("FSRAFT_TN_LIST_KSPLIT", "2"))   # k-slices of the listed d2cat GEMM (one slice with plain stores measured slower: 270 vs 210 us)
 DVOL_WMASK = os.environ.get("FSRAFT_DVOL_WMASK", "1") != "0"   # ... and the gradient volume written only where they read
 
@@ -446,7 +447,7 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None, ktile
             d2cat = torch.empty(B, P, C, device=fmap1.device, dtype=torch.float32)
             lib = _lib()
             e1 = tm.begin() if tm else None
-            L.check(lib.fsraft_gemm_rec_nt_list(L.ptr(f2r), P, C * P * 4, L.ptr(dV), P, N * P * 4, L.ptr(d1), N, C * N, B, C, N, P, s, 1, 0,
+            L.check(lib.fsraft_gemm_rec_nt_list(L.ptr(f2r), P, C * P * 4, L.ptr(dV), P, N * P * 4, L.ptr(d1), N, C * N, B, C, N, P, s, NT_LIST_KSPLIT, 0,
                                                 L.ptr(ktiles.nt_list), L.ptr(ktiles.nt_count), ktiles.nt_stride, 1, L.stream()),
                     "gemm_rec_nt_list")
             if tm:      # (the family's FLOPs stay the dense contraction's: what is skipped multiplies zeros)
