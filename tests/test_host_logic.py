@@ -46,3 +46,53 @@ def test_tf_twins_of_the_volume_refuse_to_be_trained_through():
         raft_tf.build_pyramid(torch.randn(1, 4, 4, 4, 4, requires_grad=True), 1)
     with pytest.raises(RuntimeError, match="forward-only"):
         raft_tf.CorrBlock(2, 3)([torch.randn(1, 4, 4, 4, 4)], torch.zeros(1, 4, 4, 2, requires_grad=True))
+
+
+def test_gradients_handed_out_back_to_back_come_back_as_one_tensor():
+    """update._one_tensor (what lets HeadBatch take the loss kernel's T gradients back as one [T*B,...] tensor without a copy):
+    pieces of one buffer in order -> a view of it; anything else (a gap, a copy, another order, a missing piece) -> None."""
+    from flow_supervisor_amd.core.update import _one_tensor
+    big = torch.arange(4 * 2 * 3 * 5, dtype=torch.float32).view(4, 2, 3, 5)
+    pieces = list(big.unbind(0))
+    one = _one_tensor([p.view(1, 2, 3, 5) for p in pieces])
+    assert one is not None and one.shape == (4, 2, 3, 5) and one.data_ptr() == big.data_ptr() and torch.equal(one, big)
+    two = _one_tensor([big[0:2], big[2:4]])
+    assert two is not None and two.shape == (4, 2, 3, 5) and torch.equal(two, big)
+    assert _one_tensor([pieces[0].view(1, 2, 3, 5), pieces[2].view(1, 2, 3, 5)]) is None            # a gap
+    assert _one_tensor([pieces[1].view(1, 2, 3, 5), pieces[0].view(1, 2, 3, 5)]) is None            # wrong order
+    assert _one_tensor([pieces[0].view(1, 2, 3, 5), pieces[1].clone().view(1, 2, 3, 5)]) is None    # another storage
+    assert _one_tensor([pieces[0].view(1, 2, 3, 5), None]) is None
+    assert _one_tensor([big[:, :, :, ::2][0:1]]) is None                                          # not contiguous
+
+
+def test_batched_flow_supervisor_loss_weights():
+    """train.semi_sequence_losses: the labelled half is weighted like sequence_loss (gamma, gamma2), the unlabelled half like
+    sequence_loss_unsup -- its OWN decay (the reference calls it without gamma: 0.8 whatever args.gamma, train.py:276), times
+    unsup_weight, and zero for the supervisor's predictions."""
+    from flow_supervisor_amd import train
+    seen = {}
+
+    class Fake:
+        @staticmethod
+        def apply(bs, w_sup, w_unsup, *rest):
+            seen["bs"], seen["sup"], seen["unsup"] = bs, w_sup, w_unsup
+            return None, None
+    real, train._SemiLossFn = train._SemiLossFn, Fake
+    try:
+        train.semi_sequence_losses([object()] * 6, 1, None, None, gamma=0.85, unsup_weight=0.25)
+    finally:
+        train._SemiLossFn = real
+    assert seen["bs"] == 1
+    assert seen["sup"] == [0.85 ** 2, 0.85, 1.0, 1.0, 1.0, 1.0]
+    assert seen["unsup"] == [0.25 * 0.8 ** 2, 0.25 * 0.8, 0.25, 0.0, 0.0, 0.0]
+
+
+def test_per_step_batches_respect_32_bit_offsets():
+    """HeadBatch / MotionBatch only exist where the batched buffers stay below 2 GB (the buffer-addressed kernels use 32-bit
+    byte offsets); beyond that the loops fall back to one launch per iteration."""
+    from flow_supervisor_amd.core.update import HeadBatch
+    assert HeadBatch.fits(12, 4, 55, 128)            # the bench shape: 12 x 4 x 7040 x 576 floats = 779 MB
+    assert HeadBatch.fits(12, 8, 46, 62)
+    assert not HeadBatch.fits(12, 16, 55, 128)       # 3.1 GB
+    assert HeadBatch.fits(32, 4, 55, 128)            # 2.08e9 bytes: just below 2^31
+    assert not HeadBatch.fits(34, 4, 55, 128)
