@@ -733,6 +733,30 @@ def test_mask_head_and_upsampler_of_all_iterations_as_one_launch():
         assert (ga - gb).norm().item() <= tol * gb.norm().item() + 1e-6, (n, (ga - gb).norm().item(), gb.norm().item())
 
 
+@pytest.mark.parametrize("case", ["raft_b3_iters2", "raft_alt_iters3", "l2l_offsets_per_sample", "l2l_sup_grad_samples"])
+def test_per_step_batches_against_the_per_iteration_path_on_odd_shapes(case):
+    """update.HeadBatch + MotionBatch + the batched heads backward (everything outside the recurrence once per step) against one
+    launch per iteration, beyond the shapes of the golden train steps: a batch of 3 on a 9x13 grid with two iterations,
+    alt-corr, L2L with per-sample crop offsets, and L2L with sup_grad_samples=1 (uncropped frames of sample 1 encoded without
+    a graph, supervisor-phase backward on sample 0 alone) under a loss that keeps that promise, against the plain forward.
+    Predictions to 1e-4 px, every parameter gradient outside the feature encoder to 5e-3 relative (tests/debug_batches.py)."""
+    import debug_batches as D
+    from flow_supervisor_amd.core.l2l import L2L
+    from flow_supervisor_amd.core.raft import RAFT
+    torch.manual_seed(123)
+    if case.startswith("raft"):
+        B, H, W, it, alt = (3, 72, 104, 2, False) if case == "raft_b3_iters2" else (2, 128, 192, 3, True)
+        im1, im2 = torch.rand(B, 3, H, W, device=DEV) * 255, torch.rand(B, 3, H, W, device=DEV) * 255
+        assert D.compare(case, lambda: RAFT(D.ns(alt)), lambda m: m(im1, im2, iters=it))
+    else:
+        i1, i2, c1, c2, ox, oy = D.l2l_inputs(2, ([8, 24], [16, 0]))
+        if case == "l2l_offsets_per_sample":
+            assert D.compare(case, lambda: L2L(D.ns()), lambda m: m(i1, i2, c1, c2, ox, oy, iters=4))
+        else:
+            assert D.compare(case, lambda: L2L(D.ns()), lambda m: m(i1, i2, c1, c2, ox, oy, iters=5, sup_grad_samples=1), sup_k=1,
+                             ref_call=lambda m: m(i1, i2, c1, c2, ox, oy, iters=5))
+
+
 def test_test_mode_skips_the_dropped_upsamples_with_identical_outputs():
     """test_mode returns only the last flow_up (raft.py:141-142); the mask convolution and the upsampler of
     the other iterations are skipped.  Outputs must equal the last training-mode prediction of the same weights (same kernels,
