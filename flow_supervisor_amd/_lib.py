@@ -99,7 +99,7 @@ SIGNATURES = {
     "fsraft_flow_to_nhwc": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_nhwc_to_flow": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, _S],
     "fsraft_relu_bwd": [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, _S],
-    "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, _S],
+    "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, _S],
     "fsraft_gru_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, _S],
     "fsraft_col_sum": [c_void_p, c_int, c_int64, c_int, c_void_p, c_float, _S],
     "fsraft_softmax_rows": [c_void_p, c_int64, c_int, _S],

@@ -510,6 +510,7 @@ class _Engine:
         if motion_only is None:
             # ---- heads
             hb = S.get("hb")
+            dh_more = None
             if hb is not None and hb[0].heads_done:
                 # the whole head backward of this iteration (flow head, mask head, the 3x3 convolution under both) already ran, for
                 # all iterations at once, inside the batched backward of the mask head + upsampler (_MaskUpFn): it depends on the
@@ -517,8 +518,7 @@ class _Engine:
                 dh = hb[0].dh_heads[hb[1]][:B]
                 if ddelta is not None and ddelta.data_ptr() != hb[0].dflow[hb[1]].data_ptr():
                     raise RuntimeError("HeadBatch: an iteration's delta_flow received a gradient from somewhere other than its prediction")
-                if dnet_out is not None:
-                    dh.add_(dnet_out)
+                dh_more = dnet_out.contiguous() if dnet_out is not None else None      # (added inside the first gate-gradient kernel)
             else:
                 head = S["head"]
                 if heads_only:
@@ -586,7 +586,8 @@ class _Engine:
                 else:
                     dhp = buf(hid)
                 zsum, qsum = ctx_sum("zi" + sfx, dzr), ctx_sum("qi" + sfx, dq)
-                ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid, zsum, qsum)
+                ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid, zsum, qsum, dhn2=dh_more)
+                dh_more = None
                 xs = [V(motion, self.x_c)]
                 wgrad("q" + sfx, V(dq, hid), [V(rh, hid)] + xs)
                 drh = buf(hid)

@@ -183,6 +183,57 @@ __global__ __launch_bounds__(256) void gru_bwd1_kernel(const float* __restrict__
   }
 }
 
+// the same on four channels per thread (hid, ldzr multiples of 4, 16-byte aligned pointers); dhn2 (nullable): a second summand of
+// dh' -- the hidden-state gradient arriving from the next iteration, added here instead of by a launch of its own
+__global__ __launch_bounds__(256) void gru_bwd1_v4_kernel(const float* __restrict__ dhn, const float* __restrict__ dhn2,
+                                                          const float* __restrict__ z, const float* __restrict__ q,
+                                                          const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
+                                                          float* __restrict__ dq, float* __restrict__ dh, float* __restrict__ dzr_sum,
+                                                          float* __restrict__ dq_sum, int64_t M, int hid) {
+  const int h4 = hid >> 2;
+  const int64_t total = M * h4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / h4; const int c = (int)(e % h4) * 4;
+    const int64_t o = m * hid + c, oz = m * ldzr + c;
+    f32x4 g = gload4(dhn + o);
+    const f32x4 zz = gload4(z + o), qq = gload4(q + o), hh = gload4(h + o);
+    if (dhn2) g += gload4(dhn2 + o);
+    f32x4 dz, dqv, dhv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dz[i] = g[i] * (qq[i] - hh[i]) * zz[i] * (1.f - zz[i]);
+      dqv[i] = g[i] * zz[i] * (1.f - qq[i] * qq[i]);
+      dhv[i] = g[i] * (1.f - zz[i]);
+    }
+    gstore4(dzr + oz, dz);
+    gstore4(dq + o, dqv);
+    gstore4(dh + o, dhv);
+    if (dzr_sum) gstore4(dzr_sum + oz, gload4(dzr_sum + oz) + dz);
+    if (dq_sum) gstore4(dq_sum + o, gload4(dq_sum + o) + dqv);
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_bwd2_v4_kernel(const float* __restrict__ drh, const float* __restrict__ r,
+                                                          const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
+                                                          float* __restrict__ dh, float* __restrict__ dzr_sum, int64_t M, int hid) {
+  const int h4 = hid >> 2;
+  const int64_t total = M * h4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / h4; const int c = (int)(e % h4) * 4;
+    const int64_t o = m * hid + c, oz = m * ldzr + hid + c;
+    const f32x4 g = gload4(drh + o), rr = gload4(r + o), hh = gload4(h + o);
+    f32x4 dhv = gload4(dh + o), dr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dr[i] = g[i] * hh[i] * rr[i] * (1.f - rr[i]);
+      dhv[i] += g[i] * rr[i];
+    }
+    gstore4(dzr + oz, dr);
+    gstore4(dh + o, dhv);
+    if (dzr_sum) gstore4(dzr_sum + oz, gload4(dzr_sum + oz) + dr);
+  }
+}
+
 // stage 2 (input of the q conv was r*h):  dzr[:, hid:2hid] = d(rh) * h * r (1-r);   dh += d(rh) * r
 __global__ __launch_bounds__(256) void gru_bwd2_kernel(const float* __restrict__ drh, const float* __restrict__ r,
                                                        const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
@@ -278,16 +329,26 @@ extern "C" int fsraft_relu_bwd(float* g, int ldg, const float* y, int ldy, int64
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(M * ((C + 3) / 4))), dim3(256), 0, s, g, ldg, y, ldy, M, C);
   return fs_launch_status();
 }
-extern "C" int fsraft_gru_bwd1(const float* dhn, const float* z, const float* q, const float* h, float* dzr, int ldzr,
+namespace {
+bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+}
+extern "C" int fsraft_gru_bwd1(const float* dhn, const float* dhn2, const float* z, const float* q, const float* h, float* dzr, int ldzr,
                                float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid, hipStream_t s) {
   if (!dhn || !z || !q || !h || !dzr || !dq || !dh) return FS_ERR_ARG;
-  hipLaunchKernelGGL(gru_bwd1_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, dhn, z, q, h, dzr, ldzr, dq, dh, dzr_sum, dq_sum, M, hid);
+  const bool v4 = hid % 4 == 0 && ldzr % 4 == 0 && al16(dhn) && al16(dhn2) && al16(z) && al16(q) && al16(h) && al16(dzr) && al16(dq) &&
+                  al16(dh) && al16(dzr_sum) && al16(dq_sum);
+  if (!v4 && dhn2) return FS_ERR_ARG;            // (the second summand exists for the vectorised kernel only)
+  if (v4) hipLaunchKernelGGL(gru_bwd1_v4_kernel, dim3(grid_for(M * (hid / 4))), dim3(256), 0, s, dhn, dhn2, z, q, h, dzr, ldzr, dq, dh,
+                             dzr_sum, dq_sum, M, hid);
+  else hipLaunchKernelGGL(gru_bwd1_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, dhn, z, q, h, dzr, ldzr, dq, dh, dzr_sum, dq_sum, M, hid);
   return fs_launch_status();
 }
 extern "C" int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh,
                                float* dzr_sum, int64_t M, int hid, hipStream_t s) {
   if (!drh || !r || !h || !dzr || !dh) return FS_ERR_ARG;
-  hipLaunchKernelGGL(gru_bwd2_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid);
+  if (hid % 4 == 0 && ldzr % 4 == 0 && al16(drh) && al16(r) && al16(h) && al16(dzr) && al16(dh) && al16(dzr_sum))
+    hipLaunchKernelGGL(gru_bwd2_v4_kernel, dim3(grid_for(M * (hid / 4))), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid);
+  else hipLaunchKernelGGL(gru_bwd2_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid);
   return fs_launch_status();
 }
 extern "C" int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s) {

@@ -888,9 +888,10 @@ def relu_bwd_(g, y, C):
     L.check(_lib().fsraft_relu_bwd(L.ptr(g), g.shape[-1], L.ptr(y), y.shape[-1], M, C, L.stream()), "relu_bwd")
 
 
-def gru_bwd1(dhn, z, q, h, dzr, dq, dh, hid, dzr_sum=None, dq_sum=None):
+def gru_bwd1(dhn, z, q, h, dzr, dq, dh, hid, dzr_sum=None, dq_sum=None, dhn2=None):
+    """dhn2: optional second summand of the incoming hidden-state gradient (same shape as dhn)."""
     M = dhn.numel() // hid
-    L.check(_lib().fsraft_gru_bwd1(L.ptr(dhn), L.ptr(z), L.ptr(q), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dq),
+    L.check(_lib().fsraft_gru_bwd1(L.ptr(dhn), L.ptr(dhn2), L.ptr(z), L.ptr(q), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dq),
                                    L.ptr(dh), L.ptr(dzr_sum), L.ptr(dq_sum), M, hid, L.stream()), "gru_bwd1")
 
 

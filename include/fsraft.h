@@ -401,8 +401,9 @@ int fsraft_col2im7(const float* dcols, int ld, float* dflow, int B, int H, int W
 int fsraft_flow_to_nhwc(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* dst, int ld, int coff, int B, int HW, hipStream_t s);
 int fsraft_nhwc_to_flow(const float* src, int ld, int coff, float* dflow, int B, int HW, int accumulate, hipStream_t s);
 int fsraft_relu_bwd(float* g, int ldg, const float* y, int ldy, int64_t M, int C, hipStream_t s);
-/* dzr_sum / dq_sum (nullable, same layouts as dzr / dq): running sums over the iterations of a step */
-int fsraft_gru_bwd1(const float* dhn, const float* z, const float* q, const float* h, float* dzr, int ldzr, float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid, hipStream_t s);
+/* dzr_sum / dq_sum (nullable, same layouts as dzr / dq): running sums over the iterations of a step; dhn2 (nullable): a second
+ * summand of the incoming gradient (dh' = dhn + dhn2: the heads' part and the part arriving from the next iteration) */
+int fsraft_gru_bwd1(const float* dhn, const float* dhn2, const float* z, const float* q, const float* h, float* dzr, int ldzr, float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid, hipStream_t s);
 int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh, float* dzr_sum, int64_t M, int hid, hipStream_t s);
 int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s);
 int fsraft_axpby(const float* x, float* y, float a, float b, int64_t n, hipStream_t s);
