@@ -705,6 +705,10 @@ class _CtxFn(torch.autograd.Function):
         cst.consumed = True
         dinp = ctx.engine.context_backward(cst, ctx.P, ctx.st)
         cst.bufs = None
+        # (state -> anchor -> grad_fn -> ctx -> state is a reference cycle: cut it here, or the context features and whatever else
+        #  the state holds wait for the cyclic collector -- tens of MB per step that only show up as a creeping peak)
+        cst.anchor = None
+        ctx.cst = ctx.st = ctx.P = ctx.engine = None
         return None, None, None, None, None, dinp
 
 
@@ -732,8 +736,12 @@ class _ParamFn(torch.autograd.Function):
         st = ctx.st
         st.consumed = True
         if st.arena is None:
-            return (None, None) + tuple(torch.zeros_like(p) for p in ctx.params)
-        return (None, None) + tuple(ctx.engine.unpack_param_grads(st, ctx.P, ctx.params))
+            out = (None, None) + tuple(torch.zeros_like(p) for p in ctx.params)
+        else:
+            out = (None, None) + tuple(ctx.engine.unpack_param_grads(st, ctx.P, ctx.params))
+        st.anchor = None                     # (cut the state -> anchor -> grad_fn -> ctx -> state cycle)
+        ctx.st = ctx.P = ctx.params = ctx.engine = None
+        return out
 
 
 class _AttnState:
@@ -760,6 +768,8 @@ class _AttnFn(torch.autograd.Function):
         ast = ctx.ast
         ast.consumed = True
         stash, ast.stash = ast.stash, []
+        ast.anchor = None                    # (cut the state -> anchor -> grad_fn -> ctx -> state cycle)
+        ctx.ast = None
         if not stash:
             return None, None
         D = torch.cat([d for d, _ in stash], 2) if len(stash) > 1 else stash[0][0].contiguous()

@@ -757,6 +757,31 @@ def test_per_step_batches_against_the_per_iteration_path_on_odd_shapes(case):
                              ref_call=lambda m: m(i1, i2, c1, c2, ox, oy, iters=5))
 
 
+def test_eager_train_steps_leave_no_garbage_for_the_cyclic_collector():
+    """Device memory allocated after an eager train step must not depend on how many steps ran, WITHOUT the cyclic garbage
+    collector: the once-per-step states of the update block (parameter arena, context part, GMA attention) used to sit in
+    reference cycles (state -> anchor tensor -> grad_fn -> ctx -> state) that kept the context features and friends alive until a
+    generation-2 collection happened to run -- ~27 MB per step at the bench shape, a creeping peak.  (tests/debug_leak.py)"""
+    import gc
+    from flow_supervisor_amd.train import TrainStep
+    m = _model(False, 77).train()
+    m.freeze_bn()
+    step = TrainStep(m, lr=1e-5, iters=4)
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(2, 128, 192, 78))
+    gc.collect()
+    gc.disable()
+    try:
+        seen = []
+        for i in range(7):
+            step(im1, im2)
+            torch.cuda.synchronize()
+            if i >= 2:
+                seen.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert max(seen) - min(seen) <= 1 << 20, [v / 2 ** 20 for v in seen]
+
+
 def test_test_mode_skips_the_dropped_upsamples_with_identical_outputs():
     """test_mode returns only the last flow_up (raft.py:141-142); the mask convolution and the upsampler of
     the other iterations are skipped.  Outputs must equal the last training-mode prediction of the same weights (same kernels,
