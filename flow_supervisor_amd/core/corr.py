@@ -176,8 +176,10 @@ class _AltBuildFn(torch.autograd.Function):
     `chunk` queries, two record GEMMs, no O(N^2) buffer and no atomics on the feature gradients."""
 
     @staticmethod
-    def forward(ctx, fmap1, fmap2, block):
-        ctx.block = block
+    def forward(ctx, fmap1, fmap2, state, num_levels, radius):
+        # (the node holds the block's STATE, not the block: block -> anchor -> grad_fn -> ctx -> block would be a reference cycle
+        #  that keeps the feature records and the pooled pyramid waiting for the cyclic collector, 32 MB per step at 2 x 32x48)
+        ctx.state, ctx.num_levels, ctx.radius = state, num_levels, radius
         ctx.save_for_backward(fmap1, fmap2)
         ctx.set_materialize_grads(False)
         return ops.zeros(1, device=fmap1.device)
@@ -185,34 +187,34 @@ class _AltBuildFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ganchor):
         fmap1, fmap2 = ctx.saved_tensors
-        blk = ctx.block
-        stash, blk._stash = blk._stash, []
+        st = ctx.state
+        stash, st.stash = st.stash, []
         if not stash:
-            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
-        lay = ops.VolLayout.get(fmap1.shape[2], fmap1.shape[3], blk.num_levels)
-        d1, d2 = ops.corr_bwd_chunked(fmap1, fmap2, [d for _, d in stash], [c for c, _ in stash], lay, blk.radius,
-                                      is_flow=blk._stash_is_flow)
-        return d1, d2, None
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None, None
+        lay = ops.VolLayout.get(fmap1.shape[2], fmap1.shape[3], ctx.num_levels)
+        d1, d2 = ops.corr_bwd_chunked(fmap1, fmap2, [d for _, d in stash], [c for c, _ in stash], lay, ctx.radius,
+                                      is_flow=st.is_flow)
+        return d1, d2, None, None, None
 
 
 class _AltLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, coords, block, channels_last, is_flow, out_buf=None):
         out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow, recs=block._recs, out=out_buf)
-        ctx.block, ctx.cl, ctx.is_flow = block, channels_last, is_flow
+        ctx.state, ctx.cl, ctx.is_flow = block._state, channels_last, is_flow
         ctx.save_for_backward(coords)
         return out if channels_last else ops.nhwc_to_nchw(out)
 
     @staticmethod
     def backward(ctx, dout):
         (coords,) = ctx.saved_tensors
-        blk = ctx.block
+        st = ctx.state
         dout = dout.contiguous() if ctx.cl else ops.nchw_to_nhwc(dout)
-        if ctx.is_flow != blk._stash_is_flow:
+        if ctx.is_flow != st.is_flow:
             B, _, H, W = coords.shape
             g = coords_grid(B, H, W, device=coords.device)
-            coords = coords - g if blk._stash_is_flow else coords + g
-        blk._stash.append((coords, dout))
+            coords = coords - g if st.is_flow else coords + g
+        st.stash.append((coords, dout))
         return None, None, None, None, None, None
 
 
@@ -232,9 +234,9 @@ class AlternateCorrBlock:
         self.radius = radius
         fmap1 = fmap1.float()
         fmap2 = fmap2.float()
-        self._stash, self._stash_is_flow = [], False
+        self._state = _GradState(fmap1.device)
         self._tracks_grad = torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)
-        self._anchor = _AltBuildFn.apply(fmap1, fmap2, self) if self._tracks_grad else None
+        self._anchor = _AltBuildFn.apply(fmap1, fmap2, self._state, num_levels, radius) if self._tracks_grad else None
         with torch.no_grad():
             self.pyramid = [(fmap1, fmap2)]
             f1, f2 = fmap1, fmap2
@@ -257,8 +259,8 @@ class AlternateCorrBlock:
         if out is not None and not channels_last:
             raise ValueError("out= is for channels_last lookups")
         if self._tracks_grad and torch.is_grad_enabled():
-            if not self._stash:
-                self._stash_is_flow = is_flow
+            if not self._state.stash:
+                self._state.is_flow = is_flow
             return _AltLookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow, out)
         res = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs, out=out)
         return res if channels_last else ops.nhwc_to_nchw(res)

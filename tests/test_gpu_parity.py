@@ -757,7 +757,8 @@ def test_per_step_batches_against_the_per_iteration_path_on_odd_shapes(case):
                              ref_call=lambda m: m(i1, i2, c1, c2, ox, oy, iters=5))
 
 
-def test_eager_train_steps_leave_no_garbage_for_the_cyclic_collector():
+@pytest.mark.parametrize("alt", [False, True])
+def test_eager_train_steps_leave_no_garbage_for_the_cyclic_collector(alt):
     """Device memory allocated after an eager train step must not depend on how many steps ran, WITHOUT the cyclic garbage
     collector: the once-per-step states of the update block (parameter arena, context part, GMA attention) used to sit in
     reference cycles (state -> anchor tensor -> grad_fn -> ctx -> state) that kept the context features and friends alive until a
@@ -765,6 +766,7 @@ def test_eager_train_steps_leave_no_garbage_for_the_cyclic_collector():
     import gc
     from flow_supervisor_amd.train import TrainStep
     m = _model(False, 77).train()
+    m.args.alternate_corr = alt            # (AlternateCorrBlock used to sit in a block -> anchor -> grad_fn -> ctx -> block cycle: 32 MB per step)
     m.freeze_bn()
     step = TrainStep(m, lr=1e-5, iters=4)
     im1, im2 = (t.to(DEV) for t in synthetic_pair(2, 128, 192, 78))
