@@ -119,3 +119,22 @@ def test_product_never_imports_oracle():
             if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(d, f)).read(), flags=re.M):
                 bad.append(f)
     assert not bad, bad
+
+
+def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
+    """Argument validation is host code: null pointers, sizes beyond the kernels' bitmaps and unknown switch values come back
+    as FS_ERR_ARG (1) without a HIP call -- runs on the CPU-only box.  (Round-3 entry points; the older ones behave alike.)"""
+    import ctypes
+    from flow_supervisor_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(None)
+    nullpp = ctypes.cast(null, _lib._PP)
+    strides = (ctypes.c_int64 * 3)(0, 0, 0)
+    assert lib.fsraft_corr_bwd_ktiles(nullpp, strides, 1, 4, 1, 16, 16, 4, 1, 0, 0, null, null, 0, null, null, null, 0, null, None) == 1
+    assert lib.fsraft_gemm_rec_nt_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, None) == 1
+    assert lib.fsraft_gemm_rec_tn_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, None) == 1
+    assert lib.fsraft_gru_bwd1(null, null, null, null, null, null, 128, null, null, null, null, 16, 128, None) == 1
+    assert lib.fsraft_set_lookup_policy(3) == 1 and lib.fsraft_set_lookup_policy(-1) == 0
+    assert lib.fsraft_set_ktile_exact(5) == 1 and lib.fsraft_set_ktile_exact(0) == 0
+    assert lib.fsraft_conv_workspace(ctypes.c_void_p(8), 16) == 1          # misaligned scratch
+    assert lib.fsraft_conv_workspace(null, 0) == 0
