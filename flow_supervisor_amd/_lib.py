@@ -138,6 +138,7 @@ SIGNATURES = {
     "fsraft_altcorr_mfma_fwd": [c_void_p, _PP, c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_f2cat": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_dfmap2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_f2cat_rec": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_to_records": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, _S],
     "fsraft_gemm_rec_tn": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                            c_float, c_int, c_int, _S],

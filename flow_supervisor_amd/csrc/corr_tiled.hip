@@ -695,6 +695,64 @@ __global__ __launch_bounds__(256) void corr_f2cat_kernel(const float* __restrict
   }
 }
 
+// f2cat as RECORDS in one pass, one workgroup per (sample, channel) plane: the plane (H*W floats, <= F2C_MAX_PLANE) is read once
+// with coalesced loads into LDS, pooled there level by level (the reference's own recursion, pytorch/core/corr.py:24-26: every
+// level is the 2x2 mean of the one above it), and leaves as [32 hi | 32 lo] bf16 records -- what corr_f2cat_kernel (strided
+// 4-byte reads, 46 us for 29 MB in) followed by to_records (39 MB in and out again) produced in two.
+constexpr int F2C_MAX_PLANE = 12288;          // floats of one level-0 plane kept in LDS (48 KB; + 1/3 for the pooled levels)
+__global__ __launch_bounds__(256) void corr_f2cat_rec_kernel(const float* __restrict__ f2, char* __restrict__ f2r, VolLayout L) {
+  extern __shared__ float pl[];               // level 0 | level 1 | level 2 | level 3, row-major, true sizes
+  const int H = L.H, W = L.W, HW = H * W;
+  const float* src = f2 + (int64_t)blockIdx.x * HW;
+  if ((HW & 3) == 0) {
+    for (int e = threadIdx.x * 4; e < HW; e += 1024) *reinterpret_cast<f32x4*>(pl + e) = gload4(src + e);
+  } else {
+    for (int e = threadIdx.x; e < HW; e += 256) pl[e] = gload1(src + e);
+  }
+  int lo[4];
+  lo[0] = 0;
+#pragma unroll
+  for (int l = 1; l < 4; ++l) lo[l] = lo[l - 1] + (l - 1 < L.nlev ? L.h[l - 1] * L.w[l - 1] : 0);
+#pragma unroll
+  for (int l = 1; l < 4; ++l) {
+    __syncthreads();
+    if (l < L.nlev) {
+      const int h = L.h[l], w = L.w[l], wp = L.w[l - 1];
+      const float* up = pl + lo[l - 1];
+      float* dn = pl + lo[l];
+      for (int e = threadIdx.x; e < h * w; e += 256) {
+        const int y = e / w, x = e - y * w;
+        const float* q = up + (2 * y) * wp + 2 * x;
+        dn[e] = 0.25f * ((q[0] + q[1]) + (q[wp] + q[wp + 1]));
+      }
+    }
+  }
+  __syncthreads();
+  char* dst = f2r + (int64_t)blockIdx.x * L.P * 4;
+  for (int u = threadIdx.x; u < L.P / 8; u += 256) {     // 8 cells = two rows of one 4x4 tile
+    const int p = u * 8;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) l = (k < L.nlev && p >= L.off[k]) ? k : l;
+    const int rel = p - L.off[l], t = rel >> 4, ty = t / L.tw[l], tx = t - ty * L.tw[l];
+    const int y0 = (ty << 2) + ((rel >> 2) & 3), x0 = tx << 2;
+    const float* lv = pl + lo[l];
+    const int h = L.h[l], w = L.w[l];
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int y = y0 + (i >> 2), x = x0 + (i & 3);
+      v[i] = (ty < L.th[l] && y < h && x < w) ? lv[y * w + x] : 0.f;
+    }
+    uint2 h0, l0, h1, l1;
+    rec_split4(v, h0, l0);
+    rec_split4(v + 4, h1, l1);
+    char* d = dst + (u >> 2) * 128 + (u & 3) * 16;
+    gstore4(d, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}));
+    gstore4(d + 64, __builtin_bit_cast(f32x4, u32x4{l0.x, l0.y, l1.x, l1.y}));
+  }
+}
+
 // dF2 (channels-last [B][N][C]) = sum_l 4^-l * dF2cat[b][cell_l(y >> l, x >> l)][c] over the levels whose cell exists
 __global__ __launch_bounds__(256) void corr_dfmap2_kernel(const float* __restrict__ d2cat, float* __restrict__ d2, VolLayout L, int C,
                                                           int64_t total) {
@@ -715,6 +773,36 @@ __global__ __launch_bounds__(256) void corr_dfmap2_kernel(const float* __restric
       }
     }
     d2[e] = acc;
+  }
+}
+
+// the same with four channels per thread (C % 4 == 0): 16-byte loads and stores
+__global__ __launch_bounds__(256) void corr_dfmap2_v4_kernel(const float* __restrict__ d2cat, float* __restrict__ d2, VolLayout L, int C4,
+                                                             int64_t total) {
+  const int N = L.H * L.W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    const int64_t bp = e / C4;
+    const int pix = (int)(bp % N), b = (int)(bp / N);
+    const int y = pix / L.W, x = pix % L.W;
+    const float* src = d2cat + ((int64_t)b * L.P * C4 + c) * 4;
+    f32x4 r[4];
+    bool on[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int yl = y >> l, xl = x >> l;
+      on[l] = l < L.nlev && yl < L.h[l] && xl < L.w[l];
+      const int cell = on[l] ? vol_cell(L, l, yl, xl) : 0;
+      r[l] = gload4(src + (int64_t)cell * C4 * 4);          // (unconditional: the four loads go out together)
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float wgt = 1.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (on[l]) acc += wgt * r[l];
+      wgt *= 0.25f;
+    }
+    gstore4(d2 + e * 4, acc);
   }
 }
 
@@ -887,12 +975,31 @@ extern "C" int fsraft_corr_f2cat(const float* fmap2, float* f2cat, int num_level
   return fs_launch_status();
 }
 
+// fmap2 [B][C][H][W] -> f2cat [B][C][P / 32] records (what fsraft_corr_f2cat + fsraft_to_records give), for planes of at most
+// 12288 pixels (FS_ERR_ARG above that: the caller takes the two-kernel route)
+extern "C" int fsraft_corr_f2cat_rec(const float* fmap2, void* f2r, int num_levels, int B, int C, int H, int W, hipStream_t stream) {
+  VolLayout L;
+  if (!fmap2 || !f2r || B < 1 || C < 1 || !vol_layout_make(H, W, num_levels, L) || (int64_t)H * W > F2C_MAX_PLANE ||
+      ((uintptr_t)f2r % 16) || ((uintptr_t)fmap2 % 16))
+    return FS_ERR_ARG;
+  int fl = 0;
+  for (int l = 0; l < L.nlev; ++l) fl += L.h[l] * L.w[l];
+  hipLaunchKernelGGL(corr_f2cat_rec_kernel, dim3(B * C), dim3(256), (size_t)fl * 4, stream, fmap2, (char*)f2r, L);
+  return fs_launch_status();
+}
+
 // d2cat [B][P][C] -> d2 [B][H*W][C] (channels-last feature gradient)
 extern "C" int fsraft_corr_dfmap2(const float* d2cat, float* d2, int num_levels, int B, int C, int H, int W, hipStream_t stream) {
   VolLayout L;
   if (!d2cat || !d2 || B < 1 || C < 1 || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
   const int64_t total = (int64_t)B * H * W * C;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (C % 4 == 0 && ((uintptr_t)d2cat % 16) == 0 && ((uintptr_t)d2 % 16) == 0) {
+    const int64_t t4 = total / 4;
+    const int b4 = (int)((t4 + 255) / 256 < 16384 ? (t4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(corr_dfmap2_v4_kernel, dim3(b4), dim3(256), 0, stream, d2cat, d2, L, C / 4, t4);
+    return fs_launch_status();
+  }
   hipLaunchKernelGGL(corr_dfmap2_kernel, dim3(blocks), dim3(256), 0, stream, d2cat, d2, L, C, total);
   return fs_launch_status();
 }

@@ -343,6 +343,24 @@ def corr_bwd_ktiles(coords, lay, B, radius, is_flow=False, q0=0, nq=0):
     return k
 
 
+F2CAT_REC = os.environ.get("FSRAFT_F2CAT_REC", "1") != "0"    # pooled target-side operand as records in one pass (0: two kernels)
+F2CAT_REC_MAX_PLANE = 12288                                   # csrc/corr_tiled.hip: F2C_MAX_PLANE
+
+
+def f2cat_records(fmap2, lay):
+    """[B,C,H,W] -> records of f2cat [B,C,P] (level-l cell = mean of fmap2 over its 2^l x 2^l pixels, zero in pad cells): the
+    A operand of dF1 = s * f2cat . dV^T.  One pass (plane pooled in LDS) when a plane fits, else f2cat + to_records."""
+    B, C, H, W = fmap2.shape
+    fmap2 = fmap2.contiguous()
+    if F2CAT_REC and H * W <= F2CAT_REC_MAX_PLANE:
+        f2r = torch.empty(B, C, lay.P, device=fmap2.device, dtype=torch.float32)
+        L.check(_lib().fsraft_corr_f2cat_rec(L.ptr(fmap2), L.ptr(f2r), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat_rec")
+        return f2r
+    f2cat = torch.empty(B, C, lay.P, device=fmap2.device, dtype=torch.float32)
+    L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
+    return to_records(f2cat)
+
+
 def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, chunk=2048, f1r=None):
     """Backward of volume + lookups WITHOUT an O(N^2) buffer (AlternateCorrBlock's contract, pytorch/core/corr.py:63-91): the
     gradient volume exists for `chunk` queries at a time (chunk x P floats, records), and every chunk feeds the same two
@@ -352,9 +370,7 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
     s = 1.0 / math.sqrt(C)
     tm = TIMER
     e0 = tm.begin() if tm else None
-    f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
-    L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
-    f2r = to_records(f2cat)
+    f2r = f2cat_records(fmap2, lay)
     if f1r is None:
         f1r = fmap_records(fmap1)                                   # [B, N, C] records
     Cr = f1r.shape[-1]                                              # record pitch of a pixel's channel vector (ceil32(C) floats)
@@ -434,14 +450,12 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None, ktile
     s = 1.0 / math.sqrt(C)
     tm = TIMER
     e0 = tm.begin() if tm else None
-    f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
-    L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
     dV = dvol.view(B, N, P)
     if records:
+        f2r = f2cat_records(fmap2, lay)
         if f1r is None:
             f1r = fmap_records(fmap1)
         if ktiles is not None:      # only the k-tiles the step's lookups reached (the rest of the gradient rows is zero records)
-            f2r = to_records(f2cat)
             Cr = f1r.shape[-1]
             d1 = torch.empty(B, C, N, device=fmap1.device, dtype=torch.float32)
             d2cat = torch.empty(B, P, C, device=fmap1.device, dtype=torch.float32)
@@ -459,9 +473,11 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None, ktile
             if tm:
                 tm.end("gemm_f32", e1, 2.0 * B * P * C * N, 4.0 * B * (N * P + N * C + P * C))
         else:
-            d1 = gemm_rec_nt(to_records(f2cat), dV, s)                # [B,C,N] = s * f2cat . dV^T
+            d1 = gemm_rec_nt(f2r, dV, s)                              # [B,C,N] = s * f2cat . dV^T
             d2cat = gemm_rec_tn(dV, f1r, P, C, s, ksplit=2)           # [B,P,C] = s * dV^T . f1^T
     else:
+        f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
+        L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
         f1t = nchw_to_nhwc(fmap1).view(B, N, C)
         d1 = gemm(f2cat, dV, True, s)
         if C % 4 == 0 and SPLIT_VOLUME_BWD:

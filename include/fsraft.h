@@ -92,6 +92,10 @@ int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords,
  *   fsraft_corr_dfmap2: d2 [B][H*W][C] = sum_l 4^-l * d2cat[b][cell_l(y>>l, x>>l)][c] over the levels whose cell exists. */
 int fsraft_corr_f2cat(const float* fmap2, float* f2cat, int num_levels, int B, int C, int H, int W, hipStream_t stream);
 int fsraft_corr_dfmap2(const float* d2cat, float* d2, int num_levels, int B, int C, int H, int W, hipStream_t stream);
+/* f2cat directly as records [B][C][P / 32] x ([32 hi | 32 lo] bf16) -- fsraft_corr_f2cat followed by fsraft_to_records in one
+ * pass (the plane pooled in LDS by the reference's recursion, corr.py:24-26).  Planes of at most 12288 pixels (H * W);
+ * FS_ERR_ARG above that, the caller then takes the two calls. */
+int fsraft_corr_f2cat_rec(const float* fmap2, void* f2r, int num_levels, int B, int C, int H, int W, hipStream_t stream);
 
 /* ---- radius-r pyramid lookup --------------------------------------------------------
  * Replaces CorrBlock.__call__, pytorch/core/corr.py:29-50 (+ bilinear_sampler,

@@ -289,6 +289,44 @@ def test_gradient_volume_bounding_box_kernel_matches_the_row_kernel(B, H, W, nle
         lib.fsraft_set_dvol_box(1)
 
 
+@pytest.mark.parametrize("B,C,H,W,nlev", [(2, 32, 55, 128, 4), (1, 64, 47, 156, 4), (2, 32, 13, 17, 3), (1, 32, 6, 8, 2), (1, 32, 46, 62, 4)])
+def test_pooled_target_operand_as_records_in_one_pass(B, C, H, W, nlev):
+    """fsraft_corr_f2cat_rec (the plane pooled in LDS, records out) against the reference's own recursion (corr.py:24-26:
+    avg_pool2d of the level above) laid out in the tiled rows, and against the two-kernel route it replaces: pad cells are
+    zero records and the decoded records carry the value to 2^-16 (odd sizes: the plane is then not 16-byte aligned and takes
+    the scalar loads).  The volume-backward tests above run through the one-pass route by default."""
+    import torch.nn.functional as F
+    from flow_supervisor_amd import ops
+    torch.manual_seed(8)
+    lay = ops.VolLayout.get(H, W, nlev)
+    f2 = torch.randn(B, C, H, W, device=DEV)
+
+    def dec(r):
+        w = r.contiguous().view(torch.int16).view(r.shape[0], -1, 2, 32).to(torch.int32) << 16
+        return (w[:, :, 0].view(torch.float32) + w[:, :, 1].view(torch.float32)).reshape(r.shape[0], -1)
+    old = ops.F2CAT_REC
+    try:
+        ops.F2CAT_REC = True
+        one = dec(ops.f2cat_records(f2, lay).view(B * C, -1))
+        ops.F2CAT_REC = False
+        two = dec(ops.f2cat_records(f2, lay).view(B * C, -1))
+    finally:
+        ops.F2CAT_REC = old
+    ref = torch.zeros(B * C, lay.P, device=DEV)
+    lv = f2.reshape(B * C, 1, H, W)
+    for l in range(nlev):
+        if l:
+            lv = F.avg_pool2d(lv, 2, stride=2)
+        h, w = lv.shape[-2:]
+        t = torch.zeros(B * C, lay.th[l] * 4, lay.tw[l] * 4, device=DEV)
+        t[:, :h, :w] = lv[:, 0]
+        t = t.view(B * C, lay.th[l], 4, lay.tw[l], 4).permute(0, 1, 3, 2, 4).reshape(B * C, -1)
+        ref[:, lay.off[l]:lay.off[l] + t.shape[1]] = t
+    close(one, ref, 1e-6, rtol=2e-5, what="one-pass records vs recursive avg_pool2d")
+    close(two, ref, 1e-6, rtol=2e-5, what="two-kernel records vs recursive avg_pool2d")
+    assert ((one == 0) == (ref == 0)).all(), "pad cells are zero records"
+
+
 def test_alt_cuda_corr_several_coordinate_sets():
     """coords [B,N,H1,W1,2] with N > 1 (correlation_kernel.cu:34,59; the C ABI carries N): every set against the oracle's
     restatement of one extension call, and the backward against autograd of that restatement."""
