@@ -77,6 +77,7 @@ SIGNATURES = {
     "fsraft_set_dvol_box": [c_int],
     "fsraft_set_ktile_exact": [c_int],
     "fsraft_set_lookup_policy": [c_int],
+    "fsraft_set_upsample_kernel": [c_int],
     "fsraft_conv_workspace": [c_void_p, c_int64],
     "fsraft_set_arithmetic": [c_int],
     "fsraft_get_arithmetic": [],
@@ -175,6 +176,8 @@ def load():
         lib.fsraft_set_dvol_box(int(os.environ["FSRAFT_DVOL_BOX"]))
     if os.environ.get("FSRAFT_LOOKUP_POLICY") is not None:
         lib.fsraft_set_lookup_policy(int(os.environ["FSRAFT_LOOKUP_POLICY"]))
+    if os.environ.get("FSRAFT_UPSAMPLE_V4") is not None:
+        lib.fsraft_set_upsample_kernel(int(os.environ["FSRAFT_UPSAMPLE_V4"]))
     if os.environ.get("FSRAFT_KTILE_EXACT") is not None:
         lib.fsraft_set_ktile_exact(int(os.environ["FSRAFT_KTILE_EXACT"]))
     arith = os.environ.get("FSRAFT_ARITHMETIC")     # 0: exact fp32 MFMA everywhere; 1 (default): bf16x3 products

@@ -139,6 +139,99 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const flo
   }
 }
 
+// ---- the same two kernels on 16-byte accesses (mask, up, dup, dmask 16-byte aligned).  A workgroup owns 16 neighbouring coarse
+// pixels; 16 lanes share a pixel, a lane holds four neighbouring sub-pixels (sy = sub >> 1, sx = 4 * (sub & 1) ..+3) of all nine
+// taps, so a tap of a pixel is one 256-byte run read by 16 lanes and a wave instruction moves 1 KB.  The softmax stays in
+// registers; the output / dup rows are 32 contiguous bytes per pixel and 512 per workgroup row, no LDS staging.
+__device__ __forceinline__ void softmax9x4(f32x4 (&m)[9]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float mx = m[0][i];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) mx = fmaxf(mx, m[k][i]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { m[k][i] = expf(m[k][i] - mx); s += m[k][i]; }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k][i] *= inv;
+  }
+}
+
+__device__ __forceinline__ void flow_taps(const Flow2& flow, int n, int y, int x, int H, int W, float (&f0)[9], float (&f1)[9]) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+    const int64_t a = n * flow.bs + ((int64_t)yc * W + xc) * flow.ps;
+    const float l0 = flow.p[a], l1 = flow.p[a + flow.cs];            // (address clamped: always loaded)
+    f0[k] = in ? 8.f * l0 : 0.f;
+    f1[k] = in ? 8.f * l1 : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(Flow2 flow, const float* __restrict__ mask, float* __restrict__ up,
+                                                              int H, int W) {
+  const int y = blockIdx.y, n = blockIdx.z;
+  const int xl = threadIdx.x >> 4, sub = threadIdx.x & 15, sy = sub >> 1, sx = (sub & 1) * 4;
+  const int x0 = blockIdx.x * 16 + xl;
+  const bool ok = x0 < W;
+  const int x = ok ? x0 : W - 1;
+  const float* mp = mask + (((int64_t)n * H + y) * W + x) * 576 + sy * 8 + sx;
+  f32x4 m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = gload4(mp + k * 64);
+  float f0[9], f1[9];
+  flow_taps(flow, n, y, x, H, W, f0, f1);
+  softmax9x4(m);
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { o0 += m[k] * f0[k]; o1 += m[k] * f1[k]; }
+  if (!ok) return;
+  const int W8 = 8 * W, H8 = 8 * H;
+  float* o = up + (((int64_t)n * 2) * H8 + 8 * y + sy) * W8 + 8 * x + sx;
+  gstore4(o, o0);
+  gstore4(o + (int64_t)H8 * W8, o1);
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_v4_kernel(Flow2 flow, const float* __restrict__ mask, const float* __restrict__ dup,
+                                                              float* __restrict__ dmask, float* __restrict__ T, int H, int W) {
+  const int y = blockIdx.y, n = blockIdx.z;
+  const int xl = threadIdx.x >> 4, sub = threadIdx.x & 15, sy = sub >> 1, sx = (sub & 1) * 4;
+  const int x0 = blockIdx.x * 16 + xl;
+  const bool ok = x0 < W;
+  const int x = ok ? x0 : W - 1;
+  const int W8 = 8 * W, H8 = 8 * H;
+  const int64_t pix = ((int64_t)n * H + y) * W + x;
+  const float* mp = mask + pix * 576 + sy * 8 + sx;
+  const float* gp = dup + (((int64_t)n * 2) * H8 + 8 * y + sy) * W8 + 8 * x + sx;
+  f32x4 m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = gload4(mp + k * 64);
+  const f32x4 g0 = gload4(gp), g1 = gload4(gp + (int64_t)H8 * W8);
+  float f0[9], f1[9];
+  flow_taps(flow, n, y, x, H, W, f0, f1);
+  softmax9x4(m);
+  f32x4 dot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dot += m[k] * (g0 * f0[k] + g1 * f1[k]);
+  float* dm = dmask + pix * 576 + sy * 8 + sx;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const f32x4 dp = g0 * f0[k] + g1 * f1[k];
+    if (ok) gstore4(dm + k * 64, m[k] * (dp - dot));
+    const f32x4 a = m[k] * g0, b = m[k] * g1;
+    float t0 = (a[0] + a[1]) + (a[2] + a[3]), t1 = (b[0] + b[1]) + (b[2] + b[3]);
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o, 64); t1 += __shfl_xor(t1, o, 64); }
+    if (ok && sub == 0) {
+      T[pix * 18 + k] = t0;
+      T[pix * 18 + 9 + k] = t1;
+    }
+  }
+}
+
 // dflow[n,c,y,x] = 8 * sum_k T[n, y-(ky-1), x-(kx-1), c, k]   (deterministic gather, no atomics)
 __global__ __launch_bounds__(256) void upsample_dflow_kernel(const float* __restrict__ T, float* __restrict__ dflow,
                                                              int N, int H, int W) {
@@ -218,12 +311,18 @@ __global__ __launch_bounds__(256) void upflow8_bwd_kernel(const float* __restric
 
 }  // namespace
 
+int g_upsample_v4 = 1;      // 16-byte kernels (fsraft_set_upsample_kernel; 0: the 4-byte ones, which also take unaligned tensors)
+extern "C" int fsraft_set_upsample_kernel(int v4) { g_upsample_v4 = v4 != 0; return FS_OK; }
+
 // flow element (n,c,pix) at flow[n*flow_bs + c*flow_cs + pix*flow_ps]; mask is [N,H,W,576]; up is [N,2,8H,8W].
 extern "C" int fsraft_upsample_fwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int64_t flow_ps,
                                    const float* mask_nhwc, float* up, int N, int H, int W, hipStream_t stream) {
   if (!flow || !mask_nhwc || !up || N < 1 || H < 1 || W < 1) return FS_ERR_ARG;
   Flow2 f{flow, flow_bs, flow_cs, flow_ps};
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ceil_div(W, 8), H, N), dim3(256), 0, stream, f, mask_nhwc, up, H, W);
+  if (g_upsample_v4 && (((uintptr_t)mask_nhwc | (uintptr_t)up) & 15) == 0)
+    hipLaunchKernelGGL(upsample_fwd_v4_kernel, dim3(ceil_div(W, 16), H, N), dim3(256), 0, stream, f, mask_nhwc, up, H, W);
+  else
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ceil_div(W, 8), H, N), dim3(256), 0, stream, f, mask_nhwc, up, H, W);
   return fs_launch_status();
 }
 
@@ -233,8 +332,11 @@ extern "C" int fsraft_upsample_bwd(const float* flow, int64_t flow_bs, int64_t f
                                    float* scratch, int N, int H, int W, hipStream_t stream) {
   if (!flow || !mask_nhwc || !dup || !dmask_nhwc || !dflow || !scratch || N < 1 || H < 1 || W < 1) return FS_ERR_ARG;
   Flow2 f{flow, flow_bs, flow_cs, flow_ps};
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ceil_div(W, 8), H, N), dim3(256), 0, stream, f, mask_nhwc, dup,
-                     dmask_nhwc, scratch, H, W);
+  if (g_upsample_v4 && (((uintptr_t)mask_nhwc | (uintptr_t)dup | (uintptr_t)dmask_nhwc) & 15) == 0)
+    hipLaunchKernelGGL(upsample_bwd_v4_kernel, dim3(ceil_div(W, 16), H, N), dim3(256), 0, stream, f, mask_nhwc, dup, dmask_nhwc, scratch, H, W);
+  else
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ceil_div(W, 8), H, N), dim3(256), 0, stream, f, mask_nhwc, dup,
+                       dmask_nhwc, scratch, H, W);
   const int64_t total = (int64_t)N * 2 * H * W;
   hipLaunchKernelGGL(upsample_dflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, scratch, dflow,
                      N, H, W);

@@ -364,6 +364,32 @@ def test_convex_upsample_vs_reference():
     close(mask.grad, g["dmask"], 1e-5, what="dmask")
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 5, 7), (2, 6, 16), (1, 9, 37), (3, 4, 1)])
+def test_convex_upsample_ragged_widths_both_kernels_vs_oracle(N, H, W):
+    """raft.py:72-83 at widths that are not multiples of a workgroup's 16 (or 8) pixels, on the 16-byte kernels (default) and
+    the 4-byte ones (fsraft_set_upsample_kernel(0)): forward and both gradients against the oracle's restatement."""
+    from flow_supervisor_amd import _lib
+    from flow_supervisor_amd.core.raft import RAFT
+    lib = _lib.load()
+    model = RAFT(ns(False)).to(DEV)
+    fc = rand_tensor((N, 2, H, W), 421, 2.0); mc = rand_tensor((N, 576, H, W), 422, 1.5)
+    fr, mr = fc.clone().requires_grad_(True), mc.clone().requires_grad_(True)
+    ur = O.upsample_flow(fr, mr)
+    w = rand_tensor(tuple(ur.shape), 423)
+    (ur * w).sum().backward()
+    try:
+        for v4 in (1, 0):
+            assert lib.fsraft_set_upsample_kernel(v4) == 0
+            f = fc.to(DEV).requires_grad_(True); m = mc.to(DEV).requires_grad_(True)
+            up = model.upsample_flow(f, m)
+            close(up, ur, 1e-5, what=f"up (v4={v4})")
+            (up * w.to(DEV)).sum().backward()
+            close(f.grad, fr.grad, 1e-5, what=f"dflow (v4={v4})")
+            close(m.grad, mr.grad, 1e-5, what=f"dmask (v4={v4})")
+    finally:
+        lib.fsraft_set_upsample_kernel(1)
+
+
 def test_upflow8_and_helpers():
     from flow_supervisor_amd.core.utils.utils import InputPadder, coords_grid, upflow8
     h = load("helpers")
