@@ -553,11 +553,18 @@ __global__ __launch_bounds__(KT_NQ) void corr_ktiles_mark_kernel(KtArgs a, VolLa
     int mnx[4], mny[4], mxx[4], mxy[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) { mnx[l] = mny[l] = 0x7fffffff; mxx[l] = mxy[l] = -0x7fffffff; }
+    // all lookups' coordinates are requested before the first one is used (fused with the marking, every lookup cost one
+    // round trip: 24 us per launch for 12 lookups)
+    float cxs[DV_MAXN], cys[DV_MAXN];
+#pragma unroll
+    for (int t = 0; t < DV_MAXN; ++t) {
+      cxs[t] = cys[t] = 0.f;
+      if (t < a.n) query_xy(a.co[t], bq, pix, grid_w, cxs[t], cys[t]);
+    }
 #pragma unroll
     for (int t = 0; t < DV_MAXN; ++t)
       if (t < a.n) {
-        float cx, cy;
-        query_xy(a.co[t], bq, pix, grid_w, cx, cy);
+        const float cx = cxs[t], cy = cys[t];
 #pragma unroll
         for (int l = 0; l < 4; ++l)
           if (l < nlev) {

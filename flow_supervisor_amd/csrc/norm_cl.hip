@@ -275,11 +275,22 @@ __global__ void bn_fold_bwd_kernel(const float* __restrict__ part, int R, int C,
                                    float* __restrict__ dcbias) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  // (the per-channel constants and eight rows of both sums are requested before the first add: rolled, the loop was a chain of
+  //  R dependent round trips to L2 -- 11 us per launch for R = 32, fifteen launches per step)
+  const float rsc = rs[c], rmcc = rmc[c], scc = scale[c];
   float s0 = 0.f, s1 = 0.f;
-  for (int r = 0; r < R; ++r) { s0 += part[(int64_t)r * C + c]; s1 += part[((int64_t)R + r) * C + c]; }
-  dweight[c] = rs[c] * (s1 - rmc[c] * s0);
+  int r = 0;
+  for (; r + 8 <= R; r += 8) {
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = part[(int64_t)(r + i) * C + c]; b[i] = part[((int64_t)R + r + i) * C + c]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0 += a[i]; s1 += b[i]; }
+  }
+  for (; r < R; ++r) { s0 += part[(int64_t)r * C + c]; s1 += part[((int64_t)R + r) * C + c]; }
+  dweight[c] = rsc * (s1 - rmcc * s0);
   dbias[c] = s0;
-  if (dcbias) dcbias[c] = scale[c] * s0;
+  if (dcbias) dcbias[c] = scc * s0;
 }
 }  // namespace
 

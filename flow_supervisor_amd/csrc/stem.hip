@@ -306,6 +306,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
     const int n = e / 147, r = e - n * 147, c = r / 49, ky = (r % 49) / 7, kx = r % 7;
     const float* p = scratch + n * ST_K + (c * 8 + ky) * 8 + kx;
     int i = pr;
+    for (; i + 60 < slots; i += 64) {          // sixteen partial matrices per trip, all requested before the first add (same order of adds)
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = p[(int64_t)(i + 4 * j) * 64 * ST_K];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+    }
     for (; i + 12 < slots; i += 16) {
       s0 += p[(int64_t)i * 64 * ST_K];
       s1 += p[(int64_t)(i + 4) * 64 * ST_K];

@@ -79,7 +79,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// dmask (channels-last, same layout as mask) and T[n,y,x,c,k] = sum_s p_k[s] * dup[c][s]
+// dmask (channels-last, same layout as mask) and T[n,c,k,y,x] = sum_s p_k[s] * dup[c][s]  (planar: upsample_dflow_kernel gathers along x)
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const float* __restrict__ mask,
                                                            const float* __restrict__ dup, float* __restrict__ dmask,
                                                            float* __restrict__ T, int H, int W) {
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const flo
     const int xl = wave * 2 + pp, x = xb + xl;
     if (x >= W) continue;
     const int64_t pix = ((int64_t)n * H + y) * W + x;
+    const int64_t HWp = (int64_t)H * W, pl = (int64_t)y * W + x;
     const float* mp = mask + pix * 576 + lane;
     float m[9], p[9];
 #pragma unroll
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const flo
       const float t0 = wave_sum(p[k] * g0);
       const float t1 = wave_sum(p[k] * g1);
       if (lane == 0) {
-        T[pix * 18 + k] = t0;
-        T[pix * 18 + 9 + k] = t1;
+        T[((int64_t)n * 18 + k) * HWp + pl] = t0;
+        T[((int64_t)n * 18 + 9 + k) * HWp + pl] = t1;
       }
     }
   }
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_v4_kernel(Flow2 flow, const 
   const int x = ok ? x0 : W - 1;
   const int W8 = 8 * W, H8 = 8 * H;
   const int64_t pix = ((int64_t)n * H + y) * W + x;
+  const int64_t HWp = (int64_t)H * W, pl = (int64_t)y * W + x;
   const float* mp = mask + pix * 576 + sy * 8 + sx;
   const float* gp = dup + (((int64_t)n * 2) * H8 + 8 * y + sy) * W8 + 8 * x + sx;
   f32x4 m[9];
@@ -226,13 +228,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_v4_kernel(Flow2 flow, const 
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o, 64); t1 += __shfl_xor(t1, o, 64); }
     if (ok && sub == 0) {
-      T[pix * 18 + k] = t0;
-      T[pix * 18 + 9 + k] = t1;
+      T[((int64_t)n * 18 + k) * HWp + pl] = t0;
+      T[((int64_t)n * 18 + 9 + k) * HWp + pl] = t1;
     }
   }
 }
 
-// dflow[n,c,y,x] = 8 * sum_k T[n, y-(ky-1), x-(kx-1), c, k]   (deterministic gather, no atomics)
+// dflow[n,c,y,x] = 8 * sum_k T[n, c, k, y-(ky-1), x-(kx-1)]   (deterministic gather, no atomics)
 __global__ __launch_bounds__(256) void upsample_dflow_kernel(const float* __restrict__ T, float* __restrict__ dflow,
                                                              int N, int H, int W) {
   const int64_t total = (int64_t)N * 2 * H * W;
@@ -242,12 +244,17 @@ __global__ __launch_bounds__(256) void upsample_dflow_kernel(const float* __rest
   const int y = (int)((e / W) % H);
   const int c = (int)((e / ((int64_t)W * H)) % 2);
   const int n = (int)(e / ((int64_t)2 * W * H));
+  float v[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {            // (addresses clamped, loads unconditional: `in ? *p : 0` is a branch per load, i.e. nine round trips)
+    const int yy = y - (k / 3 - 1), xx = x - (k % 3 - 1);
+    const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+    const float t = T[((int64_t)n * 18 + c * 9 + k) * ((int64_t)H * W) + yc * W + xc];
+    v[k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? t : 0.f;
+  }
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int yy = y - (k / 3 - 1), xx = x - (k % 3 - 1);
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += T[(((int64_t)n * H + yy) * W + xx) * 18 + c * 9 + k];
-  }
+  for (int k = 0; k < 9; ++k) s += v[k];
   dflow[e] = 8.f * s;
 }
 
