@@ -534,6 +534,24 @@ __device__ __forceinline__ void kt_mark(unsigned* bits, int i) {
   if (!(bits[i >> 5] & m)) atomicOr(bits + (i >> 5), m);       // (most marks are already set: the read is a broadcast)
 }
 
+// bits [i0, i1] of a bitmap in LDS: one read (+ one atomic where something is missing) per word instead of per bit
+__device__ __forceinline__ void kt_mark_range(unsigned* bits, int i0, int i1) {
+  for (int w = i0 >> 5; w <= (i1 >> 5); ++w) {
+    const int lo = w == (i0 >> 5) ? (i0 & 31) : 0, hi = w == (i1 >> 5) ? (i1 & 31) : 31;
+    const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+    if ((bits[w] & m) != m) atomicOr(bits + w, m);
+  }
+}
+// the cell rectangle [x0, x1] x [y0, y1] of level l: a row of 4x4-cell tiles is a run of consecutive cells, i.e. of consecutive
+// records (32 cells) and cell tiles (KT_MC cells), so every tile row is one range in each bitmap
+__device__ __forceinline__ void kt_mark_rect(unsigned* rb, unsigned* mbw, const VolLayout& L, int l, int x0, int x1, int y0, int y1, int mc) {
+  for (int ty = y0 >> 2; ty <= (y1 >> 2); ++ty) {
+    const int c0 = L.off[l] + (ty * L.tw[l] + (x0 >> 2)) * 16, c1 = L.off[l] + (ty * L.tw[l] + (x1 >> 2)) * 16 + 15;
+    kt_mark_range(rb, c0 >> 5, c1 >> 5);
+    kt_mark_range(mbw, c0 / mc, c1 / mc);
+  }
+}
+
 template <int EXACT>      // levels below EXACT: every lookup's window marked on its own; from EXACT on: the bounding rectangle of all
 __global__ __launch_bounds__(KT_NQ) void corr_ktiles_mark_kernel(KtArgs a, VolLayout L, int HW, int R, int grid_w, int* __restrict__ nt_list,
                                                                  int* __restrict__ nt_count, int nt_stride, unsigned* __restrict__ tn_bits,
@@ -572,13 +590,7 @@ __global__ __launch_bounds__(KT_NQ) void corr_ktiles_mark_kernel(KtArgs a, VolLa
             if (l < EXACT) {
               const int x0 = max(q.wx0, 0), x1 = min(q.wx0 + 2 * R + 1, L.w[l] - 1);
               const int y0 = max(q.wy0, 0), y1 = min(q.wy0 + 2 * R + 1, L.h[l] - 1);
-              if (x0 <= x1 && y0 <= y1)
-                for (int ty = y0 >> 2; ty <= (y1 >> 2); ++ty)
-                  for (int tx = x0 >> 2; tx <= (x1 >> 2); ++tx) {
-                    const int cell = L.off[l] + (ty * L.tw[l] + tx) * 16;
-                    kt_mark(rb, cell >> 5);
-                    kt_mark(mb[tid >> 5], cell / KT_MC);
-                  }
+              if (x0 <= x1 && y0 <= y1) kt_mark_rect(rb, mb[tid >> 5], L, l, x0, x1, y0, y1, KT_MC);
             } else {
               mnx[l] = min(mnx[l], q.wx0); mxx[l] = max(mxx[l], q.wx0);
               mny[l] = min(mny[l], q.wy0); mxy[l] = max(mxy[l], q.wy0);
@@ -591,12 +603,7 @@ __global__ __launch_bounds__(KT_NQ) void corr_ktiles_mark_kernel(KtArgs a, VolLa
         const int x0 = max(mnx[l], 0), x1 = min(mxx[l] + 2 * R + 1, L.w[l] - 1);
         const int y0 = max(mny[l], 0), y1 = min(mxy[l] + 2 * R + 1, L.h[l] - 1);
         if (x0 > x1 || y0 > y1) continue;
-        for (int ty = y0 >> 2; ty <= (y1 >> 2); ++ty)
-          for (int tx = x0 >> 2; tx <= (x1 >> 2); ++tx) {
-            const int cell = L.off[l] + (ty * L.tw[l] + tx) * 16;
-            kt_mark(rb, cell >> 5);
-            kt_mark(mb[tid >> 5], cell / KT_MC);
-          }
+        kt_mark_rect(rb, mb[tid >> 5], L, l, x0, x1, y0, y1, KT_MC);
       }
   }
   __syncthreads();
