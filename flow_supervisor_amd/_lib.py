@@ -65,6 +65,7 @@ SIGNATURES = {
     "fsraft_upflow8_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_ktot": [_IP, c_int, c_int, c_int],
     "fsraft_conv_forward": [POINTER(ConvDesc), _S],
+    "fsraft_conv_forward_stats": [POINTER(ConvDesc), c_void_p, c_void_p, c_int, POINTER(c_int), _S],
     "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_wgrad_multi": [_PP, c_int, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _S],
@@ -119,7 +120,7 @@ SIGNATURES = {
     "fsraft_get_tuning": [c_int],
     "fsraft_space_to_depth2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_forward_interpolate": [c_void_p, c_void_p, c_int, c_int, _S],
-    "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, _S],
+    "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, _S],
     "fsraft_inorm_relu_cl_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, _S],
     "fsraft_affine_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, _S],

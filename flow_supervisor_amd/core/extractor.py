@@ -139,7 +139,7 @@ class _InstNormReluCL(torch.autograd.Function):
     (and their backward) cost no extra trip over the tensor."""
 
     @staticmethod
-    def forward(ctx, x, eps, relu, res=None, link=None):
+    def forward(ctx, x, eps, relu, res=None, link=None, sums=None):
         from .. import _lib as L
         ctx.in_cl = _is_cl(x)
         ctx.link = link
@@ -148,10 +148,12 @@ class _InstNormReluCL(torch.autograd.Function):
         if res is not None:
             res = _as_cl(res)
         y = torch.empty_like(x)                                   # preserves channels_last
-        acc = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (norm_cl.hip)
+        # partial rows (norm_cl.hip) -- already filled when the convolution that produced x carried the sums in its epilogue
+        have = sums is not None and sums.acc is not None and tuple(sums.acc.shape) == (2, N * 8, C)
+        acc = sums.acc if have else ops.zeros(2, N * 8, C, device=x.device)
         stats = torch.empty(N, C, 2, device=x.device, dtype=torch.float32)
         L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W,
-                                                  C, float(eps), int(relu), L.stream()), "inorm_relu_cl_fwd")
+                                                  C, float(eps), int(relu), int(have), L.stream()), "inorm_relu_cl_fwd")
         ctx.fused = res is not None
         ctx.save_for_backward(x, stats, y if ctx.fused else None)
         ctx.relu = relu
@@ -170,7 +172,7 @@ class _InstNormReluCL(torch.autograd.Function):
                                                   L.ptr(dres), N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
         if ctx.link is not None:
             ctx.link.dres = dres
-        return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None     # an NCHW producer (MIOpen) gets an NCHW gradient
+        return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
 
 
 class _FrozenBNReluCL(torch.autograd.Function):
@@ -312,15 +314,20 @@ class _ConvCL(torch.autograd.Function):
     The storage of a channels_last [B,C,H,W] tensor IS the kernels' [B,H,W,C] layout, so nothing is transposed."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packs, link=None):
+    def forward(ctx, x, weight, bias, packs, link=None, sums=None):
         from .. import ops
         ctx.link = link if _is_cl(x) else None       # (a converted copy of x is not the tensor the shortcut gradient belongs to)
         x = _as_cl(x)
         B, C, H, W = x.shape
         N, _, KH, KW = weight.shape
         out = torch.empty(B, H, W, N, device=x.device, dtype=torch.float32)
-        ops.conv_forward([ops.V(x.permute(0, 2, 3, 1), C)], packs[1], bias, B, H, W, KH, KW, N, [ops.Dst.nhwc(out)], wpk_split=packs[2],
-                         wpk_frag=packs[5])
+        # sums (a _NormSums holder): the InstanceNorm behind this convolution wants the per-image column sums of the result; the
+        # kernel adds them up in its epilogue where it can, and the norm then skips its own statistics pass
+        acc = ops.zeros(2, B * 8, N, device=x.device) if (sums is not None and bias is None and STATS_IN_EPILOGUE) else None
+        carried = ops.conv_forward([ops.V(x.permute(0, 2, 3, 1), C)], packs[1], bias, B, H, W, KH, KW, N, [ops.Dst.nhwc(out)],
+                                   wpk_split=packs[2], wpk_frag=packs[5], stats=acc)
+        if sums is not None:
+            sums.acc = acc if carried else None
         ctx.save_for_backward(x, weight)
         ctx.packs = packs
         ctx.has_bias = bias is not None
@@ -353,7 +360,7 @@ class _ConvCL(torch.autograd.Function):
             db = ops.zeros(N, device=x.device) if want_b else None
             ops.conv_wgrad(gv, [ops.V(x.permute(0, 2, 3, 1), C)], dwpk, B, H, W, KH, KW, dbias=db)
             dw = ops.unpack_weight_grad(dwpk, tuple(weight.shape), [C])
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _StemFn(torch.autograd.Function):
@@ -382,7 +389,19 @@ def _stem_ok(conv, x):
             and x.shape[2] >= 7 and x.shape[3] >= 7)
 
 
-def _conv(conv, x, bias, link=None, stem_cl=False):
+STATS_IN_EPILOGUE = __import__("os").environ.get("FSRAFT_NORM_STATS_EPILOGUE", "1") != "0"   # 0: every InstanceNorm runs its own statistics pass
+
+
+class _NormSums:
+    """Hand-over between a convolution and the InstanceNorm behind it: `acc` = the [2, B * 8, C] partial rows of the
+    result's column sums / sums of squares when the convolution's kernel accumulated them in its epilogue, else None."""
+    __slots__ = ("acc",)
+
+    def __init__(self):
+        self.acc = None
+
+
+def _conv(conv, x, bias, link=None, stem_cl=False, sums=None):
     """conv(x) with the given bias (None: without).  A channels_last fp32 input of a stride-1 1x1 / 3x3 convolution takes
     the fsraft kernels; anything else is MIOpen on an NCHW tensor (its NHWC fp32 kernels are far slower than its NCHW
     ones on gfx950 -- the backward-weights one by two orders of magnitude -- so a channels_last input is converted)."""
@@ -390,7 +409,7 @@ def _conv(conv, x, bias, link=None, stem_cl=False):
     if (_is_cl(x) and x.is_cuda and x.dtype == torch.float32 and k in ((3, 3), (1, 1)) and conv.stride == (1, 1)
             and conv.padding == (k[0] // 2, k[1] // 2) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.padding_mode == "zeros" and x.shape[1] % 4 == 0 and not torch.is_autocast_enabled()):
-        return _ConvCL.apply(x, conv.weight, bias, _weight_packs(conv), link)
+        return _ConvCL.apply(x, conv.weight, bias, _weight_packs(conv), link, sums)
     if stem_cl and bias is None and _stem_ok(conv, x):
         return _StemFn.apply(x, conv.weight)
     return F.conv2d(_ToNCHW.apply(x) if _is_cl(x) else x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
@@ -530,9 +549,10 @@ def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=N
     fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
     if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
         if fused:
-            y = _conv(conv, x, None, link, stem_cl=to_cl)
+            sums = _NormSums() if (to_cl or _is_cl(x)) else None
+            y = _conv(conv, x, None, link, stem_cl=to_cl, sums=sums)
             if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
-                return _InstNormReluCL.apply(y, norm.eps, relu, res, res_link)
+                return _InstNormReluCL.apply(y, norm.eps, relu, res, res_link, sums)
             y = _InstNormRelu.apply(y, norm.eps, relu)
             return y if res is None else F.relu(res + y)
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)

@@ -48,6 +48,9 @@ struct ConvArgs {
   // range (j < maskc) is zeroed where rmask[m*ldmask + j] <= 0 -- the data gradient of a layer whose input came
   // out of a ReLU leaves the kernel already masked, instead of a separate pass over the tensor.
   const float* rmask[3]; int ldmask[3]; int maskc[3];
+  // InstanceNorm statistics of the OUTPUT from the epilogue (kernels whose tiles lie inside one image: conv_patch.inc, the halo
+  // kernel): st_sum / st_sq [B * st_slots][N] += column sums of the tile's results and of their squares (fsraft_conv_forward_stats)
+  float* st_sum; float* st_sq; int st_slots;
   int swz;                       // 1: XCD-aware workgroup -> tile mapping (see tile_of_block)
   int ksplit;                    // > 1: blockIdx.z owns a slice of the k-tiles and parks its RAW partial tile in a workspace (dst[0],
                                  // rows z * M + m): the first pass of the split-K route for small M (conv_finish_kernel is the second)
@@ -455,8 +458,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
   (void)owner;
   const int c4 = threadIdx.x % C4, rsub = threadIdx.x / C4;
   const int n = n0 + c4 * 4;
-  if (n >= a.N) return;
+  const bool stats = PATCH && EPI == EPI_PLAIN && a.st_sum != nullptr;      // (workgroup-uniform: the barriers below are safe)
+  if (n >= a.N && !stats) return;
   if (EPI == EPI_PLAIN) {
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+    if (n < a.N) {
     int di = 0;
     if (a.ndst > 1 && n >= a.dst[1].n0) di = 1;
     if (a.ndst > 2 && n >= a.dst[2].n0) di = 2;
@@ -480,6 +486,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
         if (a.relu) v[i] = fmaxf(v[i], 0.f);
       }
       if (nv == 4) {
+        if (stats) { ssum += v; ssq += v * v; }
         if (dacc) {
           const f32x4 old = gload4(o);
 #pragma unroll
@@ -496,6 +503,26 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
           float r = dacc ? gload1(o + i) + v[i] : v[i];
           if (mk && n - dn0 + i < mkc && gload1(mk + (int64_t)m * ldm + (n - dn0) + i) <= 0.f) r = 0.f;
           gstore1(o + i, r);
+        }
+      }
+    }
+    }
+    if constexpr (PATCH) {
+      if (stats) {
+        // column sums of the tile: every thread summed its rows of its four columns above; the RPP row groups meet in LDS
+        // (the parked tile is no longer needed) and one thread per column adds the workgroup's share to the slot row of its image
+        __syncthreads();
+        float* red = tile;
+        *reinterpret_cast<f32x4*>(red + (rsub * Cfg::BN) + c4 * 4) = ssum;
+        *reinterpret_cast<f32x4*>(red + ((RPP + rsub) * Cfg::BN) + c4 * 4) = ssq;
+        __syncthreads();
+        if (threadIdx.x < Cfg::BN && n0 + (int)threadIdx.x < a.N) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll 4
+          for (int g = 0; g < RPP; ++g) { t1 += red[g * Cfg::BN + threadIdx.x]; t2 += red[(RPP + g) * Cfg::BN + threadIdx.x]; }
+          const int64_t o = ((int64_t)pb * a.st_slots + (int)(blockIdx.y % (unsigned)a.st_slots)) * a.N + n0 + threadIdx.x;
+          atomicAdd(a.st_sum + o, t1);
+          atomicAdd(a.st_sq + o, t2);
         }
       }
     }
@@ -730,6 +757,7 @@ struct HaloArgs {
   float* out; int64_t obs, ops;       // batch / pixel strides of the destination (floats), channels contiguous
   int N, B, H, W, relu;
   int acc;                            // out += result (the data gradient of a residual unit's first convolution adds to the shortcut gradient)
+  float* st_sum; float* st_sq; int st_slots;   // as in ConvArgs (NULL: none)
 };
 
 template <int CG, int TN>
@@ -836,6 +864,37 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
       }
   }
 
+  if (a.st_sum) {
+    // InstanceNorm statistics of the result: a lane owns column n of 2 x 16 pixels per nt; the two lane halves and the two
+    // pixel-row waves (wm) meet through shuffles / LDS (the patch is no longer needed), one atomic pair per column and workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);          // [wm][2][64 * TN]
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int py = y0 + 2 * wm + mt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float v = (py < a.H && px < a.W) ? acc[mt][nt][r] : 0.f;
+          s1 += v; s2 += v * v;
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      const int col = wn * (32 * TN) + nt * 32 + l31;
+      if (lh == 0) { red[(wm * 2 + 0) * (64 * TN) + col] = s1; red[(wm * 2 + 1) * (64 * TN) + col] = s2; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 64 * TN && (int)threadIdx.x < a.N) {
+      const int col = threadIdx.x;
+      const int slot = (int)((blockIdx.y * gridDim.x + blockIdx.x) % (unsigned)a.st_slots);
+      const int64_t o = ((int64_t)b * a.st_slots + slot) * a.N + col;
+      atomicAdd(a.st_sum + o, red[col] + red[2 * (64 * TN) + col]);
+      atomicAdd(a.st_sq + o, red[(64 * TN) + col] + red[3 * (64 * TN) + col]);
+    }
+  }
   float* outb = a.out + (int64_t)b * a.obs;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -1872,8 +1931,18 @@ extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
   return conv_ktot(srcC, nsrc, KH * KW);
 }
 
+namespace {
+// fsraft_conv_forward_stats parks its request here for the call it wraps (same thread); the launch sites whose kernels can
+// carry the statistics pick it up and say so
+struct StatReq { float* sum; float* sq; int slots; bool done; };
+thread_local StatReq t_stat{nullptr, nullptr, 0, false};
+}  // namespace
+
 extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream) {
   if (!d || d->nsrc < 1 || d->nsrc > 3 || d->ndst < 1 || d->ndst > 3 || !d->wpk || d->N < 1) return FS_ERR_ARG;
+  // (statistics of the raw result only: one destination, no bias / ReLU / scale / mask / accumulation in the epilogue)
+  const bool want_stats = t_stat.sum != nullptr && d->epi == EPI_PLAIN && d->ndst == 1 && !d->relu && d->alpha == 1.0f && !d->dst_acc[0] &&
+                          !d->rmask[0] && !d->bias && d->dst_n0[0] == 0 && d->N % 4 == 0;
   ConvArgs a{};
   for (int s = 0; s < 3; ++s) {
     a.src[s] = Src{s < d->nsrc ? d->src[s] : d->src[0], s < d->nsrc ? d->srcC[s] : 0, s < d->nsrc ? d->srcld[s] : 4};
@@ -1907,8 +1976,9 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
       d->N > 32 && d->N <= 64 && (int64_t)d->B * d->H * d->W >= g_conv_patch_min_m) {
     ConvArgs p = a;
     p.wpk = d->wpk_split;
+    if (want_stats) { p.st_sum = t_stat.sum; p.st_sq = t_stat.sq; p.st_slots = t_stat.slots; }
     const int rc = launch_conv_patch(p, d->epi, stream);
-    if (rc >= 0) return rc;
+    if (rc >= 0) { t_stat.done = want_stats; return rc; }
   }
   if (g_conv_halo && g_conv_split == 1 && d->wpk_frag && d->epi == EPI_PLAIN && d->nsrc == 1 && d->KH == 3 && d->KW == 3 &&
       a.PH == 1 && a.PW == 1 &&
@@ -1916,13 +1986,16 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
       d->dst_cs[0] == 1 && d->dst_n0[0] == 0 && !(d->dst_acc[0] && d->relu) && !a.rmask[0] && d->alpha == 1.0f &&
       (int64_t)d->B * d->H * d->W >= g_conv_halo_min_m && (int64_t)d->H * d->W * d->srcld[0] * 4 < 0x7fffffff) {
     HaloArgs h{d->src[0], d->srcld[0], d->srcC[0], reinterpret_cast<const char*>(d->wpk_frag), d->bias,
-               d->dst[0], d->dst_bs[0], d->dst_ps[0], d->N, d->B, d->H, d->W, d->relu, d->dst_acc[0]};
+               d->dst[0], d->dst_bs[0], d->dst_ps[0], d->N, d->B, d->H, d->W, d->relu, d->dst_acc[0], nullptr, nullptr, 0};
+    bool halo_stats = false;
     // Measured (scripts/conv_micro.py, halo on / off): 64 -> 64 at 8x220x512 238 vs 442 us.  With three or four channel
     // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
     // GEMM (96 -> 96 at 8x110x256: 249 vs 165 us; 128 -> 128 at 8x55x128: 93 vs 65 us), so only two-group layers come here.
 #ifdef FSRAFT_EXPERIMENTS
     if (g_conv_c64 && d->srcC[0] == 64 && d->N == 64 && (int64_t)d->B * d->H * d->W >= g_conv_c64) return launch_conv_c64(h, stream);
 #endif
+    if (want_stats) { h.st_sum = t_stat.sum; h.st_sq = t_stat.sq; h.st_slots = t_stat.slots; halo_stats = true; }
+    t_stat.done = halo_stats;
     return d->N > 64 ? launch_halo<2, 2>(h, stream) : launch_halo<2, 1>(h, stream);
   }
 #ifdef FSRAFT_EXPERIMENTS
@@ -1955,8 +2028,10 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // fallback for shapes the k-tile table cannot describe.
     const bool narrow = g_conv_buf != 0 || (int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 400;
     if (g_conv_patch && g_conv_split == 1 && d->KH * d->KW > 1 && d->N > 64 && M >= g_conv_patch_min_m) {
-      const int rc = launch_conv_patch(a, d->epi, stream);
-      if (rc >= 0) return rc;
+      ConvArgs p = a;
+      if (want_stats) { p.st_sum = t_stat.sum; p.st_sq = t_stat.sq; p.st_slots = t_stat.slots; }
+      const int rc = launch_conv_patch(p, d->epi, stream);
+      if (rc >= 0) { t_stat.done = want_stats; return rc; }
     }
     if (g_conv_split == 5 || (g_conv_split == 1 && g_conv_n256 && d->N >= 256 &&
                               ceil_div(d->N, 256) * 256 <= ceil_div(d->N, 128) * 128))
@@ -1986,6 +2061,20 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   if (g_conv_tile == 1) return launch_conv<Cfg128>(a, d->epi, stream);
   if ((int64_t)ceil_div(d->N, 128) * ceil_div(M, 128) < 512) return launch_conv<CfgM64>(a, d->epi, stream);
   return launch_conv<Cfg128>(a, d->epi, stream);
+}
+
+// fsraft_conv_forward whose kernel, where it can, also accumulates the per-image column sums of its result and of its squares
+// (the statistics the InstanceNorm behind the convolution needs: fsraft_inorm_relu_cl_fwd with have_sums = 1 then skips its
+// own pass over the tensor).  sum, sq: [B * slots][N] fp32, ZERO on entry (the rows of one image are added up by the consumer);
+// *done = 1 if the launch carried them, 0 if the caller has to compute them (kernels whose tiles straddle images, epilogues
+// with a bias / ReLU / mask).
+extern "C" int fsraft_conv_forward_stats(const fsraft_conv_desc* d, float* sum, float* sq, int slots, int* done, hipStream_t stream) {
+  if (!sum || !sq || slots < 1 || !done) return FS_ERR_ARG;
+  t_stat = StatReq{sum, sq, slots, false};
+  const int rc = fsraft_conv_forward(d, stream);
+  *done = (rc == FS_OK && t_stat.done) ? 1 : 0;
+  t_stat = StatReq{nullptr, nullptr, 0, false};
+  return rc;
 }
 
 #ifdef FSRAFT_ABLATE

@@ -216,11 +216,12 @@ extern "C" int fsraft_set_norm_blocks(int target_workgroups) {     // tuning hoo
 // x, y: [B][HW][C].  sums / sumsq: [B * 8][C] partial-row scratch that must be ZERO on entry; stats: [B][C][2] = (mean, rstd) out.
 // res (nullable, [B][HW][C]): fused residual unit, y = relu(res + relu?(norm(x))).
 extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B,
-                                        int HW, int C, float eps, int relu, hipStream_t s) {
+                                        int HW, int C, float eps, int relu, int have_sums, hipStream_t s) {
   if (!x || !y || !sums || !sumsq || !stats || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
-  hipLaunchKernelGGL(cl_stats_kernel, grid, dim3(256), 0, s, x, sums, sumsq, HW, C, ppw);
+  // have_sums: the producing convolution already accumulated the partial rows (fsraft_conv_forward_stats): no pass of our own
+  if (!have_sums) hipLaunchKernelGGL(cl_stats_kernel, grid, dim3(256), 0, s, x, sums, sumsq, HW, C, ppw);
   hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw, res);
   return fs_launch_status();
 }

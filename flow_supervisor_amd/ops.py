@@ -1141,9 +1141,11 @@ def _conv_workspace(device, pixels):
 
 
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
-                 aux1=None, aux2=None, hid=0, wpk_split=None, pre=None, wpk_frag=None, pad=None):
+                 aux1=None, aux2=None, hid=0, wpk_split=None, pre=None, wpk_frag=None, pad=None, stats=None):
     """srcs: list of V (concatenated along channels).  dsts: list of Dst.
-    GRU epilogues (epi 2: z|r, epi 3: q) take h, z, aux buffers as [B,H,W,ld] tensors."""
+    GRU epilogues (epi 2: z|r, epi 3: q) take h, z, aux buffers as [B,H,W,ld] tensors.
+    stats: a zeroed [2, B * 8, N] tensor -> the kernel adds the per-image column sums of its result and of their squares to it
+    where it can (fsraft_conv_forward_stats); returns True if it did (False / None otherwise)."""
     d = L.ConvDesc()
     for i, v in enumerate(srcs):
         d.src[i] = v.ptr; d.srcC[i] = v.C; d.srcld[i] = v.ld
@@ -1179,10 +1181,18 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     _conv_workspace(dsts[0].t.device, B * H * W)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(_lib().fsraft_conv_forward(ctypes.byref(d), L.stream()), "conv_forward")
+    carried = None
+    if stats is not None:
+        done = ctypes.c_int(0)
+        L.check(_lib().fsraft_conv_forward_stats(ctypes.byref(d), L.ptr(stats[0]), L.ptr(stats[1]), stats.shape[1] // B, ctypes.byref(done),
+                                                 L.stream()), "conv_forward_stats")
+        carried = bool(done.value)
+    else:
+        L.check(_lib().fsraft_conv_forward(ctypes.byref(d), L.stream()), "conv_forward")
     if t:
         cin = sum(v.C for v in srcs)
         t.end("conv_igemm", e0, 2.0 * B * H * W * N * cin * KH * KW, 4.0 * B * H * W * (cin + N))
+    return carried
 
 
 def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW, dbias=None):

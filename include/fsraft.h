@@ -187,6 +187,13 @@ typedef struct fsraft_conv_desc {
 
 int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);
 int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream);
+/* The same convolution; where the chosen kernel's tiles lie inside one image (the resident-patch kernels) and the epilogue is
+ * the raw result (one destination, no bias / ReLU / scale / mask / accumulation) it also adds the per-image column sums of the
+ * result and of its squares to sum / sq [B * slots][N] (fp32, ZERO on entry; workgroups spread over the `slots` rows of their
+ * image) -- the statistics of the InstanceNorm2d that follows the convolution in pytorch/core/extractor.py:13-57, 118-170 --
+ * and sets *done = 1; *done = 0: not carried, the caller computes them.  Pass the buffers to fsraft_inorm_relu_cl_fwd
+ * (slots = 8, have_sums = *done). */
+int fsraft_conv_forward_stats(const fsraft_conv_desc* d, float* sum, float* sq, int slots, int* done, hipStream_t stream);
 /* dwpk[Cout][Ktot] += dY^T im2col(src);  dbias (nullable): dbias[co] += sum over pixels of dY[:, co] */
 int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
                       const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W, int KH, int KW,
@@ -349,8 +356,10 @@ int fsraft_forward_interpolate(const float* flow, float* out, int H, int W, hipS
  * Fused residual unit (pytorch/core/extractor.py:43-56, "return self.relu(x+y)"): res != NULL makes the forward write
  * y = relu(res + relu?(norm(x))); the backward then takes out = that y and writes the shortcut's gradient g * (out > 0)
  * to dres before continuing into the norm branch (out and dres both NULL: plain norm + ReLU). */
+/* have_sums != 0: sums / sumsq already hold the partial rows -- accumulated by the convolution that produced x
+ * (fsraft_conv_forward_stats, 8 slots) -- and the statistics pass over x is skipped. */
 int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B, int HW,
-                             int C, float eps, int relu, hipStream_t stream);
+                             int C, float eps, int relu, int have_sums, hipStream_t stream);
 int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2, float* dx,
                              float* dres, int B, int HW, int C, int relu, hipStream_t stream);
 int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M, int C,

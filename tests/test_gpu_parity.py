@@ -1366,6 +1366,40 @@ def test_encoder_strided_pair_space_to_depth(B, C, N, H, W, precision):
     close(got[2], blk.downsample[0].weight.grad, 1e-4 * f, 1e-4, what="shortcut dw")
 
 
+@pytest.mark.parametrize("C,N,B,H,W,carried", [(64, 64, 2, 184, 250, True), (96, 96, 2, 184, 250, True), (128, 128, 8, 55, 128, True),
+                                               (128, 128, 3, 55, 128, False), (64, 64, 1, 20, 24, False)])
+def test_instance_norm_statistics_from_the_convolution_epilogue(C, N, B, H, W, carried):
+    """fsraft_conv_forward_stats: the 3x3 encoder convolutions (extractor.py:13-57) on the halo / resident-patch kernels add the
+    per-image column sums of their result and of its squares to the [2, B * 8, N] partial rows the InstanceNorm kernels read
+    (ragged widths: pixels outside the image count as nothing); small grids take a kernel that does not and say so.  The sums
+    against float64 sums of the convolution's own output, then norm(conv(x)) with and without the hand-over."""
+    from flow_supervisor_amd.core import extractor as E
+    torch.manual_seed(31)
+    conv = torch.nn.Conv2d(C, N, 3, padding=1).to(DEV)
+    x = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        h = E._NormSums()
+        y = E._conv(conv, x, None, sums=h)
+        assert (h.acc is not None) == carried, "which kernels carry the statistics changed"
+        if carried:
+            got = h.acc.view(2, B, 8, N).sum(2).double().cpu()
+            yd = y.double()
+            ref = torch.stack([yd.sum((2, 3)), yd.square().sum((2, 3))]).cpu()
+            close(got[0], ref[0], 1e-3, rtol=1e-5, what="column sums")         # (sums of ~1e4 zero-mean terms: absolute part)
+            close(got[1], ref[1], 0.0, rtol=1e-5, what="column sums of squares")
+        norm = torch.nn.InstanceNorm2d(N)
+        outs = {}
+        old = E.STATS_IN_EPILOGUE
+        try:
+            for flag in (True, False):
+                E.STATS_IN_EPILOGUE = flag
+                outs[flag] = E._conv_norm(conv, norm, x, True)
+        finally:
+            E.STATS_IN_EPILOGUE = old
+        close(outs[True], outs[False], 2e-6, rtol=2e-6, what="relu(norm(conv(x))) with the statistics from the epilogue")
+        close(outs[True], torch.relu(norm(torch.nn.functional.conv2d(x, conv.weight, None, padding=1))), 2e-4, what="vs torch")
+
+
 def _rel_l2(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
