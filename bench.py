@@ -134,30 +134,49 @@ def corr_isolated(dev, B, H8, W8, iters):
             "note": f"forward half of the correlation path only (1 build + {iters} lookups, {B} pairs), launched back to back"}
 
 
-def loss_check(dev):
-    """The first-step loss of the benchmark's own configuration against the reference: one pair at 440x1024, 12 iterations,
-    procedural weights and inputs of tests/golden/train_step_basic_440x1024.npz (generated by running the reference)."""
+def loss_check(dev, variant="raft", height=440, width=1024, iters=12):
+    """The first-step loss of the benchmarked configuration against the reference: the procedural weights and inputs of the
+    train-step fixture generated at that very shape by running the reference (tests/golden/make_golden.py) -- RAFT at
+    440x1024 / 376x1248 (also the alt-corr variant's oracle) / 8 x 368x496, RAFT-GMA at 440x1024."""
+    import json
     import numpy as np
     from oracle.weights import procedural_state_dict, synthetic_pair
-    from flow_supervisor_amd.core.raft import RAFT
     from flow_supervisor_amd.train import raft_sequence_loss
-    f = os.path.join(ROOT, "tests", "golden", "train_step_basic_440x1024.npz")
-    if not os.path.exists(f):
+    name = {("raft", 440, 1024): "train_step_basic_440x1024", ("gma", 440, 1024): "train_step_gma_440x1024",
+            ("raft", 376, 1248): "train_step_basic_376x1248", ("alt", 376, 1248): "train_step_basic_376x1248",
+            ("raft", 368, 496): "train_step_basic_368x496_b8"}.get((variant, height, width))
+    f = os.path.join(ROOT, "tests", "golden", f"{name}.npz") if name else None
+    if not f or not os.path.exists(f):
         return None
     g = np.load(f)
+    if variant != "gma" and int(g["iters"]) != iters and "b8" not in name:
+        return None
     seed = int(g["seed"])
-    m = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False))
-    m.load_state_dict(procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed))
+    if variant == "gma":
+        from flow_supervisor_amd.core.gma_network import RAFTGMA
+        m = RAFTGMA(argparse.Namespace(small=False, mixed_precision=False, dropout=0, num_heads=1, position_only=False,
+                                       position_and_content=False, corr_levels=4, corr_radius=4))
+        shp = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", "raft_gma_shapes.json"))).items()}
+        m.load_state_dict(procedural_state_dict(shp, seed), strict=False)
+        with torch.no_grad():
+            m.update_block.aggregator.gamma.fill_(float(np.load(os.path.join(ROOT, "tests", "golden", "e2e_gma_440x1024.npz"))["gamma"]))
+    else:
+        from flow_supervisor_amd.core.raft import RAFT
+        m = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=variant == "alt"))
+        m.load_state_dict(procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed))
     m = m.to(dev).train()
     m.freeze_bn()
-    im1, im2 = synthetic_pair(1, int(g["H"]), int(g["W"]), seed + 1)
+    im1, im2 = synthetic_pair(int(g["B"]), int(g["H"]), int(g["W"]), seed + 1)
     with torch.no_grad():
         loss = float(raft_sequence_loss(m(im1.to(dev), im2.to(dev), iters=int(g["iters"]))))
     ref = float(g["loss"])
     rel = abs(loss - ref) / abs(ref)
     if rel > 1e-3:
         raise SystemExit(f"bench: first-step loss {loss} differs from the reference's {ref} (rel {rel:.2e})")
-    return {"loss": loss, "reference": ref, "rel_err": rel, "fixture": "tests/golden/train_step_basic_440x1024.npz"}
+    out = {"loss": loss, "reference": ref, "rel_err": rel, "fixture": f"tests/golden/{name}.npz"}
+    if int(g["iters"]) != iters:
+        out["note"] = f"fixture generated with {int(g['iters'])} iterations (the reference's CPU run at this batch)"
+    return out
 
 
 def set_arithmetic(split):
@@ -362,10 +381,10 @@ def main():
             os.environ["FSRAFT_ENCODER_CL"] = "0"
             extra["value_north_star_encoders"] = short_run()
             os.environ["FSRAFT_ENCODER_CL"] = "1"
-        if a.height == 440 and a.width == 1024 and a.iters == 12:
-            lc = loss_check(dev)
-            if lc:
-                extra["loss_check"] = lc
+    if world == 1 and not semi and not a.no_extra:
+        lc = loss_check(dev, a.variant, a.height, a.width, a.iters)
+        if lc:
+            extra["loss_check"] = lc
 
     if rank != 0:
         return

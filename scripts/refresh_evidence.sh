@@ -10,7 +10,7 @@ python bench.py --variant gma --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/benc
 bash scripts/prof.sh ${tag}_gma --variant gma
 python bench.py --variant alt --height 376 --width 1248 --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_alt.json; cut -c1-200 gpurun_out/bench_${tag}_alt.json
 bash scripts/prof.sh ${tag}_alt --variant alt --height 376 --width 1248 --batch-per-gpu 1
-python bench.py --height 368 --width 496 --batch-per-gpu 8 --no-cpu-baseline --no-extra 2>&1 | tail -1 > gpurun_out/bench_${tag}_chairs.json; cut -c1-200 gpurun_out/bench_${tag}_chairs.json
+python bench.py --height 368 --width 496 --batch-per-gpu 8 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_chairs.json; cut -c1-200 gpurun_out/bench_${tag}_chairs.json
 python bench.py --variant l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_l2l.json
 bash scripts/prof.sh ${tag}_l2l --variant l2l --batch-per-gpu 1
 python bench.py --variant gma_l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_gma_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_gma_l2l.json
