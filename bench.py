@@ -179,6 +179,60 @@ def loss_check(dev, variant="raft", height=440, width=1024, iters=12):
     return out
 
 
+def semi_loss_check(dev, variant, height, width, crop_h, crop_w, iters):
+    """The two losses of the flow-supervisor step at the reference's recipe (labelled pass: sequence_loss, unlabelled pass:
+    sequence_loss_unsup; pytorch/train.py:246-284) against tests/golden/l2l_recipe_{basic,gma}.npz -- generated by running the
+    reference's L2L / GMAL2L on the same procedural weights and samples."""
+    import json
+    import numpy as np
+    from oracle.weights import procedural_state_dict, rand_tensor, rand_uniform, synthetic_pair
+    from flow_supervisor_amd.train import sequence_loss, sequence_loss_unsup
+    tag = "basic" if variant == "l2l" else "gma"
+    f = os.path.join(ROOT, "tests", "golden", f"l2l_recipe_{tag}.npz")
+    if not os.path.exists(f):
+        return None
+    g = np.load(f)
+    if (int(g["H"]), int(g["W"]), int(g["h"]), int(g["w"]), int(g["iters"])) != (height, width, crop_h, crop_w, 2 * iters):
+        return None
+    seed = int(g["seed"])
+    if tag == "basic":
+        from flow_supervisor_amd.core.l2l import L2L
+        m = L2L(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False))
+    else:
+        from flow_supervisor_amd.core.gma_l2l import GMAL2L
+        m = GMAL2L(argparse.Namespace(small=False, mixed_precision=False, dropout=0, num_heads=1, position_only=False,
+                                      position_and_content=False, corr_levels=4, corr_radius=4))
+    shp = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", f"l2l_recipe_{tag}_shapes.json"))).items()}
+    m.load_state_dict(procedural_state_dict(shp, seed), strict=False)
+    if tag == "gma":
+        with torch.no_grad():
+            m.update_block.aggregator.gamma.fill_(0.1)
+    m = m.to(dev).train()
+    m.freeze_bn()
+    out = {"fixture": f"tests/golden/l2l_recipe_{tag}.npz"}
+    H, W, h, w = height, width, crop_h, crop_w
+    for which in ("sup", "unsup"):
+        sd = seed + (1 if which == "sup" else 5)
+        oy, ox = int(g[which + "_oy"]), int(g[which + "_ox"])
+        ci1, ci2 = synthetic_pair(1, H, W, sd)
+        im1 = (ci1[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), sd + 1, 3.0)).clamp(0, 255).contiguous()
+        im2 = (ci2[:, :, oy:oy + h, ox:ox + w] + rand_tensor((1, 3, h, w), sd + 2, 3.0)).clamp(0, 255).contiguous()
+        flow = rand_tensor((1, 2, h, w), sd + 3, 4.0).to(dev)
+        valid = (rand_uniform((1, h, w), sd + 4, 0.0, 1.0) > 0.1).float().to(dev)
+        with torch.no_grad():
+            preds = m(im1.to(dev), im2.to(dev), ci1.to(dev), ci2.to(dev), ox, oy, iters=2 * iters, supervisor_grad=which == "sup")
+            if which == "sup":
+                loss, _ = sequence_loss(preds, flow, valid, float(g["gamma"]))
+            else:
+                loss, _ = sequence_loss_unsup(preds, flow, valid, unsup_weight=float(g["unsup_lambda"]))
+        loss, ref = float(loss), float(g[which + "_loss"])
+        rel = abs(loss - ref) / abs(ref)
+        if rel > 1e-3:
+            raise SystemExit(f"bench: {which} loss {loss} differs from the reference's {ref} (rel {rel:.2e})")
+        out[which] = {"loss": loss, "reference": ref, "rel_err": rel}
+    return out
+
+
 def set_arithmetic(split):
     """Switch every GEMM of the path between the bf16x3 cores (the default) and the exact-fp32 MFMA cores."""
     from flow_supervisor_amd import ops
@@ -381,8 +435,9 @@ def main():
             os.environ["FSRAFT_ENCODER_CL"] = "0"
             extra["value_north_star_encoders"] = short_run()
             os.environ["FSRAFT_ENCODER_CL"] = "1"
-    if world == 1 and not semi and not a.no_extra:
-        lc = loss_check(dev, a.variant, a.height, a.width, a.iters)
+    if world == 1 and not a.no_extra:
+        lc = (semi_loss_check(dev, a.variant, a.height, a.width, a.crop_height, a.crop_width, a.iters) if semi
+              else loss_check(dev, a.variant, a.height, a.width, a.iters))
         if lc:
             extra["loss_check"] = lc
 
