@@ -127,6 +127,7 @@ SIGNATURES = {
     "fsraft_affine_relu_cl_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_int, _S],
     "fsraft_axpby": [c_void_p, c_void_p, c_float, c_float, c_int64, _S],
+    "fsraft_sum_n": [_PP, c_int, c_void_p, c_int64, c_int, _S],
     "fsraft_bn_fold": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, _S],
     "fsraft_bn_fold_bwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _S],
     "fsraft_vol_layout": [c_int, c_int, c_int, _IP],

@@ -323,6 +323,11 @@ class _Engine:
         acc = pad
         for k in self.ctx_keys:
             g = cst.dsum.get(k)
+            parts = cst.parts.get(k)
+            if parts:           # deferred sums: the kept per-iteration gradients (first grad_samples samples of the batch) in one pass
+                g = g if g is not None else ops.zeros((B,) + tuple(parts[0].shape[1:]), device=inp.device) if parts[0].shape[0] != B \
+                    else torch.empty((B,) + tuple(parts[0].shape[1:]), device=inp.device, dtype=torch.float32)
+                ops.sum_n_(parts, g, accumulate=cst.dsum.get(k) is not None)
             if g is None:
                 continue
             l = self.layers[k]
@@ -334,6 +339,7 @@ class _Engine:
         if not acc:
             dinp.zero_()
         cst.dsum = {}
+        cst.parts = {}
         return dinp
 
     def forward(self, net, ctxb, corr, flow, params, save, attn=None, attn_t=None, need_mask=True, head_out=None, mslot=None, hlast_out=None):
@@ -569,8 +575,12 @@ class _Engine:
                 return not first
 
             def ctx_sum(k, like):
-                """Running sum of the gate gradients over the iterations of the step (filled by the gru_bwd kernels)."""
+                """Running sum of the gate gradients over the iterations of the step (filled by the gru_bwd kernels) -- or, deferred:
+                the iteration's buffer is only noted and context_backward adds the kept buffers up in one pass."""
                 if cst is None:
+                    return None
+                if CTX_SUM_DEFERRED:
+                    cst.parts.setdefault(k, []).append(like)
                     return None
                 if k not in cst.dsum:
                     cst.dsum[k] = ops.zeros((Bf,) + tuple(like.shape[1:]), device=like.device)
@@ -683,10 +693,11 @@ class _Engine:
 
 class _CtxState:
     """Per-step state of the context convolution: its outputs (forward) and the summed gate gradients (backward)."""
-    __slots__ = ("key", "inp", "bufs", "dsum", "anchor", "consumed", "zero")
+    __slots__ = ("key", "inp", "bufs", "dsum", "parts", "anchor", "consumed", "zero")
 
     def __init__(self, key, inp, bufs):
         self.key, self.inp, self.bufs, self.dsum, self.anchor, self.consumed, self.zero = key, inp, bufs, {}, None, False, None
+        self.parts = {}         # CTX_SUM_DEFERRED: per key the iterations' gate-gradient buffers, summed once in context_backward
 
 
 class _CtxFn(torch.autograd.Function):
@@ -835,6 +846,7 @@ class _UpdateFn(torch.autograd.Function):
 
 HEAD_BATCH = os.environ.get("FSRAFT_HEAD_BATCH", "1") != "0"
 MOTION_BATCH = os.environ.get("FSRAFT_MOTION_BATCH", "1") != "0"
+CTX_SUM_DEFERRED = os.environ.get("FSRAFT_CTX_SUM_DEFERRED", "1") != "0"   # gate-gradient sums of a step in one pass (0: running sums in gru_bwd1/2)
 HEADS_BWD_BATCH = os.environ.get("FSRAFT_HEADS_BWD_BATCH", "1") != "0"
 
 

@@ -922,6 +922,21 @@ def col_sum_(x, C, out, scale=1.0):
     L.check(_lib().fsraft_col_sum(L.ptr(x), x.shape[-1], M, C, L.ptr(out), float(scale), L.stream()), "col_sum")
 
 
+def sum_n_(tensors, out, accumulate=False):
+    """out.flatten()[:n] = (accumulate ? same : 0) + sum of the tensors (n = their common element count, added in list order); out
+    may be larger (sample-major buffers: the leading samples are written)."""
+    n = tensors[0].numel()
+    for t in tensors:
+        L.require_cuda_f32(t)
+        if t.numel() != n or not t.is_contiguous():
+            raise ValueError("sum_n_: contiguous tensors of one size")
+    if out.numel() < n or not out.is_contiguous():
+        raise ValueError("sum_n_: out too small / not contiguous")
+    pp, keep = L.ptr_array(tensors)
+    L.check(_lib().fsraft_sum_n(pp, len(tensors), L.ptr(out), n, int(accumulate), L.stream()), "sum_n")
+    return out
+
+
 def axpby_(x, y, a=1.0, b=1.0):
     L.check(_lib().fsraft_axpby(L.ptr(x), L.ptr(y), float(a), float(b), x.numel(), L.stream()), "axpby")
 

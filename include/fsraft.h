@@ -420,6 +420,10 @@ int fsraft_gru_bwd1(const float* dhn, const float* dhn2, const float* z, const f
 int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh, float* dzr_sum, int64_t M, int hid, hipStream_t s);
 int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s);
 int fsraft_axpby(const float* x, float* y, float a, float b, int64_t n, hipStream_t s);
+/* out[0..count) = (accumulate ? out : 0) + src[0] + ... + src[n - 1], added in list order (count % 4 == 0, 16-byte aligned): the sum
+ * of the GRU gate gradients over the iterations of a step (the context part's backward, update.py:16-60 with x = cat(inp, motion)
+ * split into a per-step context convolution), formed once from the kept per-iteration gradients. */
+int fsraft_sum_n(const float* const* src, int n, float* out, int64_t count, int accumulate, hipStream_t s);
 
 #ifdef __cplusplus
 }
