@@ -120,12 +120,12 @@ SIGNATURES = {
     "fsraft_get_tuning": [c_int],
     "fsraft_space_to_depth2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_forward_interpolate": [c_void_p, c_void_p, c_int, c_int, _S],
-    "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, _S],
+    "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_int, _S],
     "fsraft_inorm_relu_cl_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                 c_int, _S],
-    "fsraft_affine_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, _S],
+                                 c_int, c_int, _S],
+    "fsraft_affine_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, _S],
     "fsraft_affine_relu_cl_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                  c_int, c_int, _S],
+                                  c_int, c_int, c_int, _S],
     "fsraft_axpby": [c_void_p, c_void_p, c_float, c_float, c_int64, _S],
     "fsraft_sum_n": [_PP, c_int, c_void_p, c_int64, c_int, _S],
     "fsraft_bn_fold": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, _S],

@@ -139,7 +139,7 @@ class _InstNormReluCL(torch.autograd.Function):
     (and their backward) cost no extra trip over the tensor."""
 
     @staticmethod
-    def forward(ctx, x, eps, relu, res=None, link=None, sums=None):
+    def forward(ctx, x, eps, relu, res=None, link=None, sums=None, s2d=False):
         from .. import _lib as L
         ctx.in_cl = _is_cl(x)
         ctx.link = link
@@ -147,13 +147,17 @@ class _InstNormReluCL(torch.autograd.Function):
         N, C, H, W = x.shape
         if res is not None:
             res = _as_cl(res)
-        y = torch.empty_like(x)                                   # preserves channels_last
+        # s2d: the result leaves in the space-to-depth layout of the stride-2 unit that consumes it -- a [N, 4C, H/2, W/2]
+        # channels_last tensor -- and the gradient comes back in it (see _emit_s2d)
+        ctx.s2w = W if s2d else 0
+        y = (torch.empty(N, H // 2, W // 2, 4 * C, device=x.device, dtype=torch.float32).permute(0, 3, 1, 2) if s2d
+             else torch.empty_like(x))                            # preserves channels_last
         # partial rows (norm_cl.hip) -- already filled when the convolution that produced x carried the sums in its epilogue
         have = sums is not None and sums.acc is not None and tuple(sums.acc.shape) == (2, N * 8, C)
         acc = sums.acc if have else ops.zeros(2, N * 8, C, device=x.device)
         stats = torch.empty(N, C, 2, device=x.device, dtype=torch.float32)
         L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W,
-                                                  C, float(eps), int(relu), int(have), L.stream()), "inorm_relu_cl_fwd")
+                                                  C, float(eps), int(relu), int(have), ctx.s2w, L.stream()), "inorm_relu_cl_fwd")
         ctx.fused = res is not None
         ctx.save_for_backward(x, stats, y if ctx.fused else None)
         ctx.relu = relu
@@ -169,22 +173,23 @@ class _InstNormReluCL(torch.autograd.Function):
         dres = torch.empty_like(x) if ctx.fused else None
         acc = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (norm_cl.hip)
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
-                                                  L.ptr(dres), N, H * W, C, int(ctx.relu), L.stream()), "inorm_relu_cl_bwd")
+                                                  L.ptr(dres), N, H * W, C, int(ctx.relu), ctx.s2w, L.stream()), "inorm_relu_cl_bwd")
         if ctx.link is not None:
             ctx.link.dres = dres
-        return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
+        return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None, None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
 
 
 class _FrozenBNReluCL(torch.autograd.Function):
     """_FrozenBNRelu for channels_last tensors; `res` as in _InstNormReluCL."""
 
     @staticmethod
-    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu, res=None, link=None):
+    def forward(ctx, x, cbias, weight, bias, rm, rv, eps, relu, res=None, link=None, s2d=False):
         from .. import _lib as L
         ctx.in_cl = _is_cl(x)
         ctx.link = link
         x = _as_cl(x)
         N, C, H, W = x.shape
+        ctx.s2w = W if s2d else 0                     # (as in _InstNormReluCL)
         if res is not None:
             res = _as_cl(res)
         fold = torch.empty(4, C, device=x.device, dtype=torch.float32)       # scale, shift, rs, rmc: one launch (csrc/norm_cl.hip)
@@ -193,9 +198,9 @@ class _FrozenBNReluCL(torch.autograd.Function):
                                         L.ptr(rm.float().contiguous()), L.ptr(rv.float().contiguous()),
                                         L.ptr(cbias.detach().float().contiguous()) if cbias is not None else None, float(eps), C,
                                         L.ptr(scale), L.ptr(shift), L.ptr(rs), L.ptr(rmc), L.stream()), "bn_fold")
-        y = torch.empty_like(x)
+        y = torch.empty(N, H // 2, W // 2, 4 * C, device=x.device, dtype=torch.float32).permute(0, 3, 1, 2) if s2d else torch.empty_like(x)
         L.check(L.load().fsraft_affine_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(scale), L.ptr(shift), L.ptr(y), N * H * W, C, int(relu),
-                                                   L.stream()), "affine_relu_cl_fwd")
+                                                   H * W, ctx.s2w, L.stream()), "affine_relu_cl_fwd")
         ctx.fused = res is not None
         ctx.save_for_backward(x, scale, shift, rs, rmc, y if ctx.fused else None)
         ctx.relu = relu
@@ -212,7 +217,7 @@ class _FrozenBNReluCL(torch.autograd.Function):
         dres = torch.empty_like(x) if ctx.fused else None
         part = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (see norm_cl.hip)
         L.check(L.load().fsraft_affine_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), L.ptr(dx), L.ptr(dres),
-                                                   L.ptr(part[0]), L.ptr(part[1]), N, H * W, C, int(ctx.relu), L.stream()),
+                                                   L.ptr(part[0]), L.ptr(part[1]), N, H * W, C, int(ctx.relu), ctx.s2w, L.stream()),
                 "affine_relu_cl_bwd")
         dpar = torch.empty(3, C, device=x.device, dtype=torch.float32)       # dweight, dbias, dcbias: one launch
         L.check(L.load().fsraft_bn_fold_bwd(L.ptr(part), N * 8, C, L.ptr(rs), L.ptr(rm), L.ptr(scale), L.ptr(dpar[0]), L.ptr(dpar[1]),
@@ -220,7 +225,7 @@ class _FrozenBNReluCL(torch.autograd.Function):
         if ctx.link is not None:
             ctx.link.dres = dres
         return (dx if ctx.in_cl else _as_nchw(dx), dpar[2] if ctx.has_cbias else None, dpar[0], dpar[1], None, None, None, None, dres,
-                None)
+                None, None)
 
 
 def _conv_key(conv):
@@ -475,13 +480,19 @@ class _StridedPairFn(torch.autograd.Function):
     folded into a frozen BatchNorm)."""
 
     @staticmethod
-    def forward(ctx, x, w3, wsc, packs):
+    def forward(ctx, x, w3, wsc, packs, pre=False):
         from .. import ops
         x = _as_cl(x)
-        B, C, H, W = x.shape
+        ctx.pre = pre
+        if pre:         # x already IS the space-to-depth tensor [B, 4C, H/2, W/2] (written by the norm before it: _S2D)
+            B, C4, h, w = x.shape
+            C, H, W = C4 // 4, 2 * h, 2 * w
+            xs = x.permute(0, 2, 3, 1)
+        else:
+            B, C, H, W = x.shape
+            h, w = H // 2, W // 2
+            xs = ops.space_to_depth2(x.permute(0, 2, 3, 1))
         N, Ns = w3.shape[0], wsc.shape[0]
-        h, w = H // 2, W // 2
-        xs = ops.space_to_depth2(x.permute(0, 2, 3, 1))
         y1 = torch.empty(B, h, w, N, device=x.device, dtype=torch.float32)
         ys = torch.empty(B, h, w, Ns, device=x.device, dtype=torch.float32)
         p, q = packs[1], packs[2]
@@ -505,7 +516,7 @@ class _StridedPairFn(torch.autograd.Function):
             dxs = torch.empty(B, h, w, C4, device=xs.device, dtype=torch.float32)
             ops.conv_forward([g1v], p[2], None, B, h, w, 2, 2, C4, [ops.Dst.nhwc(dxs)], wpk_split=p[3], pad=(0, 0))
             ops.conv_forward([gsv], q[2], None, B, h, w, 1, 1, C, [ops.Dst.nhwc(dxs, 0, 0, True)], wpk_split=q[3])
-            dx = ops.space_to_depth2(dxs, inverse=True).permute(0, 3, 1, 2)
+            dx = (dxs if ctx.pre else ops.space_to_depth2(dxs, inverse=True)).permute(0, 3, 1, 2)
         items = []
         if ctx.needs_input_grad[1]:
             dwpk = ops.zeros(N, ops.conv_ktot([C4], 2, 2), device=xs.device)
@@ -518,7 +529,7 @@ class _StridedPairFn(torch.autograd.Function):
             dwsc = torch.empty(Ns, C, 1, 1, device=xs.device, dtype=torch.float32)
             items.append((dwpk, [dwsc], [C], [0], C, 1, 1, 1.0, False))
         ops.unpack_weight_grads(items, xs.device)
-        return dx, dw3, dwsc, None
+        return dx, dw3, dwsc, None, None
 
 
 def _norm_act(norm, y, cbias, relu, res=None):
@@ -529,13 +540,30 @@ def _norm_act(norm, y, cbias, relu, res=None):
     return _FrozenBNReluCL.apply(y, cbias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu, res)
 
 
-def _pair_ok(block, x):
+def _pair_ok_shape(block, C, H, W):
     import os
-    return (os.environ.get("FSRAFT_ENCODER_S2D", "1") != "0" and _pair_shape_ok(block) and x.shape[2] % 2 == 0
-            and x.shape[3] % 2 == 0 and x.shape[1] % 4 == 0 and _cl_norm_ok(torch.empty(0, block.conv1.out_channels)))
+    return (os.environ.get("FSRAFT_ENCODER_S2D", "1") != "0" and _pair_shape_ok(block) and H % 2 == 0
+            and W % 2 == 0 and C % 4 == 0 and _cl_norm_ok(torch.empty(0, block.conv1.out_channels)))
 
 
-def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=None):
+def _pair_ok(block, x):
+    return _pair_ok_shape(block, x.shape[1], x.shape[2], x.shape[3])
+
+
+S2D_EMIT = __import__("os").environ.get("FSRAFT_NORM_S2D", "1") != "0"   # 0: the stride-2 units copy their input into the space-to-depth layout themselves
+
+
+class _S2D:
+    """A residual unit's output handed to the stride-2 unit behind it AS the space-to-depth tensor that unit's two convolutions
+    read ([B, 4C, H/2, W/2] channels_last; sub-pixel (sy, sx) of pixel (2y + sy, 2x + sx) in channels (2 sy + sx) C ..): the
+    unit's last norm kernel writes it in that layout and reads the gradient from it, so neither direction needs a copy."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=None, s2d=False):
     """relu?(norm(conv(x))) of pytorch/core/extractor.py.  The convolution stays a PyTorch-ROCm (MIOpen) call; for fp32
     CUDA tensors the normalisation + ReLU around it runs on the fused fsraft kernels:
       * non-affine InstanceNorm2d (feature encoder).  A per-channel constant added before it is removed again by its
@@ -552,7 +580,8 @@ def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=N
             sums = _NormSums() if (to_cl or _is_cl(x)) else None
             y = _conv(conv, x, None, link, stem_cl=to_cl, sums=sums)
             if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
-                return _InstNormReluCL.apply(y, norm.eps, relu, res, res_link, sums)
+                return _InstNormReluCL.apply(y, norm.eps, relu, res, res_link, sums, s2d)
+            assert not s2d
             y = _InstNormRelu.apply(y, norm.eps, relu)
             return y if res is None else F.relu(res + y)
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) if conv.bias is not None else conv(x)
@@ -561,11 +590,13 @@ def _conv_norm(conv, norm, x, relu, to_cl=False, res=None, link=None, res_link=N
         y = _conv(conv, x, None, link, stem_cl=to_cl)
         if (to_cl or _is_cl(x)) and _cl_norm_ok(y):
             return _FrozenBNReluCL.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu, res,
-                                         res_link)
+                                         res_link, s2d)
+        assert not s2d
         y = _FrozenBNRelu.apply(y, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
         return y if res is None else F.relu(res + y)
     else:
         y = norm(conv(x))
+    assert not s2d, "space-to-depth output is a feature of the fused channels_last norm kernels"
     y = F.relu(y, inplace=True) if relu else y
     return y if res is None else F.relu(res + y)
 
@@ -607,7 +638,14 @@ class _Block(nn.Module):
             setattr(self, f"norm{self.n + 1}", short)
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, stride=stride), short)
 
-    def forward(self, x):
+    def forward(self, x, emit_for=None):
+        """emit_for: the stride-2 unit that consumes this unit's output (the encoder's channels_last walk passes it): the output then
+        leaves as an _S2D holder where that unit can take it."""
+        if isinstance(x, _S2D):
+            y1, ys = _StridedPairFn.apply(x.t, self.conv1.weight, self.downsample[0].weight, _pair_packs(self), True)
+            y = _norm_act(self.norm1, y1, self.conv1.bias, True)
+            xs = _norm_act(self.downsample[1], ys, self.downsample[0].bias, False)
+            return _conv_norm(self.conv2, self.norm2, y, True, to_cl=True, res=xs)
         cl = _is_cl(x)
         if cl and self.downsample is not None and _pair_ok(self, x):
             # stride-2 unit, channels_last: both strided convolutions on the stride-1 kernels over the space-to-depth input
@@ -626,7 +664,12 @@ class _Block(nn.Module):
         for i in range(1, self.n):
             y = _conv_norm(getattr(self, f"conv{i}"), getattr(self, f"norm{i}"), y, True, to_cl=cl, link=link if i == 1 else None)
         # last convolution of the unit: relu(x + relu(norm(conv(y)))), the add and outer ReLU fused into the norm kernel
-        return _conv_norm(getattr(self, f"conv{self.n}"), getattr(self, f"norm{self.n}"), y, True, to_cl=cl, res=x, res_link=link)
+        last = getattr(self, f"conv{self.n}")
+        emit = bool(cl and S2D_EMIT and emit_for is not None and self.downsample is None and _is_cl(y) and _cl_norm_ok(torch.empty(0, last.out_channels))
+                    and _pair_ok_shape(emit_for, last.out_channels, y.shape[2], y.shape[3])
+                    and isinstance(getattr(self, f"norm{self.n}"), (nn.InstanceNorm2d, nn.BatchNorm2d)))
+        out = _conv_norm(last, getattr(self, f"norm{self.n}"), y, True, to_cl=cl, res=x, res_link=link, s2d=emit)
+        return _S2D(out) if emit else out
 
 
 class ResidualBlock(_Block):
@@ -689,7 +732,16 @@ class _Encoder(nn.Module):
         if cl:
             _prepare_packs(self)         # all packed weight images of this encoder that are stale: one batched launch
         x = _conv_norm(self.conv1, self.norm1, x, True, to_cl=bool(cl))
-        x = self.layer3(self.layer2(self.layer1(x)))
+        if cl:
+            # (the Sequential containers walked by hand: a unit in front of a stride-2 unit is told so, see _S2D)
+            stages = (self.layer1, self.layer2, self.layer3)
+            for si, seq in enumerate(stages):
+                units = list(seq)
+                for ui, unit in enumerate(units):
+                    nxt = stages[si + 1][0] if (ui == len(units) - 1 and si + 1 < len(stages)) else None
+                    x = unit(x, nxt) if isinstance(unit, _Block) else unit(x)
+        else:
+            x = self.layer3(self.layer2(self.layer1(x)))
         x = _ToNCHW.apply(_conv(self.conv2, x, self.conv2.bias)) if cl else self.conv2(x)
         if self.training and self.dropout is not None:
             x = self.dropout(x)

@@ -17,6 +17,16 @@ inline int pix_per_wg(int B, int HW) {
   return p < 128 ? 128 : p > 1024 ? 1024 : (int)p;
 }
 
+// Space-to-depth addressing of a channels-last tensor (what a stride-2 unit's two convolutions read, fsraft_space_to_depth2:
+// [B][H/2][W/2][2][2][C]): float offset of channel 0 of pixel p = y * W + x of sample b.  The norm that feeds such a unit writes
+// its result there directly (and its backward reads the gradient / its saved result from there): the 2 x 230 MB layout copies
+// per stride-2 unit and direction disappear.  s2w = W (even, H even) or 0: plain [B][HW][C].
+__device__ __forceinline__ int64_t cl_pix_off(int b, int p, int HW, int C, int s2w) {
+  if (s2w == 0) return ((int64_t)b * HW + p) * C;
+  const int y = p / s2w, x = p - y * s2w;
+  return (((int64_t)b * (HW >> 2) + (y >> 1) * (s2w >> 1) + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * C;
+}
+
 // sums[b][c] += sum_pix x, sumsq[b][c] += sum_pix x^2
 __global__ __launch_bounds__(256) void cl_stats_kernel(const float* __restrict__ x, float* __restrict__ sums,
                                                        float* __restrict__ sumsq, int HW, int C, int PIX_PER_WG) {
@@ -50,7 +60,7 @@ __global__ __launch_bounds__(256) void cl_stats_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ sums,
                                                              const float* __restrict__ sumsq, float* __restrict__ y,
                                                              float* __restrict__ stats, int HW, int C, float eps, int relu, int PIX_PER_WG,
-                                                             const float* __restrict__ res) {
+                                                             const float* __restrict__ res, int s2w) {
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int b = blockIdx.y;
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + rv[i], 0.f);
       }
-      *reinterpret_cast<f32x4*>(y + o) = v;
+      *reinterpret_cast<f32x4*>(y + (s2w ? cl_pix_off(b, p, HW, C, s2w) + cl * 4 : o)) = v;
     }
 }
 
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
                                                           const float* __restrict__ pa, const float* __restrict__ pb,
                                                           float* __restrict__ s1, float* __restrict__ s2,
                                                           float* __restrict__ dx, int HW, int C, int relu, int PIX_PER_WG,
-                                                          const float* __restrict__ out, float* __restrict__ dres) {
+                                                          const float* __restrict__ out, float* __restrict__ dres, int s2w) {
   __shared__ f32x4 red[2][256];
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
@@ -110,10 +120,11 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
 #pragma unroll 4
     for (int p = p0 + pl; p < p1; p += lanes_p) {
       const int64_t o = ((int64_t)b * HW + p) * C + cl * 4;
-      f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+      const int64_t og = s2w ? cl_pix_off(b, p, HW, C, s2w) + cl * 4 : o;      // (the gradient and the saved result: see cl_pix_off)
+      f32x4 gv = *reinterpret_cast<const f32x4*>(g + og);
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
       if (out) {                                            // fused residual: the gradient first passes relu(res + y)
-        const f32x4 ov = *reinterpret_cast<const f32x4*>(out + o);
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(out + og);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gv[i] = ov[i] > 0.f ? gv[i] : 0.f;
         *reinterpret_cast<f32x4*>(dres + o) = gv;           // ... and this is what the shortcut receives
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
 __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                  const float* __restrict__ stats, const float* __restrict__ s1,
                                                                  const float* __restrict__ s2, float* __restrict__ dx, int HW,
-                                                                 int C, int relu, int PIX_PER_WG, const float* __restrict__ out) {
+                                                                 int C, int relu, int PIX_PER_WG, const float* __restrict__ out, int s2w) {
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int b = blockIdx.y;
@@ -165,10 +176,11 @@ __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __
 #pragma unroll 4
     for (int p = p0 + pl; p < p1; p += lanes_p) {
       const int64_t o = ((int64_t)b * HW + p) * C + cl * 4;
-      f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+      const int64_t og = s2w ? cl_pix_off(b, p, HW, C, s2w) + cl * 4 : o;
+      f32x4 gv = *reinterpret_cast<const f32x4*>(g + og);
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
       if (out) {
-        const f32x4 ov = *reinterpret_cast<const f32x4*>(out + o);
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(out + og);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gv[i] = ov[i] > 0.f ? gv[i] : 0.f;
       }
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __
 // y = relu?(x * scale[c] + shift[c])
 __global__ __launch_bounds__(256) void cl_affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ y,
-                                                            int64_t M, int C, int relu, const float* __restrict__ res) {
+                                                            int64_t M, int C, int relu, const float* __restrict__ res, int HW, int s2w) {
   const int c4n = C >> 2;
   const int64_t total = M * c4n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -199,11 +211,17 @@ __global__ __launch_bounds__(256) void cl_affine_fwd_kernel(const float* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + rv[i], 0.f);
     }
-    reinterpret_cast<f32x4*>(y)[e] = v;
+    if (s2w) {
+      const int64_t m = e / c4n;
+      *reinterpret_cast<f32x4*>(y + cl_pix_off((int)(m / HW), (int)(m % HW), HW, C, s2w) + c) = v;
+    } else {
+      reinterpret_cast<f32x4*>(y)[e] = v;
+    }
   }
 }
 
 inline bool cl_ok(int C) { return C >= 4 && C <= 256 && C % 4 == 0; }      // (threads beyond (256 / (C/4)) * (C/4) idle)
+inline bool s2d_ok(int HW, int w) { return w == 0 || (w > 0 && (w & 1) == 0 && HW % w == 0 && ((HW / w) & 1) == 0); }   // even width and height
 
 }  // namespace
 
@@ -216,44 +234,45 @@ extern "C" int fsraft_set_norm_blocks(int target_workgroups) {     // tuning hoo
 // x, y: [B][HW][C].  sums / sumsq: [B * 8][C] partial-row scratch that must be ZERO on entry; stats: [B][C][2] = (mean, rstd) out.
 // res (nullable, [B][HW][C]): fused residual unit, y = relu(res + relu?(norm(x))).
 extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B,
-                                        int HW, int C, float eps, int relu, int have_sums, hipStream_t s) {
-  if (!x || !y || !sums || !sumsq || !stats || B < 1 || HW < 1 || !cl_ok(C)) return FS_ERR_ARG;
+                                        int HW, int C, float eps, int relu, int have_sums, int s2d_w, hipStream_t s) {
+  if (!x || !y || !sums || !sumsq || !stats || B < 1 || HW < 1 || !cl_ok(C) || !s2d_ok(HW, s2d_w)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
   // have_sums: the producing convolution already accumulated the partial rows (fsraft_conv_forward_stats): no pass of our own
   if (!have_sums) hipLaunchKernelGGL(cl_stats_kernel, grid, dim3(256), 0, s, x, sums, sumsq, HW, C, ppw);
-  hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw, res);
+  hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw, res, s2d_w);
   return fs_launch_status();
 }
 // s1, s2: [B * 8][C] partial-row scratch, ZERO on entry.  Fused residual unit: out = the forward result y, dres receives the shortcut's
 // gradient g * (out > 0), and the norm branch continues from that; both NULL otherwise.
 extern "C" int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2,
-                                        float* dx, float* dres, int B, int HW, int C, int relu, hipStream_t s) {
-  if (!g || !x || !stats || !s1 || !s2 || !dx || B < 1 || HW < 1 || !cl_ok(C) || (out != nullptr) != (dres != nullptr)) return FS_ERR_ARG;
+                                        float* dx, float* dres, int B, int HW, int C, int relu, int s2d_w, hipStream_t s) {
+  if (!g || !x || !stats || !s1 || !s2 || !dx || B < 1 || HW < 1 || !cl_ok(C) || (out != nullptr) != (dres != nullptr) || !s2d_ok(HW, s2d_w))
+    return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
-  hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw, out, dres);
-  hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw, out);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw, out, dres, s2d_w);
+  hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw, out, s2d_w);
   return fs_launch_status();
 }
 extern "C" int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M,
-                                         int C, int relu, hipStream_t s) {
-  if (!x || !scale || !shift || !y || M < 1 || C < 4 || C % 4) return FS_ERR_ARG;
+                                         int C, int relu, int HW, int s2d_w, hipStream_t s) {
+  if (!x || !scale || !shift || !y || M < 1 || C < 4 || C % 4 || (s2d_w && (HW < 4 || M % HW || !s2d_ok(HW, s2d_w)))) return FS_ERR_ARG;
   int64_t blocks = (M * (C / 4) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(cl_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, y, M, C, relu, res);
+  hipLaunchKernelGGL(cl_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, y, M, C, relu, res, HW > 0 ? HW : 1, s2d_w);
   return fs_launch_status();
 }
 // dx = g' * scale[c]; partial sums of g' and g' * x over pixels, spread over B * 8 rows to keep the atomics apart:
 // dsum_g, dsum_gx: [B * 8][C], ZERO on entry; the caller adds the rows up.  out / dres as in fsraft_inorm_relu_cl_bwd.
 extern "C" int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* out,
                                          float* dx, float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu,
-                                         hipStream_t s) {
+                                         int s2d_w, hipStream_t s) {
   if (!g || !x || !scale || !shift || !dx || !dsum_g || !dsum_gx || B < 1 || HW < 1 || !cl_ok(C) ||
-      (out != nullptr) != (dres != nullptr)) return FS_ERR_ARG;
+      (out != nullptr) != (dres != nullptr) || !s2d_ok(HW, s2d_w)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
-  hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw, out, dres);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw, out, dres, s2d_w);
   return fs_launch_status();
 }
 

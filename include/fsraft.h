@@ -358,14 +358,18 @@ int fsraft_forward_interpolate(const float* flow, float* out, int H, int W, hipS
  * to dres before continuing into the norm branch (out and dres both NULL: plain norm + ReLU). */
 /* have_sums != 0: sums / sumsq already hold the partial rows -- accumulated by the convolution that produced x
  * (fsraft_conv_forward_stats, 8 slots) -- and the statistics pass over x is skipped. */
+/* s2d_w != 0 (= the image width W; W and H = HW / W even): the result y is written in the space-to-depth layout of
+ * fsraft_space_to_depth2 ([B][H/2][W/2][2][2][C]) -- what the stride-2 residual unit behind it reads (extractor.py:23-57 with
+ * stride 2) -- and the backward reads the gradient g and the saved result `out` from that layout; x, res, dx, dres stay
+ * [B][HW][C].  0: everything [B][HW][C].  (fsraft_affine_relu_cl_fwd takes HW for this; ignored when s2d_w == 0.) */
 int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B, int HW,
-                             int C, float eps, int relu, int have_sums, hipStream_t stream);
+                             int C, float eps, int relu, int have_sums, int s2d_w, hipStream_t stream);
 int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2, float* dx,
-                             float* dres, int B, int HW, int C, int relu, hipStream_t stream);
+                             float* dres, int B, int HW, int C, int relu, int s2d_w, hipStream_t stream);
 int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M, int C,
-                              int relu, hipStream_t stream);
+                              int relu, int HW, int s2d_w, hipStream_t stream);
 int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* out, float* dx,
-                              float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, hipStream_t stream);
+                              float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, int s2d_w, hipStream_t stream);
 
 /* Frozen-BatchNorm parameter folding in one launch per direction (instead of ~11 framework launches on [C] tensors per layer
  * and step): scale = weight * rsqrt(var + eps), shift = bias - (mean - cbias) * scale, rs = rsqrt(var + eps), rmc = mean - cbias

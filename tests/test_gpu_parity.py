@@ -573,9 +573,10 @@ def test_gate_gradient_sums_of_a_step_in_one_pass(tag):
     assert cn
     for k in cn:
         # (two separate backward passes: the context encoder's norm sums and weight gradients are atomically accumulated, and
-        #  fifteen layers amplify the order of those adds to ~1e-4 of a gradient's maximum -- the same spread two runs of ONE
-        #  route show; what is exact is the sum kernel above)
-        close(res[True][k], res[False][k], 0.0, rtol=2e-3, what=f"{k}: deferred vs running sums")
+        #  fifteen layers amplify the order of those adds -- the same spread two runs of ONE route show, up to a few 1e-3 in
+        #  relative L2 for the bottleneck encoder; what is exact is the sum kernel above)
+        e = _rel_l2(res[True][k], res[False][k])
+        assert e < 2e-2 or res[False][k].norm().item() < 1e-3, f"{k}: deferred vs running sums, relative L2 error {e:.3e}"
 
 
 def _check_train_digest(m, preds, g, precision, skip=()):
@@ -1442,6 +1443,52 @@ def test_instance_norm_statistics_from_the_convolution_epilogue(C, N, B, H, W, c
             E.STATS_IN_EPILOGUE = old
         close(outs[True], outs[False], 2e-6, rtol=2e-6, what="relu(norm(conv(x))) with the statistics from the epilogue")
         close(outs[True], torch.relu(norm(torch.nn.functional.conv2d(x, conv.weight, None, padding=1))), 2e-4, what="vs torch")
+
+
+@pytest.mark.parametrize("norm,H,W", [("instance", 72, 104), ("batch", 72, 104), ("instance", 184, 248), ("instance", 88, 100)])
+def test_norm_writes_the_space_to_depth_input_of_the_stride_two_unit(norm, H, W, monkeypatch):
+    """The residual unit in front of a stride-2 unit (extractor.py:23-57, layer1 -> layer2 -> layer3) hands its output over AS
+    the space-to-depth tensor the unit's two convolutions read: its last norm kernel writes that layout and its backward reads
+    the gradient from it (fsraft_*_relu_cl_fwd/bwd, s2d_w).  Against the route with the two layout copies per unit
+    (extractor.S2D_EMIT = False): forward values and gradients to the run-to-run spread of the atomically accumulated
+    sums; the number of layout copies is counted.  88 x 100: the last stride-2 unit sees an odd size (22 x 25) and takes the
+    framework's strided convolutions, with an ordinary tensor handed to it."""
+    from flow_supervisor_amd.core import extractor as E
+    torch.manual_seed(5)
+    enc = E.BasicEncoder(output_dim=128, norm_fn=norm).to(DEV)
+    if norm == "batch":
+        enc.eval()
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(); m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 3, H, W, device=DEV)
+    calls = []
+    orig = E.ops.space_to_depth2
+    monkeypatch.setattr(E.ops, "space_to_depth2", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    outs = {}
+    old = E.S2D_EMIT
+    try:
+        for flag in (True, False):
+            E.S2D_EMIT = flag
+            calls.clear()
+            enc.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            y = enc(xi)
+            (y.square().sum()).backward()
+            outs[flag] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}, len(calls))
+    finally:
+        E.S2D_EMIT = old
+    # layout copies (forward + backward) of the stride-2 units that run on the space-to-depth route (even input size)
+    n_ok = sum(1 for d in (2, 4) if (H // d) % 2 == 0 and (W // d) % 2 == 0)
+    assert outs[False][3] == 2 * n_ok and outs[True][3] == 0, (outs[True][3], outs[False][3])
+    # (same arithmetic, other addresses; the statistics themselves are atomically accumulated -- in the convolution epilogues at
+    #  the larger sizes -- so two runs of ONE route already differ in the last digits)
+    close(outs[True][0], outs[False][0], 1e-4, rtol=1e-4, what="encoder output")
+    # gradients: fifteen normalisation backward passes amplify the last-digit differences of the sums (see
+    # test_encoder_channels_last_path_matches_nchw_path: ~6e-3 in the image gradient between two runs in split mode)
+    assert _rel_l2(outs[True][1], outs[False][1]) < 2e-2
+    for k, v in outs[False][2].items():
+        assert _rel_l2(outs[True][2][k], v) < 2e-2 or v.norm().item() < 1e-3, k
 
 
 def _rel_l2(a, b):
