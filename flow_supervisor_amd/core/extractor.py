@@ -742,7 +742,14 @@ class _Encoder(nn.Module):
                     x = unit(x, nxt) if isinstance(unit, _Block) else unit(x)
         else:
             x = self.layer3(self.layer2(self.layer1(x)))
-        x = _ToNCHW.apply(_conv(self.conv2, x, self.conv2.bias)) if cl else self.conv2(x)
+        if cl:
+            x = _conv(self.conv2, x, self.conv2.bias)
+            # out_channels_last (set by the models on their context encoder): the result stays a channels_last tensor -- its
+            # consumers (split, tanh / ReLU, update.to_channels_last) work on it in place of three layout copies per direction
+            if pair or not getattr(self, "out_channels_last", False) or not _is_cl(x):
+                x = _ToNCHW.apply(x)
+        else:
+            x = self.conv2(x)
         if self.training and self.dropout is not None:
             x = self.dropout(x)
         if pair:

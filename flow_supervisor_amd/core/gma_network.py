@@ -1,4 +1,6 @@
 """RAFT-GMA forward (pytorch/core/gma_network.py:26-129) on the HIP hot path (benchmark config 5)."""
+import os
+
 import torch
 import torch.nn as nn
 from torch.amp import autocast
@@ -25,6 +27,7 @@ class RAFTGMA(nn.Module):
             self.args.mixed_precision = False
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
         self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
+        self.cnet.out_channels_last = os.environ.get("FSRAFT_CNET_OUT_CL", "1") != "0"   # (extractor._Encoder.forward)
         self.update_block = GMAUpdateBlock(self.args, hidden_dim=hdim)
         self.att = Attention(args=self.args, dim=cdim, heads=self.args.num_heads, max_pos_size=160, dim_head=cdim)
 

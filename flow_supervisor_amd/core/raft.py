@@ -3,6 +3,8 @@ values and state_dict keys as pytorch/core/raft.py:24-144; the loop body differs
 tensors between the lookup, the update block and the upsampler stay channels-last so no
 layout conversion (and no torch.cat / softmax / unfold) runs per iteration.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -64,6 +66,7 @@ class RAFT(nn.Module):
         else:
             self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
             self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
+            self.cnet.out_channels_last = os.environ.get("FSRAFT_CNET_OUT_CL", "1") != "0"   # (extractor._Encoder.forward)
             self.update_block = BasicUpdateBlock(self.args, hidden_dim=hdim)
 
     def freeze_bn(self):

@@ -1045,6 +1045,8 @@ def to_channels_last(x):
     """[B,C,H,W] -> [B,H,W,C] (C must be a multiple of 4 for the GEMM kernels)."""
     if x.shape[1] % 4 != 0:
         raise RuntimeError("channel count must be a multiple of 4")
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        return x.permute(0, 2, 3, 1)          # already [B][H][W][C] in memory (the channels_last context encoder's output): a view
     return _ToCL.apply(x)
 
 

@@ -1491,6 +1491,34 @@ def test_norm_writes_the_space_to_depth_input_of_the_stride_two_unit(norm, H, W,
         assert _rel_l2(outs[True][2][k], v) < 2e-2 or v.norm().item() < 1e-3, k
 
 
+def test_context_encoder_output_stays_channels_last(monkeypatch):
+    """The context encoder's output (raft.py:107-111: split, tanh, relu) is consumed channels-last by the update block: with
+    `out_channels_last` the encoder hands it over in that layout and `to_channels_last` is a view -- three layout copies per
+    direction less.  Same predictions as with the NCHW hand-over (the values never change, only where they live), and the
+    copies are counted."""
+    from flow_supervisor_amd import ops
+    g = load("train_step_basic")
+    seed = int(g["seed"])
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(2, int(g["H"]), int(g["W"]), seed + 1))
+    calls = []
+    orig = ops.nchw_to_nhwc
+    monkeypatch.setattr(ops, "nchw_to_nhwc", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    res = {}
+    for flag in (True, False):
+        m = _model(False, seed).train()
+        m.freeze_bn()
+        m.cnet.out_channels_last = flag
+        calls.clear()
+        preds = m(im1, im2, iters=3)
+        O.sequence_loss_zero_gt(preds).backward()
+        res[flag] = (preds[-1].detach().clone(), len(calls), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert res[True][1] <= res[False][1] - 3, (res[True][1], res[False][1])
+    close(res[True][0], res[False][0], 1e-5, rtol=1e-5, what="last prediction")
+    for k, v in res[False][2].items():
+        e = _rel_l2(res[True][2][k], v)
+        assert e < 2e-2 or v.norm().item() < 1e-3, f"{k}: relative L2 error {e:.3e}"
+
+
 def _rel_l2(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
