@@ -252,7 +252,10 @@ extern "C" int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const fl
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
   hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw, out, dres, s2d_w);
-  hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw, out, s2d_w);
+  // fused residual unit: the first kernel just wrote dres = g * (out > 0) -- exactly what the second would rebuild from g and out,
+  // so it reads that one tensor instead of the two (and in the plain layout, whatever layout g arrived in)
+  if (dres) hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, dres, x, stats, s1, s2, dx, HW, C, relu, ppw, nullptr, 0);
+  else hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw, out, s2d_w);
   return fs_launch_status();
 }
 extern "C" int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M,
