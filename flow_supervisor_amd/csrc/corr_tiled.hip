@@ -529,11 +529,6 @@ struct KtArgs {
   int n;
 };
 
-__device__ __forceinline__ void kt_mark(unsigned* bits, int i) {
-  const unsigned m = 1u << (i & 31);
-  if (!(bits[i >> 5] & m)) atomicOr(bits + (i >> 5), m);       // (most marks are already set: the read is a broadcast)
-}
-
 // bits [i0, i1] of a bitmap in LDS: one read (+ one atomic where something is missing) per word instead of per bit
 __device__ __forceinline__ void kt_mark_range(unsigned* bits, int i0, int i1) {
   for (int w = i0 >> 5; w <= (i1 >> 5); ++w) {
