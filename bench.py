@@ -239,18 +239,56 @@ def set_arithmetic(split):
     ops.set_arithmetic(split)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` typed as is (no torchrun around it, WORLD_SIZE unset): start the N ranks as CHILD processes
+    through torch.distributed.run before this process has made any GPU call, let rank 0's JSON line pass through on the
+    inherited stdout and exit with the children's code (no exec of anything that touched the GPU).  On a box with fewer than
+    N devices the ranks share the devices there are (LOCAL_RANK modulo the device count) and exchange over gloo staged through
+    host memory -- RCCL refuses two ranks on one device -- which exercises every line of the N > 1 path but the RCCL call."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()                  # (does not initialise the GPU on this image)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < a.gpus:
+        env["FSRAFT_BENCH_SHARED_GPUS"] = str(max(n_dev, 1))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     from flow_supervisor_amd import ops
     from flow_supervisor_amd.core.raft import RAFT
     from flow_supervisor_amd.parallel import barrier, broadcast_parameters, init_distributed, max_over_ranks
     from flow_supervisor_amd.train import TrainStep
 
-    rank, world, local = init_distributed("cuda")
+    shared = int(os.environ.get("FSRAFT_BENCH_SHARED_GPUS", "0"))
+    if shared:                                        # fewer devices than ranks (self_launch): ranks share them, gloo through the host
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % shared)
+    rank, world, local = init_distributed("cuda", backend="gloo" if shared else None)
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
+                         f"or unset WORLD_SIZE and let bench.py start its ranks itself")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    rccl = None
+    if world > 1:
+        # proof for the reader of the line that the collective library saw every rank: a sum of ones over the data-path backend
+        import torch.distributed as dist
+        ones = torch.ones(1, device=dev)
+        if shared:
+            ones = ones.cpu()
+        dist.all_reduce(ones)
+        rccl = {"backend": dist.get_backend() + (" (= RCCL)" if dist.get_backend() == "nccl" else " staged through host memory: ranks share a device"),
+                "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(ones.item())}
     # MIOpen exhaustive find (cudnn.benchmark) costs ~7 minutes of start-up for the encoder shapes and
     # is off: the encoders are framework callers of the path, not what this benchmark is about.
     torch.backends.cudnn.benchmark = False
@@ -280,13 +318,18 @@ def main():
                                         alternate_corr=a.variant == "alt")).to(dev).train()
     model.freeze_bn()                                 # pytorch/train.py:203-204
     broadcast_parameters(model)
-    # The whole step is captured in a hipGraph and replayed -- 41.9 ms against 43.9 ms eager on the same box at one rank (866
-    # launches per step; the gaps between dependent kernels of one stream are what the graph removes, and with eight ranks on
-    # one host also eight Python threads competing for cores).  Several ranks: the capture then contains the RCCL bucket
-    # all-reduces issued from the backward hooks; tests/_rccl_worker.py captures and replays exactly that on the nccl backend
-    # (profiles/r03_rccl_world1.json).  Every rank reports whether its capture succeeded and all fall back to eager steps
-    # together if any failed (FSRAFT_BENCH_GRAPH_MULTI=0 keeps several ranks eager).
-    use_graph = a.graph == 1 or (a.graph == -1 and (world == 1 or os.environ.get("FSRAFT_BENCH_GRAPH_MULTI", "1") != "0"))
+    # The whole step is captured in a hipGraph and replayed (866 launches per step; the gaps between dependent kernels of one
+    # stream are what the graph removes, and with eight ranks on one host also eight Python threads competing for cores:
+    # profiles/r03_host_time.txt).  Several ranks: the step is replayed as TWO graphs -- forward + loss + backward with
+    # the gradients gathered into the flat buffer, then clip + AdamW + weight re-packing -- with the ONE all-reduce of the flat
+    # gradient buffer issued eagerly between them (TrainStep.forward_backward / exchange / update): no RCCL call inside a
+    # capture, no watchdog thread racing a capture, nothing that was not run here on two ranks.  The price is the overlap of the
+    # exchange with the encoders' backward (21 MB: a fraction of a millisecond per step).  FSRAFT_BENCH_GRAPH_MULTI=2 captures
+    # the whole step with the bucket all-reduces inside (verified on RCCL at world size 1 only, tests/_rccl_worker.py);
+    # =0 keeps several ranks eager (overlapped bucket all-reduces from the backward hooks).
+    multi = os.environ.get("FSRAFT_BENCH_GRAPH_MULTI", "1")
+    use_graph = a.graph == 1 or (a.graph == -1 and (world == 1 or multi != "0"))
+    split_graph = use_graph and world > 1 and multi != "2"
     # lr: a small constant (the reference's recipes: AdamW + StepLR(num_steps // 5, 0.5), pytorch/train.py:134-141, with
     # --lr 5e-6 .. 4e-4); throughput does not depend on it, the loss of synthetic steps stays finite with it
     B = a.batch_per_gpu
@@ -339,15 +382,37 @@ def main():
             # The process group's watchdog thread polls the events of finished collectives (hipEventQuery).  Under the default
             # GLOBAL capture mode such a call from another thread while this one captures is an error -- it invalidates the
             # capture and the watchdog aborts the process (seen once in ~10 runs of tests/_rccl_worker.py: hipErrorStreamCapture-
-            # Unsupported).  Thread-local mode confines the check to the capturing thread; the pause lets the watchdog reap
-            # the warm-up steps' work objects first.
-            time.sleep(0.5)
+            # Unsupported).  Thread-local mode confines the check to the capturing thread.  Before capturing, drain: every
+            # work handle of the warm-up steps was waited for by the step itself (FlatGradients.finish), the barrier below is
+            # a collective BEHIND them on every rank and the device sync retires its event, so the watchdog has nothing of
+            # this process left to poll when the capture begins.
+            barrier()
+            torch.cuda.synchronize()
             cap_kw["capture_error_mode"] = "thread_local"
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side, **cap_kw):   # same stream as the warm-up: autograd pins each AccumulateGrad node to the stream it was created on
-                loss = step(im1, im2)
-            run = graph.replay
+            if split_graph:
+                tstep = sstep if semi else step
+                g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb, stream=side, **cap_kw):   # same stream as the warm-up: autograd pins each AccumulateGrad node to the stream it was created on
+                    loss = tstep.forward_backward(sup, unsup) if semi else tstep.forward_backward(im1, im2)
+                    if semi:
+                        loss = loss[0] + loss[1]
+                tstep.exchange()                      # (between the captures as between the replays: the flat buffer holds the first capture's gradients)
+                with torch.cuda.graph(g_up, stream=side, pool=g_fb.pool(), **cap_kw):
+                    tstep.update()
+                graph = (g_fb, g_up)
+
+                def run():
+                    g_fb.replay()
+                    tstep.exchange()                  # eager: one all-reduce of the flat gradient buffer on the current stream
+                    g_up.replay()
+                graph_note = "two hipGraphs (forward + loss + backward | clip + AdamW + re-pack) with the all-reduce issued eagerly between them"
+            else:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side, **cap_kw):
+                    loss = step(im1, im2)
+                run = graph.replay
+                graph_note = "hipGraph replay of the whole step" + (" with the bucket all-reduces inside" if world > 1 else "")
         except Exception as e:                       # (never seen; the eager path below is the same step)
             print(f"bench: graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graph, loss, graph_note = None, None, f"eager (graph capture failed: {type(e).__name__})"
@@ -466,12 +531,16 @@ def main():
                                 f"{a.iters} supervisor iterations each, sequence_loss / sequence_loss_unsup, two backward passes, RCCL "
                                 f"all-reduce, clip, one AdamW step"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v,
-                   "launch": "hipGraph replay of the whole step (the short runs behind value_exact_f32 / value_north_star_encoders and the "
-                             "per-kernel timing are eager)" if graph is not None else graph_note,
+                   "launch": (graph_note + " (the short runs behind value_exact_f32 / value_north_star_encoders and the "
+                              "per-kernel timing are eager)") if graph is not None else graph_note,
                    "encoders": ("MIOpen NCHW convolutions (north_star configuration)" if os.environ.get("FSRAFT_ENCODER_CL", "1") == "0"
                                 else "channels_last on the fsraft kernels (7x7 stem on csrc/stem.hip, stride-2 units via space-to-depth; no MIOpen call left); "
                                      "value_north_star_encoders = the same step with the encoders on MIOpen")},
     }
+    if rccl is not None:
+        rccl["graph"] = "captured" if graph is not None else "eager"
+        rccl["reason"] = graph_note
+        out["rccl"] = rccl
     out.update(extra)
     if timer is not None:
         kern = {}

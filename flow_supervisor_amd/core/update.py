@@ -640,6 +640,7 @@ class _Engine:
             # gradients) runs for all slots at once when slot 0 -- the first iteration, the last to run backward -- has handed in
             # its own.  The correlation gradient returned here is the slot's view of the batch's output, filled by then.
             mb, t = mbs
+            mb.parked.add(t)
             if t == 0:
                 mb.run(self, P, st)
             return (dh_full if B != Bf else dh), mb.dcorr[t], None
@@ -912,6 +913,7 @@ class MotionBatch:
         # batch then multiplies zeros for the others
         self.dmotion = torch.zeros(T, B, H, W, _pad4(eng.x_c), device=device, dtype=torch.float32) if zero else e(eng.x_c)
         self.dcorr = e(eng.corr_c)
+        self.parked = set()             # slots whose iteration has handed in its dmotion
 
     @staticmethod
     def fits(eng, T, B, H, W):
@@ -926,6 +928,10 @@ class MotionBatch:
 
     def run(self, eng, P, st):
         n, B, H, W = self.n, self.B, self.H, self.W
+        for t in range(n):              # an iteration whose backward never ran (a loss on a subset of the predictions and no
+            if t not in self.parked:    # HeadBatch) handed in nothing: its slot is uninitialised memory, its gradient is zero
+                self.dmotion[t].zero_()
+        self.parked = set()
 
         def v(t):
             return None if t is None else t[:n].view(n * B, H, W, t.shape[-1])

@@ -261,8 +261,8 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
     H, W = lay.H, lay.W
     rows = nq if nq else B * H * W - q0
     dvol = torch.empty(rows, lay.P, device=douts[0].device, dtype=torch.float32) if out is None else out
-    if wmask is not None and not (records and len(douts) <= 16):
-        wmask = None
+    if wmask is not None and not (records and len(douts) <= 16 and os.environ.get("FSRAFT_DVOL_BOX", "1") != "0"):
+        wmask = None                      # (only the bounding-box kernel honours the mask; the row kernel writes whole rows)
     # scratch for the work list of queries whose lookups spread beyond the bounding-box kernel's box (1 + rows unsigned)
     qlist = torch.empty(rows + 1, device=douts[0].device, dtype=torch.int32) if len(douts) <= 16 else None
     t = TIMER

@@ -92,6 +92,7 @@ class FlatGradients:
         self._handles = []
         self._weight = 1.0
         self._active = False
+        self._deferred = False
         self.missing = []                 # parameters that received no gradient in the last step (FlatAdamW leaves them alone)
         # FSRAFT_DP_BUCKETS=0: no exchange from the backward hooks -- ONE all-reduce of the whole flat buffer in finish()
         self.bucketed = os.environ.get("FSRAFT_DP_BUCKETS", "1") != "0"
@@ -103,11 +104,14 @@ class FlatGradients:
             p.register_post_accumulate_grad_hook(self._hook)
 
     # ---- per step -------------------------------------------------------------------------------------------------
-    def begin(self, local_batch=None, global_batch=None, backward_passes=1):
+    def begin(self, local_batch=None, global_batch=None, backward_passes=1, exchange=True):
         """Call before backward: arms the bucket hooks for this step.  backward_passes: how many backward() calls feed this
         optimizer step (the flow-supervisor step runs a labelled and an unlabelled forward/backward before
         optimizer.step(), pytorch/train.py:270-277); a bucket is exchanged once its gradients have arrived that many
-        times, parameters that take part in fewer passes hold their bucket back until finish()."""
+        times, parameters that take part in fewer passes hold their bucket back until finish().
+        exchange=False: the hooks (and finish()) only gather the gradients into the flat buffer; the caller runs the
+        collective itself with exchange_all() -- the route of a step replayed as two hipGraphs with the all-reduce issued
+        eagerly between them (TrainStep.forward_backward / exchange / update)."""
         for p in self.params:
             p.grad = None
         self.missing = []
@@ -117,6 +121,7 @@ class FlatGradients:
         world = dist.get_world_size() if dist.is_initialized() else 1
         self._weight = (1.0 / world) if local_batch is None else float(local_batch) / float(global_batch)
         self._active = True
+        self._deferred = not exchange
 
     def zero_(self):
         """(kept for callers of the round-1 interface) equivalent to begin()."""
@@ -149,7 +154,7 @@ class FlatGradients:
             self.missing += missing
         for p in self.buckets[i]:
             p.grad = self.views[p]
-        if self.bucketed and self._exchanging():
+        if self.bucketed and not self._deferred and self._exchanging():
             a, b = self.slices[i]
             self._exchange(self.flat[a:b])
 
@@ -169,12 +174,23 @@ class FlatGradients:
             return
         for i in range(len(self.buckets)):
             self._launch(i)
-        if not self.bucketed and self._exchanging():
+        if not self.bucketed and not self._deferred and self._exchanging():
             self._exchange(self.flat)
         for h in self._handles:
             h.wait()
         self._handles = []
         self._active = False
+
+    def exchange_all(self):
+        """The whole flat buffer in ONE blocking all-reduce (after a begin(exchange=False) step's finish()): what a step split
+        into two hipGraphs issues eagerly between them.  The weight of begin() applies."""
+        if self._active:
+            self.finish()
+        if self._exchanging():
+            self._exchange(self.flat)
+            for h in self._handles:
+                h.wait()
+            self._handles = []
 
     def all_reduce_mean_(self, local_batch=None, global_batch=None):
         """Gradient of the GLOBAL-batch mean loss from per-rank gradients of local-batch mean losses: every rank's

@@ -194,22 +194,47 @@ class TrainStep:
                 else:
                     g["lr"] = float(lr)
 
-    def __call__(self, image1, image2, flow_gt=None, global_batch=None):
-        """image1/image2: this rank's shard.  global_batch: pairs over all ranks (default: equal shards)."""
-        if global_batch is None:
-            self.grads.begin()
-        else:
-            self.grads.begin(image1.shape[0], global_batch)
-        preds = self.model(image1, image2, iters=self.iters)
-        loss = raft_sequence_loss(preds, flow_gt)
-        loss.backward()                           # bucket hooks start each all-reduce as its gradients complete
-        self.grads.all_reduce_mean_()
+    def _update(self):
         if self.flat_opt:
             self.opt.step(clip=self.clip)
         else:
             self.grads.clip_norm_(self.clip)
             self.opt.step()
+
+    # The step in three parts, for callers that replay it as TWO hipGraphs with the collective issued eagerly between them
+    # (bench.py at N > 1: no RCCL call inside a capture): forward_backward() gathers the gradients into the flat buffer
+    # without exchanging them, exchange() is the one all-reduce of the step, update() is clip + AdamW.  __call__ runs the
+    # overlapped route (bucket all-reduces from the backward hooks).
+    def forward_backward(self, *args, **kw):
+        """Forward, loss, backward; gradients of this rank in grads.flat, NOT exchanged.  Same arguments as __call__."""
+        out = self._forward_backward(*args, exchange=False, **kw)
+        self.grads.finish()
+        return out
+
+    def exchange(self):
+        """The all-reduce (sum over ranks of local_batch / global_batch weighted gradients) of the whole flat buffer."""
+        self.grads.exchange_all()
+
+    def update(self):
+        """clip_grad_norm_ + AdamW on the (exchanged) flat gradient buffer."""
+        self._update()
+
+    def _forward_backward(self, image1, image2, flow_gt=None, global_batch=None, exchange=True):
+        if global_batch is None:
+            self.grads.begin(exchange=exchange)
+        else:
+            self.grads.begin(image1.shape[0], global_batch, exchange=exchange)
+        preds = self.model(image1, image2, iters=self.iters)
+        loss = raft_sequence_loss(preds, flow_gt)
+        loss.backward()                           # bucket hooks start each all-reduce as its gradients complete
         return loss.detach()
+
+    def __call__(self, *args, **kw):
+        """image1, image2[, flow_gt, global_batch]: this rank's shard.  global_batch: pairs over all ranks (default: equal shards)."""
+        out = self._forward_backward(*args, **kw)
+        self.grads.all_reduce_mean_()
+        self._update()
+        return out
 
 
 class SemiTrainStep(TrainStep):
@@ -238,20 +263,42 @@ class SemiTrainStep(TrainStep):
         self._sup_kw = "sup_grad_samples" in inspect.signature(model.forward).parameters and os.environ.get("FSRAFT_SUP_GRAD_SAMPLES", "1") != "0"
 
     def _batched_inputs(self, sup, unsup):
-        """cat of the two samples, cached while the caller passes the same tensors (the benchmark's resident inputs)."""
-        key = tuple(id(t) for t in sup[:4] + unsup[:4])
-        if self._cat is None or self._cat[0] != key:
-            self._cat = (key, tuple(torch.cat([a, b], 0).contiguous() for a, b in zip(sup[:4], unsup[:4])), (sup[:4], unsup[:4]))
-        return self._cat[1]
+        """cat of the two samples.  The key holds every input's identity AND version counter, so a caller that refreshes
+        preallocated input buffers in place (the pattern of hipGraph replays) is not served the first batch again; while a
+        stream capture is running the concatenation is always performed, into persistent buffers, so that the copies are
+        nodes of the graph and every replay re-reads the caller's buffers."""
+        srcs = sup[:4] + unsup[:4]
+        capturing = srcs[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        key = tuple((id(t), t._version) for t in srcs)
+        if self._cat is not None and self._cat[0] == key and not capturing:
+            return self._cat[1]
+        shapes = tuple((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]) for a, b in zip(sup[:4], unsup[:4]))
+        if self._cat is not None and tuple(tuple(t.shape) for t in self._cat[1]) == shapes and self._cat[1][0].device == srcs[0].device:
+            bufs = self._cat[1]                   # same addresses as in an earlier capture
+        else:
+            bufs = tuple(torch.empty(sh, device=a.device, dtype=a.dtype) for sh, a in zip(shapes, sup[:4]))
+        for buf, a, b in zip(bufs, sup[:4], unsup[:4]):
+            buf[:a.shape[0]].copy_(a)
+            buf[a.shape[0]:].copy_(b)
+        self._cat = (key, bufs, srcs)
+        return bufs
 
-    def __call__(self, sup, unsup, global_batch=None):
+    def _bn_training(self):
+        return any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training for m in self.model.modules())
+
+    def _forward_backward(self, sup, unsup, global_batch=None, exchange=True):
         if not self.batched:
-            return self._sequential(sup, unsup, global_batch)
+            return self._sequential(sup, unsup, global_batch, exchange)
+        if self._bn_training():
+            # one batch of two is the reference's two passes only while every op is per-sample: a BatchNorm in training mode
+            # (the chairs stage: pytorch/train.py:203-204 freezes it for every other stage) would take its statistics over
+            # both samples and update its running statistics once instead of twice (ADVICE r3)
+            return self._sequential(sup, unsup, global_batch, exchange)
         bs = sup[0].shape[0]
         if global_batch is None:
-            self.grads.begin()
+            self.grads.begin(exchange=exchange)
         else:
-            self.grads.begin(bs, global_batch)
+            self.grads.begin(bs, global_batch, exchange=exchange)
         from .core.l2l import _offsets
         im1, im2, ci1, ci2 = self._batched_inputs(sup, unsup)
         ox = _offsets(sup[4], bs) + _offsets(unsup[4], unsup[0].shape[0])
@@ -265,20 +312,14 @@ class SemiTrainStep(TrainStep):
             loss_u, _ = sequence_loss_unsup([p[bs:] for p in preds], unsup[6], unsup[7], unsup_weight=self.unsup_lambda, metrics=False)
         (loss + loss_u).backward()
         del preds
-        self.grads.all_reduce_mean_()
-        if self.flat_opt:
-            self.opt.step(clip=self.clip)
-        else:
-            self.grads.clip_norm_(self.clip)
-            self.opt.step()
         return loss.detach(), loss_u.detach()
 
-    def _sequential(self, sup, unsup, global_batch=None):
+    def _sequential(self, sup, unsup, global_batch=None, exchange=True):
         """The reference's order: two forward / backward passes (pytorch/train.py:270-277)."""
         if global_batch is None:
-            self.grads.begin(backward_passes=2)
+            self.grads.begin(backward_passes=2, exchange=exchange)
         else:
-            self.grads.begin(sup[0].shape[0], global_batch, backward_passes=2)
+            self.grads.begin(sup[0].shape[0], global_batch, backward_passes=2, exchange=exchange)
         im1, im2, ci1, ci2, ox, oy, flow, valid = sup
         preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters)
         loss, _ = sequence_loss(preds, flow, valid, self.gamma, metrics=False)
@@ -289,10 +330,4 @@ class SemiTrainStep(TrainStep):
         loss_u, _ = sequence_loss_unsup(preds, flow, valid, unsup_weight=self.unsup_lambda, metrics=False)
         loss_u.backward()
         del preds
-        self.grads.all_reduce_mean_()
-        if self.flat_opt:
-            self.opt.step(clip=self.clip)
-        else:
-            self.grads.clip_norm_(self.clip)
-            self.opt.step()
         return loss.detach(), loss_u.detach()

@@ -2253,6 +2253,122 @@ def test_hipgraph_replays_of_the_train_step_follow_the_eager_steps():
         assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
 
 
+def test_step_replayed_as_two_hipgraphs_with_the_exchange_between_them():
+    """bench.py at N > 1: forward + loss + backward as one hipGraph, the all-reduce of the flat gradient buffer issued eagerly,
+    clip + AdamW + re-pack as a second hipGraph (TrainStep.forward_backward / exchange / update).  At world size 1 the exchange
+    is the identity, so six replayed steps must follow six eager steps of the plain __call__ from the same start."""
+    import argparse
+    import copy
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.train import TrainStep
+    torch.manual_seed(0)
+    model = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(DEV).train()
+    model.freeze_bn()
+    twin = copy.deepcopy(model)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    im1 = torch.rand(2, 3, 184, 320, device=DEV, generator=g) * 255
+    im2 = torch.rand(2, 3, 184, 320, device=DEV, generator=g) * 255
+    eager = TrainStep(twin, lr=1e-4, iters=4, capturable=True)
+    le = [float(eager(im1, im2)) for _ in range(8)]
+    step = TrainStep(model, lr=1e-4, iters=4, capturable=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step(im1, im2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_fb, stream=side):
+        loss = step.forward_backward(im1, im2)
+    step.exchange()
+    with torch.cuda.graph(g_up, stream=side, pool=g_fb.pool()):
+        step.update()
+    lg = []
+    for _ in range(6):
+        g_fb.replay()
+        step.exchange()
+        g_up.replay()
+        torch.cuda.synchronize()
+        lg.append(float(loss))
+    del g_fb, g_up
+    for a, b in zip(le[2:], lg):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 2 ...` typed as is, no torchrun and no WORLD_SIZE around it, must start its
+    two ranks itself (children, before the parent touches the GPU), run the data-parallel step on both and print ONE JSON line
+    with n_gpus = 2.  On a one-GPU box the ranks share cuda:0 and exchange over gloo through host memory; on a box with two
+    devices the same command runs on RCCL.  The line must prove that the collective saw both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--height", "128",
+                        "--width", "192", "--iters", "3", "--batch-per-gpu", "1", "--no-cpu-baseline", "--no-extra"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    print("bench --gpus 2:", {k: out[k] for k in ("value", "n_gpus", "ms_per_step", "rccl")})
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2
+    assert out["rccl"]["world_size"] == 2 and out["rccl"]["ranks_seen_by_all_reduce"] == 2
+    assert out["rccl"]["graph"] == "captured", out["rccl"]
+    assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"]     # finite loss on the replayed steps
+
+
+def test_semi_step_reads_inputs_refreshed_in_place():
+    """SemiTrainStep cached the concatenation of the labelled and the unlabelled inputs keyed on id() alone; a loop
+    that refreshes preallocated input buffers in place (the pattern of hipGraph replays) trained on the first batch forever.
+    Eager: the second step on refreshed buffers must see the new data; captured: the replay must re-read the buffers."""
+    import argparse
+    from flow_supervisor_amd.core.l2l import L2L
+    from flow_supervisor_amd.train import SemiTrainStep
+    torch.manual_seed(0)
+    model = L2L(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(DEV).train()
+    model.freeze_bn()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    H, W, h, w = 128, 192, 96, 128
+
+    def sample(oy, ox):
+        f1 = torch.rand(1, 3, H, W, device=DEV, generator=g) * 255
+        f2 = torch.rand(1, 3, H, W, device=DEV, generator=g) * 255
+        return [f1[:, :, oy:oy + h, ox:ox + w].contiguous(), f2[:, :, oy:oy + h, ox:ox + w].contiguous(), f1, f2, ox, oy,
+                torch.randn(1, 2, h, w, device=DEV, generator=g), torch.ones(1, h, w, device=DEV)]
+
+    sup, unsup = sample(8, 16), sample(16, 32)
+    fresh = [torch.rand_like(t) * 255 for t in sup[:4]]
+    step = SemiTrainStep(model, lr=0.0, iters=2, capturable=True)       # lr 0: the weights stay, only the data moves the loss
+    l0 = float(step(sup, unsup)[0])
+    assert abs(float(step(sup, unsup)[0]) - l0) <= 1e-4 * abs(l0)
+    keep = [t.clone() for t in sup[:4]]
+    for t, f in zip(sup[:4], fresh):
+        t.copy_(f)
+    l1 = float(step(sup, unsup)[0])
+    assert abs(l1 - l0) > 1e-3 * abs(l0), (l0, l1)
+    # captured: replays follow the buffers
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(sup, unsup)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        ls, _ = step(sup, unsup)
+    graph.replay(); torch.cuda.synchronize()
+    assert abs(float(ls) - l1) <= 2e-3 * abs(l1), (float(ls), l1)
+    for t, k in zip(sup[:4], keep):
+        t.copy_(k)
+    graph.replay(); torch.cuda.synchronize()
+    assert abs(float(ls) - l0) <= 2e-3 * abs(l0), (float(ls), l0)
+    del graph
+
+
 # ----------------------------------------------------------------------------- data parallelism on the real step (row e)
 @pytest.mark.parametrize("global_batch,H,W,iters", [(4, 128, 192, 3), (3, 128, 192, 3), (2, 440, 1024, 12)])
 def test_two_process_train_step_matches_single_process(global_batch, H, W, iters, tmp_path):

@@ -96,3 +96,52 @@ def test_per_step_batches_respect_32_bit_offsets():
     assert not HeadBatch.fits(12, 16, 55, 128)       # 3.1 GB
     assert HeadBatch.fits(32, 4, 55, 128)            # 2.08e9 bytes: just below 2^31
     assert not HeadBatch.fits(34, 4, 55, 128)
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without torchrun around it starts N children through
+    torch.distributed.run on 127.0.0.1 (the driver's own launch line) and hands back their exit code; with fewer devices
+    than ranks the children are told to share them (gloo through the host)."""
+    import importlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    a = bench.parse()
+    assert bench.self_launch(a) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert "FSRAFT_BENCH_SHARED_GPUS" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    bench.self_launch(a)
+    assert seen["env"]["FSRAFT_BENCH_SHARED_GPUS"] == "1"
+
+
+def test_flat_gradients_deferred_exchange():
+    """begin(exchange=False): the hooks gather, nobody exchanges; exchange_all() is then the step's one collective
+    (world size 1 here: the identity) -- the route of a step replayed as two hipGraphs."""
+    from flow_supervisor_amd.parallel import FlatGradients
+    lin = torch.nn.Linear(3, 2)
+    fg = FlatGradients(lin.parameters(), ["update.w", "update.b"])
+    fg.begin(exchange=False)
+    lin(torch.ones(4, 3)).sum().backward()
+    fg.finish()
+    assert torch.equal(lin.weight.grad, torch.full((2, 3), 4.0)) and lin.weight.grad.data_ptr() == fg.views[lin.weight].data_ptr()
+    fg.exchange_all()
+    assert torch.equal(fg.views[lin.bias], torch.full((2,), 4.0))

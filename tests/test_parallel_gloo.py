@@ -180,3 +180,43 @@ def test_single_flat_allreduce_switch(tmp_path):
     mp.spawn(_worker_two_passes, args=(2, _free_port(), out, False), nprocs=2, join=True)
     got = torch.load(out)
     assert torch.allclose(got["flat"], _two_pass_reference(), atol=1e-6, rtol=1e-5)
+
+
+def _worker_deferred(rank, world, port, out):
+    """The route of a step replayed as two hipGraphs (bench.py at N > 1): backward only gathers (begin(exchange=False)), the ONE
+    all-reduce of the whole flat buffer is issued afterwards (exchange_all); unequal shards keep their weights."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from flow_supervisor_amd.parallel import FlatGradients, broadcast_parameters, init_distributed, shard_batch
+    init_distributed("cpu")
+    torch.manual_seed(100 + rank)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    broadcast_parameters(model)
+    grads = FlatGradients([p for _, p in model.named_parameters()], [n for n, _ in model.named_parameters()])
+    torch.manual_seed(7)
+    x = torch.randn(5, 3, 10, 12)
+    s, n = shard_batch(5, rank, world)
+    grads.begin(n, 5, exchange=False)
+    _toy_loss([model(x[s:s + n]), 0.5 * model(x[s:s + n])]).backward()
+    grads.finish()
+    local = grads.flat.clone()                         # nothing was exchanged yet: this rank's own gradient
+    grads.exchange_all()
+    if rank == 0:
+        torch.save({"flat": grads.flat.clone(), "local": local}, out)
+
+
+def test_deferred_exchange_is_one_allreduce_after_backward(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_deferred, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    sys.path.insert(0, ROOT)
+    from flow_supervisor_amd.parallel import FlatGradients
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    grads = FlatGradients(model.parameters())
+    torch.manual_seed(7)
+    x = torch.randn(5, 3, 10, 12)
+    _toy_loss([model(x), 0.5 * model(x)]).backward()
+    assert torch.allclose(got["flat"], grads.flat, atol=1e-6, rtol=1e-5)
+    assert not torch.allclose(got["local"], grads.flat, atol=1e-6, rtol=1e-3)      # rank 0's shard alone is not the global gradient
