@@ -191,6 +191,7 @@ struct DvolArgs {
 // the finished gradient rows are written once and read (by the two volume-backward GEMMs) only after 1 GB more has gone by:
 // policy 2 stores them `nt` so that they do not push the step's other working sets out of L2 (fsraft_set_dvol_policy)
 __device__ __forceinline__ void dvstore4(void* p, f32x4 v, int policy) {
+  if (policy == 3) { asm volatile("" ::"v"(p), "v"(v)); return; }      // (measurement only: the kernel without its stores)
   if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
   else if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
   else gstore4(p, v);
@@ -506,6 +507,249 @@ __global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayou
       }
     }
     wave_lds_sync();
+  }
+}
+
+// ---- round 4: the same bounding-box rows, the window gradients built SEPARABLY in registers -------------------------------
+// corr_dvol_box_kernel is instruction-bound (394 us for 285 MB of traffic; PMC, scripts/dvol_pmc.sh: 4800 vector and
+// 1070 LDS instructions per query, 620 LDS bank-conflict cycles, three waves per SIMD): per query it runs 4 levels x 12 lookups
+// x 2 rounds of "four LDS reads of gradient taps, one LDS read-add-write of the box, ~40 VALU instructions" for 19 K useful
+// multiply-adds.  Here the 16 lanes of a DPP row own one LEVEL and a lane owns one window COLUMN: lane (l, i) holds the N1
+// gradients G[i][0 .. N1-1] of lookup t (consecutive floats of dOut: channel = i * N1 + j) in registers,
+//     T[j]   = (1 - fx) G_i[j] + fx G_{i-1}[j]          one row_shr:1 DPP move + two VALU per j   (x direction: the lane to the left)
+//     W[wy] += (1 - fy) T[wy] + fy T[wy - 1]            two VALU per window row                  (y direction: registers)
+// so a lookup costs ~60 VALU instructions for all four levels at once and no LDS traffic; the dOut slices never pass through
+// LDS.  W is kept in registers while consecutive lookups have the same integer window origin at a level (after the first
+// iterations the flow moves by fractions of a cell: a handful of distinct origins per step at level 0, one or two at the
+// coarser levels) and is added into the level's box -- one LDS read-add-write per window row -- only when the origin changes
+// and once at the end.  The boxes of the coarser levels are smaller (a flow that moves <= 14 cells at level 0 moves <= 8 / 4 / 2
+// cells further up): 5 KB of LDS per wave, eight workgroups per CU.  The section writer decides per trip, on the scalar unit,
+// whether the box can be touched at all; trips that cannot store zeros without looking at it.
+// Box of level l: `side` cells of window origins + windows fit; stored tile-aligned (origin floored to a multiple of 4 cells) with
+// pitch = rows = side + 3 rounded up to 4, so that every 4x4 tile the box overlaps is two aligned 16-byte LDS reads.
+__host__ __device__ constexpr int dvs_side(int l) { return l == 0 ? 24 : l == 1 ? 18 : l == 2 ? 14 : 12; }
+__host__ __device__ constexpr int dvs_pitch(int l) { return (dvs_side(l) + 3 + 3) / 4 * 4; }              // 28, 24, 20, 16
+__host__ __device__ constexpr int dvs_base(int l) { return l == 0 ? 0 : dvs_base(l - 1) + dvs_pitch(l - 1) * dvs_pitch(l - 1); }
+constexpr int DVS_TOT = dvs_base(3) + dvs_pitch(3) * dvs_pitch(3);      // 2016 floats per wave
+
+template <int R, bool REC>
+__global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int grid_w, int64_t q0,
+                                                            unsigned nq, unsigned* __restrict__ qlist, int policy,
+                                                            const unsigned* __restrict__ wmask, int wm_hw) {
+  using S = TL<R>;
+  constexpr int N1 = S::N1, WIN = S::WIN, N2 = S::N2;
+  __shared__ __attribute__((aligned(16))) float box_s[4][DVS_TOT];           // [wave][level boxes back to back]
+  __shared__ __attribute__((aligned(16))) LevelQ lq_s[4][4][DV_MAXN];        // [wave][level][lookup]
+  __shared__ float cxy[4][DV_MAXN][2];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned qrel = blockIdx.x * 4u + (unsigned)wave;
+  if (qrel >= nq) return;                                // (wave-uniform; no workgroup barrier below)
+  const int64_t q = q0 + qrel;
+  const int b = (int)(q / HW), pix = (int)(q % HW);
+  const int n = a.n, nlev = L.nlev, CH = nlev * N2;
+  const int lv = lane >> 4, i = lane & 15;               // this lane's level and window column (or lookup, in the set-up)
+  const bool lvl_on = lv < nlev;
+  // this lane's N1 gradients of lookup t: dOut[t][q][lv * N2 + i * N1 + j], 36 (28) consecutive bytes, 4-byte aligned.  Lanes right
+  // of the gradient (i >= N1) and rows of levels that do not exist re-read a valid slice; the first get a zero x weight, the
+  // rest are never handed in.
+  const bool g_on = lvl_on && i < N1;
+  const int64_t goff = q * CH + (lvl_on ? lv : 0) * N2 + (i < N1 ? i : N1 - 1) * N1;
+  // PF lookups' slices in flight per wave (with one lookup of look-ahead the wave waited one memory latency per lookup: 335 us,
+  // 92 % of its cycles in s_waitcnt); the first PF are requested before anything else -- their addresses depend on the query
+  // number alone.  Every loaded element passes through an empty asm before its first use: left alone, the SLP vectoriser pairs
+  // the nine floats for v_pk_* instructions and re-packs them into register pairs right behind the loads, which puts the wait
+  // for a slice directly after its issue.
+  constexpr int PF = 6;
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+  struct GS { f32x4 a, b; float c; };
+  GS G[PF];
+  auto loadg = [&](int t, GS& g) {
+    // (unconditional: a load inside a wave-uniform branch makes the compiler's wait counting fall back to vmcnt(0) at the join;
+    //  slots beyond the n-th lookup re-read lookup 0's slice, which the caches hold)
+    const float* p = (a.dout[t] ? a.dout[t] : a.dout[0]) + goff;
+    g.a = *(const FS_GLOBAL f32x4u*)p;
+    if constexpr (N1 == 9) {
+      g.b = *(const FS_GLOBAL f32x4u*)(p + 4);
+      g.c = gload1(p + 8);
+    } else {
+      const f32x3u b3 = *(const FS_GLOBAL f32x3u*)(p + 4);
+      g.b = f32x4{b3[0], b3[1], b3[2], 0.f};
+      g.c = 0.f;
+    }
+  };
+  auto gval = [&](const GS& g, int j) -> float { return j < 4 ? g.a[j] : (N1 == 9 ? (j < 8 ? g.b[j - 4] : g.c) : g.b[j - 4]); };
+  // the row's record mask in registers (lane w holds word w; rows of up to 64 words = 65536 cells): one load per wave
+  const unsigned* wm = wmask ? wmask + ((int64_t)(qrel / (unsigned)wm_hw) * ((wm_hw + 31) >> 5) + ((qrel % (unsigned)wm_hw) >> 5)) *
+                                            (((L.P >> 5) + 31) >> 5) : nullptr;
+  const int wm_words = ((L.P >> 5) + 31) >> 5;
+  const bool wm_regs = wm && wm_words <= 64;
+  const unsigned wm_mine = (wm_regs && lane < wm_words) ? wm[lane] : 0u;
+  const int hl = lv == 0 ? L.h[0] : lv == 1 ? L.h[1] : lv == 2 ? L.h[2] : L.h[3];
+  const int wl = lv == 0 ? L.w[0] : lv == 1 ? L.w[1] : lv == 2 ? L.w[2] : L.w[3];
+  const int side = dvs_side(lv), pitch = dvs_pitch(lv);
+  // the n query positions: every load issued before the first LDS store (one memory latency per wave, not one per lookup)
+  float cxr[DV_MAXN], cyr[DV_MAXN];
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < DV_MAXN; ++t)
+      if (t < n) query_xy(a.co[t], b, pix, grid_w, cxr[t], cyr[t]);
+  }
+#pragma unroll
+  for (int k = 0; k < PF; ++k) loadg(k, G[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < DV_MAXN; ++t)
+      if (t < n) { cxy[wave][t][0] = cxr[t]; cxy[wave][t][1] = cyr[t]; }
+  }
+  {   // zero the boxes (16-byte stores)
+    f32x4* bz = reinterpret_cast<f32x4*>(&box_s[wave][0]);
+#pragma unroll
+    for (int k = 0; k < (DVS_TOT / 4 + 63) / 64; ++k)
+      if (lane + 64 * k < DVS_TOT / 4) bz[lane + 64 * k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  wave_lds_sync();
+  // every (level, lookup) pair's window origin and fractions in ONE pass: lane = (level, lookup); then the bounding box of a
+  // level's origins by a reduction inside its 16-lane row.  A query either fits at every level or goes to the work list.
+  int ox, oy, uw, uh;                                    // this lane's level: first window origin, extent of the windows' union
+  {
+    const int tt = i < n ? i : 0;
+    const LevelQ v = level_query(cxy[wave][tt][0], cxy[wave][tt][1], lv, R);
+    lq_s[wave][lv][i] = v;
+    int mnx = v.wx0, mny = v.wy0, mxx = v.wx0, mxy = v.wy0;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+      mnx = min(mnx, __shfl_xor(mnx, d, 64)); mny = min(mny, __shfl_xor(mny, d, 64));
+      mxx = max(mxx, __shfl_xor(mxx, d, 64)); mxy = max(mxy, __shfl_xor(mxy, d, 64));
+    }
+    ox = mnx; oy = mny; uw = mxx - mnx + WIN; uh = mxy - mny + WIN;
+    const bool fits = !lvl_on || (uw <= side && uh <= side);
+    if (__builtin_amdgcn_ballot_w64(!fits)) {
+      // (one atomic per query that does not fit: rare on real flows; when every query jumps the row kernel's time dominates anyway)
+      if (lane == 0) qlist[1 + atomicAdd(qlist, 1u)] = qrel;
+      return;
+    }
+  }
+  wave_lds_sync();
+  const int bax = ox & ~3, bay = oy & ~3;                 // the box's origin, tile-aligned
+  float* box = &box_s[wave][lv == 0 ? dvs_base(0) : lv == 1 ? dvs_base(1) : lv == 2 ? dvs_base(2) : dvs_base(3)];
+  float acc[WIN];
+#pragma unroll
+  for (int wy = 0; wy < WIN; ++wy) acc[wy] = 0.f;
+  int cur_x0 = 0, cur_y0 = 0;
+  bool have = false;                                      // acc holds lookups with window origin (cur_x0, cur_y0)
+  auto flush = [&](bool rows) {                           // rows: this lane's level hands its window in
+    float* bp = box + (cur_y0 - bay) * pitch + (cur_x0 + i - bax);
+    const bool inside = cur_x0 >= 0 && cur_x0 + WIN <= wl && cur_y0 >= 0 && cur_y0 + WIN <= hl;
+    if (!__builtin_amdgcn_ballot_w64(rows && !inside)) {  // no window of this hand-in is clipped by the image (the usual case)
+      if (rows && i < WIN) {
+#pragma unroll
+        for (int wy = 0; wy < WIN; ++wy) bp[wy * pitch] += acc[wy];
+      }
+    } else {
+      const bool xok = rows && i < WIN && (unsigned)(cur_x0 + i) < (unsigned)wl;
+#pragma unroll
+      for (int wy = 0; wy < WIN; ++wy)
+        if (xok && (unsigned)(cur_y0 + wy) < (unsigned)hl) bp[wy * pitch] += acc[wy];
+    }
+#pragma unroll
+    for (int wy = 0; wy < WIN; ++wy) acc[wy] = rows ? 0.f : acc[wy];
+  };
+#pragma unroll
+  for (int t = 0; t < DV_MAXN; ++t) {
+    if (t < n) {
+      GS& g = G[t % PF];
+      const LevelQ v = lq_s[wave][lv][t];
+      const bool moved = lvl_on && have && (v.wx0 != cur_x0 || v.wy0 != cur_y0);
+      if (__builtin_amdgcn_ballot_w64(moved)) {
+        flush(moved);
+        wave_lds_sync();
+      }
+      cur_x0 = v.wx0; cur_y0 = v.wy0; have = true;
+      const float fx = v.fx, fy = v.fy, gx1 = g_on ? 1.f - fx : 0.f, gy1 = 1.f - fy;
+      float T[N1];
+#pragma unroll
+      for (int j = 0; j < N1; ++j) {
+        float gj = gval(g, j);
+        asm volatile("" : "+v"(gj));
+        const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gj), 0x111, 0xf, 0xf, true));
+        T[j] = gx1 * gj + fx * left;
+      }
+#pragma unroll
+      for (int wy = 0; wy < WIN; ++wy) {
+        if (wy < N1) acc[wy] += gy1 * T[wy];
+        if (wy >= 1) acc[wy] += fy * T[wy - 1];
+      }
+    }
+    if (t + PF < DV_MAXN) loadg(t + PF, G[t % PF]);
+  }
+  flush(lvl_on);
+  wave_lds_sync();
+
+  char* rowb = reinterpret_cast<char*>(dvol + (int64_t)qrel * L.P);
+  if (policy == 4) { if (box_s[wave][lane] == 12345.f) dvol[0] = 1.f; return; }      // (measurement only: no row writer)
+  // ---- the row.  Pass 1: zeros, 1 KB (eight records, or 256 floats) per wave store, only where the list GEMMs read; the mask
+  // bits of a trip are a scalar: trips without a flagged record are skipped on the scalar unit.
+  {
+    const int nbytes = L.P * 4;
+    const int sub = lane >> 3;
+    for (int o = 0; o < nbytes; o += 1024) {
+      unsigned bits = 0xffu;
+      if (REC && wm) {
+        const int r0 = o >> 7;                             // first record of the trip (a multiple of 8: inside one mask word)
+        const unsigned word = wm_regs ? (unsigned)__builtin_amdgcn_readlane((int)wm_mine, r0 >> 5) : wm[r0 >> 5];
+        bits = (word >> (r0 & 31)) & 0xffu;
+        if (!bits) continue;
+      }
+      if (((bits >> sub) & 1u) && o + lane * 16 < nbytes) dvstore4(rowb + o + lane * 16, f32x4{0.f, 0.f, 0.f, 0.f}, policy);
+    }
+  }
+  // Pass 2: the 4x4 tiles that the union of a level's windows overlaps, out of the tile-aligned box: a lane takes half a tile (two
+  // rows = two aligned 16-byte LDS reads -> 8 cells -> 16 bytes of hi and of lo, or 32 bytes of fp32).  Same-address stores of one
+  // wave stay in program order, so these land on top of pass 1's zeros.
+#pragma unroll 1
+  for (int l = 0; l < nlev; ++l) {
+    const int off = L.off[l], tw = L.tw[l], th = L.th[l];
+    const int lox = __builtin_amdgcn_readlane(ox, 16 * l), loy = __builtin_amdgcn_readlane(oy, 16 * l);
+    const int luw = __builtin_amdgcn_readlane(uw, 16 * l), luh = __builtin_amdgcn_readlane(uh, 16 * l);
+    const int bpitch = dvs_pitch(l);
+    const float* bl = &box_s[wave][l == 0 ? dvs_base(0) : l == 1 ? dvs_base(1) : l == 2 ? dvs_base(2) : dvs_base(3)];
+    const int tx0 = max(lox >> 2, 0), tx1 = min((lox + luw - 1) >> 2, tw - 1);
+    const int ty0 = max(loy >> 2, 0), ty1 = min((loy + luh - 1) >> 2, th - 1);
+    const int ntx = tx1 - tx0 + 1, nty = ty1 - ty0 + 1;
+    if (ntx <= 0 || nty <= 0) continue;                    // every window of this level lies outside the image
+    const int ntask = ntx * nty * 2;
+    const float rntx = 1.0f / (float)ntx;
+    const int lbax = lox & ~3, lbay = loy & ~3;
+    for (int k0 = 0; k0 < ntask; k0 += 64) {
+      const int k = min(k0 + lane, ntask - 1);             // (surplus lanes repeat the last task up to the stores: the mask word below
+      const int half = k & 1, tidx = k >> 1;               //  comes from another LANE, and ds_bpermute reads zero from a masked-off one)
+      const int tyi = (int)(((float)tidx + 0.5f) * rntx), txi = tidx - tyi * ntx;      // (tidx < 64: exact)
+      const int ty = ty0 + tyi, tx = tx0 + txi;
+      const float* bp = bl + (4 * ty + 2 * half - lbay) * bpitch + (4 * tx - lbax);
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(bp), r1 = *reinterpret_cast<const f32x4*>(bp + bpitch);
+      const int f = off + (ty * tw + tx) * 16 + half * 8;
+      bool want = k0 + lane < ntask;
+      if (REC && wm) {
+        const int r = f >> 5;
+        const unsigned word = wm_regs ? (unsigned)__shfl((int)wm_mine, r >> 5, 64) : wm[r >> 5];
+        want = want && ((word >> (r & 31)) & 1u);
+      }
+      if (want) {
+        if (REC) {
+          const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+          uint2 h0, l0s, h1, l1s;
+          rec_split4(v, h0, l0s);
+          rec_split4(v + 4, h1, l1s);
+          char* rp = rowb + (f >> 5) * 128 + (f & 31) * 2;
+          dvstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}), policy);
+          dvstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}), policy);
+        } else {
+          dvstore4(rowb + (int64_t)f * 4, r0, policy);
+          dvstore4(rowb + (int64_t)f * 4 + 16, r1, policy);
+        }
+      }
+    }
   }
 }
 
@@ -857,7 +1101,7 @@ extern "C" int fsraft_set_dvol_policy(int policy) {
   return FS_OK;
 }
 
-int g_dvol_box = 1;       // 1: corr_dvol_box_kernel + work list where a scratch list is supplied, 0: corr_dvol_kernel for every query
+int g_dvol_box = 2;       // 2: corr_dvol_sep_kernel (round 4) / 1: corr_dvol_box_kernel, + work list where a scratch list is supplied; 0: corr_dvol_kernel for every query
 extern "C" int fsraft_set_lookup_policy(int aux) {
   if (aux != -1 && aux != 0 && aux != 2 && aux != 16 && aux != 18) return FS_ERR_ARG;
   g_lookup_policy = aux;
@@ -901,8 +1145,15 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   const int wm_hw = whole ? H * W : (int)grid;
   if (g_dvol_box && qlist && !accumulate && (L.P % 8) == 0) {
     hipLaunchKernelGGL(dvol_list_reset_kernel, dim3(1), dim3(1), 0, stream, qlist);
-#define DVBOX(RR, REC) hipLaunchKernelGGL((corr_dvol_box_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, \
-                                          add_grid ? W : 0, q0, grid, qlist, g_dvol_policy, wmask, wm_hw)
+#define DVBOX(RR, REC)                                                                                                                        \
+  do {                                                                                                                                   \
+    if (g_dvol_box == 2)                                                                                                                 \
+      hipLaunchKernelGGL((corr_dvol_sep_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, add_grid ? W : 0, \
+                         q0, grid, qlist, g_dvol_policy, wmask, wm_hw);                                                                  \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((corr_dvol_box_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, add_grid ? W : 0, \
+                         q0, grid, qlist, g_dvol_policy, wmask, wm_hw);                                                                  \
+  } while (0)
     if (radius == 4) { if (records) DVBOX(4, true); else DVBOX(4, false); }
     else { if (records) DVBOX(3, true); else DVBOX(3, false); }
 #undef DVBOX
