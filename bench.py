@@ -574,6 +574,15 @@ def main():
                          "ms_per_step": s["ms_total"] / timer.steps, "avg_launch_us": 1e3 * s["ms_avg"]}
             if basis:
                 kern[fam]["peak_basis"] = basis
+            if mfma and s.get("flops_done", s["flops"]) < 0.999 * s["flops"]:
+                # the volume-backward GEMMs visit only the k-tiles the step's lookups reached: `frac` prices what was really
+                # multiplied, `frac_dense` the dense contraction the launch replaces (a model number, not a hardware one)
+                kern[fam]["frac_dense"] = kern[fam]["frac"]
+                kern[fam]["achieved_dense"] = ach
+                kern[fam]["achieved"] = s["flops_done"] / sec / 1e12
+                kern[fam]["frac"] = kern[fam]["achieved"] / peak
+                kern[fam]["k_tiles_visited"] = s["flops_done"] / s["flops"]
+                kern[fam]["peak_basis"] = (basis or "") + "; frac = FLOPs of the k-tiles actually visited, frac_dense = the dense contraction's"
             if fam == "corr_build":     # both views: HBM (the north-star bound) and the matrix pipe in the arithmetic actually used
                 mpeak = PEAK_BF16_MFMA_TF / 3.0 if build_split else PEAK_F32_MFMA_TF
                 kern[fam]["mfma_tflops"] = s["flops"] / sec / 1e12
@@ -595,17 +604,40 @@ def main():
                                     "kernels": fams, "traffic": None,
                                     "note": "algorithmic bytes of SURVEY.md 8d (1.452 GB per pair at 55x128, 12 lookups) / summed "
                                             "kernel time of build + lookups + gradient volume + build backward"}
+        # ... and its forward half alone, which is what BASELINE.json's north_star names ("4D corr build+lookup"): the in-step build
+        # and the twelve lookups
+        ff = [f for f in ("corr_build", "corr_lookup_fwd") if f in kern]
+        if len(ff) == 2:
+            summ = timer.summary()
+            byt = sum(summ[f]["bytes"] for f in ff) / timer.steps
+            ms = sum(kern[f]["ms_per_step"] for f in ff)
+            out["roofline_corr_fwd"] = {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": byt / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_step": byt, "ms_per_step": ms,
+                                        "kernels": ff, "traffic": None,
+                                        "note": "forward half of roofline_corr, timed inside the step: volume build + pyramid (275.7 MB per "
+                                                "pair) and the lookups (20.4 MB per pair and iteration)"}
+        if "corr_lookup_bwd" in kern:
+            kern["corr_lookup_bwd"]["model_note"] = ("frac is against SURVEY.md 8d's byte model of the REFERENCE algorithm (per lookup: read dOut, "
+                                                     "read-modify-write the window taps; plus one zero fill of the dense gradient): the kernel "
+                                                     "reads dOut once and writes only the records the backward GEMMs read, so a model fraction "
+                                                     "above 1 is possible; hbm_gbs_counters is its real rate from the PMC bytes")
         tr = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
         if os.path.exists(tr):
             t = json.load(open(tr))
             for fam, v in t.items():
-                if fam in kern:                   # PMC bytes per LAUNCH (family average), like `avg_launch_us`; x launches_per_step = per step
+                if fam in kern and not fam.startswith("_"):                   # PMC bytes per LAUNCH (family average), like `avg_launch_us`; x launches_per_step = per step
                     kern[fam]["traffic"] = v
                     kern[fam]["traffic_unit"] = "HBM bytes per launch (family average; FETCH_SIZE x 2 + WRITE_SIZE, profiles/README.md)"
                     kern[fam]["traffic_per_step"] = v * kern[fam]["launches_per_step"]
+                    if not (fam in ("conv_igemm", "conv_wgrad", "gemm_f32", "altcorr_fwd", "altcorr_bwd")):
+                        kern[fam]["hbm_gbs_counters"] = v / (kern[fam]["avg_launch_us"] * 1e-6) / 1e9
             for k in ("traffic", "traffic_unit", "traffic_per_step"):
                 if k in kern[dom]:
                     out["roofline"][k] = kern[dom][k]
+            if "roofline_corr_fwd" in out and all(kern[f].get("traffic_per_step") for f in out["roofline_corr_fwd"]["kernels"]):
+                out["roofline_corr_fwd"]["traffic"] = sum(kern[f]["traffic_per_step"] for f in out["roofline_corr_fwd"]["kernels"])
+            if "_meta" in t:
+                out["traffic_source"] = t["_meta"]
             if "roofline_corr" in out and all(kern[f].get("traffic_per_step") for f in out["roofline_corr"]["kernels"] if f != "corr_build_bwd"):
                 out["roofline_corr"]["traffic"] = sum(kern[f].get("traffic_per_step") or 0.0 for f in out["roofline_corr"]["kernels"])
                 out["roofline_corr"]["traffic_unit"] = "HBM bytes per step over the families that were profiled (corr_build_bwd: its two GEMMs are counted under gemm_f32)"

@@ -25,6 +25,8 @@ class RAFTGMA(nn.Module):
             self.args.dropout = 0
         if "mixed_precision" not in self.args:
             self.args.mixed_precision = False
+        from .utils.utils import warn_mixed_precision
+        warn_mixed_precision(self.args)
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
         self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
         self.cnet.out_channels_last = os.environ.get("FSRAFT_CNET_OUT_CL", "1") != "0"   # (extractor._Encoder.forward)

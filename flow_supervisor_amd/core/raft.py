@@ -58,6 +58,8 @@ class RAFT(nn.Module):
             self.args.alternate_corr = False
         if "mixed_precision" not in self.args:
             self.args.mixed_precision = False
+        from .utils.utils import warn_mixed_precision
+        warn_mixed_precision(self.args)
         hdim, cdim = self.hidden_dim, self.context_dim
         if args.small:
             self.fnet = SmallEncoder(output_dim=128, norm_fn="instance", dropout=args.dropout)

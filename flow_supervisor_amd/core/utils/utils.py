@@ -79,3 +79,17 @@ def upflow8(flow, mode="bilinear"):
     if mode != "bilinear":
         return 8 * F.interpolate(flow, size=(8 * flow.shape[2], 8 * flow.shape[3]), mode=mode, align_corners=True)
     return _UpFlow8.apply(flow)
+
+
+_MIXED_WARNED = [False]
+
+
+def warn_mixed_precision(args):
+    """`args.mixed_precision` (pytorch/core/raft.py:99-127, train.py:232: autocast around the encoders and the update block) is
+    accepted for signature compatibility and has NO effect here: every kernel of the path stores and accumulates in fp32 (the
+    GEMM products are bf16x3 or exact fp32, fsraft_set_arithmetic).  Said once, loudly, instead of silently."""
+    if getattr(args, "mixed_precision", False) and not _MIXED_WARNED[0]:
+        import warnings
+        _MIXED_WARNED[0] = True
+        warnings.warn("flow_supervisor_amd: args.mixed_precision=True is ignored -- the fsraft kernels compute in fp32 "
+                      "(bf16x3 or exact-fp32 products); results are those of mixed_precision=False", stacklevel=3)

@@ -108,7 +108,9 @@ __device__ __forceinline__ void lookup_issue(LookupLoad<R>& ld, const float* __r
   }
 }
 
-template <int R, int QW, int AUX = 0>
+// GATHER (measurement only, fsraft_set_lookup_policy(100)): the same window loads with the same masks and the same look-ahead, but
+// nothing done with them -- no LDS staging, no blends, no output: what the memory system delivers for this access pattern.
+template <int R, int QW, int AUX = 0, bool GATHER = false>
 __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __restrict__ vol, VolLayout L, Coords co,
                                                                float* __restrict__ out, int64_t nq, int HW, int grid_w) {
   using S = TL<R>;
@@ -145,6 +147,14 @@ __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __re
     // the next query's regions are requested before this one's are consumed (the last valid query is simply requested again)
     const int qn = qq + 1 < nqw ? qq + 1 : qq;
     if (qq + 1 < QW) lookup_issue<R, AUX>(nxt, vol + (int64_t)(q0 + qn) * L.P, row_bytes, g, nlev, cxs[qn], cys[qn], tsx, tsy, r);
+    if (GATHER) {
+      float sink = 0.f;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) sink += cur.v[l][0] + cur.v[l][1] + cur.v[l][2] + cur.v[l][3];
+      if (sink == 1.2345e38f) gstore1(out + (int64_t)q * CH, sink);      // (never: keeps the loads and their waits alive)
+      if (qq + 1 < QW) cur = nxt;
+      continue;
+    }
 #pragma unroll
     for (int l = 0; l < 4; ++l)
       if (l < nlev) {
@@ -553,7 +563,9 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
   // of the gradient (i >= N1) and rows of levels that do not exist re-read a valid slice; the first get a zero x weight, the
   // rest are never handed in.
   const bool g_on = lvl_on && i < N1;
-  const int64_t goff = q * CH + (lvl_on ? lv : 0) * N2 + (i < N1 ? i : N1 - 1) * N1;
+  int64_t goff = q * CH + (lvl_on ? lv : 0) * N2 + (i < N1 ? i : N1 - 1) * N1;
+  if (policy == 5) goff = q * CH + (lane & 31) * 8;      // (measurement only: lane-linear addresses, wrong data)
+  if (policy == 6) goff = (lane & 31) * 8;               // (measurement only: cache-resident addresses)
   // PF lookups' slices in flight per wave (with one lookup of look-ahead the wave waited one memory latency per lookup: 335 us,
   // 92 % of its cycles in s_waitcnt); the first PF are requested before anything else -- their addresses depend on the query
   // number alone.  Every loaded element passes through an empty asm before its first use: left alone, the SLP vectoriser pairs
@@ -631,6 +643,7 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
     }
   }
   wave_lds_sync();
+  if (policy == 7) { if (ox == 12345678) dvol[0] = G[0].a[0] + G[1].a[0] + G[2].a[0] + G[3].a[0] + G[4].a[0] + G[5].a[0]; return; }   // (measurement only: set-up alone)
   const int bax = ox & ~3, bay = oy & ~3;                 // the box's origin, tile-aligned
   float* box = &box_s[wave][lv == 0 ? dvs_base(0) : lv == 1 ? dvs_base(1) : lv == 2 ? dvs_base(2) : dvs_base(3)];
   float acc[WIN];
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
   wave_lds_sync();
 
   char* rowb = reinterpret_cast<char*>(dvol + (int64_t)qrel * L.P);
-  if (policy == 4) { if (box_s[wave][lane] == 12345.f) dvol[0] = 1.f; return; }      // (measurement only: no row writer)
+  if (policy >= 4) { if (box_s[wave][lane] == 12345.f) dvol[0] = 1.f; return; }      // (measurement only: no row writer)
   // ---- the row.  Pass 1: zeros, 1 KB (eight records, or 256 floats) per wave store, only where the list GEMMs read; the mask
   // bits of a trip are a scalar: trips without a flagged record are skipped on the scalar unit.
   {
@@ -1067,6 +1080,7 @@ int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float*
   // 1 GB volume that will not be there next time anyway): 12 lookups 0.39 -> 0.367 ms in the step (same-box A/B,
   // scripts/lookup_policy_ab.sh; sc1 alone: no change).
   const int pol = g_lookup_policy >= 0 ? g_lookup_policy : ((int64_t)nq * L.P * 4 > ((int64_t)300 << 20) ? 2 : 0);
+  if (g_lookup_policy == 100) { hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 2, true>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w); return fs_launch_status(); }
   if (pol == 2) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 2>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
   else if (pol == 16) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 16>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
   else if (pol == 18) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 18>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
@@ -1103,7 +1117,7 @@ extern "C" int fsraft_set_dvol_policy(int policy) {
 
 int g_dvol_box = 2;       // 2: corr_dvol_sep_kernel (round 4) / 1: corr_dvol_box_kernel, + work list where a scratch list is supplied; 0: corr_dvol_kernel for every query
 extern "C" int fsraft_set_lookup_policy(int aux) {
-  if (aux != -1 && aux != 0 && aux != 2 && aux != 16 && aux != 18) return FS_ERR_ARG;
+  if (aux != -1 && aux != 0 && aux != 2 && aux != 16 && aux != 18 && aux != 100) return FS_ERR_ARG;
   g_lookup_policy = aux;
   return FS_OK;
 }

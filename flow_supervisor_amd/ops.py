@@ -48,18 +48,22 @@ class KernelTimer:
         e.record()
         return e
 
-    def end(self, family, e0, flops=0.0, nbytes=0.0):
+    def end(self, family, e0, flops=0.0, nbytes=0.0, flops_done=None):
+        """flops: the ALGORITHMIC count of the launch; flops_done (optional, a callable evaluated in summary(), i.e. after the
+        device sync): what the launch really multiplied where that is less -- the volume-backward GEMMs visit only the k-tiles
+        the step's lookups reached."""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.rec.setdefault(family, []).append((e0, e1, flops, nbytes))
+        self.rec.setdefault(family, []).append((e0, e1, flops, nbytes, flops_done))
 
     def summary(self):
-        """{family: dict(launches, ms_total, ms_avg, flops, bytes)} -- call after a device sync."""
+        """{family: dict(launches, ms_total, ms_avg, flops, bytes, flops_done)} -- call after a device sync."""
         out = {}
         for fam, rows in self.rec.items():
-            ms = sum(a.elapsed_time(b) for a, b, _, _ in rows)
+            ms = sum(r[0].elapsed_time(r[1]) for r in rows)
             out[fam] = dict(launches=len(rows), ms_total=ms, ms_avg=ms / len(rows),
-                            flops=sum(r[2] for r in rows), bytes=sum(r[3] for r in rows))
+                            flops=sum(r[2] for r in rows), bytes=sum(r[3] for r in rows),
+                            flops_done=sum((r[4]() if r[4] is not None else r[2]) for r in rows))
         return out
 
 
@@ -464,14 +468,18 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None, ktile
             L.check(lib.fsraft_gemm_rec_nt_list(L.ptr(f2r), P, C * P * 4, L.ptr(dV), P, N * P * 4, L.ptr(d1), N, C * N, B, C, N, P, s, NT_LIST_KSPLIT, 0,
                                                 L.ptr(ktiles.nt_list), L.ptr(ktiles.nt_count), ktiles.nt_stride, 1, L.stream()),
                     "gemm_rec_nt_list")
-            if tm:      # (the family's FLOPs stay the dense contraction's: what is skipped multiplies zeros)
-                tm.end("gemm_f32", e1, 2.0 * B * C * N * P, 4.0 * B * (C * P + N * P + C * N))
+            if tm:      # (algorithmic FLOPs: the dense contraction; flops_done: the listed (128-query tile, 32-cell record) pairs)
+                cnt = ktiles.nt_count
+                tm.end("gemm_f32", e1, 2.0 * B * C * N * P, 4.0 * B * (C * P + N * P + C * N),
+                       flops_done=lambda cnt=cnt: 2.0 * C * 128 * 32 * float(cnt.sum().item()))
                 e1 = tm.begin()
             L.check(lib.fsraft_gemm_rec_tn_list(L.ptr(dV), P, N * P * 4, L.ptr(f1r), Cr, N * Cr * 4, L.ptr(d2cat), C, P * C, B, P, C, N, s,
                                                 TN_LIST_KSPLIT, 0, L.ptr(ktiles.tn_list), L.ptr(ktiles.tn_count), ktiles.tn_stride, 0, L.stream()),
                     "gemm_rec_tn_list")
-            if tm:
-                tm.end("gemm_f32", e1, 2.0 * B * P * C * N, 4.0 * B * (N * P + N * C + P * C))
+            if tm:      # (flops_done: the listed (256-cell tile, 32-query block) pairs)
+                cnt = ktiles.tn_count
+                tm.end("gemm_f32", e1, 2.0 * B * P * C * N, 4.0 * B * (N * P + N * C + P * C),
+                       flops_done=lambda cnt=cnt: 2.0 * 256 * C * 32 * float(cnt.sum().item()))
         else:
             d1 = gemm_rec_nt(f2r, dV, s)                              # [B,C,N] = s * f2cat . dV^T
             d2cat = gemm_rec_tn(dV, f1r, P, C, s, ksplit=2)           # [B,P,C] = s * dV^T . f1^T

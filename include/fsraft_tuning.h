@@ -31,7 +31,8 @@ int fsraft_get_tuning(int key);   /* keys 3 / 4 */
 int fsraft_set_build_split(int on);   /* volume build: 1 bf16x3 (default), 0 exact fp32 MFMA */
 int fsraft_set_build_kernel(int which); /* record build: 1 stores from the accumulators (default), 0 round 2's LDS-parked epilogue */
 /* cache policy of the tiled lookup's window loads: -1 auto (nt for volumes beyond the Infinity Cache; default), 0 plain, 2 nt,
- * 16 sc1, 18 nt + sc1 (A/B switch) */
+ * 16 sc1, 18 nt + sc1 (A/B switch); 100 = measurement only: the nt window loads alone, no blends and no output (the gather floor of
+ * the tiled layout, scripts/lookup_gather_floor.py) */
 int fsraft_set_lookup_policy(int aux);
 /* fsraft_corr_bwd_ktiles: 0 = per query and level the bounding rectangle of its lookups' windows is marked; 1 / 2 = on the
  * first one / two levels every lookup's window is marked on its own (tighter lists, a longer pre-pass). */

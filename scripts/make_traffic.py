@@ -23,15 +23,24 @@ for k, v in raw.items():
         if k.startswith(pre):
             b = (v["fetch_KiB_avg"] * 2.0 + v["write_KiB_avg"]) * 1024.0 * v["launches"]
             a = acc.setdefault(fam, [0.0, 0])
-            a[0] += b; a[1] += v["launches"]
+            a[0] += b
+            # the gradient volume of a step: one timed launch (ops.corr_dvol_build) = the bounding-box / separable kernel plus the
+            # row kernel's (usually empty) walks over its work list -- bytes per ops-level launch, like bench.py's avg_launch_us
+            if fam != "corr_lookup_bwd" or not k.startswith("corr_dvol_kernel"):
+                a[1] += v["launches"]
             break
-# the gradient volume of a step is written by two launches (level 0; levels 1-3): per step, not per launch
-out = {fam: a[0] / a[1] for fam, a in acc.items()}
+out = {fam: a[0] / max(a[1], 1) for fam, a in acc.items()}
+# provenance: the commit and run the counters came from (bench.py copies it into the line as traffic_source)
+import os
+out["_meta"] = {"commit": os.environ.get("FSRAFT_COMMIT", "unknown"), "raw": os.path.basename(sys.argv[1]),
+                "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one eager bench step (scripts/pmc_traffic.sh)"}
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 # algorithmic bytes per launch at the bench shape (4 pairs, 55x128, C=256, r=4, 12 lookups)
 N, P, C, B = 7040, 9280, 256, 4
 ALG = {"corr_build": 4.0 * B * (2 * N * C + N * P), "corr_lookup_fwd": 4.0 * B * N * (400 + 2 + 324),
        "corr_lookup_bwd": 4.0 * B * N * (12 * (324 + 2 + 800) + P) / 2.0}
 for k, v in out.items():
+    if k.startswith("_"):
+        continue
     r = f"   traffic / algorithmic = {v / ALG[k]:.2f}" if k in ALG else ""
     print(f"{k:18s} {v / 1e6:9.1f} MB per launch{r}")
