@@ -201,7 +201,6 @@ struct DvolArgs {
 // the finished gradient rows are written once and read (by the two volume-backward GEMMs) only after 1 GB more has gone by:
 // policy 2 stores them `nt` so that they do not push the step's other working sets out of L2 (fsraft_set_dvol_policy)
 __device__ __forceinline__ void dvstore4(void* p, f32x4 v, int policy) {
-  if (policy == 3) { asm volatile("" ::"v"(p), "v"(v)); return; }      // (measurement only: the kernel without its stores)
   if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
   else if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
   else gstore4(p, v);
@@ -338,190 +337,13 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
 // ---- the same gradient rows without the whole row segment in LDS ---------------------------------------------------------
 // corr_dvol_kernel parks a level-0 row segment (28 KB at 55x128) in LDS although the twelve lookups of a query touch a few
 // hundred cells of it: five queries per CU are in flight, each a chain of [loads | zero | 12 x (read-add-write, barrier) |
-// convert, store], and the kernel runs at 2-3 TB/s of its own traffic (544 us for 1.5 GB).  Here ONE WAVE owns a query and
-// keeps, per level, only the bounding box of the lookups' windows (DVB x DVB cells, 2.3 KB) plus the level's slice of the
-// gradients; everything outside the box leaves as zeros straight from registers.  ~8 KB of LDS per wave -> twenty waves
-// per CU, no workgroup barrier (a wave's LDS operations execute in order).  A query whose lookups spread further than the box
-// at some level (a flow that jumped between iterations) is appended to a work list that corr_dvol_kernel then walks.
-constexpr int DVB = 24;
-
-template <int R, bool REC>
-__global__ __launch_bounds__(256) void corr_dvol_box_kernel(DvolArgs a, VolLayout L, float* __restrict__ dvol, int HW, int grid_w, int64_t q0,
-                                                            unsigned nq, unsigned* __restrict__ qlist, int policy,
-                                                            const unsigned* __restrict__ wmask, int wm_hw) {
-  using S = TL<R>;
-  __shared__ float box_s[4][DVB * DVB];
-  __shared__ float g_s[4][DV_MAXN * S::N2];
-  __shared__ float cxy[4][DV_MAXN][2];
-  __shared__ LevelQ lq_s[4][DV_MAXN];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  __shared__ unsigned wl_s[6];                           // work-list hand-over: [wave] = 1 if it does not fit, [4] = base slot
-  const unsigned qrel = blockIdx.x * 4u + (unsigned)wave;
-  const bool active = qrel < nq;                         // (wave-uniform)
-  const int64_t q = q0 + (active ? qrel : 0);
-  const int b = (int)(q / HW), pix = (int)(q % HW);
-  const int n = a.n, nlev = L.nlev, CH = nlev * S::N2;
-  float* box = box_s[wave];
-  float* g = g_s[wave];
-  // query positions of the n lookups (wave-uniform pointers: the lookup index is a compile-time constant per iteration)
-#pragma unroll
-  for (int t = 0; t < DV_MAXN; ++t)
-    if (t < n && lane == 0) {
-      float cx, cy;
-      query_xy(a.co[t], b, pix, grid_w, cx, cy);
-      cxy[wave][t][0] = cx; cxy[wave][t][1] = cy;
-    }
-  wave_lds_sync();
-  // bounding boxes of all levels first: a query either fits everywhere or goes to the work list untouched
-  int bx0[4], by0[4];
-  bool fits = true;
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    bx0[l] = by0[l] = 0;
-    if (l < nlev) {
-      const int tt = lane < n ? lane : 0;
-      const LevelQ v = level_query(cxy[wave][tt][0], cxy[wave][tt][1], l, R);
-      int mnx = v.wx0, mny = v.wy0, mxx = v.wx0, mxy = v.wy0;
-#pragma unroll
-      for (int d = 8; d >= 1; d >>= 1) {                // n <= 16: lanes 0..15 (the others repeat lookup 0)
-        mnx = min(mnx, __shfl_xor(mnx, d, 64)); mny = min(mny, __shfl_xor(mny, d, 64));
-        mxx = max(mxx, __shfl_xor(mxx, d, 64)); mxy = max(mxy, __shfl_xor(mxy, d, 64));
-      }
-      mnx = __builtin_amdgcn_readfirstlane(mnx); mny = __builtin_amdgcn_readfirstlane(mny);
-      mxx = __builtin_amdgcn_readfirstlane(mxx); mxy = __builtin_amdgcn_readfirstlane(mxy);
-      bx0[l] = mnx; by0[l] = mny;
-      fits = fits && (mxx - mnx + S::WIN <= DVB) && (mxy - mny + S::WIN <= DVB);
-    }
-  }
-  // one list append per WORKGROUP (a counter word takes ~90 atomics per microsecond: 28 K single appends are 0.3 ms)
-  if (lane == 0) wl_s[wave] = (active && !fits) ? 1u : 0u;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned c = wl_s[0] + wl_s[1] + wl_s[2] + wl_s[3];
-    wl_s[4] = c ? atomicAdd(qlist, c) : 0u;
-  }
-  __syncthreads();
-  if (!active) return;
-  if (!fits) {
-    unsigned slot = wl_s[4];
-    for (int w = 0; w < wave; ++w) slot += wl_s[w];
-    if (lane == 0) qlist[1 + slot] = qrel;
-    return;
-  }
-  char* rowb = reinterpret_cast<char*>(dvol + (int64_t)qrel * L.P);
-  // wmask (nullable, records only): bit r of this query's 32-query block = record r of the row will be read by a list GEMM
-  // (fsraft_corr_bwd_ktiles); the others are not written at all -- most of a row is zero records outside every list
-  // (rows of wmask: per list set -- image, or chunk of wm_hw queries starting at q0 -- and 32-query block)
-  const unsigned* wm = wmask ? wmask + ((int64_t)(qrel / (unsigned)wm_hw) * ((wm_hw + 31) >> 5) + ((qrel % (unsigned)wm_hw) >> 5)) *
-                                            (((L.P >> 5) + 31) >> 5) : nullptr;
-  // this lane's window cells (wy, wx): window cell (wy, wx) is tap (ay, ax) of output (j = wy - ay, i = wx - ax), channel i * N1 + j;
-  // a tap that does not exist gets weight 0 and re-reads the other one
-  constexpr int KC = (S::WIN * S::WIN + 63) / 64;
-  int c_wy[KC], c_wx[KC], c_g[KC], c_b[KC], c_di[KC], c_dj[KC], c_dij[KC];
-  bool c_ok[KC];
-  float c_m[KC][4];
-#pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    const int c = lane + 64 * k, wy = c / S::WIN, wx = c - wy * S::WIN;
-    c_ok[k] = c < S::WIN * S::WIN;
-    c_wy[k] = wy; c_wx[k] = wx; c_b[k] = wy * DVB + wx;
-    const int i0 = wx >= 1 ? wx - 1 : 0, j0 = wy >= 1 ? wy - 1 : 0;
-    c_g[k] = i0 * S::N1 + j0;
-    c_m[k][0] = wx < S::N1 ? 1.f : 0.f; c_m[k][1] = wx >= 1 ? 1.f : 0.f;
-    c_m[k][2] = wy < S::N1 ? 1.f : 0.f; c_m[k][3] = wy >= 1 ? 1.f : 0.f;
-    c_di[k] = (wx < S::N1 && wx >= 1) ? S::N1 : 0;
-    c_dj[k] = (wy < S::N1 && wy >= 1) ? 1 : 0;
-    c_dij[k] = c_di[k] + c_dj[k];
-  }
-#pragma unroll 1
-  for (int l = 0; l < nlev; ++l) {
-    const int off = L.off[l], tw = L.tw[l], hl = L.h[l], wl = L.w[l];
-    const int seg = (l + 1 < nlev ? L.off[l + 1] : L.P) - off;       // floats of this level's section (the last one incl. the row's pad)
-    const int ox = l == 0 ? bx0[0] : l == 1 ? bx0[1] : l == 2 ? bx0[2] : bx0[3];
-    const int oy = l == 0 ? by0[0] : l == 1 ? by0[1] : l == 2 ? by0[2] : by0[3];
-    for (int i = lane; i < DVB * DVB; i += 64) box[i] = 0.f;
-    if (lane < n) lq_s[wave][lane] = level_query(cxy[wave][lane][0], cxy[wave][lane][1], l, R);
-    // this level's slice of every lookup's gradient: all loads in flight before the first LDS store
-    {
-      float v[DV_MAXN][2];
-#pragma unroll
-      for (int t = 0; t < DV_MAXN; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int c = lane + 64 * k;
-          if (t < n && c < S::N2) v[t][k] = gload1(a.dout[t] + q * CH + l * S::N2 + c);
-        }
-#pragma unroll
-      for (int t = 0; t < DV_MAXN; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int c = lane + 64 * k;
-          if (t < n && c < S::N2) g[t * S::N2 + c] = v[t][k];
-        }
-    }
-    wave_lds_sync();
-    // the lookups one after the other (inside one lookup the window cells are distinct): lane = window cell, KC rounds.
-    // What depends on the lane only (its cells, which taps exist, where they sit in a gradient slice) was decoded before the
-    // level loop; what depends on the lookup only (window origin, fractions) is read out of lane t's registers into SGPRs.
-    const LevelQ mine = lq_s[wave][lane < n ? lane : 0];
-    for (int t = 0; t < n; ++t) {
-      const int wx0 = __builtin_amdgcn_readlane(mine.wx0, t), wy0 = __builtin_amdgcn_readlane(mine.wy0, t);
-      const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.fx), t));
-      const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.fy), t));
-      const float* gt = g + t * S::N2;
-      const int bbase = (wy0 - oy) * DVB + (wx0 - ox);
-#pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        const int gy = wy0 + c_wy[k], gx = wx0 + c_wx[k];
-        if (c_ok[k] && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) {
-          const float* gp = gt + c_g[k];
-          const float wx1 = c_m[k][0] * (1.f - fx), wx0f = c_m[k][1] * fx, wy1 = c_m[k][2] * (1.f - fy), wy0f = c_m[k][3] * fy;
-          box[bbase + c_b[k]] += wy1 * (wx1 * gp[c_dij[k]] + wx0f * gp[c_dj[k]]) + wy0f * (wx1 * gp[c_di[k]] + wx0f * gp[0]);
-        }
-      }
-      wave_lds_sync();
-    }
-    // the level's section of the row: eight cells (two rows of a 4x4 tile) per lane and trip, zeros outside the box
-    const int ntile = L.th[l] * tw;
-    for (int e = lane * 8; e < seg; e += 512) {
-      if (REC && wm) {
-        const int r = (off + e) >> 5;
-        if (!((wm[r >> 5] >> (r & 31)) & 1u)) continue;
-      }
-      const int T = e >> 4, ty = T / tw, tx = T - ty * tw;
-      const int yb = 4 * ty + 2 * ((e >> 3) & 1) - oy, xb = 4 * tx - ox;          // this lane's 2 x 4 cells, relative to the box
-      const bool touch = T < ntile && yb > -2 && yb < DVB && xb > -4 && xb < DVB;
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = 0.f;
-      if (__builtin_amdgcn_ballot_w64(touch)) {           // most trips of a level-0 section lie outside the box: zeros, no LDS read
-        if (touch) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if ((unsigned)(yb + j) < (unsigned)DVB && (unsigned)(xb + i) < (unsigned)DVB) v[4 * j + i] = box[(yb + j) * DVB + xb + i];
-        }
-      }
-      if (REC) {
-        uint2 h0, l0s, h1, l1s;
-        rec_split4(v, h0, l0s);
-        rec_split4(v + 4, h1, l1s);
-        const int f = off + e;
-        char* rp = rowb + (f >> 5) * 128 + (f & 31) * 2;
-        dvstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}), policy);
-        dvstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}), policy);
-      } else {
-        dvstore4(rowb + (off + e) * 4, f32x4{v[0], v[1], v[2], v[3]}, policy);
-        dvstore4(rowb + (off + e + 4) * 4, f32x4{v[4], v[5], v[6], v[7]}, policy);
-      }
-    }
-    wave_lds_sync();
-  }
-}
-
-// ---- round 4: the same bounding-box rows, the window gradients built SEPARABLY in registers -------------------------------
-// corr_dvol_box_kernel is instruction-bound (394 us for 285 MB of traffic; PMC, scripts/dvol_pmc.sh: 4800 vector and
+// convert, store], and the kernel runs at 2-3 TB/s of its own traffic (544 us for 1.5 GB).  ONE WAVE per query that keeps, per
+// level, only the bounding box of the lookups' windows does better: round 3's corr_dvol_box_kernel (lane = window cell, the
+// gradient slices and a 24x24 box per level in LDS: 394-402 us in the step) and, replacing it, round 4's corr_dvol_sep_kernel
+// below.  A query whose lookups spread further than the box at some level (a flow that jumped between iterations) is appended
+// to a work list that corr_dvol_kernel then walks.
+// ---- round 4: the window gradients built SEPARABLY in registers ----------------------------------------------------------
+// corr_dvol_box_kernel (round 3) was instruction-bound (394 us for 285 MB of traffic; PMC, scripts/dvol_pmc.sh: 4800 vector and
 // 1070 LDS instructions per query, 620 LDS bank-conflict cycles, three waves per SIMD): per query it runs 4 levels x 12 lookups
 // x 2 rounds of "four LDS reads of gradient taps, one LDS read-add-write of the box, ~40 VALU instructions" for 19 K useful
 // multiply-adds.  Here the 16 lanes of a DPP row own one LEVEL and a lane owns one window COLUMN: lane (l, i) holds the N1
@@ -552,8 +374,10 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
   __shared__ __attribute__((aligned(16))) LevelQ lq_s[4][4][DV_MAXN];        // [wave][level][lookup]
   __shared__ float cxy[4][DV_MAXN][2];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned qrel = blockIdx.x * 4u + (unsigned)wave;
-  if (qrel >= nq) return;                                // (wave-uniform; no workgroup barrier below)
+  __shared__ unsigned wl_s[6];                           // work-list hand-over: [wave] = 1 if its query does not fit, [4] = base slot
+  const unsigned qraw = blockIdx.x * 4u + (unsigned)wave;
+  const bool active = qraw < nq;                         // (wave-uniform; a surplus wave repeats the last query up to the hand-over)
+  const unsigned qrel = active ? qraw : nq - 1u;
   const int64_t q = q0 + qrel;
   const int b = (int)(q / HW), pix = (int)(q % HW);
   const int n = a.n, nlev = L.nlev, CH = nlev * N2;
@@ -563,9 +387,7 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
   // of the gradient (i >= N1) and rows of levels that do not exist re-read a valid slice; the first get a zero x weight, the
   // rest are never handed in.
   const bool g_on = lvl_on && i < N1;
-  int64_t goff = q * CH + (lvl_on ? lv : 0) * N2 + (i < N1 ? i : N1 - 1) * N1;
-  if (policy == 5) goff = q * CH + (lane & 31) * 8;      // (measurement only: lane-linear addresses, wrong data)
-  if (policy == 6) goff = (lane & 31) * 8;               // (measurement only: cache-resident addresses)
+  const int64_t goff = q * CH + (lvl_on ? lv : 0) * N2 + (i < N1 ? i : N1 - 1) * N1;
   // PF lookups' slices in flight per wave (with one lookup of look-ahead the wave waited one memory latency per lookup: 335 us,
   // 92 % of its cycles in s_waitcnt); the first PF are requested before anything else -- their addresses depend on the query
   // number alone.  Every loaded element passes through an empty asm before its first use: left alone, the SLP vectoriser pairs
@@ -636,14 +458,23 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
     }
     ox = mnx; oy = mny; uw = mxx - mnx + WIN; uh = mxy - mny + WIN;
     const bool fits = !lvl_on || (uw <= side && uh <= side);
-    if (__builtin_amdgcn_ballot_w64(!fits)) {
-      // (one atomic per query that does not fit: rare on real flows; when every query jumps the row kernel's time dominates anyway)
-      if (lane == 0) qlist[1 + atomicAdd(qlist, 1u)] = qrel;
+    const bool unfit = __builtin_amdgcn_ballot_w64(!fits) != 0;
+    // one list append per WORKGROUP (a counter word takes ~90 atomics per microsecond: 28 K single appends are 0.3 ms)
+    if (lane == 0) wl_s[wave] = (active && unfit) ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned c = wl_s[0] + wl_s[1] + wl_s[2] + wl_s[3];
+      wl_s[4] = c ? atomicAdd(qlist, c) : 0u;
+    }
+    __syncthreads();
+    if (!active) return;
+    if (unfit) {
+      unsigned slot = wl_s[4];
+      for (int w = 0; w < wave; ++w) slot += wl_s[w];
+      if (lane == 0) qlist[1 + slot] = qrel;
       return;
     }
   }
-  wave_lds_sync();
-  if (policy == 7) { if (ox == 12345678) dvol[0] = G[0].a[0] + G[1].a[0] + G[2].a[0] + G[3].a[0] + G[4].a[0] + G[5].a[0]; return; }   // (measurement only: set-up alone)
   const int bax = ox & ~3, bay = oy & ~3;                 // the box's origin, tile-aligned
   float* box = &box_s[wave][lv == 0 ? dvs_base(0) : lv == 1 ? dvs_base(1) : lv == 2 ? dvs_base(2) : dvs_base(3)];
   float acc[WIN];
@@ -700,7 +531,6 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
   wave_lds_sync();
 
   char* rowb = reinterpret_cast<char*>(dvol + (int64_t)qrel * L.P);
-  if (policy >= 4) { if (box_s[wave][lane] == 12345.f) dvol[0] = 1.f; return; }      // (measurement only: no row writer)
   // ---- the row.  Pass 1: zeros, 1 KB (eight records, or 256 floats) per wave store, only where the list GEMMs read; the mask
   // bits of a trip are a scalar: trips without a flagged record are skipped on the scalar unit.
   {
@@ -1115,7 +945,7 @@ extern "C" int fsraft_set_dvol_policy(int policy) {
   return FS_OK;
 }
 
-int g_dvol_box = 2;       // 2: corr_dvol_sep_kernel (round 4) / 1: corr_dvol_box_kernel, + work list where a scratch list is supplied; 0: corr_dvol_kernel for every query
+int g_dvol_box = 1;       // 1: corr_dvol_sep_kernel + work list where a scratch list is supplied, 0: corr_dvol_kernel for every query
 extern "C" int fsraft_set_lookup_policy(int aux) {
   if (aux != -1 && aux != 0 && aux != 2 && aux != 16 && aux != 18 && aux != 100) return FS_ERR_ARG;
   g_lookup_policy = aux;
@@ -1159,15 +989,8 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   const int wm_hw = whole ? H * W : (int)grid;
   if (g_dvol_box && qlist && !accumulate && (L.P % 8) == 0) {
     hipLaunchKernelGGL(dvol_list_reset_kernel, dim3(1), dim3(1), 0, stream, qlist);
-#define DVBOX(RR, REC)                                                                                                                        \
-  do {                                                                                                                                   \
-    if (g_dvol_box == 2)                                                                                                                 \
-      hipLaunchKernelGGL((corr_dvol_sep_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, add_grid ? W : 0, \
-                         q0, grid, qlist, g_dvol_policy, wmask, wm_hw);                                                                  \
-    else                                                                                                                                 \
-      hipLaunchKernelGGL((corr_dvol_box_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, add_grid ? W : 0, \
-                         q0, grid, qlist, g_dvol_policy, wmask, wm_hw);                                                                  \
-  } while (0)
+#define DVBOX(RR, REC) hipLaunchKernelGGL((corr_dvol_sep_kernel<RR, REC>), dim3((grid + 3) / 4), dim3(256), 0, stream, a, L, dvol, H * W, \
+                                          add_grid ? W : 0, q0, grid, qlist, g_dvol_policy, wmask, wm_hw)
     if (radius == 4) { if (records) DVBOX(4, true); else DVBOX(4, false); }
     else { if (records) DVBOX(3, true); else DVBOX(3, false); }
 #undef DVBOX

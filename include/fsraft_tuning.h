@@ -38,7 +38,7 @@ int fsraft_set_lookup_policy(int aux);
  * first one / two levels every lookup's window is marked on its own (tighter lists, a longer pre-pass). */
 int fsraft_set_ktile_exact(int levels);
 int fsraft_set_upsample_kernel(int v4);  /* convex upsampler: 1 (default) the 16-byte kernels for 16-byte aligned tensors, 0 the 4-byte ones */
-int fsraft_set_dvol_box(int on);        /* gradient volume: 1 (default) bounding-box kernel + work list, 0 row-segment kernel only */
+int fsraft_set_dvol_box(int on);        /* gradient volume: 1 (default) one wave per query on its lookups' bounding boxes (corr_dvol_sep_kernel) + work list, 0 row-segment kernel only */
 int fsraft_set_dvol_policy(int policy); /* cache policy of the gradient-volume stores: 0 plain, 1 sc1, 2 nt */
 int fsraft_set_gemm_split(int on);    /* fsraft_gemm_f32 with trans_b: 1 bf16x3 when operands are 16-byte aligned */
 int fsraft_set_lookup_qb(int qb);     /* queries per workgroup of the row-major lookup kernels: 0 auto, 8, 16 or 32 */

@@ -39,7 +39,7 @@ for name, fl in cases:
     lib.fsraft_set_dvol_box(0)
     ref = ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True)
     ref32 = ops.corr_dvol_build(douts, fl, lay, B, r, records=False, is_flow=True)
-    lib.fsraft_set_dvol_box(2)
+    lib.fsraft_set_dvol_box(1)
     got = ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True)
     got32 = ops.corr_dvol_build(douts, fl, lay, B, r, records=False, is_flow=True)
     d = (got32 - ref32).abs()
@@ -52,28 +52,26 @@ for name, fl in cases:
             rel = pp - lay.off[lvl]; tl = rel >> 4
             print("      q", qq, "p", pp, "level", lvl, "tile", tl, "cell", rel & 15, "ref", ref32[qq, pp].item(), "box", got32[qq, pp].item())
     assert d.max().item() <= 1e-5 * max(ref32.abs().max().item(), 1.0), name
-    res = {0: [], 1: [], 2: []}
+    res = {0: [], 1: []}
     for rnd in range(3):
-        for box in (0, 1, 2):
+        for box in (0, 1):
             lib.fsraft_set_dvol_box(box)
             res[box].append(timeit(lambda: ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True), 5))
-    print(f"{name:55s} row-segment kernel {sorted(res[0])[1]:7.1f} us   bounding-box kernel + work list {sorted(res[1])[1]:7.1f} us   "
-          f"separable kernel (round 4) {sorted(res[2])[1]:7.1f} us")
+    print(f"{name:55s} row-segment kernel {sorted(res[0])[1]:7.1f} us   wave-per-query kernel + work list {sorted(res[1])[1]:7.1f} us")
 # as in the train step: only the records the two list GEMMs read are written (fsraft_corr_bwd_ktiles' wmask)
 for name, fl in cases[:2]:
     kt = ops.corr_bwd_ktiles(fl, lay, B, r, is_flow=True)
-    res = {1: [], 2: []}
+    res = {1: []}
+    lib.fsraft_set_dvol_box(1)
     for rnd in range(3):
-        for box in (1, 2):
-            lib.fsraft_set_dvol_box(box)
-            res[box].append(timeit(lambda: ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True, wmask=kt.wmask), 5))
+        res[1].append(timeit(lambda: ops.corr_dvol_build(douts, fl, lay, B, r, records=True, is_flow=True, wmask=kt.wmask), 5))
     frac = sum(bin(v & 0xffffffff).count("1") for v in kt.wmask.tolist()) / (B * -(-H * W // 32) * (lay.P // 32))
-    print(f"{name:40s} records written {frac:.3f}: bounding-box kernel {sorted(res[1])[1]:7.1f} us   separable kernel {sorted(res[2])[1]:7.1f} us")
+    print(f"{name:40s} records written {frac:.3f}: wave-per-query kernel {sorted(res[1])[1]:7.1f} us")
 # chunked use (AlternateCorrBlock's backward): queries [q0, q0 + nq)
 lib.fsraft_set_dvol_box(0)
 ref32 = ops.corr_dvol_build(douts, flows, lay, B, r, records=False, is_flow=True)
 ref = ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True, q0=5000, nq=2048)
-lib.fsraft_set_dvol_box(2)
+lib.fsraft_set_dvol_box(1)
 got = ops.corr_dvol_build(douts, flows, lay, B, r, records=True, is_flow=True, q0=5000, nq=2048)
 print("chunk records differing words:", (got.view(torch.int32) != ref.view(torch.int32)).float().mean().item())
 assert (ops.corr_dvol_build(douts, flows, lay, B, r, records=False, is_flow=True, q0=5000, nq=2048) - ref32[5000:5000 + 2048]).abs().max().item() < 1e-5, "chunk"
