@@ -171,18 +171,9 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_int
     _lib = lib
-    # precision / tiling switches: FSRAFT_CONV_SPLIT=1 runs the forward and
-    # data-gradient GEMMs of the update block on the split-bf16 core (3 bf16 MFMAs per product,
-    # fp32 accumulation); 0 keeps them on exact-fp32 MFMA.
-    if os.environ.get("FSRAFT_DVOL_BOX") is not None:
-        lib.fsraft_set_dvol_box(int(os.environ["FSRAFT_DVOL_BOX"]))
-    if os.environ.get("FSRAFT_LOOKUP_POLICY") is not None:
-        lib.fsraft_set_lookup_policy(int(os.environ["FSRAFT_LOOKUP_POLICY"]))
-    if os.environ.get("FSRAFT_UPSAMPLE_V4") is not None:
-        lib.fsraft_set_upsample_kernel(int(os.environ["FSRAFT_UPSAMPLE_V4"]))
-    if os.environ.get("FSRAFT_KTILE_EXACT") is not None:
-        lib.fsraft_set_ktile_exact(int(os.environ["FSRAFT_KTILE_EXACT"]))
-    arith = os.environ.get("FSRAFT_ARITHMETIC")     # 0: exact fp32 MFMA everywhere; 1 (default): bf16x3 products
+    # Arithmetic per GEMM family: FSRAFT_ARITHMETIC=0 exact-fp32 MFMA everywhere, 1 (default) bf16x3 products;
+    # FSRAFT_CONV_SPLIT / FSRAFT_WGRAD_SPLIT / FSRAFT_BUILD_SPLIT switch one family (the parity suite runs both modes of each).
+    arith = os.environ.get("FSRAFT_ARITHMETIC")
     if arith is not None:
         lib.fsraft_set_arithmetic(int(arith))
     split = os.environ.get("FSRAFT_CONV_SPLIT")
@@ -191,11 +182,12 @@ def load():
     bsplit = os.environ.get("FSRAFT_BUILD_SPLIT")
     if bsplit is not None:
         lib.fsraft_set_build_split(int(bsplit))
-    for key, env in ((0, "FSRAFT_CONV_TILE"), (2, "FSRAFT_WGRAD_BLOCKS"), (5, "FSRAFT_CONV_BUF"), (8, "FSRAFT_WGRAD_BUF"), (11, "FSRAFT_WGRAD_BLOCKS_MULTI"), (13, "FSRAFT_CONV_W8"), (14, "FSRAFT_CONV_W8_MIN"), (15, "FSRAFT_WGRAD_W8"),
-                     (16, "FSRAFT_WGRAD_PACK"), (17, "FSRAFT_WGRAD_BLOCKS_PACK"), (18, "FSRAFT_CONV_N64"), (20, "FSRAFT_CONV_HALO"),
-                     (22, "FSRAFT_WGRAD_XCD"), (7, "FSRAFT_XCD_SWIZZLE"), (24, "FSRAFT_CONV_BDMA"), (25, "FSRAFT_CONV_REC"), (26, "FSRAFT_CONV_PATCH"), (27, "FSRAFT_WGRAD_PATCH"), (28, "FSRAFT_CONV_PATCH64"), (29, "FSRAFT_WGRAD_PATCH1"), (30, "FSRAFT_CONV_C64"), (31, "FSRAFT_CONV_PATCH_MIN_M"), (32, "FSRAFT_CONV_KSPLIT")):
-        if os.environ.get(env) is not None and lib.fsraft_set_tuning(key, int(os.environ[env])) != 0:
-            raise RuntimeError(f"{env}: tuning key {key} is not in this build of libfsraft (experiment kernels live in "
+    # FSRAFT_TUNING="key=value,key=value": fsraft_set_tuning keys of include/fsraft_tuning.h for A/B runs of scripts/ (round 3 had one
+    # environment variable per key)
+    for kv in filter(None, os.environ.get("FSRAFT_TUNING", "").split(",")):
+        key, val = (int(v) for v in kv.split("="))
+        if lib.fsraft_set_tuning(key, val) != 0:
+            raise RuntimeError(f"FSRAFT_TUNING: key {key} is not in this build of libfsraft (experiment kernels live in "
                                "libfsraft_ablate.so: make -C flow_supervisor_amd/csrc ablate, FSRAFT_LIB_PATH=...)")
     wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")
     if wsplit is not None:

@@ -124,9 +124,12 @@ class _ToNCHW(torch.autograd.Function):
 
 class _ResLink:
     """Ties the two consumers of a residual unit's input x together in backward: the unit's last norm kernel writes the
-    shortcut gradient dres (and hands it to autograd as x's gradient), the first convolution's data gradient -- which runs
-    later -- ACCUMULATES into that same tensor through its epilogue and reports no gradient of its own.  Autograd would
-    otherwise add the two x-sized tensors in a separate pass (12 of them per step, up to 230 MB each)."""
+    shortcut gradient dres and parks it HERE (autograd gets None from it for x); the first convolution's backward -- which always
+    runs later: the norm sits downstream of it -- accumulates its data gradient into that tensor through its epilogue and
+    returns the SUM as x's gradient.  Autograd would otherwise add the two x-sized tensors in a separate pass (12 of them per
+    step, up to 230 MB each).  Autograd sees one ordinary gradient for x from the unit, so further consumers of x, tensor
+    hooks and retain_grad behave as usual (round 3 handed dres to autograd and then added into it behind the engine's back,
+    which was only right while x had exactly these two consumers: ADVICE r2)."""
     __slots__ = ("dres",)
 
     def __init__(self):
@@ -175,7 +178,7 @@ class _InstNormReluCL(torch.autograd.Function):
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
                                                   L.ptr(dres), N, H * W, C, int(ctx.relu), ctx.s2w, L.stream()), "inorm_relu_cl_bwd")
         if ctx.link is not None:
-            ctx.link.dres = dres
+            ctx.link.dres, dres = dres, None      # the shortcut's gradient travels through the link: conv1's backward returns the sum
         return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None, None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
 
 
@@ -223,7 +226,7 @@ class _FrozenBNReluCL(torch.autograd.Function):
         L.check(L.load().fsraft_bn_fold_bwd(L.ptr(part), N * 8, C, L.ptr(rs), L.ptr(rm), L.ptr(scale), L.ptr(dpar[0]), L.ptr(dpar[1]),
                                             L.ptr(dpar[2]) if ctx.has_cbias else None, L.stream()), "bn_fold_bwd")
         if ctx.link is not None:
-            ctx.link.dres = dres
+            ctx.link.dres, dres = dres, None      # (see _ResLink)
         return (dx if ctx.in_cl else _as_nchw(dx), dpar[2] if ctx.has_cbias else None, dpar[0], dpar[1], None, None, None, None, dres,
                 None, None)
 
@@ -350,15 +353,22 @@ class _ConvCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dres = ctx.link.dres if ctx.link is not None else None
             if dres is not None and dres.shape == x.shape and _is_cl(dres) and dres.dtype == torch.float32:
-                # residual unit: add this data gradient into the shortcut gradient autograd already holds for x (see _ResLink)
+                # residual unit: this data gradient is added into the parked shortcut gradient, the sum is x's gradient (see _ResLink)
                 ctx.link.dres = None
                 ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dres.permute(0, 2, 3, 1), acc=True)],
                                  wpk_split=ctx.packs[4], wpk_frag=ctx.packs[6])
+                dx = dres
             else:
+                if dres is not None:          # (a parked gradient this route cannot add into: hand both over, the sum is made here)
+                    ctx.link.dres = None
                 dxb = torch.empty(B, H, W, C, device=x.device, dtype=torch.float32)
                 ops.conv_forward([gv], ctx.packs[3], None, B, H, W, KH, KW, C, [ops.Dst.nhwc(dxb)], wpk_split=ctx.packs[4],
                                  wpk_frag=ctx.packs[6])
                 dx = dxb.permute(0, 3, 1, 2)
+                if dres is not None:
+                    dx = dx + dres
+        elif ctx.link is not None:
+            ctx.link.dres = None              # (nobody asked for x's gradient: autograd.grad w.r.t. other inputs)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
             dwpk = ops.zeros(N, ops.conv_ktot([C], KH, KW), device=x.device)
@@ -388,13 +398,15 @@ class _StemFn(torch.autograd.Function):
 
 def _stem_ok(conv, x):
     import os
-    return (os.environ.get("FSRAFT_STEM", "1") != "0" and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+    return (STEM_KERNEL and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels == 3
             and conv.out_channels in (32, 64) and _fast(x) and not x.requires_grad and not torch.is_autocast_enabled()
             and x.shape[2] >= 7 and x.shape[3] >= 7)
 
 
-STATS_IN_EPILOGUE = __import__("os").environ.get("FSRAFT_NORM_STATS_EPILOGUE", "1") != "0"   # 0: every InstanceNorm runs its own statistics pass
+STATS_IN_EPILOGUE = True   # False: every InstanceNorm runs its own statistics pass
+STEM_KERNEL = True         # False: the 7x7 stride-2 stem as a MIOpen call
+S2D_UNITS = True           # False: the stride-2 units fall back to MIOpen behind layout hops (the path odd-sized inputs take)
 
 
 class _NormSums:
@@ -542,7 +554,7 @@ def _norm_act(norm, y, cbias, relu, res=None):
 
 def _pair_ok_shape(block, C, H, W):
     import os
-    return (os.environ.get("FSRAFT_ENCODER_S2D", "1") != "0" and _pair_shape_ok(block) and H % 2 == 0
+    return (S2D_UNITS and _pair_shape_ok(block) and H % 2 == 0
             and W % 2 == 0 and C % 4 == 0 and _cl_norm_ok(torch.empty(0, block.conv1.out_channels)))
 
 
@@ -550,7 +562,7 @@ def _pair_ok(block, x):
     return _pair_ok_shape(block, x.shape[1], x.shape[2], x.shape[3])
 
 
-S2D_EMIT = __import__("os").environ.get("FSRAFT_NORM_S2D", "1") != "0"   # 0: the stride-2 units copy their input into the space-to-depth layout themselves
+S2D_EMIT = True   # False: the stride-2 units copy their input into the space-to-depth layout themselves
 
 
 class _S2D:

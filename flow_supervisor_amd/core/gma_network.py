@@ -29,7 +29,7 @@ class RAFTGMA(nn.Module):
         warn_mixed_precision(self.args)
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
         self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
-        self.cnet.out_channels_last = os.environ.get("FSRAFT_CNET_OUT_CL", "1") != "0"   # (extractor._Encoder.forward)
+        self.cnet.out_channels_last = True   # the context features reach the update block channels_last (extractor._Encoder.forward)
         self.update_block = GMAUpdateBlock(self.args, hidden_dim=hdim)
         self.att = Attention(args=self.args, dim=cdim, heads=self.args.num_heads, max_pos_size=160, dim_head=cdim)
 

@@ -68,7 +68,7 @@ class RAFT(nn.Module):
         else:
             self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
             self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
-            self.cnet.out_channels_last = os.environ.get("FSRAFT_CNET_OUT_CL", "1") != "0"   # (extractor._Encoder.forward)
+            self.cnet.out_channels_last = True   # the context features reach the update block channels_last (extractor._Encoder.forward)
             self.update_block = BasicUpdateBlock(self.args, hidden_dim=hdim)
 
     def freeze_bn(self):

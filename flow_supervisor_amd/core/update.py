@@ -86,9 +86,9 @@ def _pad4(c):
 
 # measured: +2 % at best, and it makes per-kernel event timing meaningless (kernels of the two streams
 # overlap), so weight gradients stay on the main stream unless asked for
-_WGRAD_SIDE_STREAM = os.environ.get("FSRAFT_WGRAD_STREAM", "0") != "0"
+_WGRAD_SIDE_STREAM = False
 # one weight-gradient launch per layer per step (all iterations' operands stashed) instead of one per iteration
-_DEFER_WGRAD = os.environ.get("FSRAFT_DEFER_WGRAD", "1") != "0"
+_DEFER_WGRAD = True
 
 
 # --------------------------------------------------------------------------- layer table
@@ -845,10 +845,11 @@ class _UpdateFn(torch.autograd.Function):
         return (None, None, None, None, dnet, None, None, dcorr, dflow, None, None, None, None, None, None, None)
 
 
-HEAD_BATCH = os.environ.get("FSRAFT_HEAD_BATCH", "1") != "0"
-MOTION_BATCH = os.environ.get("FSRAFT_MOTION_BATCH", "1") != "0"
-CTX_SUM_DEFERRED = os.environ.get("FSRAFT_CTX_SUM_DEFERRED", "1") != "0"   # gate-gradient sums of a step in one pass (0: running sums in gru_bwd1/2)
-HEADS_BWD_BATCH = os.environ.get("FSRAFT_HEADS_BWD_BATCH", "1") != "0"
+# (module attributes, not environment switches: the tests that compare the per-step batches with the per-iteration route set them)
+HEAD_BATCH = True
+MOTION_BATCH = True
+CTX_SUM_DEFERRED = True   # gate-gradient sums of a step in one pass (False: running sums in gru_bwd1/2)
+HEADS_BWD_BATCH = True
 
 
 class HeadBatch:

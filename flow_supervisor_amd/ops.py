@@ -40,26 +40,31 @@ class KernelTimer:
     stream is the stream every fsraft kernel is enqueued on).  bench.py installs one for the
     timed region; when `ops.TIMER is None` (the default) nothing is recorded."""
 
-    def __init__(self):
+    def __init__(self, detail=False):
         self.rec = {}          # family -> list of (start_event, end_event, flops, bytes)
+        self.detail = detail   # also keep one entry per (family, shape tag): scripts/layer_times.py
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
-    def end(self, family, e0, flops=0.0, nbytes=0.0, flops_done=None):
+    def end(self, family, e0, flops=0.0, nbytes=0.0, flops_done=None, tag=None):
         """flops: the ALGORITHMIC count of the launch; flops_done (optional, a callable evaluated in summary(), i.e. after the
         device sync): what the launch really multiplied where that is less -- the volume-backward GEMMs visit only the k-tiles
         the step's lookups reached."""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.rec.setdefault(family, []).append((e0, e1, flops, nbytes, flops_done))
+        if self.detail and tag:
+            self.rec.setdefault(family + "|" + tag, []).append((e0, e1, flops, nbytes, flops_done))
 
     def summary(self):
         """{family: dict(launches, ms_total, ms_avg, flops, bytes, flops_done)} -- call after a device sync."""
         out = {}
         for fam, rows in self.rec.items():
+            if "|" in fam and not self.detail:
+                continue
             ms = sum(r[0].elapsed_time(r[1]) for r in rows)
             out[fam] = dict(launches=len(rows), ms_total=ms, ms_avg=ms / len(rows),
                             flops=sum(r[2] for r in rows), bytes=sum(r[3] for r in rows),
@@ -265,7 +270,7 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
     H, W = lay.H, lay.W
     rows = nq if nq else B * H * W - q0
     dvol = torch.empty(rows, lay.P, device=douts[0].device, dtype=torch.float32) if out is None else out
-    if wmask is not None and not (records and len(douts) <= 16 and os.environ.get("FSRAFT_DVOL_BOX", "1") != "0"):
+    if wmask is not None and not (records and len(douts) <= 16 and DVOL_BOX):
         wmask = None                      # (only the bounding-box kernel honours the mask; the row kernel writes whole rows)
     # scratch for the work list of queries whose lookups spread beyond the bounding-box kernel's box (1 + rows unsigned)
     qlist = torch.empty(rows + 1, device=douts[0].device, dtype=torch.int32) if len(douts) <= 16 else None
@@ -292,11 +297,14 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
     return dvol
 
 
-BWD_KSKIP = os.environ.get("FSRAFT_BWD_KSKIP", "1") != "0"     # volume-backward GEMMs over the k-tiles the lookups reached only
-CHUNK_KSKIP = os.environ.get("FSRAFT_BWD_KSKIP_CHUNKS", "0") != "0"    # ... also in the chunked backward of AlternateCorrBlock (measured slower)
-NT_LIST_KSPLIT = int(os.environ.get("FSRAFT_NT_LIST_KSPLIT", "1"))   # k-slices of the listed dF1 GEMM
-TN_LIST_KSPLIT = int(os.environ.get("FSRAFT_TN_LIST_KSPLIT", "2"))   # k-slices of the listed d2cat GEMM (one slice with plain stores measured slower: 270 vs 210 us)
-DVOL_WMASK = os.environ.get("FSRAFT_DVOL_WMASK", "1") != "0"   # ... and the gradient volume written only where they read
+# Route constants.  Each was an environment switch while its A/B was open (profiles/README.md holds the same-box numbers); they are
+# plain module attributes now -- tests and scripts/ that compare routes set them directly.
+BWD_KSKIP = True       # volume-backward GEMMs over the k-tiles the lookups reached only
+CHUNK_KSKIP = False    # ... also in the chunked backward of AlternateCorrBlock (measured slower)
+NT_LIST_KSPLIT = 1     # k-slices of the listed dF1 GEMM
+TN_LIST_KSPLIT = 2     # k-slices of the listed d2cat GEMM (one slice with plain stores measured slower: 270 vs 210 us)
+DVOL_WMASK = True      # ... and the gradient volume written only where they read
+DVOL_BOX = True        # gradient volume on the wave-per-query kernel (scripts that call fsraft_set_dvol_box(0) clear this too)
 
 
 class KTileLists:
@@ -347,7 +355,7 @@ def corr_bwd_ktiles(coords, lay, B, radius, is_flow=False, q0=0, nq=0):
     return k
 
 
-F2CAT_REC = os.environ.get("FSRAFT_F2CAT_REC", "1") != "0"    # pooled target-side operand as records in one pass (0: two kernels)
+F2CAT_REC = True       # pooled target-side operand as records in one pass (False: two kernels)
 F2CAT_REC_MAX_PLANE = 12288                                   # csrc/corr_tiled.hip: F2C_MAX_PLANE
 
 
@@ -1214,7 +1222,8 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
         L.check(_lib().fsraft_conv_forward(ctypes.byref(d), L.stream()), "conv_forward")
     if t:
         cin = sum(v.C for v in srcs)
-        t.end("conv_igemm", e0, 2.0 * B * H * W * N * cin * KH * KW, 4.0 * B * H * W * (cin + N))
+        t.end("conv_igemm", e0, 2.0 * B * H * W * N * cin * KH * KW, 4.0 * B * H * W * (cin + N),
+              tag=f"{B}x{H}x{W} {KH}x{KW} {'+'.join(str(v.C) for v in srcs)}->{N} epi{epi}{' relu' if relu else ''}{' masked' if any(ds.mask is not None for ds in dsts) else ''}")
     return carried
 
 
@@ -1229,7 +1238,8 @@ def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW, dbias=None):
                                      KH, KW, L.stream()), "conv_wgrad")
     if TIMER:
         cin = sum(v.C for v in srcs)
-        TIMER.end("conv_wgrad", e0w, 2.0 * B * H * W * dy.C * cin * KH * KW, 4.0 * B * H * W * (cin + dy.C))
+        TIMER.end("conv_wgrad", e0w, 2.0 * B * H * W * dy.C * cin * KH * KW, 4.0 * B * H * W * (cin + dy.C),
+                  tag=f"{B}x{H}x{W} {KH}x{KW} {'+'.join(str(v.C) for v in srcs)}->{dy.C} x1")
 
 
 def conv_wgrad_multi(dys, srcs, dwpk, B, H, W, KH, KW, dbias=None):
@@ -1245,7 +1255,8 @@ def conv_wgrad_multi(dys, srcs, dwpk, B, H, W, KH, KW, dbias=None):
                                            L.ptr(dwpk), L.ptr(dbias), B, H, W, KH, KW, L.stream()), "conv_wgrad_multi")
     if TIMER:
         cin = sum(v.C for v in srcs[0])
-        TIMER.end("conv_wgrad", e0w, 2.0 * n * B * H * W * dy0.C * cin * KH * KW, 4.0 * n * B * H * W * (cin + dy0.C))
+        TIMER.end("conv_wgrad", e0w, 2.0 * n * B * H * W * dy0.C * cin * KH * KW, 4.0 * n * B * H * W * (cin + dy0.C),
+                  tag=f"{B}x{H}x{W} {KH}x{KW} {'+'.join(str(v.C) for v in srcs[0])}->{dy0.C} x{n}")
 
 
 def stem_fwd(x, w, bias=None):

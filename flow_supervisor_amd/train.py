@@ -8,6 +8,7 @@ from .parallel import FlatAdamW, FlatGradients
 
 
 MAX_FLOW = 400          # pytorch/train.py:55
+SUP_GRAD_SAMPLES = True  # batched flow-supervisor step: no graph / backward for the unlabelled samples' supervisor half (known-zero gradients)
 
 
 class _SeqLossFn(torch.autograd.Function):
@@ -260,7 +261,7 @@ class SemiTrainStep(TrainStep):
         self.batched = (os.environ.get("FSRAFT_SEMI_BATCHED", "1") != "0") if batched is None else bool(batched)
         self._cat = None
         import inspect
-        self._sup_kw = "sup_grad_samples" in inspect.signature(model.forward).parameters and os.environ.get("FSRAFT_SUP_GRAD_SAMPLES", "1") != "0"
+        self._sup_kw = "sup_grad_samples" in inspect.signature(model.forward).parameters and SUP_GRAD_SAMPLES
 
     def _batched_inputs(self, sup, unsup):
         """cat of the two samples.  The key holds every input's identity AND version counter, so a caller that refreshes

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage-removal experiment on the split-bf16 conv kernel (needs `make -C flow_supervisor_amd/csrc ablate`).
-usage: FSRAFT_LIB_PATH=flow_supervisor_amd/libfsraft_ablate.so python scripts/ablate.py [buf]
+usage: FSRAFT_LIB_PATH=flow_supervisor_amd/csrc/build/ablate/libfsraft_ablate.so python scripts/ablate.py [buf]
 Times the zr-shaped (1x5, 3 sources, 384 -> 256) and hd-shaped (3x3, 128 -> 512) GEMMs with pipeline stages removed:
 bit 0 no LDS staging, bit 1 no MFMA, bit 2 no fragment reads + no MFMA, bit 3 no global loads."""
 import ctypes

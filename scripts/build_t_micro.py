@@ -15,7 +15,7 @@ lib = _lib.load()
 dev = "cuda"
 if lib.fsraft_set_tuning(24, 0) != 0 and len(sys.argv) > 1:
     sys.exit("the transposed-role / persistent build kernels live in the experiment build only: make -C flow_supervisor_amd/csrc ablate; "
-             "FSRAFT_LIB_PATH=flow_supervisor_amd/libfsraft_ablate.so python scripts/build_t_micro.py <kernel>")
+             "FSRAFT_LIB_PATH=flow_supervisor_amd/csrc/build/ablate/libfsraft_ablate.so python scripts/build_t_micro.py <kernel>")
 KERNEL = int(sys.argv[1]) if len(sys.argv) > 1 else 0        # 1: one tile per workgroup, stores from the accumulators; 2 / 3 / 4: persistent (DEFER 1 / 0 / 2)
 torch.manual_seed(0)
 

@@ -306,7 +306,7 @@ def test_sequence_loss_unsup_restatement_vs_reference_function():
             close(p.grad if p.grad is not None else torch.zeros_like(p), g[f"{name}_dpred{i}"], 1e-9, 1e-5)
 
 
-@pytest.mark.parametrize("tag", ["basic", "gma"])
+@pytest.mark.parametrize("tag", ["basic", "gma", "kitti"])
 def test_l2l_recipe_scale_forward(tag):
     """The labelled pass of the flow-supervisor step at the reference recipe's size (B = 1, crop 368x768 in a 432x1024 frame,
     12 + 12 iterations; tests/golden/l2l_recipe_*.npz hold the reference's outputs): the oracle's forward and sequence_loss
@@ -314,7 +314,7 @@ def test_l2l_recipe_scale_forward(tag):
     and the GPU suite checks every gradient norm of the fixture)."""
     from oracle.weights import rand_uniform
     g = load("l2l_recipe_" + tag)
-    shapes = json.load(open(os.path.join(G, f"l2l_recipe_{tag}_shapes.json")))
+    shapes = json.load(open(os.path.join(G, f"l2l_recipe_{'gma' if tag == 'gma' else 'basic'}_shapes.json")))     # ("kitti": the same L2L)
     seed, H, W, h, w = (int(g[k]) for k in ("seed", "H", "W", "h", "w"))
     sd = procedural_state_dict(shapes, seed)
     if tag == "gma":
