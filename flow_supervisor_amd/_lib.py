@@ -70,6 +70,7 @@ SIGNATURES = {
     "fsraft_conv_wgrad_multi": [_PP, c_int, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_wgrad": [_PP, _PP, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_conv_small_dgrad": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_pack_conv_weights": [POINTER(PackJob), c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
     "fsraft_set_rec_mfma16": [c_int],

@@ -548,7 +548,11 @@ class _Engine:
                 if ddelta is not None:
                     ops.flow_to_nhwc(ddelta, dd, 0)
                     wgrad("fh2", V(dd, 2), [V(head, self.head_c)])
-                    dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0).masked(V(head, self.head_c, 0))])
+                    if FH2_DGRAD_SMALL and "fh2.raw" in P and self.head_c % 4 == 0 and self.head_c <= 256:
+                        # 18 multiply-adds per element: a streaming kernel, not an implicit GEMM with K padded from 18 to 288
+                        ops.conv_small_dgrad(V(dd, 2), P["fh2.raw"][0], V(dhead, self.head_c, 0), V(head, self.head_c, 0), B, H, W)
+                    else:
+                        dgrad("fh2", V(dd, 2), [Dst.nhwc(dhead, 0).masked(V(head, self.head_c, 0))])
                 else:
                     dhead[..., : self.head_c].zero_()
                 # (no separate ReLU-backward pass: the two data-gradient epilogues above wrote dhead already masked by head > 0)
@@ -846,6 +850,7 @@ class _UpdateFn(torch.autograd.Function):
 
 
 # (module attributes, not environment switches: the tests that compare the per-step batches with the per-iteration route set them)
+FH2_DGRAD_SMALL = True    # data gradient of the flow head's 256 -> 2 convolution on csrc/conv_small.hip (False: implicit GEMM)
 HEAD_BATCH = True
 MOTION_BATCH = True
 CTX_SUM_DEFERRED = True   # gate-gradient sums of a step in one pass (False: running sums in gru_bwd1/2)

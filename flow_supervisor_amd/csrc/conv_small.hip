@@ -232,6 +232,83 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a)
   }
 }
 
+// Data gradient of the same 3x3 convolution to two outputs (the flow head's second layer, pytorch/core/update.py:6-14):
+//     dx[pix][c] = mask(pix, c) * sum_{o < 2, tap} w[o][c][tap] * dy[pix - shift(tap)][o]
+// 18 multiply-adds per element and 1 KB written per pixel: a streaming kernel, not a GEMM -- as an implicit GEMM the two
+// input channels are padded to a 32-deep k-tile per tap (K = 288 for 18 useful products) and the launch took 331 us for the
+// twelve iterations of a four-pair step.  One wave owns a run of pixels of an image row; a lane owns four channels and keeps
+// their 72 weights in registers; the 3 x 3 x 2 gradients around a pixel arrive through wave-uniform (scalar) loads, sliding
+// along the run one column at a time.  mask (optional): the ReLU that produced x -- dx is written only where relu_src > 0.
+constexpr int SMALL_RUN_DG = 16;
+template <int N>
+__global__ __launch_bounds__(256) void conv_small_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ w_oihw,
+                                                               float* __restrict__ dx, int lddx, const float* __restrict__ relu_src,
+                                                               int ldm, int C, int B, int H, int W) {
+  static_assert(N == 2, "two output channels");
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * 4;
+  const bool on = c0 < C;
+  // this lane's weights: w[o][c0 .. c0 + 3][ky][kx] (rows of 9 floats per (o, c))
+  float wr[N][4][9];
+#pragma unroll
+  for (int o = 0; o < N; ++o)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[o][k][t] = (on && c0 + k < C) ? w_oihw[((int64_t)o * C + c0 + k) * 9 + t] : 0.f;
+  const int runs_per_row = (W + SMALL_RUN_DG - 1) / SMALL_RUN_DG;
+  const int64_t nrun = (int64_t)B * H * runs_per_row;
+  const int nwave = gridDim.x * 4;
+  for (int64_t run = blockIdx.x * 4 + (threadIdx.x >> 6); run < nrun; run += nwave) {
+    const int64_t ru = __builtin_amdgcn_readfirstlane((int)run);       // (nrun < 2^31: checked by the host)
+    const int xr = (int)(ru % runs_per_row), row = (int)(ru / runs_per_row), y = row % H, b = row / H;
+    const int x0 = xr * SMALL_RUN_DG, x1 = min(W, x0 + SMALL_RUN_DG);
+    const float* dyb = dy + (int64_t)b * H * W * ldy;
+    // dy[o] at (y + j - 1, x + i - 1): a 3-column window that slides along the run (wave-uniform values)
+    float g[3][3][N];
+    auto col = [&](int x, float (&gc)[3][N]) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int yy = y + j - 1;
+        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)x < (unsigned)W;
+        const float* p = dyb + (int64_t)((ok ? yy : y) * W + (ok ? x : x0)) * ldy;
+#pragma unroll
+        for (int o = 0; o < N; ++o) gc[j][o] = ok ? p[o] : 0.f;
+      }
+    };
+    col(x0 - 1, g[0]);
+    col(x0, g[1]);
+    for (int x = x0; x < x1; ++x) {
+      col(x + 1, g[2]);
+      if (on) {
+        const int64_t pix = ((int64_t)b * H + y) * W + x;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // forward: y[q] = sum w[ky][kx] x[q + (ky - 1, kx - 1)]  =>  dx[p] = sum w[ky][kx] dy[p - (ky - 1, kx - 1)]: window cell (2 - ky, 2 - kx)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int o = 0; o < N; ++o) {
+              const float gv = g[2 - kx][2 - ky][o];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc[k] += wr[o][k][ky * 3 + kx] * gv;
+            }
+        if (relu_src) {
+          const f32x4 m = gload4(relu_src + pix * ldm + c0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] = m[k] > 0.f ? acc[k] : 0.f;
+        }
+        gstore4(dx + pix * lddx + c0, acc);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int o = 0; o < N; ++o) { g[0][j][o] = g[1][j][o]; g[1][j][o] = g[2][j][o]; }
+    }
+  }
+}
+
 }  // namespace
 
 // out[b][o][pix] = bias[o] + sum_{c,tap} w[o][c][tap] * x[pixel + shift(tap)][c];  N = 2 outputs, C <= 512, KH*KW <= 9.
@@ -265,4 +342,20 @@ extern "C" int fsraft_conv_small_wgrad(const float* const* dy, const float* cons
     if (rc) return rc;
   }
   return FS_OK;
+}
+
+// dx[pix][c] (channels-last, pitch lddx, 16-byte aligned, c < C) = mask * sum_{o, tap} w_oihw[o][c][tap] * dy[pix - shift(tap)][o]: the data
+// gradient of fsraft_conv_small_fwd.  dy: channels-last with pitch ldy >= 2 (the two gradients of a pixel side by side);
+// relu_src (nullable, pitch ldm): dx is zero where relu_src <= 0 (the ReLU in front of the convolution).  C % 4 == 0, C <= 256.
+extern "C" int fsraft_conv_small_dgrad(const float* dy, int ldy, const float* w_oihw, float* dx, int lddx, const float* relu_src, int ldm,
+                                       int C, int N, int B, int H, int W, int KH, int KW, hipStream_t s) {
+  if (!dy || !w_oihw || !dx || N != 2 || C < 4 || C > 256 || C % 4 || lddx % 4 || ldy < 2 || KH != 3 || KW != 3 || B < 1 ||
+      ((uintptr_t)dx % 16) || (relu_src && (ldm % 4 || ((uintptr_t)relu_src % 16))))
+    return FS_ERR_ARG;
+  const int64_t nrun = (int64_t)B * H * ((W + SMALL_RUN_DG - 1) / SMALL_RUN_DG);
+  if (nrun >= ((int64_t)1 << 31)) return FS_ERR_ARG;
+  int blocks = (int)((nrun + 3) / 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((conv_small_dgrad_kernel<2>), dim3(blocks), dim3(256), 0, s, dy, ldy, w_oihw, dx, lddx, relu_src, ldm, C, B, H, W);
+  return fs_launch_status();
 }

@@ -1314,6 +1314,19 @@ def conv_small_wgrad(dys, xs, dwpk, dbias, B, H, W):
                                            L.ptr(dwpk), L.ptr(dbias), dys[0].C, B, H, W, 3, 3, L.stream()), "conv_small_wgrad")
 
 
+def conv_small_dgrad(dy, w_oihw, dst, mask, B, H, W):
+    """Data gradient of conv_small_fwd: dy V (channels-last, two gradients per pixel), w_oihw [2,C,3,3], dst V (channels-last
+    slice that receives dx, c < C), mask V or None (dx = 0 where mask <= 0: the ReLU in front of the convolution)."""
+    C = dst.C
+    t = TIMER
+    e0 = t.begin() if t else None
+    L.check(_lib().fsraft_conv_small_dgrad(ctypes.c_void_p(dy.ptr), dy.ld, L.ptr(w_oihw), ctypes.c_void_p(dst.ptr), dst.ld,
+                                           ctypes.c_void_p(mask.ptr) if mask is not None else None, mask.ld if mask is not None else 0,
+                                           C, 2, B, H, W, 3, 3, L.stream()), "conv_small_dgrad")
+    if t:
+        t.end("conv_small", e0, 2.0 * B * H * W * 2 * C * 9, 4.0 * B * H * W * (C * (2 if mask is not None else 1) + 2))
+
+
 def col_sum_v(v, out, scale=1.0):
     M = v.t.numel() // v.ld
     L.check(_lib().fsraft_col_sum(ctypes.c_void_p(v.ptr), v.ld, M, v.C, L.ptr(out), float(scale), L.stream()), "col_sum")

@@ -238,6 +238,12 @@ int fsraft_conv_small_fwd(const float* x, int ld, int C, const float* w_oihw, co
  * dbias[o] += sum dy (nullable) */
 int fsraft_conv_small_wgrad(const float* const* dy, const float* const* x, int nseg, int ldy, int ldx, int C, float* dwpk,
                             float* dbias, int N, int B, int H, int W, int KH, int KW, hipStream_t stream);
+/* Data gradient of fsraft_conv_small_fwd (the flow head's 256 -> 2 convolution, pytorch/core/update.py:6-14, as autograd's
+ * conv2d backward w.r.t. its input): dx[pix][c] = sum_{o < 2, tap} w_oihw[o][c][tap] * dy[pix - shift(tap)][o], zero where
+ * relu_src <= 0 (nullable: the ReLU in front of the convolution, pitch ldm).  dy channels-last with pitch ldy >= 2; dx
+ * channels-last with pitch lddx, 16-byte aligned.  C % 4 == 0, C <= 256, N == 2, 3x3. */
+int fsraft_conv_small_dgrad(const float* dy, int ldy, const float* w_oihw, float* dx, int lddx, const float* relu_src, int ldm,
+                            int C, int N, int B, int H, int W, int KH, int KW, hipStream_t stream);
 
 /* Scratch buffer for the split-K route of the convolutions at small pixel counts (one or two pairs per GPU: the layer's
  * k-tiles are dealt to several workgroups per tile, which park partial tiles here; a second kernel adds them and applies the

@@ -839,6 +839,33 @@ def test_mask_head_and_upsampler_of_all_iterations_as_one_launch():
         assert (ga - gb).norm().item() <= tol * gb.norm().item() + 1e-6, (n, (ga - gb).norm().item(), gb.norm().item())
 
 
+@pytest.mark.parametrize("B,H,W,C,ld", [(2, 13, 21, 256, 512), (1, 55, 128, 256, 512), (3, 7, 5, 128, 128)])
+def test_flow_head_data_gradient_as_a_streaming_kernel(B, H, W, C, ld):
+    """fsraft_conv_small_dgrad (data gradient of the flow head's C -> 2 3x3 convolution with the ReLU mask in front of it: 18
+    multiply-adds per element) against autograd's conv2d backward on the same weights, ragged sizes and the bench grid, written
+    into a channel slice of a wider buffer as the update block does.  fp32 multiply-adds in a fixed order: 1e-6 relative."""
+    import torch.nn.functional as F
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.ops import V
+    torch.manual_seed(4)
+    w = torch.randn(2, C, 3, 3, device=DEV) * 0.1
+    x = torch.randn(B, C, H, W, device=DEV)
+    dy = torch.randn(B, 2, H, W, device=DEV)
+    xr = torch.relu(x).requires_grad_(True)
+    F.conv2d(xr, w, padding=1).backward(dy)
+    ref = (xr.grad * (x > 0)).permute(0, 2, 3, 1)                      # masked by the ReLU that produced the convolution's input
+    dd = torch.zeros(B, H, W, 4, device=DEV)
+    dd[..., :2] = dy.permute(0, 2, 3, 1)
+    head = torch.zeros(B, H, W, ld, device=DEV)
+    head[..., :C] = torch.relu(x).permute(0, 2, 3, 1)
+    out = torch.full((B, H, W, ld), 7.0, device=DEV)
+    ops.conv_small_dgrad(V(dd, 2), w, V(out, C, 0), V(head, C, 0), B, H, W)
+    close(out[..., :C], ref, 0.0, rtol=2e-6, what="flow-head data gradient")
+    assert bool((out[..., C:] == 7.0).all()), "channels beyond the slice must stay untouched"
+    ops.conv_small_dgrad(V(dd, 2), w, V(out, C, 0), None, B, H, W)
+    close(out[..., :C], xr.grad.permute(0, 2, 3, 1), 0.0, rtol=2e-6, what="flow-head data gradient, no mask")
+
+
 @pytest.mark.parametrize("case", ["raft_b3_iters2", "raft_alt_iters3", "l2l_offsets_per_sample", "l2l_sup_grad_samples"])
 def test_per_step_batches_against_the_per_iteration_path_on_odd_shapes(case):
     """update.HeadBatch + MotionBatch + the batched heads backward (everything outside the recurrence once per step) against one
