@@ -1,16 +1,24 @@
-# refresh of the judged evidence: bench line via the driver's launch line, kernel stats, PMC traffic, variants
-# usage (on the GPU box, repo root): bash scripts/refresh_evidence.sh <tag>      -> gpurun_out/*_<tag>*, copied to profiles/ by hand
-tag=${1:-r03}
+# refresh of the judged evidence: bench line via the driver's launch line, kernel stats, PMC traffic, variants, round-4 micro evidence
+# usage (on the GPU box, repo root): FSRAFT_COMMIT=<short sha> bash scripts/refresh_evidence.sh <tag>   -> gpurun_out/*_<tag>*,
+# copied to profiles/ by hand (gpurun_out/ is scratch)
+tag=${1:-r04}
 export MIOPEN_FIND_MODE=2
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench_${tag}_1gpu.json
 cut -c1-300 gpurun_out/bench_${tag}_1gpu.json
 bash scripts/prof.sh ${tag}
 bash scripts/pmc_traffic.sh ${tag} | head -14
+python scripts/make_traffic.py gpurun_out/traffic_${tag}.json > gpurun_out/traffic_${tag}.txt 2>&1; cp profiles/traffic.json gpurun_out/traffic_${tag}_families.json
+# the line again with this run's traffic.json in place (roofline.traffic, hbm_gbs_counters, traffic_source)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench_${tag}_1gpu.json
+# python bench.py --gpus 2 typed as is: the ranks share the box's GPU and exchange over gloo through the host
+python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_${tag}_gpus2_shared.json; cut -c1-200 gpurun_out/bench_${tag}_gpus2_shared.json
 python bench.py --variant gma --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_gma.json; cut -c1-200 gpurun_out/bench_${tag}_gma.json
-bash scripts/prof.sh ${tag}_gma --variant gma
 python bench.py --variant alt --height 376 --width 1248 --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_alt.json; cut -c1-200 gpurun_out/bench_${tag}_alt.json
-bash scripts/prof.sh ${tag}_alt --variant alt --height 376 --width 1248 --batch-per-gpu 1
 python bench.py --height 368 --width 496 --batch-per-gpu 8 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_chairs.json; cut -c1-200 gpurun_out/bench_${tag}_chairs.json
 python bench.py --variant l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_l2l.json
-bash scripts/prof.sh ${tag}_l2l --variant l2l --batch-per-gpu 1
 python bench.py --variant gma_l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_gma_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_gma_l2l.json
+# round 4: gradient-volume kernels under PMC, the lookup's gather floor, per-layer convolution times
+bash scripts/dvol_pmc.sh ${tag} > /dev/null 2>&1
+python scripts/dvol_micro.py 2>&1 | tail -9 > gpurun_out/dvol_micro_${tag}.txt
+python scripts/lookup_gather_floor.py 2>&1 | tail -2 > gpurun_out/lookup_gather_floor_${tag}.txt
+python scripts/layer_times.py > gpurun_out/layer_times_${tag}.txt 2>&1
