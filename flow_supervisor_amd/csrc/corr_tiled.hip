@@ -77,11 +77,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // code and the compiler can count the loads in flight (`s_waitcnt vmcnt(N)`, not 0).
 struct LevelGeo { int off, tw, h, w; };        // per-level constants of the layout, in SGPRs
 
+// (only the loaded tile rows are carried from the issue to the blends; the window origin, the fractions and the pad mask of a level
+//  are recomputed from the query position at the blend -- 36 registers per query in flight held the kernel at four waves per SIMD,
+//  i.e. two rounds of waves for the 27 per CU a four-pair lookup needs)
 template <int R>
 struct LookupLoad {
-  LevelQ lq[4];
   f32x4 v[4];
-  int xr[4];       // true width minus the x of this lane's first cell: cells at or beyond it are pad and read as zero
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* row, unsigned bytes) {
@@ -97,14 +98,13 @@ __device__ __forceinline__ void lookup_issue(LookupLoad<R>& ld, const float* __r
   const __amdgpu_buffer_rsrc_t rs = row_rsrc(row, row_bytes);
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
-    ld.lq[l] = level_query(cx, cy, l, R);
-    const int tx = (ld.lq[l].wx0 >> 2) + tsx, ty = (ld.lq[l].wy0 >> 2) + tsy;     // >> on negatives = floor division
+    const LevelQ lq = level_query(cx, cy, l, R);
+    const int tx = (lq.wx0 >> 2) + tsx, ty = (lq.wy0 >> 2) + tsy;     // >> on negatives = floor division
     const int y = 4 * ty + r, x = 4 * tx;
-    const bool need = l < nlev && tx >= 0 && tx < g[l].tw && ty >= 0 && y < g[l].h && y >= ld.lq[l].wy0 && y < ld.lq[l].wy0 + S::WIN &&
-                      x + 3 >= ld.lq[l].wx0 && x < ld.lq[l].wx0 + S::WIN;
+    const bool need = l < nlev && tx >= 0 && tx < g[l].tw && ty >= 0 && y < g[l].h && y >= lq.wy0 && y < lq.wy0 + S::WIN &&
+                      x + 3 >= lq.wx0 && x < lq.wx0 + S::WIN;
     const unsigned voff = need ? (unsigned)(g[l].off + (ty * g[l].tw + tx) * 16 + r * 4) * 4u : 0x80000000u;
     ld.v[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, AUX));
-    ld.xr[l] = g[l].w - x;
   }
 }
 
@@ -155,12 +155,16 @@ __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __re
       if (qq + 1 < QW) cur = nxt;
       continue;
     }
+    LevelQ lqs[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) lqs[l] = level_query(cxs[qq], cys[qq], l, R);
 #pragma unroll
     for (int l = 0; l < 4; ++l)
       if (l < nlev) {
         f32x4 v = cur.v[l];
+        const int xr = g[l].w - 4 * ((lqs[l].wx0 >> 2) + tsx);      // true width minus the x of this lane's first cell: cells at or beyond it are pad
 #pragma unroll
-        for (int c = 1; c < 4; ++c) v[c] = c < cur.xr[l] ? v[c] : 0.f;
+        for (int c = 1; c < 4; ++c) v[c] = c < xr ? v[c] : 0.f;
         *reinterpret_cast<f32x4*>(reg + l * S::REGION + (4 * tsy + r) * S::RP + 4 * tsx) = v;
       }
     wave_lds_sync();
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __re
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       if (l >= nlev) continue;
-      const float* base = reg + l * S::REGION + (cur.lq[l].wy0 & 3) * S::RP + (cur.lq[l].wx0 & 3);
-      const float fx = cur.lq[l].fx, fy = cur.lq[l].fy;
+      const float* base = reg + l * S::REGION + (lqs[l].wy0 & 3) * S::RP + (lqs[l].wx0 & 3);
+      const float fx = lqs[l].fx, fy = lqs[l].fy;
 #pragma unroll
       for (int k = 0; k < S::ROUNDS; ++k) {
         const float* p = base + choff[k];
