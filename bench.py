@@ -363,6 +363,19 @@ def main():
     else:
         step = TrainStep(model, lr=1.6e-5, iters=a.iters, capturable=use_graph)
 
+    eager_step = step
+    if split_graph:
+        # At N > 1 every step of this run -- warm-up, the captured one, the eager kernel-timing pass -- exchanges gradients the
+        # same way: ONE blocking all-reduce of the flat buffer between backward and the update, so the run issues a single
+        # kind of collective on a single stream (the hook-issued bucket route is FSRAFT_BENCH_GRAPH_MULTI=0 / 2).
+        tstep = sstep if semi else step
+
+        def eager_step(_a, _b):
+            l = tstep.forward_backward(sup, unsup) if semi else tstep.forward_backward(im1, im2)
+            tstep.exchange()
+            tstep.update()
+            return l[0] + l[1] if semi else l
+
     graph = None
     loss = None
     graph_note = "eager"
@@ -374,7 +387,7 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(a.warmup, 2)):
-                step(im1, im2)
+                eager_step(im1, im2)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         cap_kw = {}
@@ -391,7 +404,6 @@ def main():
             cap_kw["capture_error_mode"] = "thread_local"
         try:
             if split_graph:
-                tstep = sstep if semi else step
                 g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_fb, stream=side, **cap_kw):   # same stream as the warm-up: autograd pins each AccumulateGrad node to the stream it was created on
                     loss = tstep.forward_backward(sup, unsup) if semi else tstep.forward_backward(im1, im2)
@@ -423,11 +435,11 @@ def main():
                 graph, loss, graph_note = None, None, "eager (graph capture failed on another rank)"
     if graph is None:
         for _ in range(a.warmup if not use_graph else 0):
-            step(im1, im2)
+            eager_step(im1, im2)
 
         def run():
             nonlocal loss
-            loss = step(im1, im2)
+            loss = eager_step(im1, im2)
     if graph is not None:
         for _ in range(a.warmup):
             run()
@@ -454,7 +466,7 @@ def main():
         ops.TIMER = timer
         tsteps = min(a.steps, 3)
         for _ in range(tsteps):
-            loss_e = step(im1, im2)
+            loss_e = eager_step(im1, im2)
         torch.cuda.synchronize()
         ops.TIMER = None
         timer.steps = tsteps

@@ -750,9 +750,11 @@ def test_semi_train_step_gradients_at_the_reference_recipe(tag, batched, precisi
     assert not bad, bad[:8]
 
 
-def test_chairs_batch8_train_step(precision):
-    """BASELINE.json config 2 at its own batch size (8 pairs, 368x496; VERDICT r2 weak #2), 3 iterations, fwd + bwd."""
-    g = load("train_step_basic_368x496_b8")
+@pytest.mark.parametrize("fixture", ["train_step_basic_368x496_b8", "train_step_basic_368x496_b8_it12"])
+def test_chairs_batch8_train_step(precision, fixture):
+    """BASELINE.json config 2 at its own batch size (8 pairs, 368x496; VERDICT r2 weak #2), fwd + bwd: 3 iterations, and the
+    configuration's own 12 (VERDICT r3 weak #1)."""
+    g = load(fixture)
     seed = int(g["seed"])
     m = _model(False, seed).train()
     m.freeze_bn()
