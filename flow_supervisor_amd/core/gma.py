@@ -63,11 +63,37 @@ def _attn_t_times(attn, x, B, N, C):
     return out
 
 
+# The attention map of one pair is 198 MB in fp32 at 55 x 128 (N = 7040), 0.8 GB for a batch of four, and its only readers on
+# the training path are record GEMMs (attn @ v, attn^T @ dagg of every iteration) and the softmax backward.  ATTN_RECORDS keeps
+# ONE copy of it, as records, written by the softmax itself over the logits (N % 32 == 0: a record row is as long as the fp32
+# row).  The tensor handed from Attention.forward_cl to the update block keeps shape [B,1,N,N] and dtype float32 -- autograd only
+# needs those -- but its BYTES are records; `is_records` tells the consumers (update._UpdateBlockBase._attn_transposed).  The
+# reference API (Attention.forward) always returns the dense map.
+ATTN_RECORDS = True
+
+
+def _records_ok(D, N):
+    """Shapes the record softmax pair covers (LDS holds a row of the map and of its gradient: N <= 8192), split arithmetic."""
+    return ATTN_RECORDS and ops.SPLIT_VOLUME_BWD and D % 32 == 0 and N % 32 == 0 and 32 <= N <= 8192
+
+
+def mark_records(t, like=None):
+    """Flag `t` as holding records (or carry the flag of `like` over to a detached alias)."""
+    if like is None or is_records(like):
+        t._fs_attn_records = True
+    return t
+
+
+def is_records(t):
+    return bool(getattr(t, "_fs_attn_records", False))
+
+
 class _AttentionFn(torch.autograd.Function):
-    """context [B,H,W,C] channels-last, to_qk weight [2D,C,1,1] -> softmax(scale q k^T) as [B,1,N,N]."""
+    """context [B,H,W,C] channels-last, to_qk weight [2D,C,1,1] -> softmax(scale q k^T) as [B,1,N,N] (records=True: as
+    records in that shape, see ATTN_RECORDS)."""
 
     @staticmethod
-    def forward(ctx, x_cl, w, scale):
+    def forward(ctx, x_cl, w, scale, records=False):
         L.require_cuda_f32(x_cl, w)
         B, H, W, C = x_cl.shape
         D, N = w.shape[0] // 2, H * W
@@ -81,9 +107,13 @@ class _AttentionFn(torch.autograd.Function):
         else:
             ops.gemm_raw(qk.data_ptr(), 2 * D, N * 2 * D, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, attn.data_ptr(), N, N * N,
                          B, N, N, D, True, scale)
-        ops.softmax_rows_(attn)
+        records = bool(records) and _records_ok(D, N)
+        if records:
+            ops.softmax_rows_rec_(attn)
+        else:
+            ops.softmax_rows_(attn)
         ctx.save_for_backward(x_cl, w, qk, attn)
-        ctx.scale = scale
+        ctx.scale, ctx.records = scale, records
         return attn
 
     @staticmethod
@@ -91,13 +121,17 @@ class _AttentionFn(torch.autograd.Function):
         x_cl, w, qk, attn = ctx.saved_tensors
         B, H, W, C = x_cl.shape
         D, N, scale = w.shape[0] // 2, H * W, ctx.scale
-        dS = ops.softmax_rows_bwd_(attn, dA.contiguous().clone())
+        # (the gradient tensor is overwritten: _AttnFn.backward allocates it for us and says so; anything else is copied first)
+        own = bool(getattr(dA, "_fs_owned", False)) and dA.is_contiguous()
+        dA = dA if own else dA.contiguous().clone()
+        dS = ops.softmax_rows_bwd_rec_(attn, dA) if ctx.records else ops.softmax_rows_bwd_(attn, dA)
+        del dA
         dqk = torch.empty_like(qk)
         # dq = scale dS k ; dk = scale dS^T q
         if ops.SPLIT_VOLUME_BWD and D % 32 == 0:
             # record GEMM core: dS split to records once; dq = dS . (k^T)^T with k^T [D][N] (rows of records along j),
             # dk = dS^T . q with both operands read k-major (records along the output index)
-            dSr = ops.to_records(dS.view(B, N, N))
+            dSr = dS.view(B, N, N) if ctx.records else ops.to_records(dS.view(B, N, N))
             del dS
             Nr = dSr.shape[-1]
             qkr = ops.to_records(qk.view(B, N, 2 * D))                                   # q = records 0..D/32-1 of a row, k the rest
@@ -108,7 +142,7 @@ class _AttentionFn(torch.autograd.Function):
                                 B, N, D, N, scale, ksplit=2)
             dw = _conv1x1_wgrad(dqk, x_cl, C, 2 * D, B, H, W) if ctx.needs_input_grad[1] else None
             dx = _conv1x1(dqk, w, C, 2 * D, B, H, W, 1) if ctx.needs_input_grad[0] else None
-            return dx, dw, None
+            return dx, dw, None, None
         dSt = ops.transpose_batched(dS.view(B, N, N))        # tiled transpose: 4-6 TB/s, the strided copy reaches 1.5-2
         if N % 4 == 0 and D % 4 == 0:      # k-major operands on the transposed-read split-bf16 GEMM
             ops.gemm_tn_raw(dSt.data_ptr(), N, N * N, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, dqk.data_ptr(), 2 * D,
@@ -122,7 +156,7 @@ class _AttentionFn(torch.autograd.Function):
                          N * 2 * D, B, N, D, N, False, scale)
         dw = _conv1x1_wgrad(dqk, x_cl, C, 2 * D, B, H, W) if ctx.needs_input_grad[1] else None
         dx = _conv1x1(dqk, w, C, 2 * D, B, H, W, 1) if ctx.needs_input_grad[0] else None
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class Attention(nn.Module):
@@ -145,10 +179,14 @@ class Attention(nn.Module):
             return self.forward_cl(to_channels_last(fmap.float()))
         return self._forward_general(fmap)
 
-    def forward_cl(self, fmap_cl):
-        """Channels-last entry (content-only, single head): [B,H,W,dim] -> [B,1,N,N]."""
+    def forward_cl(self, fmap_cl, records=False):
+        """Channels-last entry (content-only, single head): [B,H,W,dim] -> [B,1,N,N].  records=True (the update block's
+        forward_cl is the consumer): the map may come back as records in that shape (ATTN_RECORDS above; `is_records`)."""
         if self.heads != 1 or self._positional():
             return self._forward_general(from_channels_last(fmap_cl))
+        _, H, W, _ = fmap_cl.shape
+        if records and _records_ok(self.to_qk.weight.shape[0] // 2, H * W):
+            return mark_records(_AttentionFn.apply(fmap_cl, self.to_qk.weight, self.scale, True))
         return _AttentionFn.apply(fmap_cl, self.to_qk.weight, self.scale)
 
     def _forward_general(self, fmap):

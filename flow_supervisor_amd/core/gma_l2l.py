@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from .corr import CorrBlock
+from .gma import mark_records
 from .gma_network import RAFTGMA
 from .l2l import _crop_back, _offsets, _pad_state
 from .raft import convex_upsample
@@ -74,7 +75,7 @@ class GMAL2L(RAFTGMA):
                         with torch.no_grad():             # (detached below, as in the reference: no graph, no saved activations)
                             _, inp, attention = self._context(ci1)
                     net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
-                    attention = attention.detach()
+                    attention = mark_records(attention.detach(), like=attention)
                     hb2 = self.update_block.head_batch(iters - half, net)
                 want_up = not test_mode or itr == iters - 1          # test_mode keeps only the last flow_up (gma_l2l.py:126-127)
                 cur = None if test_mode else (hb if itr < half else hb2)

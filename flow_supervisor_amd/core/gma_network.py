@@ -59,7 +59,7 @@ class RAFTGMA(nn.Module):
         net, inp = torch.split(cnet.float(), [self.hidden_dim, self.context_dim], dim=1)
         net = to_channels_last(torch.tanh(net))
         inp = to_channels_last(torch.relu(inp))
-        return net, inp, self.att.forward_cl(inp)
+        return net, inp, self.att.forward_cl(inp, records=True)     # (consumed by update_block.forward_cl only)
 
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()

@@ -792,6 +792,7 @@ class _AttnFn(torch.autograd.Function):
         Vc = torch.cat([v for _, v in stash], 2) if len(stash) > 1 else stash[0][1].contiguous()
         B, N, K = D.shape
         dattn = torch.empty(ctx.shape, device=D.device, dtype=torch.float32)
+        dattn._fs_owned = True           # (gma._AttentionFn.backward may turn it into dS in place: nobody else holds it)
         if ops.SPLIT_VOLUME_BWD:         # record GEMM core (K = T * 128 is a multiple of 32)
             Dr, Vr = ops.to_records(D), ops.to_records(Vc)
             ops.gemm_rec_nt_raw(Dr.data_ptr(), Dr.shape[-1], N * Dr.shape[-1], Vr.data_ptr(), Vr.shape[-1], N * Vr.shape[-1],
@@ -1094,6 +1095,9 @@ class _UpdateBlockBase(nn.Module):
         `attn^T @ dagg` (the same tensor read k-major).  (Round 1 kept a transposed fp32 copy here instead.)"""
         if attention is None or not self._engine().gma or not ops.SPLIT_VOLUME_BWD:
             return None         # (SPLIT_VOLUME_BWD off = exact-fp32 test mode: keep the exact NN GEMM)
+        from .gma import is_records
+        if is_records(attention):       # the softmax wrote records over its logits (gma.ATTN_RECORDS): this IS the one copy
+            return attention.detach().view(attention.shape[0], attention.shape[-1], attention.shape[-1])
         c = self.__dict__.get("_attn_t")
         if c is None or c[0]() is not attention or c[1] != attention._version:
             with torch.no_grad():

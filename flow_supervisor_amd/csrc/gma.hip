@@ -3,6 +3,7 @@
 //   * motion_global = motion + gamma * (attn @ v) and its backward (Aggregate.forward, gma.py:113)
 // The GEMMs around them (q k^T, attn @ v and their transposes) run on fsraft_gemm_f32 / fsraft_gemm_tn_split.
 #include "common.hpp"
+#include "gemm_rec.hpp"      // rec_split4: the [32 hi | 32 lo] bf16 records the GEMMs on the attention map read
 
 namespace {
 
@@ -82,6 +83,88 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
   for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) d[i] = ra[i] * (rd[i] - dot);
 }
 
+// The same softmax, but the probabilities leave as RECORDS ([32 bf16 hi | 32 bf16 lo] per 32 columns, gemm_rec.hpp) written over
+// the logits: for n % 32 == 0 a row of records is exactly as long as the fp32 row, so the map exists ONCE -- in the form every
+// later reader takes it in (attn @ v and attn^T @ dagg of all iterations, the softmax backward below) -- and the separate
+// fp32 -> records pass (read + write of the whole map) is gone.
+__global__ __launch_bounds__(256) void softmax_rows_rec_kernel(float* __restrict__ S, int n) {
+  extern __shared__ float row[];
+  __shared__ float red[4];
+  float* p = S + (int64_t)blockIdx.x * n;
+  const int n4 = n >> 2;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+    reinterpret_cast<f32x4*>(row)[i] = v;
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  m = block_reduce<true>(m, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { const float e = __expf(row[i] - m); row[i] = e; s += e; }
+  s = block_reduce<false>(s, red);
+  const float inv = 1.0f / s;
+  char* out = reinterpret_cast<char*>(p);
+  for (int u = threadIdx.x; u < (n >> 3); u += 256) {          // 8-float units: 16 bytes of hi and 16 of lo
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {      // (the product rounded as the dense kernel stores it: the empty asm keeps hipcc from
+      v[i] = row[u * 8 + i] * inv;       //  contracting it into the split's x - hi as an fma on the unrounded product)
+      asm volatile("" : "+v"(v[i]));
+    }
+    uint2 h0, l0, h1, l1;
+    rec_split4(v, h0, l0);
+    rec_split4(v + 4, h1, l1);
+    char* d = out + (u >> 2) * 128 + (u & 3) * 16;
+    *reinterpret_cast<u32x4*>(d) = u32x4{h0.x, h0.y, h1.x, h1.y};
+    *reinterpret_cast<u32x4*>(d + 64) = u32x4{l0.x, l0.y, l1.x, l1.y};
+  }
+}
+
+// Backward of the above: A as records (a = hi + lo), dA fp32 in, dS = A * (dA - sum_j dA_j A_j) out AS RECORDS over dA -- the
+// two GEMMs that consume dS read records, so neither the fp32 dS nor a conversion pass of it exists.
+__global__ __launch_bounds__(256) void softmax_rows_bwd_rec_kernel(const char* __restrict__ A, float* __restrict__ dA, int n) {
+  extern __shared__ float row[];          // [2][n]: A row, dA row
+  __shared__ float red[4];
+  const char* a = A + (int64_t)blockIdx.x * n * 4;
+  float* d = dA + (int64_t)blockIdx.x * n;
+  float* ra = row;
+  float* rd = row + n;
+  float dot = 0.f;
+  for (int u = threadIdx.x; u < (n >> 3); u += 256) {
+    const char* s = a + (u >> 2) * 128 + (u & 3) * 16;
+    const u32x4 h = *reinterpret_cast<const u32x4*>(s), l = *reinterpret_cast<const u32x4*>(s + 64);
+    const f32x4 d0 = reinterpret_cast<const f32x4*>(d)[u * 2], d1 = reinterpret_cast<const f32x4*>(d)[u * 2 + 1];
+    float av[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      av[2 * i] = __builtin_bit_cast(float, h[i] << 16) + __builtin_bit_cast(float, l[i] << 16);
+      av[2 * i + 1] = __builtin_bit_cast(float, h[i] & 0xffff0000u) + __builtin_bit_cast(float, l[i] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[u * 8 + i] = av[i];
+    reinterpret_cast<f32x4*>(rd)[u * 2] = d0;
+    reinterpret_cast<f32x4*>(rd)[u * 2 + 1] = d1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dot += av[i] * d0[i] + av[4 + i] * d1[i];
+  }
+  dot = block_reduce<false>(dot, red);
+  char* out = reinterpret_cast<char*>(d);
+  for (int u = threadIdx.x; u < (n >> 3); u += 256) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = ra[u * 8 + i] * (rd[u * 8 + i] - dot);
+      asm volatile("" : "+v"(v[i]));
+    }
+    uint2 h0, l0, h1, l1;
+    rec_split4(v, h0, l0);
+    rec_split4(v + 4, h1, l1);
+    char* o = out + (u >> 2) * 128 + (u & 3) * 16;
+    *reinterpret_cast<u32x4*>(o) = u32x4{h0.x, h0.y, h1.x, h1.y};
+    *reinterpret_cast<u32x4*>(o + 64) = u32x4{l0.x, l0.y, l1.x, l1.y};
+  }
+}
+
 // Rows too long for LDS: same arithmetic, the row is re-read from global memory (L2) instead.
 __global__ __launch_bounds__(256) void softmax_rows_big_kernel(float* __restrict__ S, int n) {
   __shared__ float red[4];
@@ -159,6 +242,19 @@ extern "C" int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, 
   else hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), (size_t)((n + 3) & ~3) * 8, s, A, dA, n);
   return fs_launch_status();
 }
+// In place: fp32 logits [rows][n] -> softmax probabilities as records [rows][n / 32][32 hi | 32 lo] (n % 32 == 0, n <= 16384).
+extern "C" int fsraft_softmax_rows_rec(float* S, int64_t rows, int n, hipStream_t s) {
+  if (!S || rows < 1 || n < 32 || (n % 32) || n > 16384 || rows > 0x7fffffff || ((uintptr_t)S % 16)) return FS_ERR_ARG;
+  hipLaunchKernelGGL(softmax_rows_rec_kernel, dim3((unsigned)rows), dim3(256), (size_t)n * 4, s, S, n);
+  return fs_launch_status();
+}
+// A: records of fsraft_softmax_rows_rec; dA: fp32 gradient in, records of dS out (in place).  n % 32 == 0, n <= 8192.
+extern "C" int fsraft_softmax_rows_bwd_rec(const void* A, float* dA, int64_t rows, int n, hipStream_t s) {
+  if (!A || !dA || rows < 1 || n < 32 || (n % 32) || n > 8192 || rows > 0x7fffffff || ((uintptr_t)A % 16) || ((uintptr_t)dA % 16))
+    return FS_ERR_ARG;
+  hipLaunchKernelGGL(softmax_rows_bwd_rec_kernel, dim3((unsigned)rows), dim3(256), (size_t)n * 8, s, (const char*)A, dA, n);
+  return fs_launch_status();
+}
 extern "C" int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,
                                   int64_t M, int C, hipStream_t s) {
   if (!x || !y || !gamma || !dst || C % 4 || ldx % 4 || ldy % 4 || ldd % 4) return FS_ERR_ARG;
@@ -168,7 +264,10 @@ extern "C" int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int l
 extern "C" int fsraft_gma_mix_bwd(const float* d, int ldd, const float* y, int ldy, const float* gamma, float* dx, int ldx,
                                   float* dy, int lddy, float* dgamma, int64_t M, int C, hipStream_t s) {
   if (!d || !y || !gamma || !dx || !dy || !dgamma || C % 4 || ldd % 4 || ldy % 4 || ldx % 4 || lddy % 4) return FS_ERR_ARG;
-  hipLaunchKernelGGL(gma_mix_bwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, d, ldd, y, ldy, gamma, dx, ldx, dy,
+  // one atomic per workgroup on the ONE dgamma address: 3520 of them took ~40 of the kernel's 51 us (they serialise at the
+  // memory side); 512 grid-striding workgroups leave 512
+  const int grid = grid_for(M * (C / 4));
+  hipLaunchKernelGGL(gma_mix_bwd_kernel, dim3(grid > 512 ? 512 : grid), dim3(256), 0, s, d, ldd, y, ldy, gamma, dx, ldx, dy,
                      lddy, dgamma, M, C);
   return fs_launch_status();
 }

@@ -723,6 +723,23 @@ def softmax_rows_bwd_(A, dA):
     return dA
 
 
+def softmax_rows_rec_(S):
+    """In-place softmax over the last dimension (n % 32 == 0, n <= 16384) whose result overwrites the logits as RECORDS (the
+    operand form of gemm_rec_nt / gemm_rec_tn, see to_records): the tensor keeps its shape and dtype, its bytes are records."""
+    L.require_cuda_f32(S)
+    n = S.shape[-1]
+    L.check(_lib().fsraft_softmax_rows_rec(L.ptr(S), S.numel() // n, n, L.stream()), "softmax_rows_rec")
+    return S
+
+
+def softmax_rows_bwd_rec_(Ar, dA):
+    """Ar: records of softmax_rows_rec_; dA: fp32 gradient, overwritten with the RECORDS of A * (dA - sum(dA * A, -1))."""
+    L.require_cuda_f32(Ar, dA)
+    n = Ar.shape[-1]
+    L.check(_lib().fsraft_softmax_rows_bwd_rec(L.ptr(Ar), L.ptr(dA), Ar.numel() // n, n, L.stream()), "softmax_rows_bwd_rec")
+    return dA
+
+
 def gma_mix_fwd(x, y, gamma, dst):
     """dst = x + gamma * y over V channel slices (gma.py:113); gamma: 1-element device tensor."""
     M = x.t.numel() // x.ld

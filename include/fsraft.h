@@ -319,6 +319,12 @@ int fsraft_corr_bwd_ktiles(const float* const* coords, const int64_t* coords_str
 int fsraft_softmax_rows(float* S, int64_t rows, int n, hipStream_t stream);
 /* dA <- A * (dA - rowsum(dA * A))  (softmax backward, in place over dA) */
 int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, int n, hipStream_t stream);
+/* The same softmax (gma.py:71-74) with the probabilities written over the logits as RECORDS ([32 bf16 hi | 32 bf16 lo] per 32
+ * columns: the operand form of fsraft_gemm_rec_nt / _tn): for n % 32 == 0 (n <= 16384) the record row is as long as the fp32
+ * row, so the map exists once.  The backward reads those records (a = hi + lo) and turns the fp32 gradient dA into the records
+ * of dS = A * (dA - rowsum(dA * A)) in place (n <= 8192). */
+int fsraft_softmax_rows_rec(float* S, int64_t rows, int n, hipStream_t stream);
+int fsraft_softmax_rows_bwd_rec(const void* A_records, float* dA, int64_t rows, int n, hipStream_t stream);
 /* Aggregate.forward, gma.py:113: dst = x + gamma[0] * y with gamma a device scalar (the nn.Parameter). */
 int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,
                        int64_t M, int C, hipStream_t stream);

@@ -988,6 +988,51 @@ def test_gma_attention_and_aggregate_vs_reference(precision):
         close(att._forward_general(ctx), A, 1e-5, what="general attention")
 
 
+def test_attention_map_kept_once_as_records():
+    """gma.ATTN_RECORDS: the softmax writes the map over its logits as records (the one copy the training path keeps) and the
+    softmax backward reads / writes records.  Forward: bit-identical to the dense map split by ops.to_records.  Backward: the
+    gradients of the context features and of to_qk against the dense route (the records' 2^-17 is the only difference), with the
+    gradient buffer handed over for in-place use (the `_fs_owned` protocol of update._AttnFn) and with a foreign one (copied)."""
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core import gma
+    from flow_supervisor_amd.core.gma import Attention, is_records
+    if not ops.SPLIT_VOLUME_BWD:
+        pytest.skip("records are the split-arithmetic route")
+    B, H, W, seed = 2, 8, 16, 4242
+    att = Attention(args=gma_ns(), dim=128, heads=1, max_pos_size=160, dim_head=128).to(DEV)
+    with torch.no_grad():
+        att.to_qk.weight.copy_(rand_tensor(tuple(att.to_qk.weight.shape), seed, 0.08).to(DEV))
+    x = torch.relu(rand_tensor((B, H, W, 128), seed + 1, 1.5)).to(DEV)
+    G = rand_tensor((B, 1, H * W, H * W), seed + 2).to(DEV)
+    res = {}
+    for mode in ("dense", "records_owned", "records_foreign"):
+        xa = x.clone().requires_grad_(True)
+        att.to_qk.weight.grad = None
+        A = att.forward_cl(xa, records=mode != "dense")
+        assert is_records(A) == (mode != "dense") and tuple(A.shape) == (B, 1, H * W, H * W)
+        g = G.clone()
+        if mode == "records_owned":
+            g._fs_owned = True
+        A.backward(g)
+        if mode == "records_foreign":
+            assert torch.equal(g, G), "a gradient buffer that was not handed over must not be overwritten"
+        res[mode] = (A.detach().clone(), xa.grad.clone(), att.to_qk.weight.grad.clone())
+    dense = ops.to_records(res["dense"][0].view(B, H * W, H * W))
+    for mode in ("records_owned", "records_foreign"):
+        assert torch.equal(res[mode][0].view(B, H * W, H * W).view(torch.int32), dense.view(torch.int32)), mode
+        for got, ref, what in ((res[mode][1], res["dense"][1], "dx"), (res[mode][2], res["dense"][2], "dto_qk")):
+            err = (got - ref).abs().max().item()
+            assert err <= 2e-5 * ref.abs().max().item() + 1e-9, (mode, what, err, ref.abs().max().item())
+    # the switch and the shapes the record pair does not cover fall back to the dense map
+    assert not is_records(att.forward_cl(x[:, :, :15].contiguous(), records=True))         # N = 120: not a multiple of 32
+    old = gma.ATTN_RECORDS
+    try:
+        gma.ATTN_RECORDS = False
+        assert not is_records(att.forward_cl(x, records=True))
+    finally:
+        gma.ATTN_RECORDS = old
+
+
 def test_gma_update_block_vs_reference(precision):
     from flow_supervisor_amd.core.gma_update import GMAUpdateBlock
     f = 1.0 if precision == "exact" else 8.0
