@@ -6,7 +6,9 @@ Same two-phase schedule as core/l2l.py.  As in the reference, the second phase k
 import torch
 import torch.nn.functional as F
 
+from . import streams
 from .corr import CorrBlock
+from .extractor import _prepare_packs
 from .gma import mark_records
 from .gma_network import RAFTGMA
 from .l2l import _crop_back, _offsets, _pad_state
@@ -29,9 +31,39 @@ class GMAL2L(RAFTGMA):
         if not test_mode and ci1 is None:
             raise NameError("GMAL2L.forward in training mode needs the uncropped pair ci1/ci2 and offsets ox/oy")
 
+        def uncropped(B_):
+            """Second feature pair, context and attention of the uncropped frames (gma_l2l.py:91-99)."""
+            k = sup_grad_samples
+            k = k if (k is not None and 0 < k < B_ and torch.is_grad_enabled()) else None
+            if k is not None:
+                # (extension, see core/l2l.py) only the first k samples' supervisor predictions receive gradient: the
+                # uncropped frames of the others are encoded without a graph
+                ta1, ta2 = self._features(ci1[:k], ci2[:k])
+                with torch.no_grad():
+                    tb1, tb2 = self._features(ci1[k:], ci2[k:])
+                t1, t2 = torch.cat([ta1, tb1]), torch.cat([ta2, tb2])
+            else:
+                t1, t2 = self._features(ci1, ci2)
+            with torch.no_grad():             # (detached by the reference: no graph, no saved activations)
+                _, inp2, att2 = self._context(ci1)
+            return t1, t2, inp2, att2, k
+
+        early = None
+        if streams.OVERLAP and not test_mode and ci1 is not None and image1.is_cuda and iters // 2 < iters:
+            # second stream (core/streams.py, as in core/l2l.py): the student's context + attention, then the uncropped frames
+            _prepare_packs(self.fnet)
+            _prepare_packs(self.cnet)
+            with torch.cuda.stream(streams.fork(image1.device)):
+                net, inp, attention = self._context(image1)
+                ctx_done = streams.mark(image1.device)
+                with torch.set_grad_enabled(torch.is_grad_enabled() and supervisor_grad):
+                    early = uncropped(image1.shape[0])
         fmap1, fmap2 = self._features(image1, image2)
         corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
-        net, inp, attention = self._context(image1)
+        if early is not None:
+            streams.join(image1.device, net, inp, attention, event=ctx_done)
+        else:
+            net, inp, attention = self._context(image1)
         # the loop carries the flow (see core/l2l.py): lookups add the pixel grid themselves
         B, _, Hi, Wi = image1.shape
         flow = flow_init.float() if flow_init is not None else torch.zeros(B, 2, Hi // 8, Wi // 8, device=image1.device)
@@ -59,21 +91,14 @@ class GMAL2L(RAFTGMA):
                     if ci1 is not None:
                         crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
                         net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))
-                        k = sup_grad_samples
-                        k = k if (k is not None and 0 < k < net.shape[0] and torch.is_grad_enabled()) else None
-                        if k is not None:
-                            # (extension, see core/l2l.py) only the first k samples' supervisor predictions receive gradient: the
-                            # uncropped frames of the others are encoded without a graph
-                            ta1, ta2 = self._features(ci1[:k], ci2[:k])
-                            with torch.no_grad():
-                                tb1, tb2 = self._features(ci1[k:], ci2[k:])
-                            tfmap1, tfmap2 = torch.cat([ta1, tb1]), torch.cat([ta2, tb2])
+                        if early is not None:
+                            streams.join(net.device, *early[:4])
+                            tfmap1, tfmap2, inp, attention, k = early
+                            early = None
                         else:
-                            tfmap1, tfmap2 = self._features(ci1, ci2)
+                            tfmap1, tfmap2, inp, attention, k = uncropped(net.shape[0])
                         corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius, grad_samples=k)
                         corr = corr_fn(flow, channels_last=True, is_flow=True)
-                        with torch.no_grad():             # (detached below, as in the reference: no graph, no saved activations)
-                            _, inp, attention = self._context(ci1)
                     net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                     attention = mark_records(attention.detach(), like=attention)
                     hb2 = self.update_block.head_batch(iters - half, net)

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 from torch.amp import autocast
 
+from . import streams
 from .corr import CorrBlock
 from .extractor import BasicEncoder
 from .gma import Attention
@@ -64,9 +65,17 @@ class RAFTGMA(nn.Module):
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        # context encoder + attention on the second stream beside the feature encoder and the volume build (core/streams.py)
+        overlap = streams.OVERLAP and image1.is_cuda
+        if overlap:
+            with torch.cuda.stream(streams.fork(image1.device)):
+                net, inp, attention = self._context(image1)
         fmap1, fmap2 = self._features(image1, image2)
         corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
-        net, inp, attention = self._context(image1)
+        if overlap:
+            streams.join(image1.device, net, inp, attention)
+        else:
+            net, inp, attention = self._context(image1)
 
         # as in RAFT.forward the loop carries the flow (the lookups add the pixel grid themselves), and in training the mask head
         # and the upsampler of all iterations run as one launch each after the loop (update.HeadBatch)

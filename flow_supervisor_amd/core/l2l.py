@@ -10,7 +10,9 @@ import torch
 import torch.nn.functional as F
 from torch.amp import autocast
 
+from . import streams
 from .corr import AlternateCorrBlock, CorrBlock
+from .extractor import _prepare_packs
 from .raft import RAFT, convex_upsample
 from .update import BasicUpdateBlock, to_channels_last
 from .utils.utils import upflow8
@@ -103,14 +105,49 @@ class L2L(RAFT):
                 c = self.cnet(a)
             return torch.split(c.float(), [hdim, cdim], dim=1)
 
+        def uncropped(B_):
+            """Second feature pair + context of the uncropped frames (l2l.py:95-101): (tfmap1, tfmap2, inp, k)."""
+            k = sup_grad_samples
+            if k is not None and 0 < k < B_ and torch.is_grad_enabled():
+                # (extension) the caller's loss reaches the supervisor's predictions of the first k samples only
+                # (the flow-supervisor step batches its labelled and its unlabelled sample: train.SemiTrainStep): the
+                # uncropped frames of the others are encoded without a graph -- their gradient would be zeros
+                # pushed through the whole feature encoder
+                ta1, ta2 = features(ci1[:k], ci2[:k])
+                with torch.no_grad():
+                    tb1, tb2 = features(ci1[k:], ci2[k:])
+                t1, t2 = torch.cat([ta1, tb1]), torch.cat([ta2, tb2])
+            else:
+                t1, t2 = features(ci1, ci2)
+            with torch.no_grad():         # (detached by the reference, l2l.py:104: no graph, no saved activations)
+                _, inp2 = context(ci1)
+                inp2 = to_channels_last(torch.relu(inp2))
+            return t1, t2, inp2, (k if (k is not None and 0 < k < B_) else None)
+
+        early = None
+        if streams.OVERLAP and not test_mode and ci1 is not None and image1.is_cuda and iters // 2 < iters:
+            # the uncropped frames' encodings depend on the inputs only: issued now on the second stream, joined at the switch
+            # iteration where the reference computes them (core/streams.py; 56.0 -> 58.8 pairs/s at one pair per GPU)
+            _prepare_packs(self.fnet)                   # (the packed weights both streams read are built on this one first)
+            _prepare_packs(self.cnet)
+            with torch.cuda.stream(streams.fork(image1.device)):
+                # the student's own context first (the loop waits for it, and only for it: the event), then the uncropped frames
+                net, inp = context(image1)
+                net, inp = to_channels_last(torch.tanh(net)), to_channels_last(torch.relu(inp))
+                ctx_done = streams.mark(image1.device)
+                with torch.set_grad_enabled(torch.is_grad_enabled() and supervisor_grad):
+                    early = uncropped(image1.shape[0])
         fmap1, fmap2 = features(image1, image2)
         if self.args.alternate_corr:
             corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
         else:
             corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
-        net, inp = context(image1)
-        net = to_channels_last(torch.tanh(net))
-        inp = to_channels_last(torch.relu(inp))
+        if early is not None:
+            streams.join(image1.device, net, inp, event=ctx_done)
+        else:
+            net, inp = context(image1)
+            net = to_channels_last(torch.tanh(net))
+            inp = to_channels_last(torch.relu(inp))
 
         # As in RAFT.forward the loop carries the FLOW, not coords1 = coords0 + flow (l2l.py:66-70, 110-122): the lookups add
         # the pixel grid themselves, so an iteration has one framework op (flow + delta) instead of three; same gradient
@@ -148,24 +185,14 @@ class L2L(RAFT):
                         if ci1 is not None:
                             crop = (_offsets(ox, net.shape[0]), _offsets(oy, net.shape[0]), tuple(image1.shape[-2:]))
                             net, flow = _pad_state(net, flow, crop[0], crop[1], crop[2], tuple(ci1.shape[-2:]))   # (l2l.py:90-93)
-                            k = sup_grad_samples
-                            if k is not None and 0 < k < net.shape[0] and torch.is_grad_enabled():
-                                # (extension) the caller's loss reaches the supervisor's predictions of the first k samples only
-                                # (the flow-supervisor step batches its labelled and its unlabelled sample: train.SemiTrainStep): the
-                                # uncropped frames of the others are encoded without a graph -- their gradient would be zeros
-                                # pushed through the whole feature encoder
-                                ta1, ta2 = features(ci1[:k], ci2[:k])
-                                with torch.no_grad():
-                                    tb1, tb2 = features(ci1[k:], ci2[k:])
-                                tfmap1, tfmap2 = torch.cat([ta1, tb1]), torch.cat([ta2, tb2])
+                            if early is not None:
+                                streams.join(net.device, *early[:3])
+                                tfmap1, tfmap2, inp, k = early
+                                early = None
                             else:
-                                tfmap1, tfmap2 = features(ci1, ci2)
-                            corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius,     # second volume (l2l.py:101)
-                                                grad_samples=k if (k is not None and 0 < k < net.shape[0]) else None)
+                                tfmap1, tfmap2, inp, k = uncropped(net.shape[0])
+                            corr_fn = CorrBlock(tfmap1, tfmap2, radius=self.args.corr_radius, grad_samples=k)   # second volume (l2l.py:101)
                             corr = corr_fn(flow, channels_last=True, is_flow=True)
-                            with torch.no_grad():         # (detached below, as in the reference: no graph, no saved activations)
-                                _, inp = context(ci1)
-                                inp = to_channels_last(torch.relu(inp))
                         net, corr, inp, flow = net.detach(), corr.detach(), inp.detach(), flow.detach()
                         hb2 = self.grad_update_block.head_batch(iters - half, net)
                         # (the switch iteration's own correlation features are detached: it runs outside the batch)

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from . import streams
 from .corr import AlternateCorrBlock, CorrBlock
 from .extractor import BasicEncoder, SmallEncoder
 from .update import BasicUpdateBlock, SmallUpdateBlock, to_channels_last
@@ -92,6 +93,18 @@ class RAFT(nn.Module):
         hdim, cdim = self.hidden_dim, self.context_dim
         amp = bool(self.args.mixed_precision)
 
+        def context():
+            with autocast("cuda", enabled=amp):
+                cnet = self.cnet(image1)
+            net, inp = torch.split(cnet.float(), [hdim, cdim], dim=1)
+            # hidden state stays channels-last in the loop
+            return to_channels_last(torch.tanh(net)), to_channels_last(torch.relu(inp))
+
+        # the context encoder reads image1 only: on the second stream beside the feature encoder and the volume build (core/streams.py)
+        overlap = streams.OVERLAP and image1.is_cuda
+        if overlap:
+            with torch.cuda.stream(streams.fork(image1.device)):
+                net, inp = context()
         with autocast("cuda", enabled=amp):
             fmap1, fmap2 = self.fnet([image1, image2])
         fmap1, fmap2 = fmap1.float(), fmap2.float()
@@ -99,12 +112,10 @@ class RAFT(nn.Module):
             corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
         else:
             corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
-
-        with autocast("cuda", enabled=amp):
-            cnet = self.cnet(image1)
-        net, inp = torch.split(cnet.float(), [hdim, cdim], dim=1)
-        net = to_channels_last(torch.tanh(net))          # hidden state stays channels-last in the loop
-        inp = to_channels_last(torch.relu(inp))
+        if overlap:
+            streams.join(image1.device, net, inp)
+        else:
+            net, inp = context()
 
         # The loop carries the FLOW, not coords1 = coords0 + flow (raft.py:121-131): the lookup adds the pixel grid itself,
         # the update block and the upsampler want the flow anyway, so an iteration has one framework op (flow + delta)

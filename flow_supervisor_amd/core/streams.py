@@ -1,0 +1,53 @@
+"""A second HIP stream for the independent branches of a forward pass.
+
+The feature encoder + volume build and the context encoder of RAFT.forward (pytorch/core/raft.py:99-113) read only the input
+frames; so do the uncropped frames' encodings of the flow-supervisor forward (pytorch/core/l2l.py:95-101), which the reference
+computes in the middle of the iteration loop.  Issued on two streams they overlap: the tail of one branch's kernels runs beside
+the other's, and at one or two pairs per GPU -- where the update block's launches leave half of the CUs without a workgroup --
+a whole encoder pass hides behind the student's iterations.  In a captured step the two streams become two branches of the
+hipGraph.  Autograd runs every node's backward on the stream its forward ran on and orders the streams itself, so the backward
+overlaps the same way.
+
+Rules the callers keep: weights packed for the kernels (extractor._prepare_packs) are built on the caller's stream BEFORE the
+fork when both streams will read them; tensors produced on the side stream are handed to `join`, which makes the caller's stream
+wait and tells the caching allocator about their second stream.
+"""
+import torch
+
+OVERLAP = True          # False: every branch on the caller's stream, one after the other
+_SIDE = {}
+
+
+def side_stream(device):
+    device = torch.device(device)
+    s = _SIDE.get(device.index)
+    if s is None:
+        s = _SIDE[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+def fork(device):
+    """-> the side stream, ordered behind everything the caller's stream has been given so far."""
+    side = side_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    return side
+
+
+def mark(device):
+    """An event behind what the side stream has been given so far (for a `join` that must not wait for later work on it)."""
+    ev = torch.cuda.Event()
+    ev.record(side_stream(device))
+    return ev
+
+
+def join(device, *tensors, event=None):
+    """The caller's stream waits for the side stream (or only up to `event`, see `mark`); `tensors` (allocated there) are used
+    on the caller's stream from now on."""
+    main = torch.cuda.current_stream(device)
+    if event is not None:
+        main.wait_event(event)
+    else:
+        main.wait_stream(side_stream(device))
+    for t in tensors:
+        if t is not None:
+            t.record_stream(main)

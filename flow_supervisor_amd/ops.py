@@ -1167,25 +1167,25 @@ class Dst:
         return Dst(buf, 0, C * H * W, 1, H * W, n0, acc)
 
 
-_CONV_WS = {}                 # device index -> scratch tensor registered with fsraft_conv_workspace
+_CONV_WS = {}                 # (device index, stream) -> scratch tensor; "active" -> the key registered with fsraft_conv_workspace
 CONV_WS_FLOATS = 24 << 20     # 96 MB: three slices of the largest small-M layer (8832 pixels x 512 outputs)
 CONV_WS_MAX_PIXELS = 16384    # the split-K route only exists for grids that leave CUs idle
 
 
 def _conv_workspace(device, pixels):
-    """Hand libfsraft its split-K scratch buffer the first time a small convolution runs on `device` (the C ABI allocates
-    nothing).  One process drives one GPU; a second device re-registers its own buffer before its calls."""
+    """Hand libfsraft its split-K scratch buffer before a small convolution runs on `device` (the C ABI allocates nothing).
+    One buffer per (device, stream): the library reads the registered pointer while it enqueues the launch, so convolutions
+    issued on two streams (core/l2l.py runs the supervisor's encoders beside the student's iterations) never share slabs."""
     if pixels > CONV_WS_MAX_PIXELS:
         return
-    idx = torch.device(device).index or 0
-    ws = _CONV_WS.get(idx)
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
+    ws = _CONV_WS.get(key)
     if ws is None:
         ws = torch.empty(CONV_WS_FLOATS, device=device, dtype=torch.float32)
-        _CONV_WS[idx] = ws
-        _CONV_WS["active"] = None
-    if _CONV_WS.get("active") != idx:
+        _CONV_WS[key] = ws
+    if _CONV_WS.get("active") != key:
         L.check(_lib().fsraft_conv_workspace(L.ptr(ws), ws.numel()), "conv_workspace")
-        _CONV_WS["active"] = idx
+        _CONV_WS["active"] = key
 
 
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
