@@ -8,6 +8,13 @@ a whole encoder pass hides behind the student's iterations.  In a captured step 
 hipGraph.  Autograd runs every node's backward on the stream its forward ran on and orders the streams itself, so the backward
 overlaps the same way.
 
+Measured and not kept (same A/B script, WHAT=wgrad at the time): the update block's once-per-step weight gradients on a third
+stream beside the encoders' backward (-0.3 % config 3, -1.7 % at one pair per GPU), and the batched ones of them issued early, beside
+the recurrence's data-gradient chain (-2 % / -6 %: the big launches take the CUs the serial chain is waiting for).  One thing that
+experiment showed is worth keeping in mind for any node placed on another stream: the autograd engine orders a node's stream
+behind the producers of the gradients it RECEIVES -- a node whose incoming gradients are never materialised (update._ParamFn's
+anchor) is not ordered behind anything and needs its own wait_stream.
+
 Rules the callers keep: weights packed for the kernels (extractor._prepare_packs) are built on the caller's stream BEFORE the
 fork when both streams will read them; tensors produced on the side stream are handed to `join`, which makes the caller's stream
 wait and tells the caching allocator about their second stream.
@@ -18,36 +25,36 @@ OVERLAP = True          # False: every branch on the caller's stream, one after 
 _SIDE = {}
 
 
-def side_stream(device):
+def side_stream(device, which=0):
     device = torch.device(device)
-    s = _SIDE.get(device.index)
+    s = _SIDE.get((device.index, which))
     if s is None:
-        s = _SIDE[device.index] = torch.cuda.Stream(device=device)
+        s = _SIDE[(device.index, which)] = torch.cuda.Stream(device=device)
     return s
 
 
-def fork(device):
+def fork(device, which=0):
     """-> the side stream, ordered behind everything the caller's stream has been given so far."""
-    side = side_stream(device)
+    side = side_stream(device, which)
     side.wait_stream(torch.cuda.current_stream(device))
     return side
 
 
-def mark(device):
+def mark(device, which=0):
     """An event behind what the side stream has been given so far (for a `join` that must not wait for later work on it)."""
     ev = torch.cuda.Event()
-    ev.record(side_stream(device))
+    ev.record(side_stream(device, which))
     return ev
 
 
-def join(device, *tensors, event=None):
+def join(device, *tensors, event=None, which=0):
     """The caller's stream waits for the side stream (or only up to `event`, see `mark`); `tensors` (allocated there) are used
     on the caller's stream from now on."""
     main = torch.cuda.current_stream(device)
     if event is not None:
         main.wait_event(event)
     else:
-        main.wait_stream(side_stream(device))
+        main.wait_stream(side_stream(device, which))
     for t in tensors:
         if t is not None:
             t.record_stream(main)
