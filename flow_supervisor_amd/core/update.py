@@ -23,6 +23,7 @@ import torch.nn as nn
 from .. import _lib as L
 from .. import ops
 from ..ops import Dst, V
+from . import streams
 
 
 # --------------------------------------------------------------------------- containers
@@ -87,6 +88,7 @@ def _pad4(c):
 # measured: +2 % at best, and it makes per-kernel event timing meaningless (kernels of the two streams
 # overlap), so weight gradients stay on the main stream unless asked for
 _WGRAD_SIDE_STREAM = False
+FLOW_BRANCH_STREAM = True     # the motion encoder's flow branch on a second stream beside its correlation branch (forward): +0.6 % config 3, +1.5 % at one pair
 # one weight-gradient launch per layer per step (all iterations' operands stashed) instead of one per iteration
 _DEFER_WGRAD = True
 
@@ -380,16 +382,29 @@ class _Engine:
             cols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)      # (im2col7 writes the two pad columns itself)
             flo1 = buf(self.f1)
             motion = buf(self.x_c)           # GMA: channels [mot_c, 2 mot_c) hold motion_global
+        cor_out = self.c2 if self.c2 else self.c1
+
+        def flow_branch():
+            ops.im2col7(flow, cols)
+            conv("f1", [V(cols, 98)], [Dst.nhwc(flo1)], relu=True)
+            conv("f2", [V(flo1, self.f1)], [Dst.nhwc(corflo, cor_out)], relu=True)
+
+        # the motion encoder's two branches (update.py:83-87: convc1/convc2 on the correlation features, convf1/convf2 on the
+        # flow) meet in `conv`: the flow branch on a second stream beside the correlation branch (core/streams.py; every buffer
+        # was allocated above, on the caller's stream, and the two write disjoint channels of corflo)
+        fb_side = FLOW_BRANCH_STREAM and streams.OVERLAP and dev.type == "cuda"
+        if fb_side:
+            with torch.cuda.stream(streams.fork(dev, 1)):
+                flow_branch()
         if self.c2:
             conv("c1", [V(corr, self.corr_c)], [Dst.nhwc(cor1)], relu=True)
             conv("c2", [V(cor1, self.c1)], [Dst.nhwc(corflo)], relu=True)
-            cor_out = self.c2
         else:
             conv("c1", [V(corr, self.corr_c)], [Dst.nhwc(corflo)], relu=True)
-            cor_out = self.c1
-        ops.im2col7(flow, cols)
-        conv("f1", [V(cols, 98)], [Dst.nhwc(flo1)], relu=True)
-        conv("f2", [V(flo1, self.f1)], [Dst.nhwc(corflo, cor_out)], relu=True)
+        if fb_side:
+            streams.join(dev, which=1)
+        else:
+            flow_branch()
         conv("cv", [V(corflo, self.cf_c)], [Dst.nhwc(motion)], relu=True)
         ops.flow_to_nhwc(flow, motion, self.cv)
         v = agg = None
