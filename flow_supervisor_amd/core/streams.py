@@ -58,3 +58,18 @@ def join(device, *tensors, event=None, which=0):
     for t in tensors:
         if t is not None:
             t.record_stream(main)
+
+
+def order_current_behind_all(device, *more):
+    """The current stream waits for every side stream that exists on `device` (and for `more`): for code that runs inside the
+    backward pass on whatever stream its autograd node has and reads what nodes on OTHER streams produced -- a gradient bucket's
+    pack + all-reduce issued from a hook (parallel.FlatGradients): the engine orders a node behind the producers of ITS inputs,
+    not behind the other parameters' gradients that share its bucket."""
+    device = torch.device(device)
+    cur = torch.cuda.current_stream(device)
+    for (idx, _), s in list(_SIDE.items()):
+        if idx == device.index and s != cur:
+            cur.wait_stream(s)
+    for s in more:
+        if s is not None and s != cur:
+            cur.wait_stream(s)

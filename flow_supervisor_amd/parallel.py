@@ -93,6 +93,7 @@ class FlatGradients:
         self._weight = 1.0
         self._active = False
         self._deferred = False
+        self._caller_stream = None
         self.missing = []                 # parameters that received no gradient in the last step (FlatAdamW leaves them alone)
         # FSRAFT_DP_BUCKETS=0: no exchange from the backward hooks -- ONE all-reduce of the whole flat buffer in finish()
         self.bucketed = os.environ.get("FSRAFT_DP_BUCKETS", "1") != "0"
@@ -122,6 +123,7 @@ class FlatGradients:
         self._weight = (1.0 / world) if local_batch is None else float(local_batch) / float(global_batch)
         self._active = True
         self._deferred = not exchange
+        self._caller_stream = torch.cuda.current_stream(self.flat.device) if self.flat.is_cuda else None
 
     def zero_(self):
         """(kept for callers of the round-1 interface) equivalent to begin()."""
@@ -145,6 +147,10 @@ class FlatGradients:
         if self._done[i]:
             return
         self._done[i] = True
+        if self.flat.is_cuda:
+            # (a hook runs on its gradient's stream; the bucket's other gradients may have been produced on others: core/streams.py)
+            from .core import streams
+            streams.order_current_behind_all(self.flat.device, self._caller_stream)
         have = [p for p in self.buckets[i] if p.grad is not None and p.grad is not self.views[p]]
         missing = [p for p in self.buckets[i] if p.grad is None]
         if have:
