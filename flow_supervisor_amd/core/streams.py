@@ -8,7 +8,9 @@ a whole encoder pass hides behind the student's iterations.  In a captured step 
 hipGraph.  Autograd runs every node's backward on the stream its forward ran on and orders the streams itself, so the backward
 overlaps the same way.
 
-Measured and not kept (same A/B script, WHAT=wgrad at the time): the update block's once-per-step weight gradients on a third
+Measured and not kept: the feature encoder as two chains of one frame each on two streams (-2 % config 3, -6 % at one pair: the
+half-size launches and the second gradient contribution per parameter cost more than the overlap returns); (same A/B script,
+WHAT=wgrad at the time) the update block's once-per-step weight gradients on a third
 stream beside the encoders' backward (-0.3 % config 3, -1.7 % at one pair per GPU), and the batched ones of them issued early, beside
 the recurrence's data-gradient chain (-2 % / -6 %: the big launches take the CUs the serial chain is waiting for).  One thing that
 experiment showed is worth keeping in mind for any node placed on another stream: the autograd engine orders a node's stream

@@ -521,8 +521,13 @@ def test_kitti_shape_evaluation(alternate):
     assert e_low <= 1e-3 and e <= 1e-3
 
 
+@pytest.mark.parametrize("one_stream", [False, True])
 @pytest.mark.parametrize("tag", ["basic", "small"])
-def test_train_step_loss_and_grads(tag, precision):
+def test_train_step_loss_and_grads(tag, precision, one_stream, monkeypatch):
+    """(one_stream: core/streams.py switched off -- every branch of the forward pass on the caller's stream, the route every
+    other golden test of this file runs with the switch on)"""
+    from flow_supervisor_amd.core import streams
+    monkeypatch.setattr(streams, "OVERLAP", not one_stream)
     g = load("train_step_" + tag)
     small, seed = tag == "small", int(g["seed"])
     m = _model(small, seed).train()
@@ -616,10 +621,14 @@ def test_train_step_at_bench_scale(name, alternate, precision):
     _check_train_digest(m, preds, g, precision)
 
 
-def test_l2l_two_phase_forward_and_grads(precision):
+@pytest.mark.parametrize("one_stream", [False, True])
+def test_l2l_two_phase_forward_and_grads(precision, one_stream, monkeypatch):
     """Flow-supervisor forward (core/l2l.py:29-133): student half on the crop, supervisor half on the uncropped
-    pair with zero-padded detached state and a second correlation volume; golden from the reference L2L."""
+    pair with zero-padded detached state and a second correlation volume; golden from the reference L2L.
+    one_stream: core/streams.py off (the uncropped frames are then encoded at the switch iteration, as the reference does)."""
+    from flow_supervisor_amd.core import streams
     from flow_supervisor_amd.core.l2l import L2L
+    monkeypatch.setattr(streams, "OVERLAP", not one_stream)
     g = load("l2l_basic")
     seed, B, iters = int(g["seed"]), int(g["B"]), int(g["iters"])
     H, W, h, w, oy, ox = (int(g[k]) for k in ("H", "W", "h", "w", "oy", "ox"))
