@@ -12,7 +12,9 @@ Measured and not kept: the feature encoder as two chains of one frame each on tw
 half-size launches and the second gradient contribution per parameter cost more than the overlap returns); (same A/B script,
 WHAT=wgrad at the time) the update block's once-per-step weight gradients on a third
 stream beside the encoders' backward (-0.3 % config 3, -1.7 % at one pair per GPU), and the batched ones of them issued early, beside
-the recurrence's data-gradient chain (-2 % / -6 %: the big launches take the CUs the serial chain is waiting for).  One thing that
+the recurrence's data-gradient chain (-2 % / -6 %: the big launches take the CUs the serial chain is waiting for).  A high-priority stream for the caller's chain (priority range
+on this stack: 0 and -1) is no way to make such background work cheap: the captured step on a priority -1 stream replays in 47.8
+instead of 36.6 ms (60.5 instead of 33.5 at one pair).  One thing that
 experiment showed is worth keeping in mind for any node placed on another stream: the autograd engine orders a node's stream
 behind the producers of the gradients it RECEIVES -- a node whose incoming gradients are never materialised (update._ParamFn's
 anchor) is not ordered behind anything and needs its own wait_stream.
