@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--crop-width", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="every branch of the forward pass on the caller's stream (core/streams.py "
+                    "off): the form the per-kernel profiles are taken in, so that a kernel's duration is its own")
     ap.add_argument("--no-extra", action="store_true", help="skip the exact-fp32 / north_star-encoder short runs and the loss check")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: capture the whole train step in a hipGraph and time replays; 0: eager; -1: auto")
@@ -266,6 +268,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
     from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core import streams
     from flow_supervisor_amd.core.raft import RAFT
     from flow_supervisor_amd.parallel import barrier, broadcast_parameters, init_distributed, max_over_ranks
     from flow_supervisor_amd.train import TrainStep
@@ -293,6 +296,8 @@ def main():
     # is off: the encoders are framework callers of the path, not what this benchmark is about.
     torch.backends.cudnn.benchmark = False
 
+    if a.one_stream:
+        streams.OVERLAP = False
     torch.manual_seed(0)
     semi = a.variant in ("l2l", "gma_l2l")
     if semi:
@@ -465,9 +470,13 @@ def main():
         timer = ops.KernelTimer()
         ops.TIMER = timer
         tsteps = min(a.steps, 3)
+        # (per-kernel durations are taken with the branches of the forward pass on ONE stream: beside another stream's kernels a
+        #  launch's events bracket the contention too, and the family sums would no longer add up to a step)
+        was_overlap, streams.OVERLAP = streams.OVERLAP, False
         for _ in range(tsteps):
             loss_e = eager_step(im1, im2)
         torch.cuda.synchronize()
+        streams.OVERLAP = was_overlap
         ops.TIMER = None
         timer.steps = tsteps
     if graph is not None:
@@ -545,6 +554,10 @@ def main():
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": loss_v,
                    "launch": (graph_note + " (the short runs behind value_exact_f32 / value_north_star_encoders and the "
                               "per-kernel timing are eager)") if graph is not None else graph_note,
+                   "streams": ("one stream (--one-stream)" if not streams.OVERLAP else
+                               "independent branches of the forward pass (context encoder | feature encoder + volume; the motion encoder's "
+                               "flow | correlation branch; the flow-supervisor forward's uncropped-frame encodings | student iterations) on "
+                               "two HIP streams, their backward likewise (core/streams.py); the per-kernel timing pass runs on one stream"),
                    "encoders": ("MIOpen NCHW convolutions (north_star configuration)" if os.environ.get("FSRAFT_ENCODER_CL", "1") == "0"
                                 else "channels_last on the fsraft kernels (7x7 stem on csrc/stem.hip, stride-2 units via space-to-depth; no MIOpen call left); "
                                      "value_north_star_encoders = the same step with the encoders on MIOpen")},

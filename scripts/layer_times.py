@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from flow_supervisor_amd import ops  # noqa: E402
+from flow_supervisor_amd.core import streams  # noqa: E402
 from flow_supervisor_amd.core.raft import RAFT  # noqa: E402
 from flow_supervisor_amd.train import TrainStep  # noqa: E402
 
@@ -23,6 +24,7 @@ a = ap.parse_args()
 if a.variant == "l2l" and (a.batch, a.height, a.width) == (4, 440, 1024):
     a.batch, a.height, a.width = 1, 432, 1024
 dev = torch.device("cuda")
+streams.OVERLAP = False        # one stream: a launch's events bracket that launch alone
 torch.manual_seed(0)
 if a.variant == "l2l":
     from flow_supervisor_amd.core.l2l import L2L

@@ -5,7 +5,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export MIOPEN_FIND_MODE=2
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmct_${tag}_$c -- python3 bench.py --steps 1 --warmup 1 --graph 0 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/pmct_${tag}_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmct_${tag}_$c -- python3 bench.py --steps 1 --warmup 1 --graph 0 --one-stream --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/pmct_${tag}_$c.log 2>&1
 done
 python3 - "$tag" <<'PY'
 import csv, glob, json, sys, collections

@@ -5,7 +5,7 @@ tag=$1
 shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export MIOPEN_FIND_MODE=2
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_st_$tag -- python3 bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-kernel-timing --no-extra "$@" > gpurun_out/step_trace_$tag.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_st_$tag -- python3 bench.py --steps 2 --warmup 1 --graph 0 --one-stream --no-cpu-baseline --no-kernel-timing --no-extra "$@" > gpurun_out/step_trace_$tag.log 2>&1
 f=$(find gpurun_out/prof_st_$tag -name "*kernel_trace.csv" | head -1)
 python3 - "$f" "$tag" <<'PY'
 import csv, sys, collections
