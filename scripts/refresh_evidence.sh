@@ -22,3 +22,19 @@ bash scripts/dvol_pmc.sh ${tag} > /dev/null 2>&1
 python scripts/dvol_micro.py 2>&1 | tail -9 > gpurun_out/dvol_micro_${tag}.txt
 python scripts/lookup_gather_floor.py 2>&1 | tail -2 > gpurun_out/lookup_gather_floor_${tag}.txt
 python scripts/layer_times.py > gpurun_out/layer_times_${tag}.txt 2>&1
+# matrix-pipe busy x clock of the convolution kernels (PMC + kernel trace; VERDICT r3 next #2 asks for the round-4 record)
+{
+  echo "# Matrix-pipe busy fraction and the clock the convolution kernels ran at (scripts/mfma_busy.sh: one PMC pass with the kernel trace,"
+  echo "# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and GRBM_GUI_ACTIVE / 8 / duration), commit ${FSRAFT_COMMIT:-?}."
+  for l in c2 zrc qc c1 hd; do
+    echo "== layer $l (scripts/conv_micro.py, 4 x 55 x 128; forward + 12-segment weight gradient)"
+    bash scripts/mfma_busy.sh ${tag}_$l $l
+  done
+  for cfg in "e1 8,220,512" "e2 8,110,256" "e3 8,55,128"; do
+    set -- $cfg
+    echo "== layer $1 at B,H,W = $2 (one weight-gradient segment)"
+    CONV_MICRO_BHW=$2 CONV_MICRO_NSEG=1 bash scripts/mfma_busy.sh ${tag}_$1 $1
+  done
+} > gpurun_out/mfma_busy_clock_${tag}.txt 2>&1
+# the second-stream routes off / on (core/streams.py), hipGraph replays on this box
+bash scripts/ab_stream_overlap.sh raft gma l2l gma_l2l alt > gpurun_out/stream_overlap_${tag}.txt 2>&1
