@@ -8,7 +8,8 @@ a whole encoder pass hides behind the student's iterations.  In a captured step 
 hipGraph.  Autograd runs every node's backward on the stream its forward ran on and orders the streams itself, so the backward
 overlaps the same way.
 
-Measured and not kept: the mask head's half of the fused 3x3 head convolution on the second stream, off the recurrence's chain
+Measured and not kept: an iteration's GMA Aggregate backward block (attn^T @ dagg, to_v's data gradient; nothing in the recurrence
+waits for it) on the second stream (+0.5 %, inside the noise); the mask head's half of the fused 3x3 head convolution on the second stream, off the recurrence's chain
 (-0.5 % / -1 %: two 256-output launches cost more than the 512-output one by more than the overlap returns); the feature encoder as two chains of one frame each on two streams (-2 % config 3, -6 % at one pair: the
 half-size launches and the second gradient contribution per parameter cost more than the overlap returns); (same A/B script,
 WHAT=wgrad at the time) the update block's once-per-step weight gradients on a third
