@@ -39,8 +39,19 @@ def side_stream(device, which=0):
     return s
 
 
+_QUIET = [False]
+
+
 def fork(device, which=0):
     """-> the side stream, ordered behind everything the caller's stream has been given so far."""
+    if not _QUIET[0]:
+        # A parameter used on both streams (the encoders of the flow-supervisor forward) gets gradients from nodes on two streams;
+        # its AccumulateGrad node belongs to one of them and the engine synchronises the other -- which PyTorch reports once per
+        # process as a possible mistake.  Here it is the design.
+        _QUIET[0] = True
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
     side = side_stream(device, which)
     side.wait_stream(torch.cuda.current_stream(device))
     return side
