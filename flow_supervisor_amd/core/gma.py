@@ -209,6 +209,9 @@ class _AggregateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, attn, x_cl, w, gamma):
+        if is_records(attn):
+            raise TypeError("Aggregate got an attention map that holds records (Attention.forward_cl(..., records=True) is for "
+                            "the update block's forward_cl); Attention.forward returns the dense map")
         L.require_cuda_f32(attn, x_cl, w, gamma)
         B, H, W, C = x_cl.shape
         N = H * W

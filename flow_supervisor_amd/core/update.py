@@ -1164,8 +1164,13 @@ class _UpdateBlockBase(nn.Module):
         track = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params))
         cst = self._ctx_state(eng, st, params, anchor, inp, track)
         attn = attention.detach() if attention is not None else None
+        attn_r = self._attn_transposed(attention)
+        if attn_r is None and attention is not None:
+            from .gma import is_records
+            if is_records(attention):       # (made under the split arithmetic, used under the exact one: there is no dense copy to fall back to)
+                raise RuntimeError("the attention map holds records but the record GEMMs are switched off (exact arithmetic)")
         h, mask, delta = _UpdateFn.apply(eng, st, params, anchor, net, cst, cst.anchor, corr, flow, ast, attn, aanchor,
-                                         self._attn_transposed(attention), head_batch, grad_samples, motion_batch)
+                                         attn_r, head_batch, grad_samples, motion_batch)
         return h, (mask if (eng.has_mask and head_batch is None) else None), delta
 
     def motion_batch(self, iters, net, grad_samples=None):

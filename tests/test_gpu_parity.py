@@ -1032,6 +1032,10 @@ def test_attention_map_kept_once_as_records():
         for got, ref, what in ((res[mode][1], res["dense"][1], "dx"), (res[mode][2], res["dense"][2], "dto_qk")):
             err = (got - ref).abs().max().item()
             assert err <= 2e-5 * ref.abs().max().item() + 1e-9, (mode, what, err, ref.abs().max().item())
+    # the reference-API Aggregate refuses a map that holds records (it would read them as probabilities)
+    from flow_supervisor_amd.core.gma import Aggregate
+    with pytest.raises(TypeError):
+        Aggregate(args=gma_ns(), dim=128, dim_head=128, heads=1).to(DEV)(att.forward_cl(x, records=True), x.permute(0, 3, 1, 2))
     # the switch and the shapes the record pair does not cover fall back to the dense map
     assert not is_records(att.forward_cl(x[:, :, :15].contiguous(), records=True))         # N = 120: not a multiple of 32
     old = gma.ATTN_RECORDS
