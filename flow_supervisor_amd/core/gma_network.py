@@ -49,13 +49,13 @@ class RAFTGMA(nn.Module):
 
     # -- pieces shared with GMAL2L ------------------------------------------------------
     def _features(self, a, b):
-        with autocast("cuda", enabled=bool(self.args.mixed_precision)):
+        with autocast("cuda", enabled=False):        # (args.mixed_precision: utils.warn_mixed_precision)
             f1, f2 = self.fnet([a, b])
         return f1.float(), f2.float()
 
     def _context(self, img):
         """-> (net, inp) channels-last and the attention map of inp."""
-        with autocast("cuda", enabled=bool(self.args.mixed_precision)):
+        with autocast("cuda", enabled=False):        # (args.mixed_precision: utils.warn_mixed_precision)
             cnet = self.cnet(img)
         net, inp = torch.split(cnet.float(), [self.hidden_dim, self.context_dim], dim=1)
         net = to_channels_last(torch.tanh(net))

@@ -90,7 +90,7 @@ class L2L(RAFT):
         if ci1 is not None:
             ci1, ci2 = norm(ci1), norm(ci2)
         hdim, cdim = self.hidden_dim, self.context_dim
-        amp = bool(self.args.mixed_precision)
+        amp = False          # args.mixed_precision: no autocast here, see utils.warn_mixed_precision (fp32 storage everywhere, at full speed)
         if not test_mode and ci1 is None:
             # the reference reads oy_/ox_ in the second half without having set them (l2l.py:124-125)
             raise NameError("L2L.forward in training mode needs the uncropped pair ci1/ci2 and offsets ox/oy")

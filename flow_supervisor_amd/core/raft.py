@@ -91,7 +91,7 @@ class RAFT(nn.Module):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         hdim, cdim = self.hidden_dim, self.context_dim
-        amp = bool(self.args.mixed_precision)
+        amp = False          # args.mixed_precision: no autocast here, see utils.warn_mixed_precision (fp32 storage everywhere, at full speed)
 
         def context():
             with autocast("cuda", enabled=amp):

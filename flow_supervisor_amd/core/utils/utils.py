@@ -85,14 +85,14 @@ _MIXED_WARNED = [False]
 
 
 def warn_mixed_precision(args):
-    """`args.mixed_precision` (pytorch/core/raft.py:99-127, train.py:232: autocast around the encoders and the update block).
-    Here it reaches the ENCODERS only: the models keep the reference's `autocast` blocks around fnet / cnet, and under autocast the
-    encoders leave the fsraft kernels for the framework's half-precision convolutions (MIOpen) -- results move by ~1e-3 of the flow
-    and the encoders get slower, not faster.  Correlation, update block and upsampler have one storage precision, fp32 (bf16x3 or
-    exact-fp32 products, fsraft_set_arithmetic), whatever the flag says.  Said once, loudly, instead of silently."""
+    """`args.mixed_precision` (pytorch/core/raft.py:99-127, train.py:232: autocast around the encoders and the update block) is
+    accepted for signature compatibility and has NO effect here: the models do not enter autocast -- under it the encoders would
+    leave the fsraft kernels for the framework's half-precision convolutions, which are SLOWER on this stack than the fp32 path
+    (bench.py's value_north_star_encoders) -- and every kernel of the path stores and accumulates in fp32 (GEMM products bf16x3 or
+    exact fp32, fsraft_set_arithmetic): at least the precision the flag would give, at full speed.  Said once, loudly."""
     if getattr(args, "mixed_precision", False) and not _MIXED_WARNED[0]:
         import warnings
         _MIXED_WARNED[0] = True
-        warnings.warn("flow_supervisor_amd: args.mixed_precision=True only puts the encoders under the framework's autocast (MIOpen "
-                      "half-precision convolutions, slower than the fp32 fsraft encoder path); correlation, update block and "
-                      "upsampler compute in fp32 (bf16x3 or exact-fp32 products) regardless", stacklevel=3)
+        warnings.warn("flow_supervisor_amd: args.mixed_precision=True has no effect -- the models do not enter autocast and the "
+                      "fsraft kernels compute in fp32 (bf16x3 or exact-fp32 products); results are those of mixed_precision=False",
+                      stacklevel=3)
