@@ -470,6 +470,31 @@ def _model(small, seed):
     return m.to(DEV)
 
 
+def test_mixed_precision_flag_is_accepted_and_has_no_effect():
+    """args.mixed_precision (raft.py:99-127): accepted, warned about once, and without effect -- the models do not enter autocast
+    (it would send the encoders to the framework's half-precision convolutions) and the path stores fp32 either way."""
+    import warnings
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.core.utils import utils as U
+    sd = procedural_state_dict(shapes("raft_basic"), 77)
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(1, 128, 192, 78))
+    outs = []
+    for mp in (False, True):
+        U._MIXED_WARNED[0] = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            a = ns(False)
+            a.mixed_precision = mp
+            m = RAFT(a)
+        assert any("mixed_precision" in str(x.message) for x in w) == mp
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            outs.append(m(im1, im2, iters=4, test_mode=True)[1])
+    # (the same kernels twice: atomics' summation order is the only difference; under autocast the encoders moved the flow by 3e-3)
+    assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
+
+
 @pytest.mark.parametrize("name", ["e2e_small_128x256", "e2e_basic_368x496", "e2e_basic_440x1024"])
 def test_end_to_end_flow_epe(name, precision):
     g = load(name)
