@@ -6,6 +6,7 @@ library is missing or a kernel launch fails, the caller gets a RuntimeError.
 resolves to the HIP runtime torch already loaded (one runtime per process).
 """
 import ctypes
+import functools
 import os
 from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
 
@@ -33,6 +34,7 @@ class ConvDesc(Structure):
         ("pre", c_void_p), ("ldpre", c_int),
         ("rmask", c_void_p * 3), ("ldmask", c_int * 3), ("maskc", c_int * 3),
         ("wpk_frag", c_void_p), ("srcr", c_void_p * 3), ("srcrld", c_int * 3), ("pad_h1", c_int), ("pad_w1", c_int),
+        ("ws", c_void_p), ("ws_floats", c_int64),
     ]
 
 
@@ -222,6 +224,11 @@ def int_array(vals):
 
 
 def require_cuda_f32(*tensors):
+    """Every tensor fp32, on ONE cuda device, and that device the calling thread's current one: the kernels are enqueued on
+    the current device's current stream (`stream()`), so a tensor living elsewhere would be dereferenced by the wrong GPU.  The
+    module-level entry points (`on_tensor_device`) make their input's device current themselves; a caller of `ops.*` does it
+    with `torch.cuda.device(t.device)`, as the reference's nn.DataParallel worker threads do (pytorch/train.py:192)."""
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -229,3 +236,40 @@ def require_cuda_f32(*tensors):
             raise RuntimeError("fsraft ops need CUDA (ROCm) tensors; the hot path has no CPU implementation")
         if t.dtype != torch.float32:
             raise RuntimeError(f"fsraft ops are fp32-only, got {t.dtype}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"fsraft ops need all tensors on one device, got {dev} and {t.device}")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"fsraft op called with tensors on {dev} while cuda:{torch.cuda.current_device()} is the current device; "
+                           f"wrap the call in `with torch.cuda.device({dev.index}):`")
+
+
+def _first_cuda_device(values):
+    for v in values:
+        if isinstance(v, torch.Tensor):
+            if v.is_cuda:
+                return v.device
+        elif isinstance(v, (list, tuple)):
+            d = _first_cuda_device(v)
+            if d is not None:
+                return d
+    return None
+
+
+def on_tensor_device(fn):
+    """Decorator of the path's public entry points (the reference's callables of SURVEY.md 8b): run `fn` with the device of its
+    first CUDA tensor argument as the thread's current device, so that a single process driving several GPUs -- one host thread
+    per device, the reference's `nn.DataParallel(L2L(args))`, pytorch/train.py:192 -- launches on the tensors' device and its
+    current stream whatever device the thread had selected (the reference's extension launches on the legacy default stream
+    without a guard, alt_cuda_corr/correlation_kernel.cu:260-323)."""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        dev = _first_cuda_device(args)
+        if dev is None and kwargs:
+            dev = _first_cuda_device(kwargs.values())
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return guarded

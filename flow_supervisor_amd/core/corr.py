@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from .._lib import on_tensor_device
 from .utils.utils import coords_grid
 
 
@@ -120,6 +121,7 @@ class CorrBlock:
     (core/l2l.py: the supervisor phase of a batched flow-supervisor step); the backward then builds and contracts the gradient
     volume of those samples only."""
 
+    @on_tensor_device
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4, grad_samples=None):
         if not 1 <= num_levels <= 4:
             raise NotImplementedError("the HIP correlation kernels are built for 1..4 pyramid levels (all RAFT variants use 4)")
@@ -147,6 +149,7 @@ class CorrBlock:
             self._pyr = [self._lay.level_view(self._vol, l) for l in range(self.num_levels)]
         return self._pyr
 
+    @on_tensor_device
     def __call__(self, coords, channels_last=False, is_flow=False, out=None):
         """coords [B,2,H,W] (x,y).  Returns [B, L*(2r+1)^2, H, W] contiguous (or [B,H,W,C] when
         channels_last=True, the layout our update block consumes directly).  is_flow=True: the tensor holds the flow and
@@ -163,6 +166,7 @@ class CorrBlock:
         return res if channels_last else ops.nhwc_to_nchw(res)
 
     @staticmethod
+    @on_tensor_device
     def corr(fmap1, fmap2):
         """[B,H,W,1,H,W] all-pairs volume / sqrt(C) (corr.py:52-60); level 0 of the HIP build."""
         B, C, H, W = fmap1.shape
@@ -225,6 +229,7 @@ class AlternateCorrBlock:
     chunks of the gradient volume (no O(N^2) buffer, no atomics).  alt_cuda_corr.forward / .backward themselves (one
     level per call, the extension's signature) are in flow_supervisor_amd/alt_cuda_corr.py."""
 
+    @on_tensor_device
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         if not 1 <= num_levels <= 4:
             raise NotImplementedError("the HIP correlation kernels are built for 1..4 pyramid levels")
@@ -254,6 +259,7 @@ class AlternateCorrBlock:
                 B = fmap1.shape[0]
                 self._recs = (ops.to_records(self._f1.view(B, -1, C)), [ops.to_records(f.view(B, -1, C)) for f in self._f2])
 
+    @on_tensor_device
     def __call__(self, coords, channels_last=False, is_flow=False, out=None):
         coords = coords.float()
         if out is not None and not channels_last:

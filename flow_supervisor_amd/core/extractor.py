@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .._lib import on_tensor_device
 
 
 class _InstNormRelu(torch.autograd.Function):
@@ -129,11 +130,15 @@ class _ResLink:
     returns the SUM as x's gradient.  Autograd would otherwise add the two x-sized tensors in a separate pass (12 of them per
     step, up to 230 MB each).  Autograd sees one ordinary gradient for x from the unit, so further consumers of x, tensor
     hooks and retain_grad behave as usual (round 3 handed dres to autograd and then added into it behind the engine's back,
-    which was only right while x had exactly these two consumers: ADVICE r2)."""
-    __slots__ = ("dres",)
+    which was only right while x had exactly these two consumers: ADVICE r2).
+    `armed` is set by the first convolution's forward (_ConvCL, the only consumer that looks into the link): a norm whose unit's
+    first convolution took another route (F.conv2d / MIOpen never sees the link) hands dres to autograd as usual instead of
+    parking it where nobody collects it."""
+    __slots__ = ("dres", "armed")
 
     def __init__(self):
         self.dres = None
+        self.armed = False
 
 
 class _InstNormReluCL(torch.autograd.Function):
@@ -177,7 +182,7 @@ class _InstNormReluCL(torch.autograd.Function):
         acc = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (norm_cl.hip)
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
                                                   L.ptr(dres), N, H * W, C, int(ctx.relu), ctx.s2w, L.stream()), "inorm_relu_cl_bwd")
-        if ctx.link is not None:
+        if ctx.link is not None and ctx.link.armed:
             ctx.link.dres, dres = dres, None      # the shortcut's gradient travels through the link: conv1's backward returns the sum
         return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None, None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
 
@@ -225,7 +230,7 @@ class _FrozenBNReluCL(torch.autograd.Function):
         dpar = torch.empty(3, C, device=x.device, dtype=torch.float32)       # dweight, dbias, dcbias: one launch
         L.check(L.load().fsraft_bn_fold_bwd(L.ptr(part), N * 8, C, L.ptr(rs), L.ptr(rm), L.ptr(scale), L.ptr(dpar[0]), L.ptr(dpar[1]),
                                             L.ptr(dpar[2]) if ctx.has_cbias else None, L.stream()), "bn_fold_bwd")
-        if ctx.link is not None:
+        if ctx.link is not None and ctx.link.armed:
             ctx.link.dres, dres = dres, None      # (see _ResLink)
         return (dx if ctx.in_cl else _as_nchw(dx), dpar[2] if ctx.has_cbias else None, dpar[0], dpar[1], None, None, None, None, dres,
                 None, None)
@@ -325,6 +330,8 @@ class _ConvCL(torch.autograd.Function):
     def forward(ctx, x, weight, bias, packs, link=None, sums=None):
         from .. import ops
         ctx.link = link if _is_cl(x) else None       # (a converted copy of x is not the tensor the shortcut gradient belongs to)
+        if ctx.link is not None:
+            ctx.link.armed = True                    # this node's backward will collect the parked shortcut gradient
         x = _as_cl(x)
         B, C, H, W = x.shape
         N, _, KH, KW = weight.shape
@@ -733,6 +740,7 @@ class _Encoder(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
+    @on_tensor_device
     def forward(self, x):
         pair = isinstance(x, (tuple, list))
         if pair:

@@ -73,8 +73,9 @@ ATTN_RECORDS = True
 
 
 def _records_ok(D, N):
-    """Shapes the record softmax pair covers (LDS holds a row of the map and of its gradient: N <= 8192), split arithmetic."""
-    return ATTN_RECORDS and ops.SPLIT_VOLUME_BWD and D % 32 == 0 and N % 32 == 0 and 32 <= N <= 8192
+    """Shapes the record softmax pair covers (LDS holds a row of the map and of its gradient, 8 bytes per element, within the
+    64 KB a launch gets without an opt-in: N <= 8160), split arithmetic."""
+    return ATTN_RECORDS and ops.SPLIT_VOLUME_BWD and D % 32 == 0 and N % 32 == 0 and 32 <= N <= 8160
 
 
 def mark_records(t, like=None):
@@ -174,11 +175,13 @@ class Attention(nn.Module):
     def _positional(self):
         return bool(getattr(self.args, "position_only", False) or getattr(self.args, "position_and_content", False))
 
+    @L.on_tensor_device
     def forward(self, fmap):
         if self.heads == 1 and not self._positional() and fmap.shape[1] % 4 == 0:
             return self.forward_cl(to_channels_last(fmap.float()))
         return self._forward_general(fmap)
 
+    @L.on_tensor_device
     def forward_cl(self, fmap_cl, records=False):
         """Channels-last entry (content-only, single head): [B,H,W,dim] -> [B,1,N,N].  records=True (the update block's
         forward_cl is the consumer): the map may come back as records in that shape (ATTN_RECORDS above; `is_records`)."""
@@ -261,6 +264,7 @@ class Aggregate(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
         self.project = nn.Conv2d(inner_dim, dim, 1, bias=False) if dim != inner_dim else None
 
+    @L.on_tensor_device
     def forward(self, attn, fmap):
         if self.heads == 1 and self.project is None and fmap.shape[1] % 4 == 0:
             return from_channels_last(_AggregateFn.apply(attn, to_channels_last(fmap.float()), self.to_v.weight, self.gamma))

@@ -15,6 +15,7 @@ from .l2l import _crop_back, _offsets, _pad_state
 from .raft import convex_upsample
 from .update import GMAUpdateBlock
 from .utils.utils import upflow8
+from .._lib import on_tensor_device
 
 
 class GMAL2L(RAFTGMA):
@@ -22,6 +23,7 @@ class GMAL2L(RAFTGMA):
         super().__init__(args)
         self.grad_update_block = GMAUpdateBlock(self.args, hidden_dim=self.hidden_dim)
 
+    @on_tensor_device
     def forward(self, image1, image2, ci1=None, ci2=None, ox=None, oy=None, iters=12, flow_init=None,
                 upsample=True, test_mode=False, supervisor_grad=True, sup_grad_samples=None):
         norm = lambda im: (2 * (im / 255.0) - 1.0).contiguous()

@@ -12,6 +12,7 @@ from .gma import Attention
 from .raft import convex_upsample
 from .update import GMAUpdateBlock, to_channels_last
 from .utils.utils import coords_grid, upflow8
+from .._lib import on_tensor_device
 
 
 class RAFTGMA(nn.Module):
@@ -44,6 +45,7 @@ class RAFTGMA(nn.Module):
         c = coords_grid(N, H // 8, W // 8, device=img.device)
         return c, c.clone()
 
+    @on_tensor_device
     def upsample_flow(self, flow, mask):
         return convex_upsample(flow, mask)
 
@@ -62,6 +64,7 @@ class RAFTGMA(nn.Module):
         inp = to_channels_last(torch.relu(inp))
         return net, inp, self.att.forward_cl(inp, records=True)     # (consumed by update_block.forward_cl only)
 
+    @on_tensor_device
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()

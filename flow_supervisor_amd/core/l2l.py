@@ -16,6 +16,7 @@ from .extractor import _prepare_packs
 from .raft import RAFT, convex_upsample
 from .update import BasicUpdateBlock, to_channels_last
 from .utils.utils import upflow8
+from .._lib import on_tensor_device
 
 
 def _offsets(v, B):
@@ -83,6 +84,7 @@ class L2L(RAFT):
         super().__init__(args)
         self.grad_update_block = BasicUpdateBlock(self.args, hidden_dim=self.hidden_dim)   # l2l.py:27
 
+    @on_tensor_device
     def forward(self, image1, image2, ci1=None, ci2=None, ox=None, oy=None, iters=24, flow_init=None,
                 upsample=True, test_mode=False, supervisor_grad=True, sup_grad_samples=None):
         norm = lambda im: (2 * (im / 255.0) - 1.0).contiguous()

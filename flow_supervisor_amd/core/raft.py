@@ -14,6 +14,7 @@ from .corr import AlternateCorrBlock, CorrBlock
 from .extractor import BasicEncoder, SmallEncoder
 from .update import BasicUpdateBlock, SmallUpdateBlock, to_channels_last
 from .utils.utils import coords_grid, upflow8
+from .._lib import on_tensor_device
 
 autocast = torch.autocast
 
@@ -83,10 +84,12 @@ class RAFT(nn.Module):
         c = coords_grid(N, H // 8, W // 8, device=img.device)
         return c, c.clone()
 
+    @on_tensor_device
     def upsample_flow(self, flow, mask):
         """[N,2,H,W], [N,576,H,W] -> [N,2,8H,8W] convex combination (raft.py:72-83)."""
         return convex_upsample(flow, mask)
 
+    @on_tensor_device
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()

@@ -39,19 +39,34 @@ def side_stream(device, which=0):
     return s
 
 
-_QUIET = [False]
+_QUIET_DEPTH = [0]
+
+
+class accumulate_grad_warning_off:
+    """Context manager: torch's once-per-process warning about an AccumulateGrad node whose gradient arrives from another stream
+    is switched off INSIDE this package's forward / backward only (round 4 switched it off for the whole process).
+    A parameter used on both streams (the encoders of the flow-supervisor forward) gets gradients from nodes on two streams; its
+    AccumulateGrad node belongs to one of them and the engine synchronises the other -- here that is the design."""
+
+    def __enter__(self):
+        setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if setter is not None:
+            if _QUIET_DEPTH[0] == 0:
+                setter(False)
+            _QUIET_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if setter is not None:
+            _QUIET_DEPTH[0] -= 1
+            if _QUIET_DEPTH[0] == 0:
+                setter(True)
+        return False
 
 
 def fork(device, which=0):
     """-> the side stream, ordered behind everything the caller's stream has been given so far."""
-    if not _QUIET[0]:
-        # A parameter used on both streams (the encoders of the flow-supervisor forward) gets gradients from nodes on two streams;
-        # its AccumulateGrad node belongs to one of them and the engine synchronises the other -- which PyTorch reports once per
-        # process as a possible mistake.  Here it is the design.
-        _QUIET[0] = True
-        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-        if quiet is not None:
-            quiet(False)
     side = side_stream(device, which)
     side.wait_stream(torch.cuda.current_stream(device))
     return side
@@ -77,15 +92,29 @@ def join(device, *tensors, event=None, which=0):
             t.record_stream(main)
 
 
+def _capturing(stream):
+    with torch.cuda.stream(stream):
+        return torch.cuda.is_current_stream_capturing()
+
+
 def order_current_behind_all(device, *more):
-    """The current stream waits for every side stream that exists on `device` (and for `more`): for code that runs inside the
-    backward pass on whatever stream its autograd node has and reads what nodes on OTHER streams produced -- a gradient bucket's
-    pack + all-reduce issued from a hook (parallel.FlatGradients): the engine orders a node behind the producers of ITS inputs,
-    not behind the other parameters' gradients that share its bucket."""
+    """The current stream waits for every side stream of `device` that has work in flight (and for `more`): for code that runs
+    inside the backward pass on whatever stream its autograd node has and reads what nodes on OTHER streams produced -- a
+    gradient bucket's pack + all-reduce issued from a hook (parallel.FlatGradients): the engine orders a node behind the
+    producers of ITS inputs, not behind the other parameters' gradients that share its bucket.
+    Which streams: inside a hipGraph capture only the side streams that are part of the capture -- a wait on
+    un-captured work is a capture error, and a stream this step never forked cannot hold anything the capture reads; eagerly,
+    streams that report idle are skipped (nothing to wait for; two event operations per bucket saved each)."""
     device = torch.device(device)
     cur = torch.cuda.current_stream(device)
+    capturing = torch.cuda.is_current_stream_capturing()
     for (idx, _), s in list(_SIDE.items()):
-        if idx == device.index and s != cur:
+        if idx != device.index or s == cur:
+            continue
+        if capturing:
+            if _capturing(s):
+                cur.wait_stream(s)
+        elif not s.query():
             cur.wait_stream(s)
     for s in more:
         if s is not None and s != cur:

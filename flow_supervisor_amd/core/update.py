@@ -1139,6 +1139,7 @@ class _UpdateBlockBase(nn.Module):
             self.__dict__["_cst"] = cst
         return cst
 
+    @L.on_tensor_device
     def forward_cl(self, net, inp, corr, flow, attention=None, need_mask=True, head_batch=None, grad_samples=None, motion_batch=None):
         """Channels-last entry used by our RAFT loop: no layout conversion at all.
         net/inp/corr: [B,H,W,C]; flow: [B,2,H,W]; attention (GMA only): [B,1,N,N].
@@ -1228,6 +1229,7 @@ class SmallUpdateBlock(_UpdateBlockBase):
         if hidden_dim != 96:
             raise NotImplementedError("the HIP small update block is built for hidden_dim=96 (the only value RAFT uses)")
 
+    @L.on_tensor_device
     def forward(self, net, inp, corr, flow):
         return self._forward_nchw(net, inp, corr, flow)
 
@@ -1256,6 +1258,7 @@ class GMAUpdateBlock(_UpdateBlockBase):
         if self.args.num_heads != 1:
             raise NotImplementedError("the fused Aggregate step is built for num_heads=1 (train_gma.py:354 default)")
 
+    @L.on_tensor_device
     def forward(self, net, inp, corr, flow, attention):
         return self._forward_nchw(net, inp, corr, flow, attention)
 
@@ -1277,5 +1280,6 @@ class BasicUpdateBlock(_UpdateBlockBase):
         if hidden_dim != 128 or input_dim != 128:
             raise NotImplementedError("the HIP update block is built for hidden_dim=input_dim=128 (RAFT's values)")
 
+    @L.on_tensor_device
     def forward(self, net, inp, corr, flow, upsample=True):
         return self._forward_nchw(net, inp, corr, flow)

@@ -3,6 +3,7 @@ import torch
 import torch.nn.functional as F
 
 from ... import ops
+from ..._lib import on_tensor_device
 
 
 class InputPadder:
@@ -50,6 +51,7 @@ def coords_grid(batch, ht, wd, device=None):
     return torch.stack([xs, ys], dim=0)[None].repeat(batch, 1, 1, 1)
 
 
+@on_tensor_device
 def bilinear_sampler(img, coords, mode="bilinear", mask=False):
     """grid_sample in pixel coordinates, align_corners=True, zero padding (utils.py:57-71).
     Kept as a framework op: the hot loop does not call it (CorrBlock uses the fused HIP lookup)."""
@@ -74,6 +76,7 @@ class _UpFlow8(torch.autograd.Function):
         return ops.upflow8_bwd(g, *ctx.hw)
 
 
+@on_tensor_device
 def upflow8(flow, mode="bilinear"):
     """8 * bilinear x8 upsampling with align_corners=True (utils.py:80-82) on the HIP kernel."""
     if mode != "bilinear":

@@ -1760,8 +1760,14 @@ inline bool g_conv_bdma_on() {
 #endif
 }
 int g_conv_ksplit = -1;          // -1 auto (small grids only), 0 / 1 off, >= 2 forced slice count (fsraft_set_tuning key 32)
-float* g_conv_ws = nullptr;      // workspace handed over by the binding (fsraft_conv_workspace): the ABI allocates nothing
-int64_t g_conv_ws_floats = 0;
+// Split-K scratch: the ABI allocates nothing, the caller lends it -- per CALL (fsraft_conv_desc.ws, what the Python mirror does) or,
+// for bindings written against the round-3 header, per calling THREAD (fsraft_conv_workspace).  Both live in thread_local storage,
+// so two host threads enqueueing convolutions for two devices / streams (the reference's nn.DataParallel caller,
+// pytorch/train.py:192) never see each other's pointer.
+thread_local float* t_reg_ws = nullptr;        // fsraft_conv_workspace of this thread
+thread_local int64_t t_reg_ws_floats = 0;
+thread_local float* g_conv_ws = nullptr;       // the scratch of the call this thread is inside (set by fsraft_conv_forward)
+thread_local int64_t g_conv_ws_floats = 0;
 
 // Slices for a tile grid of `tiles` workgroups, KT k-tiles and N outputs.  Measured (scripts/conv_micro.py, 1 x 47x156, 1 x 46x96,
 // 2 x 46x96, 2 x 54x128; scripts/smallm_sweep.sh): the route pays where fewer than ~half of the CUs have a workgroup AND
@@ -1924,6 +1930,7 @@ struct fsraft_conv_desc {
   const float* wpk_frag;         // wpk_split in fragment order (or NULL): enables the resident-patch 3x3 kernel
   const float* srcr[3]; int srcrld[3];   // the sources as record tensors (or NULL): enables the LDS-DMA kernel (conv_rec.inc)
   int pad_h1, pad_w1;            // 0: taps centred (KH / 2, KW / 2); else 1 + the top / left padding (even kernel sizes)
+  float* ws; int64_t ws_floats;  // split-K scratch of THIS call (NULL: the calling thread's fsraft_conv_workspace registration)
 };
 
 extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
@@ -1943,6 +1950,9 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
   // (statistics of the raw result only: one destination, no bias / ReLU / scale / mask / accumulation in the epilogue)
   const bool want_stats = t_stat.sum != nullptr && d->epi == EPI_PLAIN && d->ndst == 1 && !d->relu && d->alpha == 1.0f && !d->dst_acc[0] &&
                           !d->rmask[0] && !d->bias && d->dst_n0[0] == 0 && d->N % 4 == 0;
+  if (d->ws && (((uintptr_t)d->ws & 15) || d->ws_floats < 0)) return FS_ERR_ARG;
+  g_conv_ws = d->ws ? d->ws : t_reg_ws;                     // scratch of THIS call (thread_local: see the declaration)
+  g_conv_ws_floats = d->ws ? d->ws_floats : t_reg_ws_floats;
   ConvArgs a{};
   for (int s = 0; s < 3; ++s) {
     a.src[s] = Src{s < d->nsrc ? d->src[s] : d->src[0], s < d->nsrc ? d->srcC[s] : 0, s < d->nsrc ? d->srcld[s] : 4};
@@ -2084,11 +2094,12 @@ extern "C" int fsraft_set_ablate(int mask) {
 #endif
 
 // The split-K route of the small-M convolutions needs a scratch buffer; the ABI allocates nothing, so the binding hands one
-// over (and keeps it alive).  Calls that enqueue convolutions on DIFFERENT streams concurrently must not share it.
+// over (and keeps it alive): per call in fsraft_conv_desc.ws, or -- this entry point -- for every later call of the CALLING THREAD
+// whose descriptor carries none.  Calls that enqueue convolutions on DIFFERENT streams concurrently must not share a buffer.
 extern "C" int fsraft_conv_workspace(float* ws, int64_t floats) {
   if (ws && (((uintptr_t)ws & 15) || floats < 0)) return FS_ERR_ARG;
-  g_conv_ws = ws;
-  g_conv_ws_floats = ws ? floats : 0;
+  t_reg_ws = ws;
+  t_reg_ws_floats = ws ? floats : 0;
   return FS_OK;
 }
 

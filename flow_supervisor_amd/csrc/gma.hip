@@ -242,15 +242,18 @@ extern "C" int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, 
   else hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), (size_t)((n + 3) & ~3) * 8, s, A, dA, n);
   return fs_launch_status();
 }
-// In place: fp32 logits [rows][n] -> softmax probabilities as records [rows][n / 32][32 hi | 32 lo] (n % 32 == 0, n <= 16384).
+// In place: fp32 logits [rows][n] -> softmax probabilities as records [rows][n / 32][32 hi | 32 lo] (n % 32 == 0, n <= 16352:
+// the row in dynamic LDS plus the kernel's static reduction words stay within 64 KB, the launch limit without an opt-in -- there
+// is no second copy of the logits to fall back to if a launch were refused).
 extern "C" int fsraft_softmax_rows_rec(float* S, int64_t rows, int n, hipStream_t s) {
-  if (!S || rows < 1 || n < 32 || (n % 32) || n > 16384 || rows > 0x7fffffff || ((uintptr_t)S % 16)) return FS_ERR_ARG;
+  if (!S || rows < 1 || n < 32 || (n % 32) || n > 16352 || rows > 0x7fffffff || ((uintptr_t)S % 16)) return FS_ERR_ARG;
   hipLaunchKernelGGL(softmax_rows_rec_kernel, dim3((unsigned)rows), dim3(256), (size_t)n * 4, s, S, n);
   return fs_launch_status();
 }
-// A: records of fsraft_softmax_rows_rec; dA: fp32 gradient in, records of dS out (in place).  n % 32 == 0, n <= 8192.
+// A: records of fsraft_softmax_rows_rec; dA: fp32 gradient in, records of dS out (in place).  n % 32 == 0, n <= 8160 (two rows
+// in dynamic LDS + the static reduction words within 64 KB).
 extern "C" int fsraft_softmax_rows_bwd_rec(const void* A, float* dA, int64_t rows, int n, hipStream_t s) {
-  if (!A || !dA || rows < 1 || n < 32 || (n % 32) || n > 8192 || rows > 0x7fffffff || ((uintptr_t)A % 16) || ((uintptr_t)dA % 16))
+  if (!A || !dA || rows < 1 || n < 32 || (n % 32) || n > 8160 || rows > 0x7fffffff || ((uintptr_t)A % 16) || ((uintptr_t)dA % 16))
     return FS_ERR_ARG;
   hipLaunchKernelGGL(softmax_rows_bwd_rec_kernel, dim3((unsigned)rows), dim3(256), (size_t)n * 8, s, (const char*)A, dA, n);
   return fs_launch_status();

@@ -724,7 +724,7 @@ def softmax_rows_bwd_(A, dA):
 
 
 def softmax_rows_rec_(S):
-    """In-place softmax over the last dimension (n % 32 == 0, n <= 16384) whose result overwrites the logits as RECORDS (the
+    """In-place softmax over the last dimension (n % 32 == 0, n <= 16352) whose result overwrites the logits as RECORDS (the
     operand form of gemm_rec_nt / gemm_rec_tn, see to_records): the tensor keeps its shape and dtype, its bytes are records."""
     L.require_cuda_f32(S)
     n = S.shape[-1]
@@ -1167,25 +1167,23 @@ class Dst:
         return Dst(buf, 0, C * H * W, 1, H * W, n0, acc)
 
 
-_CONV_WS = {}                 # (device index, stream) -> scratch tensor; "active" -> the key registered with fsraft_conv_workspace
+_CONV_WS = {}                 # (device index, stream) -> scratch tensor
 CONV_WS_FLOATS = 24 << 20     # 96 MB: three slices of the largest small-M layer (8832 pixels x 512 outputs)
 CONV_WS_MAX_PIXELS = 16384    # the split-K route only exists for grids that leave CUs idle
 
 
 def _conv_workspace(device, pixels):
-    """Hand libfsraft its split-K scratch buffer before a small convolution runs on `device` (the C ABI allocates nothing).
-    One buffer per (device, stream): the library reads the registered pointer while it enqueues the launch, so convolutions
-    issued on two streams (core/l2l.py runs the supervisor's encoders beside the student's iterations) never share slabs."""
+    """The split-K scratch buffer of a small convolution enqueued on `device`'s current stream, or None (the C ABI allocates
+    nothing; the buffer travels in the call's descriptor, fsraft_conv_desc.ws).  One buffer per (device, stream): convolutions
+    issued on two streams (core/l2l.py runs the supervisor's encoders beside the student's iterations) or by two host threads
+    (one per device, the reference's nn.DataParallel caller) never share slabs, and nothing is registered process-wide."""
     if pixels > CONV_WS_MAX_PIXELS:
-        return
+        return None
     key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
     ws = _CONV_WS.get(key)
     if ws is None:
-        ws = torch.empty(CONV_WS_FLOATS, device=device, dtype=torch.float32)
-        _CONV_WS[key] = ws
-    if _CONV_WS.get("active") != key:
-        L.check(_lib().fsraft_conv_workspace(L.ptr(ws), ws.numel()), "conv_workspace")
-        _CONV_WS["active"] = key
+        ws = _CONV_WS.setdefault(key, torch.empty(CONV_WS_FLOATS, device=device, dtype=torch.float32))
+    return ws
 
 
 def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.0, epi=0, h=None, z=None,
@@ -1226,7 +1224,9 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     d.hid = hid
     if pre is not None:
         d.pre = pre.data_ptr(); d.ldpre = pre.shape[-1]
-    _conv_workspace(dsts[0].t.device, B * H * W)
+    ws = _conv_workspace(dsts[0].t.device, B * H * W)
+    if ws is not None:
+        d.ws = ws.data_ptr(); d.ws_floats = ws.numel()
     t = TIMER
     e0 = t.begin() if t else None
     carried = None

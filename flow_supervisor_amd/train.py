@@ -4,6 +4,7 @@ import torch
 
 import os
 
+from .core import streams
 from .parallel import FlatAdamW, FlatGradients
 
 
@@ -227,7 +228,8 @@ class TrainStep:
             self.grads.begin(image1.shape[0], global_batch, exchange=exchange)
         preds = self.model(image1, image2, iters=self.iters)
         loss = raft_sequence_loss(preds, flow_gt)
-        loss.backward()                           # bucket hooks start each all-reduce as its gradients complete
+        with streams.accumulate_grad_warning_off():
+            loss.backward()                       # bucket hooks start each all-reduce as its gradients complete
         return loss.detach()
 
     def __call__(self, *args, **kw):
@@ -281,7 +283,9 @@ class SemiTrainStep(TrainStep):
         for buf, a, b in zip(bufs, sup[:4], unsup[:4]):
             buf[:a.shape[0]].copy_(a)
             buf[a.shape[0]:].copy_(b)
-        self._cat = (key, bufs, srcs)
+        # (while capturing the copies above were only recorded: the buffers hold nothing yet, so the key is not remembered and the
+        # next eager call copies again instead of being served never-filled buffers -- ADVICE r4)
+        self._cat = (None if capturing else key, bufs, srcs)
         return bufs
 
     def _bn_training(self):
@@ -311,7 +315,8 @@ class SemiTrainStep(TrainStep):
         else:
             loss, _ = sequence_loss([p[:bs] for p in preds], sup[6], sup[7], self.gamma, metrics=False)
             loss_u, _ = sequence_loss_unsup([p[bs:] for p in preds], unsup[6], unsup[7], unsup_weight=self.unsup_lambda, metrics=False)
-        (loss + loss_u).backward()
+        with streams.accumulate_grad_warning_off():
+            (loss + loss_u).backward()
         del preds
         return loss.detach(), loss_u.detach()
 
@@ -324,11 +329,13 @@ class SemiTrainStep(TrainStep):
         im1, im2, ci1, ci2, ox, oy, flow, valid = sup
         preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters)
         loss, _ = sequence_loss(preds, flow, valid, self.gamma, metrics=False)
-        loss.backward()
+        with streams.accumulate_grad_warning_off():
+            loss.backward()
         del preds
         im1, im2, ci1, ci2, ox, oy, flow, valid = unsup
         preds = self.model(im1, im2, ci1, ci2, ox, oy, iters=2 * self.iters, supervisor_grad=False)
         loss_u, _ = sequence_loss_unsup(preds, flow, valid, unsup_weight=self.unsup_lambda, metrics=False)
-        loss_u.backward()
+        with streams.accumulate_grad_warning_off():
+            loss_u.backward()
         del preds
         return loss.detach(), loss_u.detach()

@@ -183,6 +183,10 @@ typedef struct fsraft_conv_desc {
   int pad_h1, pad_w1;                                         /* 0: taps centred (KH/2, KW/2 rows / columns above / left of
                                                                  the output pixel); else 1 + that count -- even kernel sizes:
                                                                  a 2x2 kernel has pad 1 forward and pad 0 in its data gradient */
+  float* ws; int64_t ws_floats;                               /* scratch of THIS call for the split-K route at small pixel
+                                                                 counts (16-byte aligned, on the device the call runs on, not
+                                                                 shared with a call on another stream); NULL: the buffer the
+                                                                 calling thread registered with fsraft_conv_workspace, if any */
 } fsraft_conv_desc;
 
 int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);
@@ -247,8 +251,10 @@ int fsraft_conv_small_dgrad(const float* dy, int ldy, const float* w_oihw, float
 
 /* Scratch buffer for the split-K route of the convolutions at small pixel counts (one or two pairs per GPU: the layer's
  * k-tiles are dealt to several workgroups per tile, which park partial tiles here; a second kernel adds them and applies the
- * layer's epilogue).  The library allocates nothing: the caller owns `ws` (16-byte aligned, `floats` fp32) and keeps it alive;
- * NULL switches the route off.  One buffer per process: convolutions enqueued concurrently on different streams must not use it. */
+ * layer's epilogue).  The library allocates nothing: the caller owns `ws` (16-byte aligned, `floats` fp32) and keeps it alive.
+ * Preferred: hand it over per call in fsraft_conv_desc.ws.  This entry point registers a buffer for the CALLING THREAD only
+ * (thread-local; NULL clears it) and serves descriptors whose ws is NULL -- a worker thread per device, as in the reference's
+ * nn.DataParallel caller (pytorch/train.py:192), registers its own device's buffer and never sees another thread's. */
 int fsraft_conv_workspace(float* ws, int64_t floats);
 
 /* ---- arithmetic of the dense contractions -------------------------------------------------------------------------
@@ -320,9 +326,9 @@ int fsraft_softmax_rows(float* S, int64_t rows, int n, hipStream_t stream);
 /* dA <- A * (dA - rowsum(dA * A))  (softmax backward, in place over dA) */
 int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, int n, hipStream_t stream);
 /* The same softmax (gma.py:71-74) with the probabilities written over the logits as RECORDS ([32 bf16 hi | 32 bf16 lo] per 32
- * columns: the operand form of fsraft_gemm_rec_nt / _tn): for n % 32 == 0 (n <= 16384) the record row is as long as the fp32
+ * columns: the operand form of fsraft_gemm_rec_nt / _tn): for n % 32 == 0 (n <= 16352) the record row is as long as the fp32
  * row, so the map exists once.  The backward reads those records (a = hi + lo) and turns the fp32 gradient dA into the records
- * of dS = A * (dA - rowsum(dA * A)) in place (n <= 8192). */
+ * of dS = A * (dA - rowsum(dA * A)) in place (n <= 8160). */
 int fsraft_softmax_rows_rec(float* S, int64_t rows, int n, hipStream_t stream);
 int fsraft_softmax_rows_bwd_rec(const void* A_records, float* dA, int64_t rows, int n, hipStream_t stream);
 /* Aggregate.forward, gma.py:113: dst = x + gamma[0] * y with gamma a device scalar (the nn.Parameter). */

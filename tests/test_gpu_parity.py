@@ -2617,3 +2617,165 @@ def test_nchw_entry_does_not_reuse_context_of_a_freed_tensor():
         rn, _, rd = O.basic_update_block({k: v.cpu() for k, v in sd.items()}, "update_block.", net.cpu(), inp, corr.cpu(), flow.cpu())
         close(n2, rn, 2e-4, what="net (pair %d)" % len(ptrs)); close(delta, rd, 2e-4, what="delta")
     print("inp addresses of the two pairs:", ptrs, "(equal = the allocator reused the block)")
+
+
+# ---------------------------------------------------------------- several host threads (the reference's nn.DataParallel caller)
+def _small_grid_conv(seed, B=1, H=46, W=96, cs=(256,), N=126, kh=3, kw=3):
+    """One small-grid convolution (fewer tiles than CUs: the split-K route with its scratch buffer) with seeded operands."""
+    from flow_supervisor_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    srcs = [torch.randn(B, H, W, c, generator=g).to(DEV) for c in cs]
+    w = (torch.randn(N, sum(cs), kh, kw, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    packs = (ops.pack_weight(w, list(cs), 0), ops.pack_weight(w, list(cs), 10))
+
+    def run():
+        out = torch.full((B, H, W, N), float("nan"), device=DEV)
+        ops.conv_forward([ops.V(t, c) for t, c in zip(srcs, cs)], packs[0], bias, B, H, W, kh, kw, N, [ops.Dst.nhwc(out)], relu=True,
+                         wpk_split=packs[1])
+        return out
+    return run
+
+
+def test_two_host_threads_on_two_streams_use_their_own_split_k_scratch():
+    """VERDICT r4 next #5 / SURVEY 8b "Threading": the reference's multi-GPU caller is nn.DataParallel (pytorch/train.py:192) --
+    one host thread per replica, all inside one process -- and ctypes releases the GIL around every libfsraft call, so two threads'
+    calls interleave freely.  Round 4 registered ONE process-wide split-K scratch pointer (fsraft_conv_workspace) and switched it
+    on the host: thread A's launch could pick up thread B's buffer.  Now the buffer travels in each call's descriptor.  Two threads,
+    each on its own stream, run different small-grid convolutions (the route that parks partial tiles in the scratch) 40 times
+    each, concurrently; every result must be bit-equal to the same convolution run alone."""
+    import threading
+    from flow_supervisor_amd import ops
+    runs = [_small_grid_conv(11), _small_grid_conv(12, H=47, W=156, cs=(128, 128), N=128, kh=1, kw=5)]
+    alone = [r() for r in runs]
+    torch.cuda.synchronize()
+    errors, results = [], [None, None]
+    barrier = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                barrier.wait()
+                outs = [runs[i]() for _ in range(40)]
+                s.synchronize()
+            results[i] = outs
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    keys = [k for k in ops._CONV_WS if k[0] == torch.cuda.current_device()]
+    assert len(keys) >= 3, keys                  # the main thread's stream and one per worker: nothing shared
+    for i in range(2):
+        for k, o in enumerate(results[i]):
+            assert torch.equal(o, alone[i]), (i, k, float((o - alone[i]).abs().max()))
+
+
+def test_legacy_workspace_registration_is_per_thread():
+    """fsraft_conv_workspace (kept for bindings written against the round-3 header) registers a buffer for the CALLING THREAD only:
+    a descriptor without `ws` enqueued by another thread must not touch it (that thread simply gets no split-K route), while the
+    registering thread's own call does use it.  Checked through a sentinel pattern in the buffer."""
+    import ctypes
+    import threading
+    from flow_supervisor_amd import _lib, ops
+    lib = _lib.load()
+    run = _small_grid_conv(13)
+    ref = run()
+    ws = torch.full((ops.CONV_WS_FLOATS,), -7.0, device=DEV)
+    saved = dict(ops._CONV_WS)
+    real = ops._conv_workspace
+    ops._conv_workspace = lambda device, pixels: None          # descriptors without ws: the registration decides
+    try:
+        assert lib.fsraft_conv_workspace(ctypes.c_void_p(ws.data_ptr()), ws.numel()) == 0       # this (main) thread
+        box = {}
+
+        def other():
+            box["out"] = run()
+            torch.cuda.synchronize()
+        t = threading.Thread(target=other)
+        t.start(); t.join()
+        assert bool((ws == -7.0).all()), "another thread's launch wrote into this thread's registered scratch"
+        close(box["out"], ref, 2e-5, what="convolution without a scratch buffer (no split-K route)")
+        mine = run()
+        torch.cuda.synchronize()
+        assert not bool((ws == -7.0).all()), "the registering thread's own call did not use its scratch"
+        assert torch.equal(mine, ref)
+    finally:
+        lib.fsraft_conv_workspace(ctypes.c_void_p(0), 0)
+        ops._conv_workspace = real
+        ops._CONV_WS.clear(); ops._CONV_WS.update(saved)
+
+
+def test_two_host_threads_train_two_models_concurrently():
+    """The whole path from two host threads at once (one model replica and one stream per thread, as a DataParallel-style caller
+    would drive two devices; here both on the box's one GPU): forward + loss + backward of a small RAFT, three steps each, must give
+    the losses and gradients of the same steps run one thread after the other."""
+    import threading
+    from flow_supervisor_amd.train import raft_sequence_loss
+
+    def steps(seed, out):
+        m = _model(False, seed).train()
+        m.freeze_bn()
+        im1, im2 = (t.to(DEV) for t in synthetic_pair(1, 128, 192, seed + 1))
+        for _ in range(3):
+            for p in m.parameters():
+                p.grad = None
+            loss = raft_sequence_loss(m(im1, im2, iters=3))
+            loss.backward()
+        torch.cuda.current_stream().synchronize()
+        out.append((float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+
+    serial = [[], []]
+    for i in range(2):
+        steps(50 + 10 * i, serial[i])
+    errors, conc = [], [[], []]
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                steps(50 + 10 * i, conc[i])
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        (l0, g0), (l1, g1) = serial[i][0], conc[i][0]
+        assert abs(l0 - l1) <= 2e-5 * abs(l0), (l0, l1)
+        for k in g0:
+            if k.startswith("fnet."):
+                continue            # (atomically accumulated InstanceNorm statistics: run-to-run noise of its own, TRAIN_TOL)
+            close(g1[k], g0[k], 1e-6, rtol=2e-3, what=f"thread {i} {k}")
+
+
+def test_ops_refuse_tensors_of_another_device():
+    """"use the current device + current stream, re-entrant across devices".  The kernels are enqueued on the current
+    device's current stream, so tensors living on another device are refused with a RuntimeError (require_cuda_f32) instead of
+    being dereferenced by the wrong GPU; the module-level entry points make their input's device current themselves
+    (_lib.on_tensor_device).  Needs two devices for the cross-device half."""
+    from flow_supervisor_amd import _lib, ops
+    from flow_supervisor_amd.core.corr import CorrBlock
+    a = torch.randn(1, 64, 8, 12, device=DEV)
+    _lib.require_cuda_f32(a, None, a)
+    with pytest.raises(RuntimeError):
+        _lib.require_cuda_f32(a, a.cpu())
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device: the cross-device refusal needs two")
+    b = a.to("cuda:1")
+    with pytest.raises(RuntimeError, match="one device"):
+        _lib.require_cuda_f32(a, b)
+    with pytest.raises(RuntimeError, match="current device"):
+        ops.to_records(b.permute(0, 2, 3, 1).contiguous())          # current device is cuda:0
+    blk = CorrBlock(b, b)                                             # the entry point switches to the tensors' device
+    out = blk(torch.zeros(1, 2, 8, 12, device="cuda:1"))
+    ref = CorrBlock(a, a)(torch.zeros(1, 2, 8, 12, device=DEV))
+    assert out.device == b.device and torch.cuda.current_device() == 0
+    close(out.cpu(), ref.cpu(), 1e-6, what="CorrBlock on cuda:1 from a thread whose current device is cuda:0")
