@@ -946,7 +946,8 @@ def test_eager_train_steps_leave_no_garbage_for_the_cyclic_collector(alt):
         for i in range(7):
             step(im1, im2)
             torch.cuda.synchronize()
-            if i >= 2:
+            torch.cuda.empty_cache()        # (blocks freed while a second stream still used them -- record_stream -- are only returned
+            if i >= 2:                      #  once the allocator looks at their events again: without this the count depends on timing)
                 seen.append(torch.cuda.memory_allocated())
     finally:
         gc.enable()
@@ -2728,7 +2729,7 @@ def test_two_host_threads_train_two_models_concurrently():
             loss = raft_sequence_loss(m(im1, im2, iters=3))
             loss.backward()
         torch.cuda.current_stream().synchronize()
-        out.append((float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+        out.append((float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
 
     serial = [[], []]
     for i in range(2):
