@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--height", type=int, default=440)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--variant", choices=["raft", "gma", "alt", "l2l", "gma_l2l"], default="raft",
+    ap.add_argument("--variant", choices=["raft", "gma", "alt", "l2l", "gma_l2l", "dropin"], default="raft",
                     help="raft: BASELINE.json config 3 (the default, the judged line); gma: config 5 (RAFT-GMA); "
+                         "dropin: config 3 through the REFERENCE's model shell over the swapped blocks (INTEGRATION.md section 1); "
                          "alt: config 4 (AlternateCorrBlock, use --height 376 --width 1248 --batch-per-gpu 1); "
                          "l2l / gma_l2l: the flow-supervisor step of the reference recipe (train_semi.sh:3-11): L2L / GMAL2L, one "
                          "labelled + one unlabelled sample per step, crop 368x768 inside a 432x1024 frame, 12 + 12 iterations, "
@@ -145,6 +146,7 @@ def loss_check(dev, variant="raft", height=440, width=1024, iters=12):
     from oracle.weights import procedural_state_dict, synthetic_pair
     from flow_supervisor_amd.train import raft_sequence_loss
     name = {("raft", 440, 1024): "train_step_basic_440x1024", ("gma", 440, 1024): "train_step_gma_440x1024",
+            ("dropin", 440, 1024): "train_step_basic_440x1024",
             ("raft", 376, 1248): "train_step_basic_376x1248", ("alt", 376, 1248): "train_step_basic_376x1248",
             ("raft", 368, 496): "train_step_basic_368x496_b8"}.get((variant, height, width))
     f = os.path.join(ROOT, "tests", "golden", f"{name}.npz") if name else None
@@ -164,7 +166,9 @@ def loss_check(dev, variant="raft", height=440, width=1024, iters=12):
             m.update_block.aggregator.gamma.fill_(float(np.load(os.path.join(ROOT, "tests", "golden", "e2e_gma_440x1024.npz"))["gamma"]))
     else:
         from flow_supervisor_amd.core.raft import RAFT
-        m = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=variant == "alt"))
+        from flow_supervisor_amd.core.raft_dropin import ReferenceShapedRAFT
+        m = (ReferenceShapedRAFT if variant == "dropin" else RAFT)(argparse.Namespace(small=False, mixed_precision=False,
+                                                                                         alternate_corr=variant == "alt"))
         m.load_state_dict(procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed))
     m = m.to(dev).train()
     m.freeze_bn()
@@ -318,6 +322,11 @@ def main():
                                            position_and_content=False)).to(dev).train()
         with torch.no_grad():
             model.update_block.aggregator.gamma.fill_(0.1)      # zero-init gamma would leave the aggregate path unexercised
+    elif a.variant == "dropin":
+        # the INTEGRATION.md section 1 route: the reference's model shell (NCHW, per-iteration CorrBlock(coords) -> BasicUpdateBlock.forward
+        # -> upsample_flow, coords1 carried) over the swapped blocks -- core/raft_dropin.py
+        from flow_supervisor_amd.core.raft_dropin import ReferenceShapedRAFT
+        model = ReferenceShapedRAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).to(dev).train()
     else:
         model = RAFT(argparse.Namespace(small=False, mixed_precision=False,
                                         alternate_corr=a.variant == "alt")).to(dev).train()
@@ -544,7 +553,9 @@ def main():
                        "value_exact_f32 = the same step on the exact-fp32 MFMA cores")
                       if split_mode else "exact fp32 MFMA",
         "data": "synthetic",
-        "config": {"workload": ({"raft": "RAFT full", "gma": "RAFT-GMA (config 5)", "alt": "RAFT full, AlternateCorrBlock (config 4)"}[a.variant] +
+        "config": {"workload": ({"raft": "RAFT full", "gma": "RAFT-GMA (config 5)", "alt": "RAFT full, AlternateCorrBlock (config 4)",
+                                 "dropin": "RAFT full, the REFERENCE's model shell (NCHW tensors, per-iteration CorrBlock(coords) -> "
+                                           "BasicUpdateBlock.forward -> upsample_flow, INTEGRATION.md section 1) over the swapped blocks"}[a.variant] +
                                 f", {a.height}x{a.width}{shape_note}, {a.iters} GRU iters, "
                                 f"{B} pairs/GPU, train step = fwd + sequence loss + bwd + RCCL all-reduce + clip + AdamW") if not semi else
                                (f"flow-supervisor step ({'L2L' if a.variant == 'l2l' else 'GMAL2L'}, pytorch/train.py:246-284): per GPU {B} labelled + {B} "

@@ -2780,3 +2780,38 @@ def test_ops_refuse_tensors_of_another_device():
     ref = CorrBlock(a, a)(torch.zeros(1, 2, 8, 12, device=DEV))
     assert out.device == b.device and torch.cuda.current_device() == 0
     close(out.cpu(), ref.cpu(), 1e-6, what="CorrBlock on cuda:1 from a thread whose current device is cuda:0")
+
+
+def test_reference_shaped_shell_matches_the_package_shell():
+    """INTEGRATION.md section 1 / `bench.py --variant dropin`: the reference's own model shell (core/raft_dropin.py restates
+    pytorch/core/raft.py:99-144: NCHW tensors, `corr_fn(coords1)` -> `update_block(net, inp, corr, flow)` -> `upsample_flow` every
+    iteration, `coords1` carried and detached) over the swapped blocks must give the predictions and parameter gradients of this
+    package's own shell (flow-carrying channels-last loop, once-per-step head / motion-encoder batches, second stream) -- and both are
+    held to the reference-generated fixture by the train-step goldens."""
+    from flow_supervisor_amd.core.raft import RAFT
+    from flow_supervisor_amd.core.raft_dropin import ReferenceShapedRAFT
+    from flow_supervisor_amd.train import raft_sequence_loss
+    ns = argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)
+    a = RAFT(ns).to(DEV).train()
+    b = ReferenceShapedRAFT(ns).to(DEV).train()
+    b.load_state_dict(a.state_dict())
+    a.freeze_bn(); b.freeze_bn()
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(2, 128, 192, 33))
+    outs = []
+    for m in (a, b):
+        preds = m(im1, im2, iters=4)
+        raft_sequence_loss(preds).backward()
+        outs.append((preds, {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    (pa, ga), (pb, gb) = outs
+    assert len(pa) == len(pb) == 4 and pb[0].shape == (2, 2, 128, 192)
+    for i in range(4):
+        close(pb[i], pa[i], 2e-4, what=f"prediction {i}")
+    assert set(ga) == set(gb)
+    for k in ga:
+        if k.startswith("fnet."):
+            continue                # (its own run-to-run noise: atomically accumulated InstanceNorm statistics, TRAIN_TOL)
+        close(gb[k], ga[k], 1e-6, rtol=3e-3, what=f"gradient {k}")
+    # test_mode contract of the shell: (flow at 1/8 resolution, last upsampled flow)
+    with torch.no_grad():
+        lo, up = b.eval()(im1, im2, iters=3, test_mode=True)
+    assert lo.shape == (2, 2, 16, 24) and up.shape == (2, 2, 128, 192)
