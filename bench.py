@@ -280,7 +280,17 @@ def main():
     shared = int(os.environ.get("FSRAFT_BENCH_SHARED_GPUS", "0"))
     if shared:                                        # fewer devices than ranks (self_launch): ranks share them, gloo through the host
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % shared)
-    rank, world, local = init_distributed("cuda", backend="gloo" if shared else None)
+    # Bounded start-up: the rendezvous and every collective carry a time limit, and a failure here ends THIS
+    # process with a clear message and exit code 3 -- torch.distributed.run then tears the other ranks down and reports the failing
+    # rank -- instead of a silent hang of the first 8-GPU run.  (Nothing is re-executed: ranks are fresh children of the launcher.)
+    init_timeout = float(os.environ.get("FSRAFT_DIST_TIMEOUT_S", "180"))
+    try:
+        rank, world, local = init_distributed("cuda", backend="gloo" if shared else None, timeout_s=init_timeout)
+    except Exception as e:       # noqa: BLE001
+        print(f"bench: rank {os.environ.get('RANK', '?')} could not join the process group within {init_timeout:.0f} s "
+              f"({type(e).__name__}: {e}); MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+              f"WORLD_SIZE={os.environ.get('WORLD_SIZE')} LOCAL_RANK={os.environ.get('LOCAL_RANK')}", file=sys.stderr, flush=True)
+        sys.exit(3)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
                          f"or unset WORLD_SIZE and let bench.py start its ranks itself")
@@ -293,9 +303,20 @@ def main():
         ones = torch.ones(1, device=dev)
         if shared:
             ones = ones.cpu()
-        dist.all_reduce(ones)
+        t_first = time.perf_counter()
+        try:
+            dist.all_reduce(ones)
+            seen = int(ones.item())
+        except Exception as e:       # noqa: BLE001
+            print(f"bench: rank {rank}: the first all-reduce over {dist.get_backend()} failed ({type(e).__name__}: {e}); "
+                  f"device cuda:{local}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
+            sys.exit(3)
+        if seen != world:            # a collective that did not see every rank would make every later number meaningless: fail the run
+            print(f"bench: rank {rank}: the all-reduce of ones returned {seen}, expected {world} ranks", file=sys.stderr, flush=True)
+            sys.exit(4)
         rccl = {"backend": dist.get_backend() + (" (= RCCL)" if dist.get_backend() == "nccl" else " staged through host memory: ranks share a device"),
-                "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(ones.item())}
+                "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": seen,
+                "first_all_reduce_ms": 1e3 * (time.perf_counter() - t_first), "init_timeout_s": init_timeout}
     # MIOpen exhaustive find (cudnn.benchmark) costs ~7 minutes of start-up for the encoder shapes and
     # is off: the encoders are framework callers of the path, not what this benchmark is about.
     torch.backends.cudnn.benchmark = False
@@ -428,10 +449,18 @@ def main():
                     tstep.update()
                 graph = (g_fb, g_up)
 
+                part_events = []                      # per timed step: events around the three parts (self-diagnosing N > 1 line)
+
                 def run():
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    ev[0].record()
                     g_fb.replay()
+                    ev[1].record()
                     tstep.exchange()                  # eager: one all-reduce of the flat gradient buffer on the current stream
+                    ev[2].record()
                     g_up.replay()
+                    ev[3].record()
+                    part_events.append(ev)
                 graph_note = "two hipGraphs (forward + loss + backward | clip + AdamW + re-pack) with the all-reduce issued eagerly between them"
             else:
                 graph = torch.cuda.CUDAGraph()
@@ -465,7 +494,28 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_local = dt
     dt = max_over_ranks(dt, dev)
+    if rccl is not None:
+        # per-rank view of the timed region: wall time, and for the two-graph route the mean time of each part (forward + backward
+        # graph | the all-reduce | clip + AdamW graph) -- a slow rank, a slow link or a slow exchange shows here, not only in `value`
+        import torch.distributed as dist
+        mine = [1e3 * dt_local / a.steps, 0.0, 0.0, 0.0]
+        if split_graph and graph is not None and 'part_events' in locals() and part_events:
+            evs = part_events[-a.steps:]
+            for k in range(3):
+                mine[1 + k] = sum(e[k].elapsed_time(e[k + 1]) for e in evs) / len(evs)
+        t_mine = torch.tensor(mine, device=dev, dtype=torch.float64)
+        if shared:
+            t_mine = t_mine.cpu()
+        gathered = [torch.zeros_like(t_mine) for _ in range(world)]
+        dist.all_gather(gathered, t_mine)
+        rows = [g.tolist() for g in gathered]
+        rccl["per_rank_ms_per_step"] = [round(r[0], 3) for r in rows]
+        if any(r[1] > 0 for r in rows):
+            rccl["per_rank_graph_fb_ms"] = [round(r[1], 3) for r in rows]
+            rccl["per_rank_exchange_ms"] = [round(r[2], 3) for r in rows]
+            rccl["per_rank_graph_up_ms"] = [round(r[3], 3) for r in rows]
 
     # Per-launch kernel timing with events on the launching stream.  Eager steps are timed directly
     # inside the region above when --graph 0; with the hipGraph the same step is re-run eagerly right

@@ -33,7 +33,7 @@ class ConvDesc(Structure):
         ("aux1", c_void_p), ("ld1", c_int), ("aux2", c_void_p), ("ld2", c_int), ("hid", c_int),
         ("pre", c_void_p), ("ldpre", c_int),
         ("rmask", c_void_p * 3), ("ldmask", c_int * 3), ("maskc", c_int * 3),
-        ("wpk_frag", c_void_p), ("srcr", c_void_p * 3), ("srcrld", c_int * 3), ("pad_h1", c_int), ("pad_w1", c_int),
+        ("wpk_frag", c_void_p), ("pad_h1", c_int), ("pad_w1", c_int),
         ("ws", c_void_p), ("ws_floats", c_int64),
     ]
 
@@ -192,8 +192,7 @@ def load():
     for kv in filter(None, os.environ.get("FSRAFT_TUNING", "").split(",")):
         key, val = (int(v) for v in kv.split("="))
         if lib.fsraft_set_tuning(key, val) != 0:
-            raise RuntimeError(f"FSRAFT_TUNING: key {key} is not in this build of libfsraft (experiment kernels live in "
-                               "libfsraft_ablate.so: make -C flow_supervisor_amd/csrc ablate, FSRAFT_LIB_PATH=...)")
+            raise RuntimeError(f"FSRAFT_TUNING: key {key} is not a tuning key of this libfsraft (include/fsraft_tuning.h)")
     wsplit = os.environ.get("FSRAFT_WGRAD_SPLIT")
     if wsplit is not None:
         lib.fsraft_set_tuning(4, int(wsplit))

@@ -220,10 +220,6 @@ struct BufConvALoader {
     }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
-#ifdef FSRAFT_ABLATE
-    // experiment: bit 4 stages A as if it were stored pre-split (copy, no conversion) -- wrong numbers, right cost
-    if (__builtin_amdgcn_readfirstlane(g_fsraft_ablate) & 16) { stage_copy<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4); return; }
-#endif
     stage_convert<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
   }
 };
@@ -273,19 +269,6 @@ struct BufWeightLoader {                  // pre-split packed weights through on
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
     stage_copy<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
-  }
-  // LDS-direct form (split_mainloop_bdma): chunk e lands at image + 16 e; dvoff[j] = the SOURCE offset of the 16 bytes
-  // that belong there under the row swizzle (row e >> 3, physical slot e & 7 <- logical slot (e & 7) ^ ((row >> 1) & 7))
-  unsigned dvoff[NCH];
-  __device__ __forceinline__ void dma_tile(int kt, char* image) const {
-    const int ku = __builtin_amdgcn_readfirstlane(kt);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ku < 0 ? 0u : nbytes);
-    const unsigned soff = ku < 0 ? 0u : (unsigned)ku * 128u;
-    const int w0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(image + (w0 * 64 + Cfg::NT * j) * 16), 16,
-                                               dvoff[j], soff, 0, 0);
   }
 };
 
@@ -682,7 +665,6 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
     for (int j = 0; j < BufWeightLoader<Cfg>::NCH; ++j) {
       const int e = threadIdx.x + Cfg::NT * j;
       lb.voff[j] = (e >> 3) < a.N - n0 ? (unsigned)((e >> 3) * a.Ktot * 4 + (e & 7) * 16) : FS_OOB;
-      lb.dvoff[j] = (e >> 3) < a.N - n0 ? (unsigned)((e >> 3) * a.Ktot * 4 + (((e & 7) ^ ((e >> 4) & 7)) * 16)) : FS_OOB;
     }
     if constexpr (BUF >= 2) {
       BufConvALoaderU<Cfg> la;
@@ -690,8 +672,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
       const unsigned ldb = uni((unsigned)args.uld * 4u);
 #pragma unroll
       for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.voff0[j] = pofs[j] * ldb + la.kq16; }
-      if constexpr (BUF == 3) split_mainloop_bdma<Cfg>(lds, KTs, la, lb, acc);
-      else split_mainloop<Cfg, BufConvALoaderU<Cfg>, BufWeightLoader<Cfg>, true>(lds, KTs, la, lb, acc);
+      split_mainloop<Cfg, BufConvALoaderU<Cfg>, BufWeightLoader<Cfg>, true>(lds, KTs, la, lb, acc);
     } else {
       BufConvALoader<Cfg> la;
       la.ld0x4 = uni(a.src[0].ld * 4); la.ld1x4 = uni(a.src[1].ld * 4); la.ld2x4 = uni(a.src[2].ld * 4);
@@ -930,9 +911,6 @@ int launch_halo(const HaloArgs& h, hipStream_t s) {
   return fs_launch_status();
 }
 
-#ifdef FSRAFT_EXPERIMENTS
-#include "conv_c64.inc"      // lost its A/B (322 vs 237 us): only in the experiment build (make ablate)
-#endif
 
 // ---------------------------------------------------------------- weight gradient
 struct WgradArgs {
@@ -1604,9 +1582,6 @@ int g_conv_halo = 1;           // resident-patch 3x3 kernel for few-channel laye
 int g_conv_halo_min_m = 65536;
 int g_wgrad_xcd = 1;           // XCD-aware workgroup order in the multi-segment weight gradient (key 22; 2: the few-channel kernel too).
                                // Measured: 10.73 -> 9.72 ms/step of weight-gradient time (15 K-tiles re-read each dY tile)
-#ifdef FSRAFT_EXPERIMENTS
-int g_conv_bdma = 0;           // LDS-direct weight tiles in the wide implicit-GEMM kernels (key 24, experiment)
-#endif
 int g_wgrad_patch = 1;         // resident-pixel-block weight gradient for the 3x3 / 1x5 / 5x1 layers (wgrad_patch.inc, key 27)
 int g_wgrad_pack = 1;          // few-channel single-source layers on conv_wgrad_pack_kernel (key 16)
 int g_wgrad_patch1 = 8192;     // single-segment 3x3 layers with at least this many pixels on the resident-block kernel (key 29; 0: never)
@@ -1752,13 +1727,6 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvArgs a, cons
   }
 }
 
-inline bool g_conv_bdma_on() {
-#ifdef FSRAFT_EXPERIMENTS
-  return g_conv_bdma != 0;
-#else
-  return false;
-#endif
-}
 int g_conv_ksplit = -1;          // -1 auto (small grids only), 0 / 1 off, >= 2 forced slice count (fsraft_set_tuning key 32)
 // Split-K scratch: the ABI allocates nothing, the caller lends it -- per CALL (fsraft_conv_desc.ws, what the Python mirror does) or,
 // for bindings written against the round-3 header, per calling THREAD (fsraft_conv_workspace).  Both live in thread_local storage,
@@ -1807,7 +1775,7 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
     // split-K route (small M): partial tiles into the workspace, then conv_finish_kernel with the layer's own epilogue
     const int ldw = (a.N + 3) / 4 * 4;
     const bool gru_ok = epi == EPI_PLAIN || (a.N % 4 == 0 && (!a.pre || a.ldpre % 4 == 0));
-    const int S = (buf && g_conv_ws && gru_ok && !(g_conv_bdma_on()) && (Cfg::BM == 64 || (Cfg::BM == 128 && Cfg::NT == 512) || g_conv_ksplit >= 2)) ? pick_ksplit((int64_t)grid.x * grid.y, a.Ktot / 32, a.N, M, ldw, Cfg::BM) : 1;
+    const int S = (buf && g_conv_ws && gru_ok && (Cfg::BM == 64 || (Cfg::BM == 128 && Cfg::NT == 512) || g_conv_ksplit >= 2)) ? pick_ksplit((int64_t)grid.x * grid.y, a.Ktot / 32, a.N, M, ldw, Cfg::BM) : 1;
     if (S > 1) {
       const bool uni_tab = build_ktab_uniform(a, t);
       if (uni_tab || build_ktab(a, t)) {
@@ -1834,14 +1802,6 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
   }
   if (buf && build_ktab_uniform(a, t)) {
     t.a.swz = swz;
-#ifdef FSRAFT_EXPERIMENTS
-    if constexpr (Cfg::NT != 256 && Cfg::PITCH == 128 && Cfg::BN == 128) {
-      if (g_conv_bdma && epi == EPI_PLAIN) {      // experiment (key 24): weight tiles by LDS-direct loads
-        hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 3>), grid, dim3(Cfg::NT), 0, s, t);
-        return fs_launch_status();
-      }
-    }
-#endif
     if (epi == EPI_PLAIN) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else if (epi == EPI_ZR) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_ZR, 2>), grid, dim3(Cfg::NT), 0, s, t);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_Q, 2>), grid, dim3(Cfg::NT), 0, s, t);
@@ -1891,15 +1851,8 @@ int launch_conv(const ConvArgs& a, int epi, hipStream_t s) {
   return fs_launch_status();
 }
 
-#ifdef FSRAFT_EXPERIMENTS
-int g_conv_rec = 1;        // record-activation kernel (conv_rec.inc): 0 off, 1 layers with > 128 outputs, 2 every layer it can run
-#include "conv_rec.inc"
-#endif
 int g_conv_patch_min_m = 8192;   // ... from this many pixels on (key 31)
 int g_conv_patch = 1;      // resident-patch, channel-streaming kernel for the 3x3 / 1x5 / 5x1 layers (conv_patch.inc, key 26; 2: 128-pixel tiles too)
-#ifdef FSRAFT_EXPERIMENTS
-int g_conv_c64 = 0;        // experiment (key 30 = minimum pixel count): 64 -> 64 3x3 layers on conv3x3_c64_kernel (resident weights) -- 322 vs 237 us, off
-#endif
 int g_conv_patch64 = 1;    // ... also for the 3x3 layers with 33..64 outputs (64-column tiles; key 28; 2: 128-pixel tiles)
 #include "conv_patch.inc"
 
@@ -1928,7 +1881,6 @@ struct fsraft_conv_desc {
   const float* pre; int ldpre;   // GRU epilogues: addend to the pre-activation (e.g. the context part of the conv), or NULL
   const float* rmask[3]; int ldmask[3]; int maskc[3];   // epi 0, per destination: zero column j < maskc where rmask[m*ldmask+j] <= 0
   const float* wpk_frag;         // wpk_split in fragment order (or NULL): enables the resident-patch 3x3 kernel
-  const float* srcr[3]; int srcrld[3];   // the sources as record tensors (or NULL): enables the LDS-DMA kernel (conv_rec.inc)
   int pad_h1, pad_w1;            // 0: taps centred (KH / 2, KW / 2); else 1 + the top / left padding (even kernel sizes)
   float* ws; int64_t ws_floats;  // split-K scratch of THIS call (NULL: the calling thread's fsraft_conv_workspace registration)
 };
@@ -2001,29 +1953,10 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     // Measured (scripts/conv_micro.py, halo on / off): 64 -> 64 at 8x220x512 238 vs 442 us.  With three or four channel
     // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
     // GEMM (96 -> 96 at 8x110x256: 249 vs 165 us; 128 -> 128 at 8x55x128: 93 vs 65 us), so only two-group layers come here.
-#ifdef FSRAFT_EXPERIMENTS
-    if (g_conv_c64 && d->srcC[0] == 64 && d->N == 64 && (int64_t)d->B * d->H * d->W >= g_conv_c64) return launch_conv_c64(h, stream);
-#endif
     if (want_stats) { h.st_sum = t_stat.sum; h.st_sq = t_stat.sq; h.st_slots = t_stat.slots; halo_stats = true; }
     t_stat.done = halo_stats;
     return d->N > 64 ? launch_halo<2, 2>(h, stream) : launch_halo<2, 1>(h, stream);
   }
-#ifdef FSRAFT_EXPERIMENTS
-  if (g_conv_rec && g_conv_split == 1 && d->wpk_split && d->srcr[0] && (d->N > 128 || g_conv_rec == 2) && d->N > 32 &&
-      (d->epi != EPI_PLAIN || epilogue_rows_ok_host(a))) {
-    ConvArgs r = a;
-    bool ok = true;
-    for (int s = 0; s < d->nsrc; ++s) {
-      ok = ok && d->srcr[s] != nullptr;
-      r.src[s].p = d->srcr[s]; r.src[s].ld = d->srcrld[s];
-    }
-    r.wpk = d->wpk_split;
-    if (ok) {
-      const int rc = launch_conv_rec(r, d->epi, stream);
-      if (rc >= 0) return rc;
-    }
-  }
-#endif
   if (d->N <= 32 && d->epi == EPI_PLAIN) return launch_conv<Cfg32>(a, d->epi, stream);
   // 33..64 outputs: half of a 64x128 split tile is padding, still ~2x faster than the exact 64-wide kernel
   if (d->N <= 64 && d->epi == EPI_PLAIN && !(g_conv_split && d->wpk_split && g_conv_buf)) return launch_conv<Cfg64>(a, d->epi, stream);
@@ -2087,11 +2020,6 @@ extern "C" int fsraft_conv_forward_stats(const fsraft_conv_desc* d, float* sum, 
   return rc;
 }
 
-#ifdef FSRAFT_ABLATE
-extern "C" int fsraft_set_ablate(int mask) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_fsraft_ablate), &mask, sizeof(int)) == hipSuccess ? FS_OK : FS_ERR_LAUNCH;
-}
-#endif
 
 // The split-K route of the small-M convolutions needs a scratch buffer; the ABI allocates nothing, so the binding hands one
 // over (and keeps it alive): per call in fsraft_conv_desc.ws, or -- this entry point -- for every later call of the CALLING THREAD
@@ -2139,11 +2067,6 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 20) g_conv_halo = value;
   else if (key == 21) g_conv_halo_min_m = value;
   else if (key == 22) g_wgrad_xcd = value;
-#ifdef FSRAFT_EXPERIMENTS
-  else if (key == 24) g_conv_bdma = value;
-  else if (key == 25) g_conv_rec = value;
-  else if (key == 30) g_conv_c64 = value;
-#endif
   else if (key == 26) g_conv_patch = value;
   else if (key == 31) g_conv_patch_min_m = value;
   else if (key == 32) g_conv_ksplit = value;

@@ -541,489 +541,9 @@ __global__ __launch_bounds__(512) void corr_build_rec_kernel(const char* __restr
   }
 }
 
-#ifdef FSRAFT_EXPERIMENTS
-// ---- the same build with the roles of the operands swapped: TARGETS on the MFMA's M (register) axis, QUERIES on its N
-// (lane) axis -- so that the finished tile leaves straight from the accumulators.  In the 32x32 accumulator layout a lane
-// owns one column and registers 4 j .. 4 j + 3 hold four consecutive rows: with the 256 targets of an 8x32 patch numbered
-// in tiled-row order ((8x8 block = wave row wm) (tile row mt) (tile column) (row of the tile) (cell)), those four rows are
-// the 16 contiguous bytes of one row of a 4x4 tile in the volume row of the lane's QUERY.  Every store instruction of the
-// epilogue writes 16 bytes per lane (the two half-waves write the two halves of a 32-byte run of each of 32 queries); the
-// pyramid levels are pooled in registers (v_permlane32_swap adds the two rows a half-wave pair holds and redistributes
-// whole tile rows), nothing is parked in LDS and no barrier follows the k-loop: the workgroup retires while its stores
-// drain and the next one starts staging on the same CU.  (Round 2's epilogue parked the tile in LDS in two halves with ten
-// barriers; measured 455-490 us against 210 us of store time and 171 us of MFMA time.)
-using BT = RecCfg<256, 128, 4, 2>;                         // 256 targets (M) x 128 queries (N), K = C
-constexpr int BT_PH = 8, BT_PW = 32;                       // the target patch
-
-__device__ __forceinline__ void swap32(float& a, float& b) {       // a.upper <-> b.lower (rows of 32 lanes)
-  // Inline asm, not __builtin_amdgcn_permlane32_swap: with the builtin hipcc (ROCm 7.2) SLP-packed the neighbouring adds
-  // and then consumed the FIRST result twice (`v_add_f32 v, r0, r0`) while the register of the second was reused -- every
-  // pooled level came out wrong (scripts/build_t_micro.py caught it).  The s_nop covers the VALU-write -> permlane-read
-  // hazard the assembler does not see inside an asm statement.
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
-// STAMP (experiment build only, scripts/build_stamps.py): lane 0 of wave 0 records s_memtime at the phase boundaries, the
-// constant-rate clock at both ends and the hardware id of its CU -- where a workgroup's 20 us go, and what its CU ran before.
-template <bool STAMP>
-__global__ __launch_bounds__(512) void corr_build_rec_t_kernel(const char* __restrict__ f1r, const char* __restrict__ f2r,
-                                                               float* __restrict__ vol, VolLayout L, int C, float scale, int stagger,
-                                                               unsigned long long* __restrict__ stamps) {
-  __shared__ __attribute__((aligned(1024))) char lds[BT::LDS_BYTES];
-  unsigned long long st[8];
-  if constexpr (STAMP) { st[0] = __builtin_amdgcn_s_memtime(); st[5] = __builtin_amdgcn_s_memrealtime(); }
-  build_stagger(STAMP ? (stagger & 63) : stagger);
-  const int H = L.H, W = L.W, N = H * W;
-  const int npx = ceil_div_dev(W, BT_PW);
-  const int px0 = (blockIdx.x % npx) * BT_PW, py0 = (blockIdx.x / npx) * BT_PH;
-  const int q0 = blockIdx.y * BT::BN;
-  const int b = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned pitch = (unsigned)C * 4u;
-  RecOperands<BT> o;
-  o.da = rec_desc(f2r + (int64_t)b * N * pitch, (unsigned)min((int64_t)N * pitch, (int64_t)0x7fffffff));
-  const int br = min(BT::BN, N - q0);
-  o.db = rec_desc(f1r + ((int64_t)b * N + q0) * pitch, (unsigned)br * pitch);
-  o.b_step = 128u;
-#pragma unroll
-  for (int j = 0; j < BT::NPB; ++j) o.vb[j] = rec_piece_voff(wave + BT::NWAVE * j, lane, br, pitch);
-  RecPlainA<BT> pa;
-#pragma unroll
-  for (int j = 0; j < BT::NPA; ++j) {                      // tile row m = target in tiled-row order of the patch
-    const int m = (wave + BT::NWAVE * j) * 8 + (lane >> 3);
-    const int i32 = m & 31;
-    const int y = py0 + 4 * ((m >> 5) & 1) + ((i32 >> 2) & 3), x = px0 + 8 * (m >> 6) + 4 * (i32 >> 4) + (i32 & 3);
-    const int ls = (lane & 7) ^ ((m >> 1) & 7);
-    pa.va[j] = (y < H && x < W) ? (unsigned)(y * W + x) * pitch + (unsigned)ls * 16u : 0x80000000u;
-  }
-  pa.kt0 = 0; pa.step = 128u;
-  f32x16 acc[BT::TM][BT::TN];
-#pragma unroll
-  for (int a = 0; a < BT::TM; ++a)
-#pragma unroll
-    for (int c = 0; c < BT::TN; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-  if constexpr (STAMP) st[1] = __builtin_amdgcn_s_memtime();
-  rec_mainloop<BT>(lds, o, pa, 0, C / 32, acc);
-  if constexpr (STAMP) st[2] = __builtin_amdgcn_s_memtime();
-
-  // ---- epilogue, from registers.  Lane (l31, lh) of wave (wm, wn): query q0 + 64 wn + 32 nt + l31; accumulator register
-  // 4 j + e of tile mt is target (tile row mt, tile column j >> 1, row lh + 2 (j & 1) of the tile, cell e) of 8x8 block wm.
-  const int wm = wave / BT::WN, wn = wave % BT::WN, l31 = lane & 31, lh = lane >> 5;
-  const int nlev = L.nlev;
-  const int bx0 = px0 + 8 * wm;                            // the wave's 8x8 block of targets: (py0, bx0)
-#pragma unroll
-  for (int nt = 0; nt < BT::TN; ++nt) {
-    const int q = q0 + wn * 64 + nt * 32 + l31;
-    const bool qok = q < N && !(STAMP && (stagger & 64));        // (stamp build: bit 6 of `stagger` = ablate the stores)
-    float* row = vol + ((int64_t)b * N + (qok ? q : 0)) * L.P;
-    float l1v[2][4];                                       // level-1 cell (y1 = 2 mt + (j & 1), x1 = 2 (j >> 1) + lh)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int gty = (py0 >> 2) + mt;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] * scale;
-        const int gtx = (bx0 >> 2) + (j >> 1);
-        if (qok && gty < L.th[0] && gtx < L.tw[0])
-          gstore4(row + L.off[0] + (gty * L.tw[0] + gtx) * 16 + (lh + 2 * (j & 1)) * 4, v);
-        float p0 = v[0] + v[1], p1 = v[2] + v[3];          // this lane's row of the two 2x2 cells; the partner half-wave has the other row
-        swap32(p0, p1);
-        l1v[mt][j] = (p0 + p1) * 0.25f;
-      }
-    }
-    if (nlev > 1) {
-      const int h1 = L.h[1], w1 = L.w[1];
-      const int gty = py0 >> 3, gtx = bx0 >> 3;            // the block is exactly one level-1 tile
-      float l2p[2][2];                                     // own half of level-2 cell (y2 = mt, x2 = tx)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        l2p[mt][0] = l1v[mt][0] + l1v[mt][1];
-        l2p[mt][1] = l1v[mt][2] + l1v[mt][3];
-        // cells beyond the floor-halved size do not exist in the reference pyramid: the tile's pad cells hold 0
-        float r[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int y1 = (py0 >> 1) + 2 * mt + (j & 1), x1 = (bx0 >> 1) + 2 * (j >> 1) + lh;
-          r[j] = (y1 < h1 && x1 < w1) ? l1v[mt][j] : 0.f;
-        }
-        // rows a = 2 mt (j = 0, 2) and b = 2 mt + 1 (j = 1, 3): lower half-wave collects row a, upper row b
-        swap32(r[0], r[1]);
-        swap32(r[2], r[3]);
-        if (qok && gty < L.th[1] && gtx < L.tw[1])
-          gstore4(row + L.off[1] + (gty * L.tw[1] + gtx) * 16 + (2 * mt + lh) * 4, f32x4{r[0], r[1], r[2], r[3]});
-      }
-      if (nlev > 2) {
-        const int h2 = L.h[2], w2 = L.w[2];
-        float c0[2];                                       // level-2 cell (y2 = mt, x2 = lh)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          float a0 = l2p[mt][0], a1 = l2p[mt][1];
-          swap32(a0, a1);
-          c0[mt] = (a0 + a1) * 0.25f;
-        }
-        const int Y2 = py0 >> 2, X2 = bx0 >> 2;            // level-2 cells (Y2 + mt, X2 + lh); both even
-        float m0 = (Y2 < h2 && X2 + lh < w2) ? c0[0] : 0.f, m1 = (Y2 + 1 < h2 && X2 + lh < w2) ? c0[1] : 0.f;
-        swap32(m0, m1);                                    // lower half-wave: row Y2, cells X2, X2 + 1; upper: row Y2 + 1
-        const int gy = Y2 + lh;
-        if (qok && (gy >> 2) < L.th[2] && (X2 >> 2) < L.tw[2]) {
-          float* d = row + L.off[2] + ((gy >> 2) * L.tw[2] + (X2 >> 2)) * 16 + (gy & 3) * 4 + (X2 & 3);
-          gstore1(d, m0);
-          gstore1(d + 1, m1);
-        }
-        if (nlev > 3) {
-          float t0 = c0[0] + c0[1], t1 = t0;
-          swap32(t0, t1);
-          const float v3 = (t0 + t1) * 0.25f;
-          const int gy3 = py0 >> 3, gx3 = bx0 >> 3;
-          if (qok && lh == 0 && (gy3 >> 2) < L.th[3] && (gx3 >> 2) < L.tw[3])
-            gstore1(row + vol_cell(L, 3, gy3, gx3), (gy3 < L.h[3] && gx3 < L.w[3]) ? v3 : 0.f);
-        }
-      }
-    }
-  }
-  if constexpr (STAMP) {
-    st[3] = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    st[4] = __builtin_amdgcn_s_memtime();
-    st[6] = __builtin_amdgcn_s_memrealtime();
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    st[7] = (unsigned long long)hw | (unsigned long long)xcc << 32;
-    if (threadIdx.x == 0) {
-      const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) stamps[(size_t)id * 8 + i] = st[i];
-    }
-  }
-}
-
-// ---- persistent build: one workgroup per CU walks a list of tiles as ONE continuous k-step pipeline ---------------------
-// What the stamps of corr_build_rec_t_kernel showed (scripts/build_stamps.py, 4 x 55x128, per workgroup = per tile):
-// 0.5 us of setup + ~2 us until the first k-tile has landed + 8.2 us for the eight k-steps (+3.7 us when the rest of the chip
-// is storing) + 4.5 us of store issue + 0.9 us of drain, one after the other because a CU holds one workgroup (147 KB of LDS)
-// and a wave cannot retire under its stores.  Here the DMA ring never drains between tiles (the pieces of the next tile's
-// first k-tiles are issued during the last k-steps of this one), and a tile's epilogue is DEFERRED: at the end of a tile
-// the accumulators move to a second register set and their scaling, pooling and stores are cut into sixteen chunks that
-// ride in the sixteen MFMA phases of the NEXT tile.  vmcnt is one in-order counter for DMA pieces and stores, so the
-// counted waits of the ring include the stores of the last two phases -- which is only exact if every store is issued:
-// nothing in a chunk is predicated, lanes without a valid destination write to a dump area.
-// Tile order: blocks of 4 patches x 8 query blocks; the 32 workgroups that share blockIdx.x % 8 (one XCD under round-robin
-// dispatch -- speed only) work on the 32 tiles of one block at a time: 2 MB of operands for 12 MB of staging.
-__device__ float g_build_dump[8 * 64 * 4];
-
-struct PTileInfo {          // what the deferred epilogue needs to know about the tile it stores
-  unsigned row[2];          // byte offset of the volume row of this lane's query for nt = 0, 1
-  int py0, bx0;             // the wave's 8x8 block of targets
-  bool qok[2];
-};
-
-// DEFER: how many of a wave's two query halves (nt) have their epilogue deferred into the next tile's MFMA phases (the other
-// 2 - DEFER are stored in a burst at the end of the tile).  DEFER = 2 needs a full second accumulator set and spills
-// (256 VGPRs + scratch traffic that also counts in vmcnt); DEFER = 1 keeps the kernel at two waves per SIMD without spills.
-template <int KT, int DEFER>
-__global__ __launch_bounds__(512) void corr_build_rec_p_kernel(const char* __restrict__ f1r, const char* __restrict__ f2r,
-                                                               float* __restrict__ vol, VolLayout L, int C, float scale, int Bn, int policy) {
-  using Cfg = BT;
-  constexpr int NPA = Cfg::NPA, NPB = Cfg::NPB;
-  __shared__ __attribute__((aligned(1024))) char lds[Cfg::LDS_BYTES];
-  const int H = L.H, W = L.W, N = H * W;
-  const int npx = ceil_div_dev(W, BT_PW), NP = npx * ceil_div_dev(H, BT_PH), NQB = ceil_div_dev(N, Cfg::BN);
-  const int NPG = ceil_div_dev(NP, 4), NQG = ceil_div_dev(NQB, 8), NB = Bn * NPG * NQG;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN, l31 = lane & 31, lh = lane >> 5;
-  const unsigned pitch = (unsigned)C * 4u;
-  const int xg = blockIdx.x & 7, li = blockIdx.x >> 3, pi = li >> 3, qi = li & 7;
-  const int nlev = L.nlev;
-  char* const dump = reinterpret_cast<char*>(g_build_dump + (wave * 64 + lane) * 4);
-  char* const volb = reinterpret_cast<char*>(vol);
-  // ONE descriptor per operand for the whole launch (all samples); a tile lives in the per-lane offsets, rows that do not
-  // exist get an offset beyond the descriptor's range (-> zeros)
-  const unsigned all_bytes = (unsigned)min((int64_t)Bn * N * pitch, (int64_t)0x7fffffff);
-  const u32x4 da = rec_desc(f2r, all_bytes), db = rec_desc(f1r, all_bytes);
-
-  struct Ops { unsigned va[NPA], vb[NPB]; int b, py0, px0, q0; bool valid; };
-  int blk = xg - 8;
-  auto next_tile = [&](Ops& o) {                        // advance to this workgroup's next existing tile and stage its operand addressing
-    o.valid = false;
-    for (;;) {
-      blk += 8;
-      if (blk >= NB) break;
-      const int qg = blk % NQG, pg = (blk / NQG) % NPG, b = blk / (NQG * NPG);
-      const int patch = pg * 4 + pi, qb = qg * 8 + qi;
-      if (patch >= NP || qb >= NQB) continue;
-      o.b = b; o.px0 = (patch % npx) * BT_PW; o.py0 = (patch / npx) * BT_PH; o.q0 = qb * Cfg::BN; o.valid = true;
-      break;
-    }
-#pragma unroll
-    for (int j = 0; j < NPB; ++j) {
-      const int r = (wave + Cfg::NWAVE * j) * 8 + (lane >> 3);
-      const int ls = (lane & 7) ^ ((r >> 1) & 7);
-      o.vb[j] = (o.valid && o.q0 + r < N) ? (unsigned)(o.b * N + o.q0 + r) * pitch + (unsigned)ls * 16u : 0x80000000u;
-    }
-#pragma unroll
-    for (int j = 0; j < NPA; ++j) {
-      const int m = (wave + Cfg::NWAVE * j) * 8 + (lane >> 3);
-      const int i32 = m & 31;
-      const int y = o.py0 + 4 * ((m >> 5) & 1) + ((i32 >> 2) & 3), x = o.px0 + 8 * (m >> 6) + 4 * (i32 >> 4) + (i32 & 3);
-      const int ls = (lane & 7) ^ ((m >> 1) & 7);
-      o.va[j] = (o.valid && y < H && x < W) ? (unsigned)(o.b * N + y * W + x) * pitch + (unsigned)ls * 16u : 0x80000000u;
-    }
-  };
-
-  const unsigned wbase = (unsigned)(uintptr_t)lds + (unsigned)wave * 1024u;
-  auto issue_a = [&](const Ops& o, int kt, int SL, int j) {
-    rec_dma16(o.va[j], da, (unsigned)kt * 128u, wbase + (unsigned)(SL * Cfg::SLOT + Cfg::NWAVE * j * 1024));
-  };
-  auto issue_b = [&](const Ops& o, int kt, int SL, int j) {
-    rec_dma16(o.vb[j], db, (unsigned)kt * 128u, wbase + (unsigned)(SL * Cfg::SLOT + Cfg::A_BYTES + Cfg::NWAVE * j * 1024));
-  };
-  struct Frag { bf16x8r ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN]; };
-  const int ra = wm * (Cfg::TM * 32) + l31, rb = wn * (Cfg::TN * 32) + l31;
-  const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
-  const char* fa = lds + ra * 128;
-  const char* fb = lds + Cfg::A_BYTES + rb * 128;
-  auto read_frag = [&](int SL, int s, Frag& f) {
-#pragma unroll
-    for (int mt = 0; mt < Cfg::TM; ++mt) {
-      f.ah[mt] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((2 * s + lh) ^ sa) << 4));
-      f.al[mt] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((4 + 2 * s + lh) ^ sa) << 4));
-    }
-#pragma unroll
-    for (int nt = 0; nt < Cfg::TN; ++nt) {
-      f.bh[nt] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((2 * s + lh) ^ sb) << 4));
-      f.bl[nt] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((4 + 2 * s + lh) ^ sb) << 4));
-    }
-  };
-  constexpr int NIMM = 2 - DEFER, ND = DEFER > 0 ? DEFER : 1;
-  f32x16 acc[2][2], accp[2][ND];                         // accp[mt][d]: query half nt = NIMM + d of the previous tile
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) acc[a][c][r] = 0.f;
-#pragma unroll
-      for (int c = 0; c < ND; ++c) accp[a][c][r] = 0.f;
-    }
-  auto mfmas = [&](const Frag& f, auto&& piece, int npiece) {
-    constexpr int NM = Cfg::TM * Cfg::TN;
-#pragma unroll
-    for (int mt = 0; mt < Cfg::TM; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < Cfg::TN; ++nt) {
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
-        const int i = mt * Cfg::TN + nt;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (k < npiece && (k * NM) / npiece == i) {
-            __builtin_amdgcn_sched_barrier(0);
-            piece(k);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-      }
-  };
-
-  // ---- the epilogue in 24 pieces of ONE store each (see corr_build_rec_t_kernel for the register maths): per query half nt,
-  // pieces 12 nt + 0..7 = the (mt, j) groups of level 0, + 8 / 9 = level 1 rows of mt = 0 / 1, + 10 = level 2, + 11 = level 3.
-  // Every store is issued (a lane without a destination writes to the dump): the ring's waits count them.
-  PTileInfo pvd, pvi;                                    // the tile whose deferred pieces are running / the tile that just finished
-  pvd.row[0] = pvd.row[1] = 0u; pvd.py0 = 0; pvd.bx0 = 0; pvd.qok[0] = pvd.qok[1] = false;
-  pvi = pvd;
-  float l1v[2][4], c2[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    c2[a] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) l1v[a][r] = 0.f;
-  }
-  auto st4 = [&](bool ok, unsigned off, f32x4 v) { vstore4(reinterpret_cast<float*>(ok ? volb + off : dump), v, policy); };
-  // s0 / s1 = the accumulators of (mt = 0 / 1, nt) of the tile `pv` describes
-  auto piece_ep = [&](auto IDc, const PTileInfo& pv, const f32x16& s0, const f32x16& s1) {
-    constexpr int id = decltype(IDc)::value, nt = id / 12, w = id % 12;
-    if constexpr (w < 8) {                               // level 0, group (mt, j)
-      constexpr int mt = w >> 2, j = w & 3;
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (mt ? s1 : s0)[4 * j + e] * scale;
-      const int gty = (pv.py0 >> 2) + mt, gtx = (pv.bx0 >> 2) + (j >> 1);
-      st4(pv.qok[nt] && gty < L.th[0] && gtx < L.tw[0],
-          pv.row[nt] + (unsigned)(L.off[0] + (gty * L.tw[0] + gtx) * 16 + (lh + 2 * (j & 1)) * 4) * 4u, v);
-      float p0 = v[0] + v[1], p1 = v[2] + v[3];
-      swap32(p0, p1);
-      l1v[mt][j] = (p0 + p1) * 0.25f;
-    } else if constexpr (w < 10) {                       // level 1, tile rows 2 mt and 2 mt + 1
-      constexpr int mt = w - 8;
-      const int gty = pv.py0 >> 3, gtx = pv.bx0 >> 3;
-      float r[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int y1 = (pv.py0 >> 1) + 2 * mt + (j & 1), x1 = (pv.bx0 >> 1) + 2 * (j >> 1) + lh;
-        r[j] = (y1 < L.h[1] && x1 < L.w[1]) ? l1v[mt][j] : 0.f;
-      }
-      float a0 = l1v[mt][0] + l1v[mt][1], a1 = l1v[mt][2] + l1v[mt][3];
-      swap32(a0, a1);
-      c2[mt] = (a0 + a1) * 0.25f;
-      swap32(r[0], r[1]);
-      swap32(r[2], r[3]);
-      st4(nlev > 1 && pv.qok[nt] && gty < L.th[1] && gtx < L.tw[1],
-          pv.row[nt] + (unsigned)(L.off[1] + (gty * L.tw[1] + gtx) * 16 + (2 * mt + lh) * 4) * 4u, f32x4{r[0], r[1], r[2], r[3]});
-    } else if constexpr (w == 10) {                      // level 2: rows Y2, Y2 + 1, cells X2, X2 + 1
-      const int Y2 = pv.py0 >> 2, X2 = pv.bx0 >> 2;
-      float m0 = (Y2 < L.h[2] && X2 + lh < L.w[2]) ? c2[0] : 0.f, m1 = (Y2 + 1 < L.h[2] && X2 + lh < L.w[2]) ? c2[1] : 0.f;
-      swap32(m0, m1);
-      const int gy = Y2 + lh;
-      const bool ok = nlev > 2 && pv.qok[nt] && (gy >> 2) < L.th[2] && (X2 >> 2) < L.tw[2];
-      char* d = ok ? volb + pv.row[nt] + (unsigned)(L.off[2] + ((gy >> 2) * L.tw[2] + (X2 >> 2)) * 16 + (gy & 3) * 4 + (X2 & 3)) * 4u : dump;
-      typedef float f32x2s __attribute__((ext_vector_type(2)));
-      *(FS_GLOBAL f32x2s*)d = f32x2s{m0, m1};
-    } else {                                             // level 3: the block's mean
-      float t0 = c2[0] + c2[1], t1 = t0;
-      swap32(t0, t1);
-      const float v3 = (t0 + t1) * 0.25f;
-      const int gy3 = pv.py0 >> 3, gx3 = pv.bx0 >> 3;
-      const bool ok = nlev > 3 && pv.qok[nt] && lh == 0 && (gy3 >> 2) < L.th[3] && (gx3 >> 2) < L.tw[3];
-      gstore1(reinterpret_cast<float*>(ok ? volb + pv.row[nt] + (unsigned)vol_cell(L, 3, gy3, gx3) * 4u : dump),
-              (gy3 < L.h[3] && gx3 < L.w[3]) ? v3 : 0.f);
-    }
-  };
-  // the 12 DEFER deferred pieces (ids 12 NIMM ..) are dealt over the 2 KT MFMA phases of the next tile
-  constexpr int NPH = 2 * KT, NDEF = 12 * DEFER, DBASE = NDEF / NPH, DEXTRA = NDEF % NPH;
-  auto dcount = [](int p) constexpr { return DBASE + (p < DEXTRA ? 1 : 0); };
-  auto deferred = [&](auto Pc) {
-    constexpr int p = decltype(Pc)::value;
-    constexpr int n = DBASE + (p < DEXTRA ? 1 : 0), f = 12 * NIMM + p * DBASE + (p < DEXTRA ? p : DEXTRA);
-    if constexpr (n > 0) piece_ep(std::integral_constant<int, f>{}, pvd, accp[0][f / 12 - NIMM], accp[1][f / 12 - NIMM]);
-    if constexpr (n > 1) piece_ep(std::integral_constant<int, f + 1>{}, pvd, accp[0][(f + 1) / 12 - NIMM], accp[1][(f + 1) / 12 - NIMM]);
-    if constexpr (n > 2) piece_ep(std::integral_constant<int, f + 2>{}, pvd, accp[0][(f + 2) / 12 - NIMM], accp[1][(f + 2) / 12 - NIMM]);
-    static_assert(n <= 3, "at most three pieces per phase");
-  };
-
-  Ops cur, nxt;
-  next_tile(cur);
-  if (!cur.valid) return;
-  // ring prologue: k-tiles 0 and 1 whole, the A pieces of k-tile 2
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-#pragma unroll
-    for (int j = 0; j < NPA; ++j) issue_a(cur, t, t, j);
-#pragma unroll
-    for (int j = 0; j < NPB; ++j) issue_b(cur, t, t, j);
-  }
-#pragma unroll
-  for (int j = 0; j < NPA; ++j) issue_a(cur, 2, 2, j);
-  rec_wait_vm<NPA + NPA + NPB>();
-  __builtin_amdgcn_s_barrier();
-  Frag f0, f1;
-  read_frag(0, 0, f0);
-
-  // one tile = KT k-steps; S0 = ring slot of its first k-tile
-  auto tile_body = [&](auto S0c) {
-    constexpr int S0 = decltype(S0c)::value;
-    next_tile(nxt);
-    auto kstep = [&](auto KTc) {
-      constexpr int kt = decltype(KTc)::value;
-      constexpr int SL = (S0 + kt) % 3, SN = (SL + 1) % 3, SP = (SL + 2) % 3;
-      constexpr int p0 = 2 * kt, p1 = 2 * kt + 1, pprev = (p0 + NPH - 1) % NPH;
-      read_frag(SL, 1, f1);
-      __builtin_amdgcn_sched_barrier(0);
-      deferred(std::integral_constant<int, p0>{});
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(f0, [&](int k) { if constexpr (kt + 2 < KT) issue_b(cur, kt + 2, SP, k); else issue_b(nxt, kt + 2 - KT, SP, k); }, NPB);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // k-tile (this + 1) landed; in flight: the pieces of (this + 2), the stores of the last two phases and, behind the last
-      // phase of a tile, the burst of the halves that are not deferred
-      rec_wait_vm<NPA + NPB + dcount(pprev) + dcount(p0) + (kt == 0 ? 12 * NIMM : 0)>();
-      __builtin_amdgcn_s_barrier();
-      read_frag(SN, 0, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      deferred(std::integral_constant<int, p1>{});
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(f1, [&](int k) { if constexpr (kt + 3 < KT) issue_a(cur, kt + 3, SL, k); else issue_a(nxt, kt + 3 - KT, SL, k); }, NPA);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
-    kstep(std::integral_constant<int, 3>{});
-    if constexpr (KT == 8) {
-      kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{}); kstep(std::integral_constant<int, 6>{});
-      kstep(std::integral_constant<int, 7>{});
-    }
-    // the finished tile: the halves that are not deferred leave now, the others move to the deferred set
-    pvi.py0 = cur.py0; pvi.bx0 = cur.px0 + 8 * wm;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int q = cur.q0 + wn * 64 + nt * 32 + l31;
-      pvi.qok[nt] = q < N;
-      pvi.row[nt] = (unsigned)(cur.b * N + (pvi.qok[nt] ? q : 0)) * (unsigned)(L.P * 4);
-    }
-    if constexpr (NIMM > 0) {
-      auto burst = [&](auto NTc) {
-        constexpr int nt = decltype(NTc)::value;
-        piece_ep(std::integral_constant<int, 12 * nt + 0>{}, pvi, acc[0][nt], acc[1][nt]); piece_ep(std::integral_constant<int, 12 * nt + 1>{}, pvi, acc[0][nt], acc[1][nt]);
-        piece_ep(std::integral_constant<int, 12 * nt + 2>{}, pvi, acc[0][nt], acc[1][nt]); piece_ep(std::integral_constant<int, 12 * nt + 3>{}, pvi, acc[0][nt], acc[1][nt]);
-        piece_ep(std::integral_constant<int, 12 * nt + 4>{}, pvi, acc[0][nt], acc[1][nt]); piece_ep(std::integral_constant<int, 12 * nt + 5>{}, pvi, acc[0][nt], acc[1][nt]);
-        piece_ep(std::integral_constant<int, 12 * nt + 6>{}, pvi, acc[0][nt], acc[1][nt]); piece_ep(std::integral_constant<int, 12 * nt + 7>{}, pvi, acc[0][nt], acc[1][nt]);
-        piece_ep(std::integral_constant<int, 12 * nt + 8>{}, pvi, acc[0][nt], acc[1][nt]); piece_ep(std::integral_constant<int, 12 * nt + 9>{}, pvi, acc[0][nt], acc[1][nt]);
-        piece_ep(std::integral_constant<int, 12 * nt + 10>{}, pvi, acc[0][nt], acc[1][nt]); piece_ep(std::integral_constant<int, 12 * nt + 11>{}, pvi, acc[0][nt], acc[1][nt]);
-      };
-      burst(std::integral_constant<int, 0>{});
-      if constexpr (NIMM > 1) burst(std::integral_constant<int, 1>{});
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if constexpr (DEFER > 0) {
-#pragma unroll
-          for (int d = 0; d < DEFER; ++d) accp[a][d][r] = acc[a][NIMM + d][r];
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[a][c][r] = 0.f;
-      }
-    pvd = pvi;
-    cur = nxt;
-  };
-  static_assert(KT == 8 || KT == 4, "unrolled for C = 256 / 128");
-  for (;;) {                                             // the ring slot of a tile's first k-tile cycles with period 3
-    tile_body(std::integral_constant<int, 0>{});
-    if (!cur.valid) break;
-    tile_body(std::integral_constant<int, KT % 3>{});
-    if (!cur.valid) break;
-    tile_body(std::integral_constant<int, (2 * KT) % 3>{});
-    if (!cur.valid) break;
-  }
-  // the last tile's deferred pieces have no MFMA phases to ride in
-  if constexpr (DEFER > 0) {
-    auto flush = [&](auto Dc) {
-      constexpr int d = decltype(Dc)::value, nt = NIMM + d;
-      piece_ep(std::integral_constant<int, 12 * nt + 0>{}, pvd, accp[0][d], accp[1][d]); piece_ep(std::integral_constant<int, 12 * nt + 1>{}, pvd, accp[0][d], accp[1][d]);
-      piece_ep(std::integral_constant<int, 12 * nt + 2>{}, pvd, accp[0][d], accp[1][d]); piece_ep(std::integral_constant<int, 12 * nt + 3>{}, pvd, accp[0][d], accp[1][d]);
-      piece_ep(std::integral_constant<int, 12 * nt + 4>{}, pvd, accp[0][d], accp[1][d]); piece_ep(std::integral_constant<int, 12 * nt + 5>{}, pvd, accp[0][d], accp[1][d]);
-      piece_ep(std::integral_constant<int, 12 * nt + 6>{}, pvd, accp[0][d], accp[1][d]); piece_ep(std::integral_constant<int, 12 * nt + 7>{}, pvd, accp[0][d], accp[1][d]);
-      piece_ep(std::integral_constant<int, 12 * nt + 8>{}, pvd, accp[0][d], accp[1][d]); piece_ep(std::integral_constant<int, 12 * nt + 9>{}, pvd, accp[0][d], accp[1][d]);
-      piece_ep(std::integral_constant<int, 12 * nt + 10>{}, pvd, accp[0][d], accp[1][d]); piece_ep(std::integral_constant<int, 12 * nt + 11>{}, pvd, accp[0][d], accp[1][d]);
-    };
-    flush(std::integral_constant<int, 0>{});
-    if constexpr (DEFER > 1) flush(std::integral_constant<int, 1>{});
-  }
-  rec_wait_vm<0>();
-}
-
-#endif  // FSRAFT_EXPERIMENTS
 
 int g_build_policy = -1;  // cache policy of the volume stores (vstore4): -1 auto, 0 plain, 1 sc1, 2 nt
 int g_build_stagger = 0;  // see build_stagger (fsraft_set_build_kernel: bits 8.. of the argument)
-int g_build_t = 0;        // 0: corr_build_rec_kernel (LDS-parked epilogue); experiment build only: 1: corr_build_rec_t_kernel (stores from the accumulators:
-                          // measured 8-14 % SLOWER as a one-tile-per-workgroup kernel, scripts/build_t_micro.py -- it is the epilogue
-                          // of the persistent kernel below)
 int g_build_split = 1;    // 0: exact fp32 MFMA build, 1: split-bf16 (fsraft_set_build_split)
 
 // Backward of the pooling chain, folded into level 0 in place:
@@ -1184,22 +704,6 @@ extern "C" int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vo
   if (!f1r || !f2r || !vol || B < 1 || C < 32 || (C % 32) || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
   if (((uintptr_t)vol % 16) || ((uintptr_t)f1r % 16) || ((uintptr_t)f2r % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff) return FS_ERR_ARG;
   const int N = H * W;
-#ifdef FSRAFT_EXPERIMENTS
-  if (g_build_t >= 2 && (C == 256 || C == 128) && (int64_t)B * N * C * 4 < 0x7fffffff && (int64_t)B * N * L.P * 4 < (int64_t)0xffffffff) {
-#define BUILD_P(KTV, DEF) hipLaunchKernelGGL((corr_build_rec_p_kernel<KTV, DEF>), dim3(256), dim3(512), 0, stream, (const char*)f1r, \
-                                             (const char*)f2r, vol, L, C, 1.0f / sqrtf((float)C), B, g_build_policy)
-    if (C == 256) { if (g_build_t == 3) BUILD_P(8, 0); else if (g_build_t == 4) BUILD_P(8, 2); else BUILD_P(8, 1); }
-    else { if (g_build_t == 3) BUILD_P(4, 0); else BUILD_P(4, 1); }
-#undef BUILD_P
-    return fs_launch_status();
-  }
-  if (g_build_t) {
-    dim3 grid(ceil_div(W, BT_PW) * ceil_div(H, BT_PH), ceil_div(N, BT::BN), B);
-    hipLaunchKernelGGL(corr_build_rec_t_kernel<false>, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
-                       1.0f / sqrtf((float)C), g_build_stagger, (unsigned long long*)nullptr);
-    return fs_launch_status();
-  }
-#endif
   dim3 grid(ceil_div(W, BR_PW) * ceil_div(H, BR_PH), ceil_div(N, BR::BM), B);
   // `nt` stores once the volume is larger than the Infinity Cache: measured 497 -> 430 us at 4 x 55x128 (1.08 GB), 196 -> 165 us
   // at 8 x 46x62; at one pair (270 MB) plain stores are as fast or faster (scripts/build_t_micro.py)
@@ -1209,26 +713,12 @@ extern "C" int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vo
   return fs_launch_status();
 }
 
-#ifdef FSRAFT_EXPERIMENTS
-// fsraft_corr_build_rec with per-workgroup time stamps: stamps[8 * workgroups] (see corr_build_rec_t_kernel<true>)
-extern "C" int fsraft_corr_build_rec_stamps(const void* f1r, const void* f2r, float* vol, int num_levels, int B, int C, int H, int W,
-                                            unsigned long long* stamps, hipStream_t stream) {
-  VolLayout L;
-  if (!f1r || !f2r || !vol || !stamps || !vol_layout_make(H, W, num_levels & 0xff, L)) return FS_ERR_ARG;     // (bits 8..: stagger / ablation)
-  const int N = H * W;
-  dim3 grid(ceil_div(W, BT_PW) * ceil_div(H, BT_PH), ceil_div(N, BT::BN), B);
-  hipLaunchKernelGGL(corr_build_rec_t_kernel<true>, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
-                     1.0f / sqrtf((float)C), num_levels >> 8, stamps);
-  return fs_launch_status();
-}
-#endif
 
 extern "C" int fsraft_set_build_split(int on) {
   g_build_split = on ? 1 : 0;
   return FS_OK;
 }
-extern "C" int fsraft_set_build_kernel(int which) {      // 1: stores from the accumulators (default), 0: LDS-parked epilogue
-  g_build_t = which & 0xff;
+extern "C" int fsraft_set_build_kernel(int which) {      // bits 8..15: start-up stagger (build_stagger); bits 16..18: store policy
   g_build_stagger = (which >> 8) & 0xff;
   g_build_policy = ((which >> 16) & 7) - 1;           // bits 16..18: 0 auto, 1 plain, 2 sc1, 3 nt
   return FS_OK;

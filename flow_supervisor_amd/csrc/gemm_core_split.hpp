@@ -107,11 +107,6 @@ __device__ __forceinline__ void stage_copy(char* tile, int e, const float* r) {
   *reinterpret_cast<f32x4*>(tile + slot_offset<PITCH>(e >> 3, e & 7)) = f32x4{r[0], r[1], r[2], r[3]};
 }
 
-#ifdef FSRAFT_ABLATE
-// Experiment build only (make ablate): a run-time mask removes pipeline stages so their cost can be measured.
-// bit 0: no LDS staging, bit 1: no MFMA, bit 2: no LDS fragment reads (and no MFMA), bit 3: no global loads.
-__device__ int g_fsraft_ablate;
-#endif
 
 // STRAIGHT selects the shape of the k-loop (both compute the same thing):
 //   false: tail conditions inside the body.  The compiler re-shapes that loop and waits for vmcnt(0) before each
@@ -144,11 +139,7 @@ __device__ int g_fsraft_ablate;
 template <class Cfg, class LA, class LB, bool STRAIGHT = false>
 __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
                                                f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
-#ifdef FSRAFT_ABLATE
-  const int abl = __builtin_amdgcn_readfirstlane(g_fsraft_ablate);
-#else
   constexpr int abl = 0;
-#endif
   static_assert(LA::NCH == Cfg::NCH_A && LB::NCH == Cfg::NCH_B, "loader tile shape must match the config");
   static_assert(Cfg::NBUF == 2, "the two-deep prefetch schedule needs two LDS images");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -250,88 +241,6 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
     stage(buf0, ra0, rb0);                           // tile kt+2
     fetch(kt + 4, ra0, rb0);
     FSRAFT_SCHED_GROUPS();
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Variant of the branch-free k-loop in which the pre-split weight tile never passes through registers: every wave
-// moves its 1 KB slice(s) of the B image with `buffer_load ... lds` (the swizzle is applied by permuting which 16 bytes a
-// lane FETCHES; the LDS side of the instruction is fixed at lane * 16).  The compiler waits vmcnt(0) before the first
-// LDS read that follows an outstanding LDS-DMA, so the half-trip is ordered: all fragment reads -> A loads for tile
-// t+2 -> DMA of B tile t+1 -> MFMAs -> convert / store A tile t+1 -> barrier; the wait then falls at the top of the next
-// half, one k-tile of MFMA time after the loads were issued.
-template <class Cfg, class LA, class LB>
-__device__ __forceinline__ void split_mainloop_bdma(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
-                                                    f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
-  static_assert(Cfg::NBUF == 2 && Cfg::PITCH == 128, "two swizzled LDS images");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const int l31 = lane & 31, lh = lane >> 5;
-  float ra0[LA::NREG], ra1[LA::NREG];
-  auto fetch_a = [&](int kt, float (&ra)[LA::NREG]) { fetch_all(la, kt < KT ? kt : KT - 1, ra); };
-  auto stage_a = [&](char* dst, const float (&ra)[LA::NREG]) {
-#pragma unroll
-    for (int c = 0; c < LA::NCH; ++c) la.stage_chunk(dst, ra + 4 * c, c);
-  };
-  struct Frags { bf16x8 ah[2][Cfg::TM], al[2][Cfg::TM], bh[2][Cfg::TN], bl[2][Cfg::TN]; };
-  auto read_frags = [&](const char* cur, Frags& f) {
-    const int ra = wm * (Cfg::TM * 32) + l31, rb = wn * (Cfg::TN * 32) + l31;
-    const char* As = cur + ra * 128;
-    const char* Bs = cur + Cfg::A_BYTES + rb * 128;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int oah = slot_offset<128>(ra, 2 * s + lh) - ra * 128, oal = slot_offset<128>(ra, 4 + 2 * s + lh) - ra * 128;
-      const int obh = slot_offset<128>(rb, 2 * s + lh) - rb * 128, obl = slot_offset<128>(rb, 4 + 2 * s + lh) - rb * 128;
-#pragma unroll
-      for (int mt = 0; mt < Cfg::TM; ++mt) {
-        f.ah[s][mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * 128 + oah);
-        f.al[s][mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * 128 + oal);
-      }
-#pragma unroll
-      for (int nt = 0; nt < Cfg::TN; ++nt) {
-        f.bh[s][nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * 128 + obh);
-        f.bl[s][nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * 128 + obl);
-      }
-    }
-  };
-  auto mfmas = [&](const Frags& f) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int mt = 0; mt < Cfg::TM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < Cfg::TN; ++nt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[s][mt], f.bh[s][nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[s][mt], f.bl[s][nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[s][mt], f.bh[s][nt], acc[mt][nt], 0, 0, 0);
-        }
-  };
-  if (KT <= 0) return;
-  char* buf0 = lds;
-  char* buf1 = lds + Cfg::STAGE;
-  fetch_a(0, ra0);
-  lb.dma_tile(0, buf0 + Cfg::A_BYTES);
-  fetch_a(1, ra1);
-  stage_a(buf0, ra0);
-  __syncthreads();
-  Frags f;
-  for (int kt = 0; kt < KT; kt += 2) {
-    read_frags(buf0, f);                                   // tile kt
-    __builtin_amdgcn_sched_barrier(0);
-    fetch_a(kt + 2, ra0);
-    lb.dma_tile(kt + 1 < KT ? kt + 1 : -1, buf1 + Cfg::A_BYTES);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(f);
-    stage_a(buf1, ra1);                                    // tile kt+1
-    __syncthreads();
-    read_frags(buf1, f);                                   // tile kt+1 (B zero when past the end)
-    __builtin_amdgcn_sched_barrier(0);
-    fetch_a(kt + 3, ra1);
-    lb.dma_tile(kt + 2 < KT ? kt + 2 : -1, buf0 + Cfg::A_BYTES);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(f);
-    stage_a(buf0, ra0);                                    // tile kt+2
     __syncthreads();
   }
 }

@@ -1128,14 +1128,12 @@ def unpack_weight_grad(dwpk, shape, srcC, out=None, accumulate=False):
 
 
 class V:
-    """Channels [off, off+C) of a channels-last buffer [B,H,W,ld] (pitch = the buffer's ld).  `rec`: optionally the same
-    buffer as records (to_records(t): [B,H,W,ceil32(ld)]) for the LDS-DMA convolution kernel; needs off % 32 == 0."""
-    __slots__ = ("t", "off", "C", "ld", "rec")
+    """Channels [off, off+C) of a channels-last buffer [B,H,W,ld] (pitch = the buffer's ld)."""
+    __slots__ = ("t", "off", "C", "ld")
 
-    def __init__(self, t, C=None, off=0, rec=None):
+    def __init__(self, t, C=None, off=0):
         self.t, self.off, self.ld = t, off, t.shape[-1]
         self.C = (t.shape[-1] - off) if C is None else C
-        self.rec = rec if (rec is not None and off % 32 == 0) else None
         assert off % 4 == 0 and self.ld % 4 == 0, "channel slices must stay 16-byte aligned"
 
     @property
@@ -1195,8 +1193,6 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     d = L.ConvDesc()
     for i, v in enumerate(srcs):
         d.src[i] = v.ptr; d.srcC[i] = v.C; d.srcld[i] = v.ld
-        if v.rec is not None:
-            d.srcr[i] = v.rec.data_ptr() + 4 * v.off; d.srcrld[i] = v.rec.shape[-1]
     d.nsrc = len(srcs)
     d.wpk = wpk.data_ptr()
     d.wpk_split = wpk_split.data_ptr() if wpk_split is not None else None

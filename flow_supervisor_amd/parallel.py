@@ -19,10 +19,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(device_type=None, backend=None):
+def init_distributed(device_type=None, backend=None, timeout_s=None):
     """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
     backend: nccl (= RCCL on ROCm) for GPU tensors, gloo for CPU tests; backend="gloo" with GPU tensors (several ranks
-    sharing one device, which RCCL refuses -- the 2-process GPU test) stages the exchange through host memory."""
+    sharing one device, which RCCL refuses -- the 2-process GPU test) stages the exchange through host memory.
+    timeout_s: bound on the rendezvous and on every collective (default: torch's, 10 min for nccl) -- a rank that never
+    arrives then ends the job with an exception on the others instead of a hang (bench.py sets it)."""
+    kw = {}
+    if timeout_s is not None:
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -33,12 +39,12 @@ def init_distributed(device_type=None, backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if device_type == "cuda" and backend == "gloo":
             torch.cuda.set_device(local)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
         elif device_type == "cuda":
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

@@ -176,10 +176,6 @@ typedef struct fsraft_conv_desc {
                                                                  [lane = 32 * (k half) + row][16 B], rows zero-padded to 32;
                                                                  enables the resident-patch 3x3 kernel (one source, 33..64
                                                                  channels in, N <= 64, large B*H*W).  NULL: never used */
-  const float* srcr[3]; int srcrld[3];                        /* optional: the same sources as RECORD tensors (fsraft_to_records of
-                                                                 the whole channels-last buffer; pointer = its channel slice, which
-                                                                 must start at a multiple of 32 channels; pitch in floats): the
-                                                                 operand is then staged by LDS-DMA with no conversion.  NULL: unused */
   int pad_h1, pad_w1;                                         /* 0: taps centred (KH/2, KW/2 rows / columns above / left of
                                                                  the output pixel); else 1 + that count -- even kernel sizes:
                                                                  a 2x2 kernel has pad 1 forward and pad 0 in its data gradient */

@@ -6,9 +6,9 @@
  * kernel variants inside one process, and so that the parity suite can run the GEMM families in either arithmetic mode
  * one by one (fsraft_set_arithmetic of fsraft.h switches them together).
  *
- * Kernels that lost their A/B (LDS-direct weight tiles, key 24; record-activation convolution, key 25; resident-weight
- * 64 -> 64 kernel, key 30) are compiled only into the experiment build (`make -C flow_supervisor_amd/csrc ablate` ->
- * libfsraft_ablate.so, -DFSRAFT_EXPERIMENTS); in libfsraft.so those keys return FSRAFT_ERR_ARG.
+ * Kernels that lost their A/B twice (LDS-direct weight tiles, record-activation convolution, resident-weight 64 -> 64 kernel,
+ * the transposed-role / persistent volume builds; keys 24 / 25 / 30 of earlier rounds) were removed from the tree in round 5: their
+ * measurements are in docs/history/ and profiles/; the keys return FSRAFT_ERR_ARG.
  */
 #ifndef FSRAFT_TUNING_H
 #define FSRAFT_TUNING_H
@@ -29,7 +29,7 @@ extern "C" {
 int fsraft_set_tuning(int key, int value);
 int fsraft_get_tuning(int key);   /* keys 3 / 4 */
 int fsraft_set_build_split(int on);   /* volume build: 1 bf16x3 (default), 0 exact fp32 MFMA */
-int fsraft_set_build_kernel(int which); /* record build: 1 stores from the accumulators (default), 0 round 2's LDS-parked epilogue */
+int fsraft_set_build_kernel(int which); /* record build: bits 8..15 start-up stagger of odd workgroups (x 64 x 127 cycles), bits 16..18 store policy (0 auto, 1 plain, 2 sc1, 3 nt) */
 /* cache policy of the tiled lookup's window loads: -1 auto (nt for volumes beyond the Infinity Cache; default), 0 plain, 2 nt,
  * 16 sc1, 18 nt + sc1 (A/B switch); 100 = measurement only: the nt window loads alone, no blends and no output (the gather floor of
  * the tiled layout, scripts/lookup_gather_floor.py) */

@@ -1,7 +1,7 @@
 # refresh of the judged evidence: bench line via the driver's launch line, kernel stats, PMC traffic, variants, round-4 micro evidence
 # usage (on the GPU box, repo root): FSRAFT_COMMIT=<short sha> bash scripts/refresh_evidence.sh <tag>   -> gpurun_out/*_<tag>*,
 # copied to profiles/ by hand (gpurun_out/ is scratch)
-tag=${1:-r04}
+tag=${1:-r05}
 export MIOPEN_FIND_MODE=2
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench_${tag}_1gpu.json
 cut -c1-300 gpurun_out/bench_${tag}_1gpu.json
@@ -14,15 +14,18 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_${tag}_gpus2_shared.json; cut -c1-200 gpurun_out/bench_${tag}_gpus2_shared.json
 python bench.py --variant gma --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_gma.json; cut -c1-200 gpurun_out/bench_${tag}_gma.json
 python bench.py --variant alt --height 376 --width 1248 --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_alt.json; cut -c1-200 gpurun_out/bench_${tag}_alt.json
+# the alt variant's kernel summary (no r04 summary was kept) and the reference-shaped shell over the swapped blocks
+bash scripts/prof.sh ${tag}_alt --variant alt --height 376 --width 1248 --batch-per-gpu 1
+python bench.py --variant dropin --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_dropin.json; cut -c1-200 gpurun_out/bench_${tag}_dropin.json
 python bench.py --height 368 --width 496 --batch-per-gpu 8 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_chairs.json; cut -c1-200 gpurun_out/bench_${tag}_chairs.json
 python bench.py --variant l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_l2l.json
 python bench.py --variant gma_l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_gma_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_gma_l2l.json
-# round 4: gradient-volume kernels under PMC, the lookup's gather floor, per-layer convolution times
+# gradient-volume kernels under PMC, the lookup's gather floor, per-layer convolution times
 bash scripts/dvol_pmc.sh ${tag} > /dev/null 2>&1
 python scripts/dvol_micro.py 2>&1 | tail -9 > gpurun_out/dvol_micro_${tag}.txt
 python scripts/lookup_gather_floor.py 2>&1 | tail -2 > gpurun_out/lookup_gather_floor_${tag}.txt
 python scripts/layer_times.py > gpurun_out/layer_times_${tag}.txt 2>&1
-# matrix-pipe busy x clock of the convolution kernels (PMC + kernel trace; VERDICT r3 next #2 asks for the round-4 record)
+# matrix-pipe busy x clock of the convolution kernels (PMC + kernel trace)
 {
   echo "# Matrix-pipe busy fraction and the clock the convolution kernels ran at (scripts/mfma_busy.sh: one PMC pass with the kernel trace,"
   echo "# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and GRBM_GUI_ACTIVE / 8 / duration), commit ${FSRAFT_COMMIT:-?}."

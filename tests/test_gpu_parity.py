@@ -42,13 +42,6 @@ def precision(request):
     _ops.set_arithmetic(True)
 
 
-def _experiment_build(lib, key):
-    """Kernels that lost their A/B live in libfsraft_ablate.so only (make -C flow_supervisor_amd/csrc ablate;
-    FSRAFT_LIB_PATH=flow_supervisor_amd/csrc/build/ablate/libfsraft_ablate.so): in the shipped library their tuning keys are refused."""
-    if lib.fsraft_set_tuning(key, 0) != 0:
-        pytest.skip(f"tuning key {key}: experiment kernel, not in the shipped libfsraft.so")
-
-
 def _native():
     from flow_supervisor_amd import _lib
     _lib.load()
@@ -1453,39 +1446,6 @@ def test_conv3x3_resident_patch_kernel(B, C, N, H, W):
         lib.fsraft_set_tuning(21, 65536)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 20, 32), (1, 13, 37), (3, 33, 70), (1, 3, 5), (2, 220, 96)])
-def test_conv3x3_resident_weights_kernel(B, H, W):
-    """conv3x3_c64_kernel (csrc/conv_c64.inc, fsraft_set_tuning key 30): 64 -> 64 3x3 layers with one 32-column block of the
-    weights resident in LDS and a persistent walk over 4x32 tiles -- forward with bias + ReLU, the data gradient, and the
-    accumulating epilogue (out += result), against F.conv2d; ragged sizes, more tiles than workgroup pairs (2 x 220 x 96 =
-    330 tiles on 128 sequences) and fewer."""
-    from flow_supervisor_amd import _lib, ops
-    lib = _lib.load()
-    _experiment_build(lib, 30)
-    lib.fsraft_set_tuning(3, 1); lib.fsraft_set_tuning(4, 2)
-    lib.fsraft_set_tuning(21, 0); lib.fsraft_set_tuning(30, 1)
-    try:
-        C = N = 64
-        torch.manual_seed(11 + H)
-        w = torch.randn(N, C, 3, 3, device=DEV) * 0.1
-        bias = torch.randn(N, device=DEV)
-        x = torch.randn(B, H, W, C, device=DEV)
-        packs = dict(wpk_split=ops.pack_weight(w, [C], 10), wpk_frag=ops.fragment_order(ops.pack_weight(w, [C], 10)))
-        out = torch.full((B, H, W, N), float("nan"), device=DEV)
-        ops.conv_forward([ops.V(x, C)], ops.pack_weight(w, [C], 0), bias, B, H, W, 3, 3, N, [ops.Dst.nhwc(out)], relu=True, **packs)
-        ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=1)).permute(0, 2, 3, 1)
-        close(out, ref, 1e-4, what="resident-weights conv fwd")
-        g = torch.randn(B, H, W, N, device=DEV)
-        base = torch.randn(B, H, W, C, device=DEV)
-        dx = base.clone()
-        ops.conv_forward([ops.V(g, N)], ops.pack_weight(w, [C], 1), None, B, H, W, 3, 3, C, [ops.Dst.nhwc(dx, acc=True)],
-                         wpk_split=ops.pack_weight(w, [C], 11), wpk_frag=ops.fragment_order(ops.pack_weight(w, [C], 11)))
-        dref = torch.nn.grad.conv2d_input((B, C, H, W), w, g.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
-        close(dx, base + dref, 1e-4, what="resident-weights conv dgrad, accumulating")
-    finally:
-        lib.fsraft_set_tuning(21, 65536); lib.fsraft_set_tuning(30, 0)
-
-
 @pytest.mark.parametrize("B,C,N,H,W", [(2, 64, 96, 20, 32), (1, 96, 128, 6, 10), (2, 8, 16, 14, 4)])
 def test_encoder_strided_pair_space_to_depth(B, C, N, H, W, precision):
     """_StridedPairFn: the 3x3 stride-2 convolution and the 1x1 stride-2 shortcut of a stride-2 residual unit as 2x2 / 1x1
@@ -1932,35 +1892,6 @@ def test_tf_same_pooling_pyramid_and_lookup(H, W):
     close(out.permute(0, 3, 1, 2), ref, 2e-5, what="lookup on the SAME pyramid")
 
 
-def test_lds_direct_weight_tiles_variant_matches_default():
-    """Experiment kept in the library (fsraft_set_tuning key 24, off by default): the wide implicit-GEMM kernels with the weight
-    tile moved by `buffer_load ... lds` (split_mainloop_bdma; the swizzle is applied by permuting the source offsets).  Must
-    give bit-identical results to the register-staged path: same products, same accumulation order."""
-    from flow_supervisor_amd import _lib, ops
-    lib = _lib.load()
-    _experiment_build(lib, 24)
-    lib.fsraft_set_tuning(3, 1); lib.fsraft_set_tuning(4, 2)
-    lib.fsraft_set_tuning(32, 0)        # (no split-K: the default route would cut small grids' k-loops into slices, a different summation order)
-    torch.manual_seed(17)
-    outs = []
-    for B, H, W, cs, N, kh, kw in ((4, 55, 128, [128, 128], 256, 1, 5), (2, 40, 64, [256], 192, 3, 3), (1, 33, 47, [96], 128, 3, 3)):
-        srcs = [torch.randn(B, H, W, c, device=DEV) for c in cs]
-        w = torch.randn(N, sum(cs), kh, kw, device=DEV) * 0.05
-        bias = torch.randn(N, device=DEV)
-        res = []
-        for flag in (0, 1):
-            lib.fsraft_set_tuning(24, flag)
-            out = torch.full((B, H, W, N), float("nan"), device=DEV)
-            ops.conv_forward([ops.V(t, c) for t, c in zip(srcs, cs)], ops.pack_weight(w, cs, 0), bias, B, H, W, kh, kw, N,
-                             [ops.Dst.nhwc(out)], relu=True, wpk_split=ops.pack_weight(w, cs, 10))
-            res.append(out)
-        lib.fsraft_set_tuning(24, 0)
-        if not torch.equal(res[0], res[1]):
-            lib.fsraft_set_tuning(32, -1)
-        assert torch.equal(res[0], res[1]), (B, H, W, cs, N)
-    lib.fsraft_set_tuning(32, -1)
-
-
 @pytest.mark.parametrize("B,H,W,cs,N,kh,kw,nseg", [(2, 13, 37, [128, 128, 128], 256, 1, 5, 3), (1, 21, 40, [256], 192, 3, 3, 2),
                                                     (2, 9, 33, [128, 128], 128, 5, 1, 2), (1, 7, 70, [126], 96, 3, 3, 4),
                                                     (3, 55, 128, [64], 126, 3, 3, 2), (1, 3, 5, [48, 20], 40, 1, 5, 2)])
@@ -2088,37 +2019,6 @@ def test_tiled_row_volume_kernels_match_the_row_major_ones(B, H, W, nlev):
     d1r, d2r = ops.corr_build_bwd_tiled(f1, f2, dvol_r, lay, records=True, f1r=recs[0])
     for got, ref, what in ((d1n, d1o, "dfmap1"), (d2n, d2o, "dfmap2"), (d1r, d1o, "dfmap1 (records)"), (d2r, d2o, "dfmap2 (records)")):
         assert ((got - ref).norm() / ref.norm()).item() < 5e-5, what
-
-
-def test_record_activation_convolution_matches_the_default_kernels():
-    """conv_rec_kernel (csrc/conv_rec.inc: activations supplied as records, staged by LDS-DMA) against the register-staged
-    implicit GEMM on the update block's layer shapes, ragged M, one and two sources, plain and odd-line record pitch."""
-    from flow_supervisor_amd import _lib, ops
-    from flow_supervisor_amd.ops import Dst, V
-    lib = _lib.load()
-    _experiment_build(lib, 25)
-    torch.manual_seed(43)
-    B, H, W = 2, 13, 21
-    try:
-        for kh, kw, cs, cout in ((1, 1, [324], 256), (3, 3, [256], 192), (1, 5, [128, 128], 256), (5, 1, [128, 128], 256), (3, 3, [128], 512),
-                                 (3, 3, [126], 256), (1, 1, [98], 128)):
-            bufs = [torch.randn(B, H, W, (c + 3) // 4 * 4, device=DEV) for c in cs]
-            for b, c in zip(bufs, cs):
-                b[..., c:] = 0
-            w = torch.randn(cout, sum(cs), kh, kw, device=DEV) * 0.05
-            bias = torch.randn(cout, device=DEV)
-            wps = ops.pack_weight(w, cs, 10)
-            outs = []
-            for rec in (0, 1, 2):
-                srcs = [V(b, c, 0, ops.to_records(b, pad=rec == 2) if rec else None) for b, c in zip(bufs, cs)]
-                out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=DEV)
-                lib.fsraft_set_tuning(25, 2 if rec else 0)
-                ops.conv_forward(srcs, wps, bias, B, H, W, kh, kw, cout, [Dst.nhwc(out)], relu=True, wpk_split=wps)
-                outs.append(out)
-            for o in outs[1:]:
-                close(o, outs[0], 2e-5 * max(outs[0].abs().max().item(), 1.0), what=f"conv_rec {kh}x{kw} {cs}->{cout}")
-    finally:
-        lib.fsraft_set_tuning(25, 1)
 
 
 def test_frozen_batchnorm_fold_kernels():
@@ -2465,6 +2365,30 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out["rccl"]["world_size"] == 2 and out["rccl"]["ranks_seen_by_all_reduce"] == 2
     assert out["rccl"]["graph"] == "captured", out["rccl"]
     assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"]     # finite loss on the replayed steps
+    # the self-diagnosing part of the line: one entry per rank for the wall time and for each of the three parts
+    # of the two-graph route, and they add up to the step
+    for k in ("per_rank_ms_per_step", "per_rank_graph_fb_ms", "per_rank_exchange_ms", "per_rank_graph_up_ms"):
+        assert len(out["rccl"][k]) == 2 and all(v > 0 for v in out["rccl"][k]), (k, out["rccl"])
+    parts = [sum(out["rccl"][k][r] for k in ("per_rank_graph_fb_ms", "per_rank_exchange_ms", "per_rank_graph_up_ms")) for r in range(2)]
+    assert all(p <= 1.15 * max(out["rccl"]["per_rank_ms_per_step"]) for p in parts), (parts, out["rccl"])
+
+
+def test_bench_rank_that_cannot_rendezvous_exits_with_a_message(tmp_path):
+    """the first multi-GPU run must not hang.  A rank whose peers never arrive leaves the rendezvous after
+    FSRAFT_DIST_TIMEOUT_S with exit code 3 and one line on stderr that names the rank and the rendezvous address."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               FSRAFT_DIST_TIMEOUT_S="8", FSRAFT_BENCH_SHARED_GPUS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--height", "128",
+                        "--width", "192", "--iters", "2", "--batch-per-gpu", "1", "--no-cpu-baseline", "--no-extra"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert "could not join the process group" in r.stderr and "rank 1" in r.stderr, r.stderr[-1500:]
 
 
 def test_semi_step_reads_inputs_refreshed_in_place():
