@@ -60,7 +60,8 @@ struct SplitCfg {
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NBUF_ * STAGE;
   static constexpr int EPI_BYTES = BM_ * (BN_ + 4) * 4;                         // fp32 tile parked for the row-wise epilogue
-  static constexpr int LDS_ALLOC = LDS_BYTES > EPI_BYTES ? LDS_BYTES : EPI_BYTES;
+  // (a parked tile that does not fit the CU's 160 KB is not parked: the kernels then take the register epilogue)
+  static constexpr int LDS_ALLOC = (LDS_BYTES > EPI_BYTES || EPI_BYTES > 160 * 1024) ? LDS_BYTES : EPI_BYTES;
   static constexpr int NCH_A = BM_ * 8 / NT_, NCH_B = BN_ * 8 / NT_;
   static_assert(WM_ * WN_ * 64 == NT_, "one 64-lane wave per (WM, WN) cell");
 };
