@@ -1560,12 +1560,6 @@ using SCfg128 = SplitCfg<128, 128, 2, 2>;
 using SCfgN256 = SplitCfg<64, 256, 1, 4, 2, true>;   // 80 KB of LDS: two workgroups per CU; each wave owns 64x64, A rows are read once for N = 256
 using SCfg256W16 = SplitCfg<256, 128, 4, 4, 2, true, 1024>;  // sixteen waves, one workgroup per CU
 using SCfg128W8 = SplitCfg<128, 128, 2, 4, 2, true, 512>;   // eight waves per workgroup, 66 KB of LDS: two workgroups per CU
-// wide tiles for the once-per-step 1x1 layers (M = 338 K pixels: mask head and its data gradient, convc1's data gradient): those
-// run at 2.3-2.5 GHz with the matrix pipe 20 % busy -- bound by the 48 KB of fresh A and B tile per k-tile over the ~38 GB/s a CU pulls
-// out of L2, not by power -- so fewer staged bytes per MFMA is time: 256 x 256 stages 64 KB for twice the MFMAs of 256 x 128, 256 x 192
-// 56 KB for 1.5x (N = 576 = 3 x 192, N = 324 -> 2 x 192).  Eight waves of 64 x 128 / 64 x 96.  (key 36)
-using SCfg256N256 = SplitCfg<256, 256, 4, 2, 2, true, 512>;
-using SCfg256N192 = SplitCfg<256, 192, 4, 2, 2, true, 512>;
 using SCfg256N64 = SplitCfg<256, 64, 4, 2, 2, true, 512>;   // N <= 64 layers at large M (encoder layer1, f2): a 128-wide tile would be half empty
 using SCfgM64 = SplitCfg<64, 128, 1, 4, 2, true>;    // swizzled 128-byte rows: 48 KB of LDS -> three workgroups per CU
 int g_wgrad_split = 2;  // 0: exact fp32; 1/2: split-bf16 weight gradient (double / single LDS image)   (key 4)
@@ -1585,8 +1579,6 @@ int g_wgrad_tile = 0;   // 0 auto (128x128), 3 force 64x64                      
 int g_conv_n64 = 1;            // 256x64 tiles for N <= 64 (key 18) once M reaches g_conv_n64_min_m (key 19)
 int g_conv_n64_min_m = 65536;
 int g_conv_halo = 1;           // resident-patch 3x3 kernel for few-channel layers at large M (key 20; threshold key 21)
-int g_conv_wide = 0;           // 256x256 / 256x192 tiles for the 1x1 layers at very large M (key 36: 0 off, 1 auto, 2 force 192, 3 force 256; key 37: minimum pixel count)
-int g_conv_wide_min_m = 200000;
 int g_conv_halo_min_m = 65536;
 int g_wgrad_xcd = 1;           // XCD-aware workgroup order in the multi-segment weight gradient (key 22; 2: the few-channel kernel too).
                                // Measured: 10.73 -> 9.72 ms/step of weight-gradient time (15 K-tiles re-read each dY tile)
@@ -1991,12 +1983,6 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
       const int rc = launch_conv_split_plain<SCfg256N64>(a, stream);
       if (rc >= 0) return rc;
     }
-    if (g_conv_split == 1 && g_conv_wide && d->KH * d->KW == 1 && d->epi == EPI_PLAIN && M >= g_conv_wide_min_m && d->N >= 256) {
-      const int w256 = ceil_div(d->N, 256) * 256, w192 = ceil_div(d->N, 192) * 192;
-      const int rc = (g_conv_wide == 2 || (g_conv_wide == 1 && w192 < w256)) ? launch_conv_split<SCfg256N192>(a, d->epi, stream)
-                                                                            : launch_conv_split<SCfg256N256>(a, d->epi, stream);
-      if (rc >= 0) return rc;
-    }
     // eight-wave 128x128 tiles where they fill the machine in one round (N >= 256 at M ~ 28 K): key 13
     // sixteen-wave 256x128 tiles: a further 3-6 % on the 192..512-output layers (zr 93 -> 87 us), slower on m2 (N = 576)
     if (g_conv_split == 1 && ((g_conv_w8 == 1 && d->N >= 192 && d->N <= 512 && M >= 16384) || g_conv_w8 == 2) && d->N >= 192) {
@@ -2084,8 +2070,6 @@ extern "C" int fsraft_set_tuning(int key, int value) {
   else if (key == 26) g_conv_patch = value;
   else if (key == 31) g_conv_patch_min_m = value;
   else if (key == 32) g_conv_ksplit = value;
-  else if (key == 36) g_conv_wide = value;
-  else if (key == 37) g_conv_wide_min_m = value;
   else if (key == 27) g_wgrad_patch = value;
   else if (key == 28) g_conv_patch64 = value;
   else if (key == 29) g_wgrad_patch1 = value;
