@@ -6,6 +6,13 @@
  * `stream` (no allocation, no synchronisation -> safe under hipGraph capture) and
  * returns 0 (FSRAFT_OK), 1 (bad argument) or 2 (launch failed).
  *
+ * Threads and devices (the reference's multi-GPU caller is nn.DataParallel, pytorch/train.py:192: one host thread per device in
+ * one process).  A call launches on the CALLER's current device -- bind the device of the pointers first (hipSetDevice) -- and
+ * on the stream it is given.  Entry points may be called concurrently from several host threads: no per-call state is shared
+ * (scratch travels in the call, fsraft_conv_desc.ws; fsraft_conv_workspace and the statistics request of
+ * fsraft_conv_forward_stats are per calling thread).  What IS process-wide is configuration -- fsraft_set_arithmetic and the
+ * switches of fsraft_tuning.h -- to be set once, before worker threads start.
+ *
  * Each entry point names the reference interface it replaces, as file:line under
  * /root/reference.  The Python binding a maintainer would add is shown in
  * INTEGRATION.md; ours lives in flow_supervisor_amd/_lib.py.
