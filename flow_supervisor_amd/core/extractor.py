@@ -91,7 +91,7 @@ def _fast(x):
 
 def _as_cl(x):
     """x as a channels_last tensor (no autograd: for use inside Functions).  The tiled fsraft transposes move an NCHW
-    activation at 4-6 TB/s; the framework's strided copy reaches 1.4-2 TB/s on the same tensors (scripts/layout_micro.py)."""
+    activation at 4-6 TB/s; the framework's strided copy reaches 1.4-2 TB/s on the same tensors (round 2, docs/history)."""
     if _is_cl(x):
         return x
     if _fast(x) and x.is_contiguous():

@@ -922,7 +922,7 @@ class MotionBatch:
     into slots of [T,B,H,W,C] buffers; an iteration's backward parks its dmotion in a slot and returns its slot of `dcorr`;
     when slot 0 -- the first iteration, the last to run backward -- has parked its own, `run` executes the four data
     gradients and queues the five weight gradients over T x B x H x W pixels.  4 x T launches become 4, on grids that fill the
-    chip at one pair per GPU (per layer -10..-35 % at four pairs, -50..-75 % at one or two: scripts/batch_gain.sh)."""
+    chip at one pair per GPU (per layer -10..-35 % at four pairs, -50..-75 % at one or two: round 3, docs/history)."""
 
     def __init__(self, eng, T, B, H, W, device, zero=False):
         def e(c):

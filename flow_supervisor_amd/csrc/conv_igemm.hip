@@ -1738,7 +1738,7 @@ thread_local float* g_conv_ws = nullptr;       // the scratch of the call this t
 thread_local int64_t g_conv_ws_floats = 0;
 
 // Slices for a tile grid of `tiles` workgroups, KT k-tiles and N outputs.  Measured (scripts/conv_micro.py, 1 x 47x156, 1 x 46x96,
-// 2 x 46x96, 2 x 54x128; scripts/smallm_sweep.sh): the route pays where fewer than ~half of the CUs have a workgroup AND
+// 2 x 46x96, 2 x 54x128; round 3, docs/history): the route pays where fewer than ~half of the CUs have a workgroup AND
 // the second pass is small -- layers with <= 256 outputs (3x3 256 -> 126: 52 -> 40 us, 1x5 384 -> 128: 42 -> 34, the 3x3
 // 512 -> 128 data gradient: 87 -> 52 us; at 4416 pixels 3x3 256 -> 192: 55 -> 44, 1x5 384 -> 256: 46 -> 39); with 512 outputs
 // the slabs cost more than the shorter k-loops save (3x3 128 -> 512: 37 -> 55 us), and from ~230 tiles on the CUs are busy

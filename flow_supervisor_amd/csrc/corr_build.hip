@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void corr_build_tiled_split_kernel(const float
 // three-slot ring of rec_mainloop.  Epilogue as above, in two halves of 128 queries: parked in LDS, level 0 written as
 // whole 64-byte tiles, levels 1-3 pooled out of LDS.
 // store of the finished volume with a cache policy chosen at run time (fsraft_set_build_kernel bits 16..17; A/B in
-// scripts/build_t_micro.py): 0 plain, 1 `sc1` (write through and DROP the line from the XCD's L2: the 1.08 GB of output then
+// round 3, docs/history): 0 plain, 1 `sc1` (write through and DROP the line from the XCD's L2: the 1.08 GB of output then
 // does not evict the 58 MB of feature records every workgroup re-reads), 2 `nt`.
 __device__ __forceinline__ void vstore4(float* p, f32x4 v, int policy) {
   if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
@@ -706,7 +706,7 @@ extern "C" int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vo
   const int N = H * W;
   dim3 grid(ceil_div(W, BR_PW) * ceil_div(H, BR_PH), ceil_div(N, BR::BM), B);
   // `nt` stores once the volume is larger than the Infinity Cache: measured 497 -> 430 us at 4 x 55x128 (1.08 GB), 196 -> 165 us
-  // at 8 x 46x62; at one pair (270 MB) plain stores are as fast or faster (scripts/build_t_micro.py)
+  // at 8 x 46x62; at one pair (270 MB) plain stores are as fast or faster (round 3, docs/history)
   const int policy = g_build_policy >= 0 ? g_build_policy : ((int64_t)B * N * L.P * 4 > ((int64_t)300 << 20) ? 2 : 0);
   hipLaunchKernelGGL(corr_build_rec_kernel, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
                      1.0f / sqrtf((float)C), g_build_stagger, policy);

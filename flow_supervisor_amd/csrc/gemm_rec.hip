@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void to_records_kernel(const float* __restrict
 namespace {
 // C[b][m][0..N) = 0 for the split-K / accumulate path.  A kernel, not hipMemsetAsync: inside a captured hipGraph the memset
 // node of these calls left the matrix untouched on every replay after the first (the partial tiles were then added to the
-// previous replay's result -- scripts/graph_check.py); a fill kernel is an ordinary graph node.
+// previous replay's result -- found by the round-2 graph-replay checker, docs/history); a fill kernel is an ordinary graph node.
 __global__ __launch_bounds__(256) void zero_matrices_kernel(float* __restrict__ C, int64_t ldc, int64_t sC, int M, int N) {
   float* row = C + (int64_t)blockIdx.z * sC + (int64_t)blockIdx.y * ldc;
   for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) row[n] = 0.f;

@@ -225,7 +225,7 @@ inline bool s2d_ok(int HW, int w) { return w == 0 || (w > 0 && (w & 1) == 0 && H
 
 }  // namespace
 
-extern "C" int fsraft_set_norm_blocks(int target_workgroups) {     // tuning hook (scripts/norm_micro.py)
+extern "C" int fsraft_set_norm_blocks(int target_workgroups) {     // tuning hook
   if (target_workgroups < 64) return FS_ERR_ARG;
   g_cl_target_wgs = target_workgroups;
   return FS_OK;

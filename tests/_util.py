@@ -47,7 +47,7 @@ def _log_margin(what, err, lim, detail):
 def grad_digest_check(named_params, g, tol, prefix="gnorm.", hprefix="ghead.", skip=(), atol_norm=1e-5):
     """Every parameter-gradient norm (and, where the fixture has it, the first 32 elements) against a reference-generated
     digest.  tol: dict(gnorm, ghead, gnorm_fnet, ghead_fnet) -- the feature encoder's gradients pass through InstanceNorm
-    and the volume backward and carry ~1e-3 of summation-order noise in the REFERENCE itself (scripts/encoder_grad_noise.py),
+    and the volume backward and carry ~1e-3 of summation-order noise in the REFERENCE itself (measured in round 2, docs/history),
     so `fnet.*` has its own, wider pair of limits; everything else (update blocks, context encoder, GMA attention) is held
     to the tighter pair.  norm: |ours - ref| <= rtol * ref + atol_norm (atol: biases in front of InstanceNorm have a zero
     gradient in exact arithmetic and ~1e-6 of rounding noise in the reference); head: max abs error <= rtol_head *

@@ -23,7 +23,7 @@ DEV = "cuda"
 # Set to ~4x the worst error measured on MI355X over the whole suite (profiles/r03_parity_margins.txt lists every comparison
 # with the share of its limit it used).  Worst observed, exact / split: loss 7e-7 / 6e-6, prediction 1.2e-4 / 2.2e-4 px,
 # gnorm 3.1e-4 / 3.8e-4, ghead 2.3e-3 / 3.6e-3; fnet: gnorm ~1e-3, ghead 1.9e-2 in BOTH modes (the reference's own
-# run-to-run noise on those gradients, scripts/encoder_grad_noise.py) -- so the fnet pair is not mode dependent.
+# run-to-run noise on those gradients, measured in round 2, docs/history) -- so the fnet pair is not mode dependent.
 # Round 2 ran all of these at 1e-4 / 4e-3 / 5e-3 / 2e-2.
 TRAIN_TOL = {"exact": dict(loss=5e-6, pred=5e-4, gnorm=1.5e-3, ghead=1e-2, gnorm_fnet=5e-3, ghead_fnet=3e-2),
              "split": dict(loss=3e-5, pred=1e-3, gnorm=1.5e-3, ghead=1.5e-2, gnorm_fnet=5e-3, ghead_fnet=3e-2)}
@@ -1619,7 +1619,7 @@ def test_encoder_channels_last_path_matches_nchw_path(kind, norm, s2d, precision
     # Gradients: the exact-mode kernels agree with MIOpen to ~4e-6 (basic/instance) .. 3e-4 (mask flips).  In split mode
     # every layer's data gradient carries ~2^-17 relative rounding noise, and fifteen normalisation backward passes (each
     # subtracts the mean and the xhat-projection of the incoming gradient -- a difference of large numbers for this
-    # random-init, squared-output objective) amplify it to ~6e-3 in the image gradient (scripts/encoder_grad_noise.py measures it).
+    # random-init, squared-output objective) amplify it to ~6e-3 in the image gradient (measured in round 2, docs/history).
     # The bottleneck (small) encoder has half as many channels again per norm and measures 2.8e-2.  The wiring of the path is
     # what the exact-mode run pins down; the split arithmetic itself is bounded per layer by the convolution tests above.
     # (atomic accumulation order makes the flips differ from run to run: the exact-mode bound leaves room for them)
