@@ -34,18 +34,24 @@ def test_s2d_weight_grad_is_the_adjoint():
     assert int((_s2d_weight(torch.ones(1, 1, 3, 3)) != 0).sum()) == 9
 
 
-def test_tf_twins_of_the_volume_refuse_to_be_trained_through():
-    """raft_tf.calc_all_field / build_pyramid / transpose_volume / CorrBlock have no autograd behind them: with a tensor that
-    requires grad they must fail loudly instead of returning outputs without grad_fn."""
+def test_tf_twins_with_same_pooling_refuse_to_be_trained_through():
+    """raft_tf.calc_all_field / build_pyramid / CorrBlock are differentiable on floor-sized pyramids since round 5 (GPU test
+    test_tf_twins_train_through_volume_pyramid_and_lookup); a pyramid that needs TensorFlow's 'SAME' pooling (a pooled size is odd:
+    TF-only semantics, parity-unpinned, no backward kernels) must still fail loudly with a tensor that requires grad instead of
+    returning outputs without grad_fn.  The refusal is decided on the host, before any kernel is asked for."""
     import pytest
     from flow_supervisor_amd import raft_tf
-    a = torch.randn(1, 8, 8, 16, requires_grad=True)
+    a = torch.randn(1, 6, 10, 16, requires_grad=True)            # 6 x 10 -> 3 x 5 -> odd: 'SAME' pooling at num_pool = 2
     with pytest.raises(RuntimeError, match="forward-only"):
-        raft_tf.calc_all_field(a, a.detach(), num_pool=1)
+        raft_tf.calc_all_field(a, a.detach(), num_pool=2)
     with pytest.raises(RuntimeError, match="forward-only"):
-        raft_tf.build_pyramid(torch.randn(1, 4, 4, 4, 4, requires_grad=True), 1)
+        raft_tf.build_pyramid(torch.randn(1, 6, 10, 6, 10, requires_grad=True), 2)
     with pytest.raises(RuntimeError, match="forward-only"):
-        raft_tf.CorrBlock(2, 3)([torch.randn(1, 4, 4, 4, 4)], torch.zeros(1, 4, 4, 2, requires_grad=True))
+        raft_tf.CorrBlock(2, 3)([torch.randn(1, 4, 4, 5, 5, requires_grad=True), torch.randn(1, 4, 4, 3, 3)], torch.zeros(1, 4, 4, 2))
+    # floor-sized pyramids reach the kernels: on CPU tensors that is the library's "no CPU implementation" error, not a silent result
+    b = torch.randn(1, 8, 8, 16, requires_grad=True)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        raft_tf.calc_all_field(b, b.detach(), num_pool=1)
 
 
 def test_gradients_handed_out_back_to_back_come_back_as_one_tensor():
