@@ -390,9 +390,8 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __res
                                                                AltCoords co, float* __restrict__ out, int nlev, int H, int W, int C,
                                                                float scale) {
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN, NRND = (NPOS + 63) / 64;
-  constexpr int PARK = AM_NQ * AM_DP * 4;
+  constexpr int PARK = AM_NQ * AM_DP * 4 + AM_NQ * (NPOS + 1) * 4;      // parked products + every query's window values
   __shared__ __attribute__((aligned(1024))) char lds[AM::LDS_BYTES > PARK ? AM::LDS_BYTES : PARK];
-  __shared__ float win[4][NPOS + 4];
   __shared__ int org[2];
   __shared__ float qxy[AM_NQ][2];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -466,30 +465,31 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __res
   }
   __syncthreads();
 
-  // ---- every wave: its six queries, one after the other (lane = window position, then lane = output channel)
+  // ---- all four waves over all (query, window position) pairs, then over all (query, output channel) pairs (round 5).
+  // Round 3 gave every wave six queries and walked them one after the other -- gather 100 window positions, fence, blend 81
+  // channels, fence: ~29 latency-bound (query, level) rounds per wave at four waves per CU, which is what the 55-60 us of a lookup
+  // were (larger query tiles at the coarse levels, which halve the operand staging, changed nothing: measured).  Now the window
+  // values of ALL the tile's queries go to LDS in one pass of the 256 threads (the ring is free; a position outside the staged
+  // region -- flow discontinuity -- is still computed in fp32 from the channels-last maps by the thread that owns it), one barrier,
+  // and the blends of all queries run in one pass.
   const int CH = nlev * RD * RD;
   const float* f2b = lv.f2[l] + (int64_t)b * H2 * W2 * C;
-  for (int qi = 0; qi < AM_NQ / 4; ++qi) {
-    const int n = wave * (AM_NQ / 4) + qi;
+  float* wins = dots + AM_NQ * AM_DP;                       // [AM_NQ][NPOS], behind the parked products
+  constexpr int WP = NPOS + 1;
+  for (int e = threadIdx.x; e < AM_NQ * NPOS; e += 256) {
+    const int n = e / NPOS, p = e - n * NPOS;
     const int qx = tx * AM_TW + n % AM_TW, qy = ty * AM_TH + n / AM_TW;
-    if (qx >= W || qy >= H) continue;                     // (wave-uniform)
-    const int64_t q = (int64_t)b * N + qy * W + qx;
-    const float cx = qxy[n][0], cy = qxy[n][1];
-    const float flx = floorf(cx), fly = floorf(cy);
-    const int wx0 = (int)flx - R, wy0 = (int)fly - R;
-    const float dx = cx - flx, dy = cy - fly;
-#pragma unroll
-    for (int k = 0; k < NRND; ++k) {
-      const int p = lane + 64 * k;
-      if (p >= NPOS) continue;
+    float v = 0.f;
+    if (qx < W && qy < H) {
+      const float cx = qxy[n][0], cy = qxy[n][1];
+      const int wx0 = (int)floorf(cx) - R, wy0 = (int)floorf(cy) - R;
       const int iy = p / WIN, ix = p - iy * WIN;
       const int gx = wx0 + ix, gy = wy0 + iy, ux = gx - rx0, uy = gy - ry0;
-      float v = 0.f;
       if (gx >= 0 && gx < W2 && gy >= 0 && gy < H2) {
         if (ux >= 0 && ux < RW && uy >= 0 && uy < RH) {
           v = dots[n * AM_DP + uy * RW + ux];
         } else {                                           // outside the staged region: fp32 rows from L2
-          const float* a = f1 + q * C;
+          const float* a = f1 + ((int64_t)b * N + qy * W + qx) * C;
           const float* row = f2b + (int64_t)(gy * W2 + gx) * C;
           for (int c = 0; c < C; c += 4) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(a + c), rv = *reinterpret_cast<const f32x4*>(row + c);
@@ -497,20 +497,20 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __res
           }
         }
       }
-      win[wave][p] = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    float* op = out + q * CH + l * RD * RD;
-    for (int oc = lane; oc < RD * RD; oc += 64) {
-      const int iyo = oc % RD, ixo = oc / RD;             // channel = iy + RD * ix (x offset slow, as the reference)
-      const float* d = win[wave] + iyo * WIN + ixo;
-      op[oc] = scale * ((1.f - dy) * (1.f - dx) * d[0] + (1.f - dy) * dx * d[1] + dy * (1.f - dx) * d[WIN] + dy * dx * d[WIN + 1]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wins[n * WP + p] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < AM_NQ * RD * RD; e += 256) {
+    const int n = e / (RD * RD), oc = e - n * (RD * RD);
+    const int qx = tx * AM_TW + n % AM_TW, qy = ty * AM_TH + n / AM_TW;
+    if (qx >= W || qy >= H) continue;
+    const float cx = qxy[n][0], cy = qxy[n][1];
+    const float dx = cx - floorf(cx), dy = cy - floorf(cy);
+    const int iyo = oc % RD, ixo = oc / RD;                 // channel = iy + RD * ix (x offset slow, as the reference)
+    const float* d = wins + n * WP + iyo * WIN + ixo;
+    out[((int64_t)b * N + qy * W + qx) * CH + l * RD * RD + oc] =
+        scale * ((1.f - dy) * (1.f - dx) * d[0] + (1.f - dy) * dx * d[1] + dy * (1.f - dx) * d[WIN] + dy * dx * d[WIN + 1]);
   }
 }
 
