@@ -35,6 +35,7 @@ class ConvDesc(Structure):
         ("rmask", c_void_p * 3), ("ldmask", c_int * 3), ("maskc", c_int * 3),
         ("wpk_frag", c_void_p), ("pad_h1", c_int), ("pad_w1", c_int),
         ("ws", c_void_p), ("ws_floats", c_int64),
+        ("src_amax", c_void_p * 3), ("w_amax", c_void_p), ("dst_amax", c_void_p * 3),
     ]
 
 
@@ -47,6 +48,7 @@ class PackJob(Structure):
         ("srcC", c_int * 3), ("srcOff", c_int * 3), ("nsrc", c_int),
         ("mode", c_int), ("flags", c_int),
         ("scale", c_float), ("accumulate", c_int),
+        ("amax", c_void_p),
     ]
 
 
@@ -55,7 +57,7 @@ _IP = POINTER(c_int)
 _S = c_void_p   # hipStream_t
 
 SIGNATURES = {
-    "fsraft_corr_build": [c_void_p, c_void_p, _PP, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_build": [c_void_p, c_void_p, _PP, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_corr_unpool_bwd": [_PP, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_lookup_fwd": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_lookup_bwd": [_PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
@@ -68,13 +70,16 @@ SIGNATURES = {
     "fsraft_conv_ktot": [_IP, c_int, c_int, c_int],
     "fsraft_conv_forward": [POINTER(ConvDesc), _S],
     "fsraft_conv_forward_stats": [POINTER(ConvDesc), c_void_p, c_void_p, c_int, POINTER(c_int), _S],
-    "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_conv_wgrad_multi": [_PP, c_int, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_conv_wgrad": [c_void_p, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, _PP, _S],
+    "fsraft_conv_wgrad_multi": [_PP, c_int, c_int, c_int, _PP, _IP, _IP, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _PP, _PP, _S],
+    "fsraft_amax_jobs": [_PP, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), _PP, c_int, _S],
+    "fsraft_amax": [c_void_p, c_int64, c_int64, c_int64, c_void_p, _S],
+    "fsraft_abi_version": [],
     "fsraft_conv_small_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_wgrad": [_PP, _PP, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_dgrad": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_pack_conv_weights": [POINTER(PackJob), c_int, _S],
-    "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, _S],
+    "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_set_rec_mfma16": [c_int],
     "fsraft_set_build_kernel": [c_int],
     "fsraft_set_dvol_policy": [c_int],
@@ -90,13 +95,13 @@ SIGNATURES = {
                           c_float, c_void_p, c_void_p, _S],
     "fsraft_stream_capture_id": [_S, c_void_p],
     "fsraft_stem_slots": [],
-    "fsraft_stem7x7s2_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
-    "fsraft_stem7x7s2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_stem7x7s2_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, _S],
+    "fsraft_stem7x7s2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_set_lookup_qb": [c_int],
     "fsraft_set_build_split": [c_int],
     "fsraft_set_gemm_split": [c_int],
-    "fsraft_gemm_tn_split": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _S],
-    "fsraft_gemm_f32": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _S],
+    "fsraft_gemm_tn_split": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, _S],
+    "fsraft_gemm_f32": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, _S],
     "fsraft_nchw_to_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_im2col7": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
@@ -110,7 +115,7 @@ SIGNATURES = {
     "fsraft_softmax_rows": [c_void_p, c_int64, c_int, _S],
     "fsraft_softmax_rows_bwd": [c_void_p, c_void_p, c_int64, c_int, _S],
     "fsraft_softmax_rows_rec": [c_void_p, c_int64, c_int, _S],
-    "fsraft_softmax_rows_bwd_rec": [c_void_p, c_void_p, c_int64, c_int, _S],
+    "fsraft_softmax_rows_bwd_rec": [c_void_p, c_void_p, c_int64, c_int, c_void_p, _S],
     "fsraft_gma_mix_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, _S],
     "fsraft_gma_mix_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, _S],
     "fsraft_inorm_relu_fwd": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, _S],
@@ -136,26 +141,27 @@ SIGNATURES = {
     "fsraft_bn_fold": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, _S],
     "fsraft_bn_fold_bwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _S],
     "fsraft_vol_layout": [c_int, c_int, c_int, _IP],
-    "fsraft_corr_build_tiled": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_corr_build_rec": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_build_tiled": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _S],
+    "fsraft_corr_build_rec": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_corr_lookup_tiled_fwd": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_dvol_build": [_PP, _PP, POINTER(c_int64), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
-                               c_int64, c_void_p, c_void_p, _S],
+                               c_int64, c_void_p, c_void_p, c_void_p, _S],
+    "fsraft_amax_scaled": [c_void_p, c_float, c_void_p, _S],
     "fsraft_set_alt_tile": [c_int],
     "fsraft_altcorr_fused_fwd": [c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_altcorr_mfma_fwd": [c_void_p, _PP, c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_altcorr_mfma_fwd": [c_void_p, _PP, c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_corr_f2cat": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_dfmap2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_corr_f2cat_rec": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_to_records": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, _S],
+    "fsraft_corr_f2cat_rec": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, _S],
+    "fsraft_to_records": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, _S],
     "fsraft_gemm_rec_tn": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
-                           c_float, c_int, c_int, _S],
+                           c_float, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_gemm_rec_nt": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
-                           c_float, c_int, c_int, _S],
+                           c_float, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_gemm_rec_nt_list": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
-                                c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, _S],
+                                c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_gemm_rec_tn_list": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
-                                c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, _S],
+                                c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_corr_bwd_ktiles": [_PP, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, _S],
 }

@@ -104,7 +104,7 @@ class _AttentionFn(torch.autograd.Function):
         if ops.SPLIT_VOLUME_BWD and D % 32 == 0:          # record GEMM core: q and k are record slices of one [N][2D] tensor
             qkr = ops.to_records(qk.view(B, N, 2 * D))
             ops.gemm_rec_nt_raw(qkr.data_ptr(), 2 * D, N * 2 * D, qkr.data_ptr() + 4 * D, 2 * D, N * 2 * D, attn.data_ptr(), N, N * N,
-                                B, N, N, D, scale)
+                                B, N, N, D, scale, a_amax=ops.amax_of(qkr), b_amax=ops.amax_of(qkr))
         else:
             ops.gemm_raw(qk.data_ptr(), 2 * D, N * 2 * D, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, attn.data_ptr(), N, N * N,
                          B, N, N, D, True, scale)
@@ -126,6 +126,7 @@ class _AttentionFn(torch.autograd.Function):
         own = bool(getattr(dA, "_fs_owned", False)) and dA.is_contiguous()
         dA = dA if own else dA.contiguous().clone()
         dS = ops.softmax_rows_bwd_rec_(attn, dA) if ctx.records else ops.softmax_rows_bwd_(attn, dA)
+        ds_word = ops.amax_of(dS)             # records: the word softmax_rows_bwd_rec_ split them with
         del dA
         dqk = torch.empty_like(qk)
         # dq = scale dS k ; dk = scale dS^T q
@@ -133,14 +134,15 @@ class _AttentionFn(torch.autograd.Function):
             # record GEMM core: dS split to records once; dq = dS . (k^T)^T with k^T [D][N] (rows of records along j),
             # dk = dS^T . q with both operands read k-major (records along the output index)
             dSr = dS.view(B, N, N) if ctx.records else ops.to_records(dS.view(B, N, N))
+            ds_word = ds_word if ctx.records else ops.amax_of(dSr)
             del dS
             Nr = dSr.shape[-1]
             qkr = ops.to_records(qk.view(B, N, 2 * D))                                   # q = records 0..D/32-1 of a row, k the rest
             kt = ops.to_records(ops.transpose_batched(qk.view(B, N, 2 * D)[:, :, D:].contiguous()))    # [B, D, Nr]
             ops.gemm_rec_nt_raw(dSr.data_ptr(), Nr, N * Nr, kt.data_ptr(), Nr, D * Nr, dqk.data_ptr(), 2 * D, N * 2 * D, B, N, D, Nr,
-                                scale, ksplit=2)
+                                scale, ksplit=2, a_amax=ds_word, b_amax=ops.amax_of(kt))
             ops.gemm_rec_tn_raw(dSr.data_ptr(), Nr, N * Nr, qkr.data_ptr(), 2 * D, N * 2 * D, dqk.data_ptr() + 4 * D, 2 * D, N * 2 * D,
-                                B, N, D, N, scale, ksplit=2)
+                                B, N, D, N, scale, ksplit=2, a_amax=ds_word, b_amax=ops.amax_of(qkr))
             dw = _conv1x1_wgrad(dqk, x_cl, C, 2 * D, B, H, W) if ctx.needs_input_grad[1] else None
             dx = _conv1x1(dqk, w, C, 2 * D, B, H, W, 1) if ctx.needs_input_grad[0] else None
             return dx, dw, None, None

@@ -423,7 +423,7 @@ class _Engine:
                 Nr = attn_t.shape[-1]
                 vt = ops.to_records(ops.transpose_batched(v.view(B, N, mc)))          # [B, mc, Nr]
                 ops.gemm_rec_nt_raw(attn_t.data_ptr(), Nr, N * Nr, vt.data_ptr(), Nr, mc * Nr, agg.data_ptr(), mc, N * mc, B, N, mc, Nr,
-                                    ksplit=2)
+                                    ksplit=2, a_amax=ops.amax_of(attn_t), b_amax=ops.amax_of(vt))
             else:
                 ops.gemm_raw(attn.data_ptr(), N, N * N, v.data_ptr(), mc, N * mc, agg.data_ptr(), mc, N * mc, B, N, mc, N, False)
             ops.gma_mix_fwd(V(motion, mc, 0), V(agg), P["aggregator.gamma"], V(motion, mc, mc))
@@ -643,7 +643,7 @@ class _Engine:
                     Nr = attn_r.shape[-1]
                     dr = ops.to_records(dagg.view(B, N, mc))
                     ops.gemm_rec_tn_raw(attn_r.data_ptr(), Nr, N * Nr, dr.data_ptr(), dr.shape[-1], N * dr.shape[-1], dv.data_ptr(), mc,
-                                        N * mc, B, N, mc, N, ksplit=2)
+                                        N * mc, B, N, mc, N, ksplit=2, a_amax=ops.amax_of(attn_r), b_amax=ops.amax_of(dr))
                 elif N % 4 == 0:     # (exact-fp32 test mode) both operands k-major -> transposed-read split GEMM
                     ops.gemm_tn_raw(attn.data_ptr(), N, N * N, dagg.data_ptr(), mc, N * mc, dv.data_ptr(), mc, N * mc, B, N, mc, N)
                 else:
@@ -811,7 +811,7 @@ class _AttnFn(torch.autograd.Function):
         if ops.SPLIT_VOLUME_BWD:         # record GEMM core (K = T * 128 is a multiple of 32)
             Dr, Vr = ops.to_records(D), ops.to_records(Vc)
             ops.gemm_rec_nt_raw(Dr.data_ptr(), Dr.shape[-1], N * Dr.shape[-1], Vr.data_ptr(), Vr.shape[-1], N * Vr.shape[-1],
-                                dattn.data_ptr(), N, N * N, B, N, N, Dr.shape[-1])
+                                dattn.data_ptr(), N, N * N, B, N, N, Dr.shape[-1], a_amax=ops.amax_of(Dr), b_amax=ops.amax_of(Vr))
         else:
             ops.gemm_raw(D.data_ptr(), K, N * K, Vc.data_ptr(), K, N * K, dattn.data_ptr(), N, N * N, B, N, N, K, True)
         return None, dattn
@@ -1112,7 +1112,9 @@ class _UpdateBlockBase(nn.Module):
             return None         # (SPLIT_VOLUME_BWD off = exact-fp32 test mode: keep the exact NN GEMM)
         from .gma import is_records
         if is_records(attention):       # the softmax wrote records over its logits (gma.ATTN_RECORDS): this IS the one copy
-            return attention.detach().view(attention.shape[0], attention.shape[-1], attention.shape[-1])
+            t = attention.detach().view(attention.shape[0], attention.shape[-1], attention.shape[-1])
+            t._fs_amax = ops.amax_one(t.device)         # (probabilities: split with the scale of a word holding 1.0)
+            return t
         c = self.__dict__.get("_attn_t")
         if c is None or c[0]() is not attention or c[1] != attention._version:
             with torch.no_grad():

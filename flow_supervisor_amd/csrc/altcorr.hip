@@ -388,8 +388,9 @@ struct AltRecLevels {
 template <int R>
 __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __restrict__ f1r, const float* __restrict__ f1, AltRecLevels lv,
                                                                AltCoords co, float* __restrict__ out, int nlev, int H, int W, int C,
-                                                               float scale) {
+                                                               float scale, const unsigned* am1, const unsigned* am2) {   // words the records were split with
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN, NRND = (NPOS + 63) / 64;
+  const float rec_inv = fs_inv_scale(fs_scale_of_amax(fs_amax_load(am1))) * fs_inv_scale(fs_scale_of_amax(fs_amax_load(am2)));
   constexpr int PARK = AM_NQ * AM_DP * 4 + AM_NQ * (NPOS + 1) * 4;      // parked products + every query's window values
   __shared__ __attribute__((aligned(1024))) char lds[AM::LDS_BYTES > PARK ? AM::LDS_BYTES : PARK];
   __shared__ int org[2];
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __res
       for (int mt = 0; mt < AM::TM; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          dots[l31 * AM_DP + wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[mt][0][r];
+          dots[l31 * AM_DP + wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[mt][0][r] * rec_inv;
     }
   }
   __syncthreads();
@@ -582,7 +583,8 @@ extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* 
 // does not cover are taken from them).  C % 32 == 0, C <= 256.
 extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
                                        int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
-                                       int add_grid, float* out, int B, int H, int W, int C, int radius, hipStream_t stream) {
+                                       int add_grid, float* out, int B, int H, int W, int C, int radius, const unsigned* amax1,
+                                       const unsigned* amax2, hipStream_t stream) {      // amax1 / amax2: the words f1r / every f2r level were split with
   if (!f1r || !f2r_levels || !fmap1 || !fmap2_levels || !coords || !out || num_levels < 1 || num_levels > 4 || B < 1 || H < 1 || W < 1 ||
       C < 32 || C % 32 || C > 256 || ((uintptr_t)f1r % 16) || ((uintptr_t)fmap1 % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff)
     return FS_ERR_ARG;
@@ -599,8 +601,8 @@ extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_l
   AltCoords co{coords, coords_bs, coords_cs, coords_ps, add_grid ? W : 0};
   dim3 grid((unsigned)(((W + AM_TW - 1) / AM_TW) * ((H + AM_TH - 1) / AM_TH)), (unsigned)num_levels, (unsigned)B);
   const float scale = 1.0f / sqrtf((float)C);
-  if (radius == 4) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<4>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale);
-  else if (radius == 3) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<3>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale);
+  if (radius == 4) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<4>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1, amax2);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<3>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1, amax2);
   else return FS_ERR_ARG;
   return fs_launch_status();
 }

@@ -54,7 +54,21 @@ struct ConvArgs {
   int swz;                       // 1: XCD-aware workgroup -> tile mapping (see tile_of_block)
   int ksplit;                    // > 1: blockIdx.z owns a slice of the k-tiles and parks its RAW partial tile in a workspace (dst[0],
                                  // rows z * M + m): the first pass of the split-K route for small M (conv_finish_kernel is the second)
+  // split arithmetic (split_arith.hpp): amax words of the sources and of the packed weights (NULL: scale 1), and per
+  // destination an optional word the epilogue raises to the largest magnitude it stored (GRU epilogues: damax[0] for the
+  // new state h' (Q) / damax[1] for r*h (ZR); the gates themselves are bounded by 1)
+  const unsigned* samax[3]; const unsigned* wamax; unsigned* damax[3];
 };
+
+// scale of the A operand (one for all sources: they share the accumulators) and the factor that takes the accumulators
+// back: 1 / (s_a s_w), exact (powers of two)
+__device__ __forceinline__ void conv_scales(const ConvArgs& a, float& sa, float& inv) {
+  unsigned m = fs_amax_load(a.samax[0]);
+  if (a.nsrc > 1) m = fs_umax(m, fs_amax_load(a.samax[1]));
+  if (a.nsrc > 2) m = fs_umax(m, fs_amax_load(a.samax[2]));
+  sa = fs_scale_of_amax(m);
+  inv = fs_inv_scale(sa) * fs_inv_scale(fs_scale_of_amax(fs_amax_load(a.wamax)));
+}
 
 // Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  With the plain
 // (x = N tile, y = M tile) mapping the N tiles of one M tile -- which read the same activation rows -- land on
@@ -138,6 +152,7 @@ struct SplitConvALoader {                 // implicit-GEMM gather of fp32 activa
   int taps, KW, PH, PW, H, W;
   int py[NCH], px[NCH];                   // pixel coordinates of this thread's rows (py < 0: row outside M)
   int pofs[NCH];                          // pixel index b*H*W + y*W + x of the row
+  float s;                                // scale of the activations (split_arith.hpp)
   __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
     const int n0 = taps * cpt0, n1 = taps * cpt1;
     const bool is1 = kt >= n0, is2 = kt >= n0 + n1;
@@ -156,7 +171,7 @@ struct SplitConvALoader {                 // implicit-GEMM gather of fp32 activa
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
-    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4, s);
   }
 };
 
@@ -197,6 +212,7 @@ struct BufConvALoader {
   unsigned tapmask[NCH];                  // bit t: tap t of this thread's pixel row lies inside the image (0: row outside M)
   unsigned pofs[NCH];                     // pixel index of the row
   unsigned kq16;                          // byte offset of this thread's 16-byte column inside a 128-byte chunk row
+  float s;                                // scale of the activations
   __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
     // kt is wave-uniform; saying so explicitly lets the table entry come in with s_load_dword and keeps everything
     // derived from it (descriptor, SGPR offset) in scalar registers -- once per tile, not once per chunk
@@ -220,7 +236,7 @@ struct BufConvALoader {
     }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
-    stage_convert<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4, s);
   }
 };
 
@@ -232,6 +248,7 @@ struct BufConvALoaderU {                  // uniform form: one base, one pitch, 
   unsigned tapmask[NCH];                  // bit t: tap t of this thread's pixel row lies inside the image (0: row outside M)
   unsigned voff0[NCH];                    // pixel * pitch + 16-byte column, in bytes (constant over the k-loop)
   unsigned kq16;
+  float s;                                // scale of the activations
   __device__ __forceinline__ void fetch_tile(int kt, float (&r)[NREG]) const {
     const int ku = __builtin_amdgcn_readfirstlane(kt);
     const unsigned soff = ktab[2 * ku], e = ktab[2 * ku + 1];
@@ -247,7 +264,7 @@ struct BufConvALoaderU {                  // uniform form: one base, one pitch, 
     }
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
-    stage_convert<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4);
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + Cfg::NT * j, r4, s);
   }
 };
 
@@ -291,10 +308,12 @@ struct SplitWeightLoader {                // pre-split packed weights: row n = K
   }
 };
 
+// inv: factor that un-scales the accumulators of the split kernels (conv_scales); 1 for the exact-fp32 kernels
 template <class Cfg, int EPI>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0, float inv = 1.0f) {
   const int HW = a.H * a.W;
   const int M = a.B * HW;
+  unsigned mx[3] = {0u, 0u, 0u};              // largest stored magnitude per destination (bit patterns), for a.damax
   // Epilogue.  Everything is batched per 32x32 MFMA tile: 16 addresses, then (optionally) 16
   // loads in flight, then 16 stores, with no wait between consecutive stores.  Rows of one
   // accumulator tile are m = mbase + (r&3) + 8*(r>>2); a 128-row tile crosses at most one
@@ -340,7 +359,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
           for (int q = 0; q < 8; ++q) old[q] = (dacc && off[q] >= 0) ? dp[off[q]] : 0.f;
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            float v = (acc[mt][nt][hb * 8 + q] + bias) * a.alpha;
+            float v = __builtin_fmaf(acc[mt][nt][hb * 8 + q], inv, bias) * a.alpha;
             if (a.relu) v = fmaxf(v, 0.f);
             v += old[q];
             if (off[q] >= 0 && mk && n - dn0 < mkc) {
@@ -348,7 +367,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
               const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
               if (mk[m * ldm + (n - dn0)] <= 0.f) v = 0.f;
             }
-            if (off[q] >= 0) dp[off[q]] = v;
+            if (off[q] >= 0) { dp[off[q]] = v; mx[di] = fs_umax(mx[di], fs_abs_bits(v)); }
           }
         }
       } else if (EPI == EPI_ZR) {
@@ -366,13 +385,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
         for (int r = 0; r < 16; ++r) {
           const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
           const float pre = (a.pre && ok[r]) ? a.pre[m * a.ldpre + n] : 0.f;
-          const float sg = 1.0f / (1.0f + expf(-(acc[mt][nt][r] + bias + pre)));
+          const float sg = 1.0f / (1.0f + expf(-(__builtin_fmaf(acc[mt][nt][r], inv, bias) + pre)));
           if (ok[r]) {
             if (isz) {
               a.dst[0].p[m * a.dst[0].ps + c] = sg;                 // z
             } else {
               a.aux2[m * a.ld2 + c] = sg;                           // r
               a.aux1[m * a.ld1 + c] = sg * hh[r];                   // r*h
+              mx[1] = fs_umax(mx[1], fs_abs_bits(sg * hh[r]));
             }
           }
         }
@@ -390,14 +410,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
         for (int r = 0; r < 16; ++r) {
           const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
           const float pre = (a.pre && ok[r]) ? a.pre[m * a.ldpre + n] : 0.f;
-          const float q = tanhf(acc[mt][nt][r] + bias + pre);
+          const float q = tanhf(__builtin_fmaf(acc[mt][nt][r], inv, bias) + pre);
           if (ok[r]) {
+            const float hn = (1.f - zz[r]) * hh[r] + zz[r] * q;
             a.aux1[m * a.ld1 + n] = q;
-            a.dst[0].p[m * a.dst[0].ps + n] = (1.f - zz[r]) * hh[r] + zz[r] * q;
+            a.dst[0].p[m * a.dst[0].ps + n] = hn;
+            mx[0] = fs_umax(mx[0], fs_abs_bits(hn));
           }
         }
       }
     }
+  }
+  if (a.damax[0] || a.damax[1] || a.damax[2]) {          // (workgroup-uniform)
+    __shared__ unsigned red[16];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (a.damax[i]) fs_amax_commit(a.damax[i], mx[i], red);
   }
 }
 
@@ -409,7 +437,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
 template <class Cfg, int EPI, int NTW = Cfg::NT, bool PATCH = false>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
                                                   float* __restrict__ tile, bool owner = true, int pb = 0, int py0 = 0, int px0 = 0,
-                                                  int64_t mofs = 0) {
+                                                  int64_t mofs = 0, float inv = 1.0f) {
   constexpr int LD = Cfg::BN + 4;
   const int HW = a.H * a.W;
   const int M = a.B * HW;
@@ -432,7 +460,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
     for (int mt = 0; mt < Cfg::TM; ++mt) {
       const int rbase = (wave / Cfg::WN) * (Cfg::TM * 32) + mt * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tile[(rbase + (r & 3) + 8 * (r >> 2)) * LD + nl] = acc[mt][nt][r] + bias;
+      for (int r = 0; r < 16; ++r) tile[(rbase + (r & 3) + 8 * (r >> 2)) * LD + nl] = __builtin_fmaf(acc[mt][nt][r], inv, bias);
     }
   }
   __syncthreads();
@@ -442,13 +470,17 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
   const int c4 = threadIdx.x % C4, rsub = threadIdx.x / C4;
   const int n = n0 + c4 * 4;
   const bool stats = PATCH && EPI == EPI_PLAIN && a.st_sum != nullptr;      // (workgroup-uniform: the barriers below are safe)
-  if (n >= a.N && !stats) return;
+  const bool track = a.damax[0] != nullptr || a.damax[1] != nullptr || a.damax[2] != nullptr;   // (workgroup-uniform too)
+  if (n >= a.N && !stats && !track) return;
+  unsigned mx = 0u;                                  // largest magnitude this thread stored (bit pattern), for a.damax
+  int mydi = 0;
   if (EPI == EPI_PLAIN) {
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
     if (n < a.N) {
     int di = 0;
     if (a.ndst > 1 && n >= a.dst[1].n0) di = 1;
     if (a.ndst > 2 && n >= a.dst[2].n0) di = 2;
+    mydi = di;
     float* dp = di == 0 ? a.dst[0].p : di == 1 ? a.dst[1].p : a.dst[2].p;
     const int64_t dps = di == 0 ? a.dst[0].ps : di == 1 ? a.dst[1].ps : a.dst[2].ps;
     const int dn0 = di == 0 ? a.dst[0].n0 : di == 1 ? a.dst[1].n0 : a.dst[2].n0;
@@ -481,11 +513,13 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
           for (int i = 0; i < 4; ++i) if (n - dn0 + i < mkc && y[i] <= 0.f) v[i] = 0.f;
         }
         gstore4(o, v);
+        if (track) mx = fs_umax(fs_umax(mx, fs_umax(fs_abs_bits(v[0]), fs_abs_bits(v[1]))), fs_umax(fs_abs_bits(v[2]), fs_abs_bits(v[3])));
       } else {
         for (int i = 0; i < nv; ++i) {
           float r = dacc ? gload1(o + i) + v[i] : v[i];
           if (mk && n - dn0 + i < mkc && gload1(mk + (int64_t)m * ldm + (n - dn0) + i) <= 0.f) r = 0.f;
           gstore1(o + i, r);
+          mx = fs_umax(mx, fs_abs_bits(r));
         }
       }
     }
@@ -512,6 +546,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
   } else if (EPI == EPI_ZR) {
     const bool isz = n < a.hid;
     const int c = isz ? n : n - a.hid;
+    mydi = 1;
+    if (n < a.N) {
 #pragma unroll 4
     for (int row = rsub; row < Cfg::BM; row += RPP) {
       const int64_t mr = row_m(row);
@@ -534,9 +570,12 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
 #pragma unroll
         for (int i = 0; i < 4; ++i) rh[i] = v[i] * hh[i];
         *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + c) = rh;                           // r*h
+        if (track) mx = fs_umax(fs_umax(mx, fs_umax(fs_abs_bits(rh[0]), fs_abs_bits(rh[1]))), fs_umax(fs_abs_bits(rh[2]), fs_abs_bits(rh[3])));
       }
     }
+    }
   } else {   // EPI_Q
+    if (n < a.N) {
 #pragma unroll 4
     for (int row = rsub; row < Cfg::BM; row += RPP) {
       const int64_t m = row_m(row);
@@ -553,7 +592,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       }
       *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + n) = v;                              // q
       *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + n) = hn;                   // h'
+      if (track) mx = fs_umax(fs_umax(mx, fs_umax(fs_abs_bits(hn[0]), fs_abs_bits(hn[1]))), fs_umax(fs_abs_bits(hn[2]), fs_abs_bits(hn[3])));
     }
+    }
+  }
+  if (track) {                                       // the parked tile is no longer needed: its memory takes the reduction
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (a.damax[i]) fs_amax_commit(a.damax[i], mydi == i ? mx : 0u, reinterpret_cast<unsigned*>(tile));
   }
 }
 
@@ -623,6 +669,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
   int bx = blockIdx.x, by = blockIdx.y;
   tile_of_block(a.swz, bx, by);
   const int n0 = bx * Cfg::BN, m0 = by * Cfg::BM;
+  float sa, inv;
+  conv_scales(a, sa, inv);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -668,7 +716,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
     }
     if constexpr (BUF >= 2) {
       BufConvALoaderU<Cfg> la;
-      la.base = uni_ptr(args.ubase); la.ktab = ktab; la.kq16 = (threadIdx.x & 7) * 16;
+      la.base = uni_ptr(args.ubase); la.ktab = ktab; la.kq16 = (threadIdx.x & 7) * 16; la.s = sa;
       const unsigned ldb = uni((unsigned)args.uld * 4u);
 #pragma unroll
       for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.voff0[j] = pofs[j] * ldb + la.kq16; }
@@ -681,14 +729,14 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
       la.b1 = uni_ptr(a.src[1].p - (int64_t)(PH * a.W + PW) * a.src[1].ld); la.nb1 = 0x7fffffffu;
       la.b2 = uni_ptr(a.src[2].p - (int64_t)(PH * a.W + PW) * a.src[2].ld); la.nb2 = 0x7fffffffu;
       la.ktab = ktab;
-      la.kq16 = (threadIdx.x & 7) * 16;
+      la.kq16 = (threadIdx.x & 7) * 16; la.s = sa;
 #pragma unroll
       for (int j = 0; j < Cfg::NCH_A; ++j) { la.tapmask[j] = tapmask[j]; la.pofs[j] = pofs[j]; }
       split_mainloop<Cfg, BufConvALoader<Cfg>, BufWeightLoader<Cfg>, true>(lds, KTs, la, lb, acc);
     }
     if constexpr (EPI == EPI_PLAIN && Cfg::LDS_ALLOC >= Cfg::BM * (Cfg::BN + 4) * 4) {
       if (a.ksplit > 1) {               // first pass of the split-K route: the raw partial tile -> slab blockIdx.z of the workspace
-        conv_epilogue_lds<Cfg, EPI_PLAIN>(a, acc, m0, n0, reinterpret_cast<float*>(lds), true, 0, 0, 0, (int64_t)blockIdx.z * M);
+        conv_epilogue_lds<Cfg, EPI_PLAIN>(a, acc, m0, n0, reinterpret_cast<float*>(lds), true, 0, 0, 0, (int64_t)blockIdx.z * M, inv);
         return;
       }
     }
@@ -699,7 +747,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
   la.p2 = a.src[2].p; la.C2 = a.src[2].C; la.ld2 = a.src[2].ld; la.cpt2 = a.nsrc > 2 ? (a.src[2].C + 31) / 32 : 0;
   if (a.nsrc < 2) { la.p1 = a.src[0].p; la.C1 = 0; la.ld1 = 4; la.cpt1 = 1; }
   if (a.nsrc < 3) { la.p2 = a.src[0].p; la.C2 = 0; la.ld2 = 4; la.cpt2 = 1; }
-  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.PH; la.PW = a.PW; la.H = a.H; la.W = a.W;
+  la.taps = a.KH * a.KW; la.KW = a.KW; la.PH = a.PH; la.PW = a.PW; la.H = a.H; la.W = a.W; la.s = sa;
 #pragma unroll
   for (int j = 0; j < SplitConvALoader<Cfg>::NCH; ++j) {
     const int m = m0 + ((threadIdx.x + 256 * j) >> 3);
@@ -715,11 +763,11 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_split_kernel(const std::co
   }
   if constexpr (Cfg::LDS_ALLOC >= Cfg::BM * (Cfg::BN + 4) * 4) {     // the parked tile must fit the LDS allocation
     if (EPI != EPI_PLAIN || epilogue_rows_ok(a)) {
-      conv_epilogue_lds<Cfg, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(lds));
+      conv_epilogue_lds<Cfg, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(lds), true, 0, 0, 0, 0, inv);
       return;
     }
   }
-  conv_epilogue<Cfg, EPI>(a, acc, m0, n0);
+  conv_epilogue<Cfg, EPI>(a, acc, m0, n0, inv);
 }
 
 // ---------------------------------------------------------------- 3x3 convolution over a resident input patch
@@ -739,6 +787,7 @@ struct HaloArgs {
   int N, B, H, W, relu;
   int acc;                            // out += result (the data gradient of a residual unit's first convolution adds to the shortcut gradient)
   float* st_sum; float* st_sq; int st_slots;   // as in ConvArgs (NULL: none)
+  const unsigned* xamax; const unsigned* wamax; unsigned* damax;   // as ConvArgs::samax / wamax / damax
 };
 
 template <int CG, int TN>
@@ -749,6 +798,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
   const int x0 = blockIdx.x * HALO_TW, y0 = blockIdx.y * HALO_TH, b = blockIdx.z;
+  const float sa = fs_scale_of_amax(fs_amax_load(a.xamax));
+  const float inv = fs_inv_scale(sa) * fs_inv_scale(fs_scale_of_amax(fs_amax_load(a.wamax)));
 
   // Weight fragments come straight from the packed matrix (L1/L2-resident: 4 * N * Ktot bytes for the whole grid): lane
   // (n, k half) reads its 16 bytes of hi and of lo for both k-steps of a k-tile.  No B image in LDS, hence no barrier in
@@ -798,7 +849,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
     for (int j = 0; j < NCHH; ++j) {
       const int e = threadIdx.x + 256 * j;
       const int row = e / (CG * 8), rem = e % (CG * 8);
-      if (row < HALO_ROWS) stage_convert<128>(lds + (rem >> 3) * PLANE, row * 8 + (rem & 7), rh + 4 * j);
+      if (row < HALO_ROWS) stage_convert<128>(lds + (rem >> 3) * PLANE, row * 8 + (rem & 7), rh + 4 * j, sa);
     }
   }
   __syncthreads();
@@ -818,21 +869,21 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
     const int rowa = (2 * wm + dy) * HALO_PW + dx + l31;          // patch row of this lane for mt = 0; mt = 1 is one patch line down
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[2], al[2];
+      p16x8 ah[2], al[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = rowa + mt * HALO_PW;
-        ah[mt] = *reinterpret_cast<const bf16x8*>(Ap + slot_offset<128>(row, 2 * s + lh));
-        al[mt] = *reinterpret_cast<const bf16x8*>(Ap + slot_offset<128>(row, 4 + 2 * s + lh));
+        ah[mt] = *reinterpret_cast<const p16x8*>(Ap + slot_offset<128>(row, 2 * s + lh));
+        al[mt] = *reinterpret_cast<const p16x8*>(Ap + slot_offset<128>(row, 4 + 2 * s + lh));
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, f.v[nt][s]), bl = __builtin_bit_cast(bf16x8, f.v[nt][2 + s]);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+          const p16x8 bh = __builtin_bit_cast(p16x8, f.v[nt][s]), bl = __builtin_bit_cast(p16x8, f.v[nt][2 + s]);
+          acc[mt][nt] = fs_mfma_32x32x16(al[mt], bh, acc[mt][nt]);
+          acc[mt][nt] = fs_mfma_32x32x16(ah[mt], bl, acc[mt][nt]);
+          acc[mt][nt] = fs_mfma_32x32x16(ah[mt], bh, acc[mt][nt]);
         }
     }
   };
@@ -845,6 +896,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
       }
   }
 
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] *= inv;
   if (a.st_sum) {
     // InstanceNorm statistics of the result: a lane owns column n of 2 x 16 pixels per nt; the two lane halves and the two
     // pixel-row waves (wm) meet through shuffles / LDS (the patch is no longer needed), one atomic pair per column and workgroup
@@ -877,6 +932,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
     }
   }
   float* outb = a.out + (int64_t)b * a.obs;
+  unsigned mx = 0u;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int py = y0 + 2 * wm + mt;
@@ -898,10 +954,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
         if (px >= a.W) continue;
         float v = acc[mt][nt][r] + bv;
         if (a.relu) v = fmaxf(v, 0.f);
-        outb[(int64_t)(py * a.W + px) * a.ops + n] = v + old[r];
+        v += old[r];
+        outb[(int64_t)(py * a.W + px) * a.ops + n] = v;
+        mx = fs_umax(mx, fs_abs_bits(v));
       }
     }
   }
+  if (a.damax) fs_amax_commit(a.damax, mx, reinterpret_cast<unsigned*>(lds));
 }
 
 template <int CG, int TN>
@@ -923,6 +982,7 @@ struct WgradArgs {
   // XCD-aware launch (xcd_xt > 0): 1-D grid; the xcd_xt packed-K tiles that read the SAME dY tile -- one (Cout tile, pixel
   // split) group -- get linear ids 8 apart, i.e. the same XCD and its L2, instead of being dealt round-robin over all 8.
   int xcd_xt, xcd_yt, xcd_groups;
+  const unsigned* dyamax; const unsigned* samax[3];     // amax words of dY and of the sources (NULL: scale 1), single-segment launches
 };
 
 // Several (dY, X) pairs of identical shape in one launch -- the 12 iterations of a step: dW = sum_t dY_t^T X_t is one
@@ -934,7 +994,31 @@ struct WgradArgsM {
   int nseg, zs;
   const float* dys[WGRAD_MAX_SEG];
   const float* srcs[3][WGRAD_MAX_SEG];
+  const unsigned* dyam[WGRAD_MAX_SEG];        // amax words per segment (NULL: scale 1); a launch uses ONE scale per operand,
+  const unsigned* sam[3][WGRAD_MAX_SEG];      // from the largest word over its segments (their products share accumulators)
 };
+
+// scales of the weight gradient's two operands: dY (all segments) and source s (all segments)
+template <bool MULTI, class Args>
+__device__ __forceinline__ void wgrad_scales(const Args& args, const WgradArgs& a, int s, size_t table_base, float& sdy, float& sx) {
+  unsigned mdy, mx;
+  if constexpr (MULTI) {
+    typedef const unsigned* uptr;
+    const auto* karg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + table_base;
+    const auto* tdy = (const uptr __attribute__((address_space(4)))*)(karg + offsetof(WgradArgsM, dyam));
+    const auto* tsx = (const uptr __attribute__((address_space(4)))*)(karg + offsetof(WgradArgsM, sam)) + s * WGRAD_MAX_SEG;
+    mdy = 0u; mx = 0u;
+    for (int i = 0; i < args.nseg; ++i) {
+      mdy = fs_umax(mdy, fs_amax_load(tdy[i]));
+      mx = fs_umax(mx, fs_amax_load(tsx[i]));
+    }
+  } else {
+    mdy = fs_amax_load(a.dyamax);
+    mx = fs_amax_load(s == 0 ? a.samax[0] : s == 1 ? a.samax[1] : a.samax[2]);
+  }
+  sdy = fs_scale_of_amax(mdy);
+  sx = fs_scale_of_amax(mx);
+}
 
 template <class Cfg>
 struct ShiftedXLoader {                    // Bs[k = pixel][n = ci] <- X[pixel + off][ci0 + n]
@@ -1127,6 +1211,9 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_split_kernel(const std::co
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.dbias != nullptr && bx == 0;        // one x-tile per (co tile, pixel split) owns the bias
+  float sdy, sx;
+  wgrad_scales<MULTI>(args, a, s, 0, sdy, sx);
+  const float inv = fs_inv_scale(sdy) * fs_inv_scale(sx);
   if constexpr (BUF) {
     // pixel mask: bit k of word w <=> pixel mb + 32 w + k exists and its (dy, dx)-shifted neighbour is inside the image
     for (int i = threadIdx.x; i < KT * 32; i += Cfg::NT) {
@@ -1156,13 +1243,13 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_split_kernel(const std::co
       const int e = threadIdx.x + Cfg::NT * j, k = e / (Cfg::BN / 4), c4 = e % (Cfg::BN / 4);
       lb.krow[j] = k; lb.voff[j] = c4 * 4 < cvb ? (unsigned)(k * sc.ld + c4 * 4) * 4u : FS_OOB;
     }
-    if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
-    else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
+    if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum, sdy, sx);
+    else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc, nullptr, sdy, sx);
   } else {
   SplitDyLoader<Cfg> la{dyp + co0, a.ldy, coleft < Cfg::BM ? coleft : Cfg::BM, mb, me};
   SplitShiftedXLoader<Cfg> lb{sc.p + ci0, sc.ld, cleft < Cfg::BN ? cleft : Cfg::BN, dyy, dxx, a.H, a.W, HW, mb, me};
-  if (want_bias) split_mainloop_tn<Cfg, SplitDyLoader<Cfg>, SplitShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
-  else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
+  if (want_bias) split_mainloop_tn<Cfg, SplitDyLoader<Cfg>, SplitShiftedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum, sdy, sx);
+  else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc, nullptr, sdy, sx);
   }
   if (want_bias) {
     // this thread's columns are co0 + 4*(tid % 32) .. +3; NT/32 threads (tid / 32) share them
@@ -1187,7 +1274,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_split_kernel(const std::co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + acc_row<Cfg>(mt, r);
-        if (co < a.Cout) atomicAdd(a.dwpk + (int64_t)co * a.Ktot + kofs + n, acc[mt][nt][r]);
+        if (co < a.Cout) atomicAdd(a.dwpk + (int64_t)co * a.Ktot + kofs + n, acc[mt][nt][r] * inv);
       }
   }
 }
@@ -1261,6 +1348,9 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_pack_kernel(const WgradArg
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.dbias != nullptr && bx == 0;
+  float sdy, sx;
+  wgrad_scales<false>(a, a, 0, 0, sdy, sx);
+  const float inv = fs_inv_scale(sdy) * fs_inv_scale(sx);
   // pixel masks, one per tap slot: bit k of word w <=> pixel mb + 32 w + k exists and its shifted neighbour is inside the image
   for (int i = threadIdx.x; i < KT * 32; i += Cfg::NT) {
     const int64_t m = mb + i;
@@ -1297,8 +1387,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_pack_kernel(const WgradArg
     lb.krow[j] = k; lb.slot[j] = valid ? tp : 0;
     lb.voff[j] = valid ? (unsigned)((k + shift) * sc.ld + cc) * 4u : FS_OOB;
   }
-  if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufPackedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum);
-  else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc);
+  if (want_bias) split_mainloop_tn<Cfg, BufDyLoader<Cfg>, BufPackedXLoader<Cfg>, true>(lds, KT, la, lb, acc, colsum, sdy, sx);
+  else split_mainloop_tn<Cfg>(lds, KT, la, lb, acc, nullptr, sdy, sx);
   if (want_bias) {
     // this thread's dY columns are co0 + 4*(tid % (BM/4)) .. +3; NT / (BM/4) threads share them
     constexpr int Q = Cfg::BM / 4, G = Cfg::NT / Q;
@@ -1323,7 +1413,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_wgrad_pack_kernel(const WgradArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + acc_row<Cfg>(mt, r);
-        if (co < a.Cout) atomicAdd(a.dwpk + (int64_t)co * a.Ktot + kofs + n, acc[mt][nt][r]);
+        if (co < a.Cout) atomicAdd(a.dwpk + (int64_t)co * a.Ktot + kofs + n, acc[mt][nt][r] * inv);
       }
   }
 }
@@ -1394,15 +1484,16 @@ struct PackArgs {
   int C[3]; int nsrc;  // forward source split of Cin (mode 0/2); ignored for mode 1
   int Ktot, rows;
   int mode, accumulate;
-  int split;           // modes 0/1: write [32 hi | 32 lo] bf16 records instead of fp32 (same byte size)
+  int split;           // modes 0/1: write [32 hi | 32 lo] fp16 records of w * scale instead of fp32 (same byte size)
+  const unsigned* amax; // split: amax word of the weights (NULL: scale 1)
 };
 
 __device__ __forceinline__ void store_packed(const PackArgs& a, int64_t e, float v) {
   if (!a.split) { a.wpk[e] = v; return; }
   // element e = n*Ktot + k  ->  record (e / 32) of 64 shorts: hi at [k % 32], lo at [32 + k % 32]
-  const __bf16 h = (__bf16)v;
-  const __bf16 l = (__bf16)(v - (float)h);
-  __bf16* rec = reinterpret_cast<__bf16*>(a.wpk) + (e >> 5) * 64;
+  _Float16 h, l;
+  fs_split1(v, fs_scale_of_amax(fs_amax_load(a.amax)), h, l);
+  _Float16* rec = reinterpret_cast<_Float16*>(a.wpk) + (e >> 5) * 64;
   rec[e & 31] = h;
   rec[32 + (e & 31)] = l;
 }
@@ -1450,6 +1541,7 @@ struct PackJob {
   int srcC[3], srcOff[3], nsrc;
   int mode, flags;
   float scale; int accumulate;
+  const unsigned* amax;          // modes 10 / 11: amax word of the job's weights (fsraft_amax_jobs over its pieces); NULL: scale 1
 };
 constexpr int PACK_JOBS = 16;
 struct PackJobs { PackJob j[PACK_JOBS]; };
@@ -1475,11 +1567,11 @@ __device__ __forceinline__ float* pack_elem(const PackJob& j, int n, int s, int 
 __device__ __forceinline__ void pack_store(const PackJob& j, int Ktot, int rows, int n, int k, float v) {
   const int64_t e = (int64_t)n * Ktot + k;
   if (j.mode < 10) { j.wpk[e] = v; return; }
-  const __bf16 h = (__bf16)v;
-  const __bf16 l = (__bf16)(v - (float)h);
-  __bf16* out = reinterpret_cast<__bf16*>(j.wpk);
+  _Float16 h, l;
+  fs_split1(v, fs_scale_of_amax(fs_amax_load(j.amax)), h, l);
+  _Float16* out = reinterpret_cast<_Float16*>(j.wpk);
   if (!(j.flags & 1)) {
-    __bf16* rec = out + (e >> 5) * 64;
+    _Float16* rec = out + (e >> 5) * 64;
     rec[e & 31] = h;
     rec[32 + (e & 31)] = l;
     return;
@@ -1659,6 +1751,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvArgs a, cons
   const int HW = a.H * a.W;
   const int64_t M = (int64_t)a.B * HW;
   const int C4 = (a.N + 3) / 4;
+  unsigned mx[3] = {0u, 0u, 0u};
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < M * C4; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / C4;
     const int n = (int)(e % C4) * 4;
@@ -1694,6 +1787,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvArgs a, cons
         if (dacc) r += o[i * dcs];
         if (mk && n - dn0 + i < mkc && mk[m * ldm + (n - dn0) + i] <= 0.f) r = 0.f;
         o[i * dcs] = r;
+        mx[di] = fs_umax(mx[di], fs_abs_bits(r));
       }
     } else if (EPI == EPI_ZR) {
       const bool isz = n < a.hid;
@@ -1708,7 +1802,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvArgs a, cons
         *reinterpret_cast<f32x4*>(a.aux2 + m * a.ld2 + c) = v;                            // r
         f32x4 rh;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rh[i] = v[i] * hh[i];
+        for (int i = 0; i < 4; ++i) { rh[i] = v[i] * hh[i]; mx[1] = fs_umax(mx[1], fs_abs_bits(rh[i])); }
         *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + c) = rh;                           // r*h
       }
     } else {   // EPI_Q
@@ -1720,10 +1814,17 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvArgs a, cons
       for (int i = 0; i < 4; ++i) {
         v[i] = tanhf(v[i]);
         hn[i] = (1.f - zz[i]) * hh[i] + zz[i] * v[i];
+        mx[0] = fs_umax(mx[0], fs_abs_bits(hn[i]));
       }
       *reinterpret_cast<f32x4*>(a.aux1 + m * a.ld1 + n) = v;                              // q
       *reinterpret_cast<f32x4*>(a.dst[0].p + m * a.dst[0].ps + n) = hn;                   // h'
     }
+  }
+  if (a.damax[0] || a.damax[1] || a.damax[2]) {
+    __shared__ unsigned red[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (a.damax[i]) fs_amax_commit(a.damax[i], mx[i], red);
   }
 }
 
@@ -1785,7 +1886,7 @@ int launch_conv_split(const ConvArgs& a, int epi, hipStream_t s) {
         p.dst[0] = Dst{g_conv_ws, (int64_t)a.H * a.W * ldw, ldw, 1, 0, 0};
         p.dst[1] = p.dst[2] = p.dst[0];
         p.ndst = 1; p.bias = nullptr; p.relu = 0; p.alpha = 1.0f;
-        for (int i = 0; i < 3; ++i) p.rmask[i] = nullptr;
+        for (int i = 0; i < 3; ++i) { p.rmask[i] = nullptr; p.damax[i] = nullptr; }      // (the finish pass raises the amax words)
         dim3 g3(grid.x, grid.y, S);
         if (uni_tab) hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 2>), g3, dim3(Cfg::NT), 0, s, t);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<Cfg, EPI_PLAIN, 1>), g3, dim3(Cfg::NT), 0, s, t);
@@ -1883,6 +1984,9 @@ struct fsraft_conv_desc {
   const float* wpk_frag;         // wpk_split in fragment order (or NULL): enables the resident-patch 3x3 kernel
   int pad_h1, pad_w1;            // 0: taps centred (KH / 2, KW / 2); else 1 + the top / left padding (even kernel sizes)
   float* ws; int64_t ws_floats;  // split-K scratch of THIS call (NULL: the calling thread's fsraft_conv_workspace registration)
+  // split arithmetic (fsraft.h "amax words"): per source the word of its tensor, the word wpk_split / wpk_frag were packed
+  // with, and per destination an optional word the epilogue raises (GRU epilogues: [0] new state, [1] r*h)
+  const unsigned* src_amax[3]; const unsigned* w_amax; unsigned* dst_amax[3];
 };
 
 extern "C" int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW) {
@@ -1931,6 +2035,12 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
     if (on && (d->ldmask[i] % 4 != 0 || ((uintptr_t)d->rmask[i] & 15))) return FS_ERR_ARG;
   }
   a.swz = g_xcd_swizzle;
+  for (int i = 0; i < 3; ++i) {
+    a.samax[i] = i < d->nsrc ? d->src_amax[i] : nullptr;
+    a.damax[i] = (i < d->ndst || d->epi != EPI_PLAIN) ? d->dst_amax[i] : nullptr;
+    if ((uintptr_t)a.samax[i] & 3 || (uintptr_t)a.damax[i] & 3) return FS_ERR_ARG;
+  }
+  a.wamax = d->w_amax;
   if (d->epi == EPI_ZR && (!d->h || !d->aux1 || !d->aux2 || d->hid * 2 != d->N)) return FS_ERR_ARG;
   if (d->epi == EPI_Q && (!d->h || !d->z || !d->aux1)) return FS_ERR_ARG;
   if (d->epi != EPI_PLAIN && d->epi != EPI_ZR && d->epi != EPI_Q) return FS_ERR_ARG;
@@ -1948,7 +2058,8 @@ extern "C" int fsraft_conv_forward(const fsraft_conv_desc* d, hipStream_t stream
       d->dst_cs[0] == 1 && d->dst_n0[0] == 0 && !(d->dst_acc[0] && d->relu) && !a.rmask[0] && d->alpha == 1.0f &&
       (int64_t)d->B * d->H * d->W >= g_conv_halo_min_m && (int64_t)d->H * d->W * d->srcld[0] * 4 < 0x7fffffff) {
     HaloArgs h{d->src[0], d->srcld[0], d->srcC[0], reinterpret_cast<const char*>(d->wpk_frag), d->bias,
-               d->dst[0], d->dst_bs[0], d->dst_ps[0], d->N, d->B, d->H, d->W, d->relu, d->dst_acc[0], nullptr, nullptr, 0};
+               d->dst[0], d->dst_bs[0], d->dst_ps[0], d->N, d->B, d->H, d->W, d->relu, d->dst_acc[0], nullptr, nullptr, 0,
+               d->src_amax[0], d->w_amax, d->dst_amax[0]};
     bool halo_stats = false;
     // Measured (scripts/conv_micro.py, halo on / off): 64 -> 64 at 8x220x512 238 vs 442 us.  With three or four channel
     // groups the patch takes 78 / 104 KB of LDS, one or two 4-wave workgroups per CU, and the kernel loses to the implicit
@@ -2092,10 +2203,12 @@ namespace { int launch_wgrad_patch(WgradArgsM m, hipStream_t s); }
 
 extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
                                  const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W, int KH,
-                                 int KW, hipStream_t stream) {
+                                 int KW, const unsigned* dy_amax, const unsigned* const* src_amax, hipStream_t stream) {
   if (!dy || !src || !dwpk || nsrc < 1 || nsrc > 3 || ldy % 4 != 0) return FS_ERR_ARG;
   WgradArgs a{};
   a.dy = dy; a.ldy = ldy; a.Cout = Cout;
+  a.dyamax = dy_amax;
+  for (int s = 0; s < 3; ++s) a.samax[s] = (src_amax && s < nsrc) ? src_amax[s] : nullptr;
   const bool small_m = Cout <= 32;
   const bool t64 = !small_m && g_wgrad_tile == 3;
   const int bn = t64 ? 64 : 128, bm = small_m ? 32 : (t64 ? 64 : 128);
@@ -2116,8 +2229,8 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
     WgradArgsM m{};
     m.a = a; m.a.dbias = dbias;
     m.nseg = 1;
-    m.dys[0] = dy;
-    for (int s = 0; s < nsrc; ++s) m.srcs[s][0] = src[s];
+    m.dys[0] = dy; m.dyam[0] = dy_amax;
+    for (int s = 0; s < nsrc; ++s) { m.srcs[s][0] = src[s]; m.sam[s][0] = a.samax[s]; }
     const int rc = launch_wgrad_patch(m, stream);
     if (rc >= 0) return rc;
   }
@@ -2181,7 +2294,8 @@ extern "C" int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float
 
 extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy, int Cout, const float* const* src,
                                        const int* srcC, const int* srcld, int nsrc, float* dwpk, float* dbias, int B,
-                                       int H, int W, int KH, int KW, hipStream_t stream) {
+                                       int H, int W, int KH, int KW, const unsigned* const* dy_amax,
+                                       const unsigned* const* src_amax, hipStream_t stream) {
   if (!dy || !src || !dwpk || nseg < 1 || nsrc < 1 || nsrc > 3 || ldy % 4 != 0) return FS_ERR_ARG;
   const int64_t M = (int64_t)B * H * W;
   const bool fast = g_wgrad_multi && nseg > 1 && Cout > 32 && g_wgrad_tile != 3 && g_wgrad_split == 2 && g_wgrad_buf;
@@ -2190,7 +2304,8 @@ extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy
     if (!fast || n == 1) {
       for (int i = 0; i < n; ++i) {
         const int rc = fsraft_conv_wgrad(dy[base + i], ldy, Cout, src + (size_t)(base + i) * nsrc, srcC, srcld, nsrc, dwpk,
-                                         dbias, B, H, W, KH, KW, stream);
+                                         dbias, B, H, W, KH, KW, dy_amax ? dy_amax[base + i] : nullptr,
+                                         src_amax ? src_amax + (size_t)(base + i) * nsrc : nullptr, stream);
         if (rc) return rc;
       }
       continue;
@@ -2209,9 +2324,11 @@ extern "C" int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy
     for (int i = 0; i < n; ++i) {
       if (!dy[base + i]) return FS_ERR_ARG;
       m.dys[i] = dy[base + i];
+      m.dyam[i] = dy_amax ? dy_amax[base + i] : nullptr;
       for (int s = 0; s < nsrc; ++s) {
         if (!src[(size_t)(base + i) * nsrc + s]) return FS_ERR_ARG;
         m.srcs[s][i] = src[(size_t)(base + i) * nsrc + s];
+        m.sam[s][i] = src_amax ? src_amax[(size_t)(base + i) * nsrc + s] : nullptr;
       }
     }
     a.nsrc = nsrc; a.dwpk = dwpk; a.Ktot = conv_ktot(srcC, nsrc, KH * KW);
@@ -2286,9 +2403,10 @@ extern "C" int fsraft_pack_conv_weights(const PackJob* jobs, int njobs, hipStrea
 }
 
 extern "C" int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
-                                       int nsrc, int mode, int accumulate, hipStream_t stream) {
-  if (!w_oihw || !wpk || mode < 0 || (mode > 2 && mode != 10 && mode != 11)) return FS_ERR_ARG;
+                                       int nsrc, int mode, int accumulate, const unsigned* w_amax, hipStream_t stream) {
+  if (!w_oihw || !wpk || mode < 0 || (mode > 2 && mode != 10 && mode != 11) || ((uintptr_t)w_amax & 3)) return FS_ERR_ARG;
   PackArgs a{};
+  a.amax = w_amax;
   a.split = mode >= 10;                      // modes 10 / 11: split-bf16 variants of modes 0 / 1
   if (mode >= 10) mode -= 10;
   if (a.split && mode > 1) return FS_ERR_ARG;

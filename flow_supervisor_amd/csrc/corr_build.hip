@@ -318,8 +318,12 @@ struct F2SplitLoader {        // chunk e: channel k = e / 64, tile columns n = 4
 
 constexpr int LDS_SPLIT_BYTES = BuildSplitCfg::LDS_BYTES > EPI_FLOATS * 4 ? BuildSplitCfg::LDS_BYTES : EPI_FLOATS * 4;
 
+// am1 / am2: amax words of the two feature maps (split_arith.hpp; NULL: scale 1)
 __global__ __launch_bounds__(256) void corr_build_split_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                               Levels lv, int nlev, int C, int H, int W, float scale) {
+                                                               Levels lv, int nlev, int C, int H, int W, float scale,
+                                                               const unsigned* am1, const unsigned* am2) {
+  const float s1 = fs_scale_of_amax(fs_amax_load(am1)), s2 = fs_scale_of_amax(fs_amax_load(am2));
+  scale *= fs_inv_scale(s1) * fs_inv_scale(s2);
   __shared__ __attribute__((aligned(16))) char lds[LDS_SPLIT_BYTES];
   const int N = H * W;
   const int npx = ceil_div_dev(W, 32);
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void corr_build_split_kernel(const float* __re
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-  split_mainloop_tn<BuildSplitCfg>(lds, ceil_div_dev(C, 32), la, lb, acc);
+  split_mainloop_tn<BuildSplitCfg>(lds, ceil_div_dev(C, 32), la, lb, acc, nullptr, s1, s2);
   __syncthreads();
   build_epilogue(acc, reinterpret_cast<float*>(lds), lv, nlev, H, W, N, b, i0, px0, py0, scale);
 }
@@ -365,7 +369,10 @@ __global__ __launch_bounds__(256) void corr_build_tiled_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(256) void corr_build_tiled_split_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                                     float* __restrict__ vol, VolLayout L, int C, float scale) {
+                                                                     float* __restrict__ vol, VolLayout L, int C, float scale,
+                                                                     const unsigned* am1, const unsigned* am2) {
+  const float s1 = fs_scale_of_amax(fs_amax_load(am1)), s2 = fs_scale_of_amax(fs_amax_load(am2));
+  scale *= fs_inv_scale(s1) * fs_inv_scale(s2);
   __shared__ __attribute__((aligned(16))) char lds[LDS_SPLIT_BYTES];
   const int H = L.H, W = L.W, N = H * W;
   const int npx = ceil_div_dev(W, 32);
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void corr_build_tiled_split_kernel(const float
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-  split_mainloop_tn<BuildSplitCfg>(lds, ceil_div_dev(C, 32), la, lb, acc);
+  split_mainloop_tn<BuildSplitCfg>(lds, ceil_div_dev(C, 32), la, lb, acc, nullptr, s1, s2);
   __syncthreads();
   build_epilogue_tiled(acc, reinterpret_cast<float*>(lds), vol, L, N, b, i0, px0, py0, scale);
 }
@@ -413,7 +420,9 @@ __device__ __forceinline__ void build_stagger(int stagger) {
 }
 
 __global__ __launch_bounds__(512) void corr_build_rec_kernel(const char* __restrict__ f1r, const char* __restrict__ f2r,
-                                                             float* __restrict__ vol, VolLayout L, int C, float scale, int stagger, int policy) {
+                                                             float* __restrict__ vol, VolLayout L, int C, float scale, int stagger, int policy,
+                                                             const unsigned* am1, const unsigned* am2) {   // the words the records were split with
+  scale *= fs_inv_scale(fs_scale_of_amax(fs_amax_load(am1))) * fs_inv_scale(fs_scale_of_amax(fs_amax_load(am2)));
   __shared__ __attribute__((aligned(1024))) char lds[BR::LDS_BYTES > BR_EPI_FLOATS * 4 ? BR::LDS_BYTES : BR_EPI_FLOATS * 4];
   build_stagger(stagger);
   const int H = L.H, W = L.W, N = H * W;
@@ -651,7 +660,7 @@ extern "C" int fsraft_corr_pool_pyramid(float* const* levels, int num_levels, in
 }
 
 extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* levels, int num_levels,
-                                 int B, int C, int H, int W, hipStream_t stream) {
+                                 int B, int C, int H, int W, const unsigned* amax1, const unsigned* amax2, hipStream_t stream) {
   if (!fmap1 || !fmap2 || !levels || num_levels < 1 || num_levels > 4 || B < 1 || C < 2 || (C & 1) || H < 1 || W < 1) return FS_ERR_ARG;
   Levels lv;
   int h = H, w = W;
@@ -665,7 +674,7 @@ extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* 
   dim3 grid(ceil_div(W, 32) * ceil_div(H, 8), ceil_div(N, 64), B);
   if (g_build_split)
     hipLaunchKernelGGL(corr_build_split_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, lv, num_levels, C, H, W,
-                       1.0f / sqrtf((float)C));
+                       1.0f / sqrtf((float)C), amax1, amax2);
   else
     hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, lv, num_levels, C, H, W,
                        1.0f / sqrtf((float)C));
@@ -674,14 +683,14 @@ extern "C" int fsraft_corr_build(const float* fmap1, const float* fmap2, float* 
 
 // Volume + pyramid of one batch in the tiled-row layout: vol [B*H*W][P] (fsraft_vol_layout gives P and the level offsets).
 extern "C" int fsraft_corr_build_tiled(const float* fmap1, const float* fmap2, float* vol, int num_levels, int B, int C, int H,
-                                       int W, hipStream_t stream) {
+                                       int W, const unsigned* amax1, const unsigned* amax2, hipStream_t stream) {
   VolLayout L;
   if (!fmap1 || !fmap2 || !vol || B < 1 || C < 2 || (C & 1) || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
   if ((uintptr_t)vol % 16) return FS_ERR_ARG;
   const int N = H * W;
   dim3 grid(ceil_div(W, 32) * ceil_div(H, 8), ceil_div(N, 64), B);
   if (g_build_split)
-    hipLaunchKernelGGL(corr_build_tiled_split_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, vol, L, C, 1.0f / sqrtf((float)C));
+    hipLaunchKernelGGL(corr_build_tiled_split_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, vol, L, C, 1.0f / sqrtf((float)C), amax1, amax2);
   else
     hipLaunchKernelGGL(corr_build_tiled_kernel, grid, dim3(256), 0, stream, fmap1, fmap2, vol, L, C, 1.0f / sqrtf((float)C));
   return fs_launch_status();
@@ -697,9 +706,9 @@ extern "C" int fsraft_vol_layout(int H, int W, int num_levels, int* out) {
 }
 
 // The same build from PRE-SPLIT feature maps: f1r, f2r = [B][H*W][C / 32] records (fsraft_to_records of the channels-last
-// maps), C % 32 == 0.  Always bf16x3 arithmetic (the exact-fp32 build is fsraft_corr_build_tiled with the split switched off).
+// maps, split with the words amax1 / amax2), C % 32 == 0.  Always split arithmetic (the exact-fp32 build is fsraft_corr_build_tiled with the split switched off).
 extern "C" int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vol, int num_levels, int B, int C, int H, int W,
-                                     hipStream_t stream) {
+                                     const unsigned* amax1, const unsigned* amax2, hipStream_t stream) {
   VolLayout L;
   if (!f1r || !f2r || !vol || B < 1 || C < 32 || (C % 32) || !vol_layout_make(H, W, num_levels, L)) return FS_ERR_ARG;
   if (((uintptr_t)vol % 16) || ((uintptr_t)f1r % 16) || ((uintptr_t)f2r % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff) return FS_ERR_ARG;
@@ -709,7 +718,7 @@ extern "C" int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vo
   // at 8 x 46x62; at one pair (270 MB) plain stores are as fast or faster (round 3, docs/history)
   const int policy = g_build_policy >= 0 ? g_build_policy : ((int64_t)B * N * L.P * 4 > ((int64_t)300 << 20) ? 2 : 0);
   hipLaunchKernelGGL(corr_build_rec_kernel, grid, dim3(512), 0, stream, (const char*)f1r, (const char*)f2r, vol, L, C,
-                     1.0f / sqrtf((float)C), g_build_stagger, policy);
+                     1.0f / sqrtf((float)C), g_build_stagger, policy, amax1, amax2);
   return fs_launch_status();
 }
 

@@ -196,6 +196,8 @@ struct DvolArgs {
   const float* dout[DV_MAXN];      // [B,H,W,CH] channels-last gradient of each lookup's output
   Coords co[DV_MAXN];
   int n;
+  const unsigned* amax;            // records: the word the gradient rows are split with (a bound of |dV|: the lookups' windows
+                                   // overlap, a cell collects at most one unit of bilinear weight per lookup); NULL: scale 1
 };
 
 // One workgroup = one (query, job): a job is a run of whole pyramid levels [l0, l1] whose cells fit the LDS segment
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
   //  register count -- 49 -> 158 VGPRs, 7 -> 3 waves per SIMD -- and cost 35 % on the plain route)
   if (qlist && blockIdx.x >= qlist[0]) return;
   const unsigned qrel = qlist ? qlist[1 + blockIdx.x] : blockIdx.x;
+  const float rec_s = REC ? fs_scale_of_amax(fs_amax_load(a.amax)) : 1.0f, rec_inv = fs_inv_scale(rec_s);
   float* seg = smem;                                   // [min(run, DV_SEG)]
   const int nlev = L.nlev, CH = nlev * S::N2, n = a.n, nl = l1 - l0 + 1;
   const int rbeg = L.off[l0], rend = (l1 + 1 < nlev) ? L.off[l1 + 1] : L.P;       // the run, in floats of the row
@@ -259,14 +262,11 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
     const int len = min(seglen, rend - s0);
     __syncthreads();
     if (REC && accumulate) {
-      for (int e = threadIdx.x * 8; e < len; e += 2048) {        // hi + lo back to fp32 (exact to ~2^-17 relative)
+      for (int e = threadIdx.x * 8; e < len; e += 2048) {        // hi + lo back to fp32 (exact to ~2^-22 relative)
         const char* rp = reinterpret_cast<const char*>(row + s0) + (e >> 5) * 128 + (e & 31) * 2;
         const u32x4 h = __builtin_bit_cast(u32x4, gload4(rp)), l = __builtin_bit_cast(u32x4, gload4(rp + 64));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          seg[e + 2 * i] = __builtin_bit_cast(float, h[i] << 16) + __builtin_bit_cast(float, l[i] << 16);
-          seg[e + 2 * i + 1] = __builtin_bit_cast(float, h[i] & 0xffff0000u) + __builtin_bit_cast(float, l[i] & 0xffff0000u);
-        }
+        for (int i = 0; i < 4; ++i) fs_unsplit2(h[i], l[i], rec_inv, seg[e + 2 * i], seg[e + 2 * i + 1]);
       }
     } else {
       for (int e = threadIdx.x * 4; e < len; e += 1024)
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256) void corr_dvol_kernel(DvolArgs a, VolLayout L,
     if (REC) {
       for (int e = threadIdx.x * 8; e < len; e += 2048) {        // (level sections are multiples of 16 cells; runs start on 32)
         uint2 h0, l0s, h1, l1s;
-        rec_split4(seg + e, h0, l0s);
-        rec_split4(seg + e + 4, h1, l1s);
+        rec_split4(seg + e, h0, l0s, rec_s);
+        rec_split4(seg + e + 4, h1, l1s, rec_s);
         char* rp = reinterpret_cast<char*>(row + s0) + (e >> 5) * 128 + (e & 31) * 2;
         dvstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}), policy);
         dvstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}), policy);
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
                                                             const unsigned* __restrict__ wmask, int wm_hw) {
   using S = TL<R>;
   constexpr int N1 = S::N1, WIN = S::WIN, N2 = S::N2;
+  const float rec_s = REC ? fs_scale_of_amax(fs_amax_load(a.amax)) : 1.0f;
   __shared__ __attribute__((aligned(16))) float box_s[4][DVS_TOT];           // [wave][level boxes back to back]
   __shared__ __attribute__((aligned(16))) LevelQ lq_s[4][4][DV_MAXN];        // [wave][level][lookup]
   __shared__ float cxy[4][DV_MAXN][2];
@@ -586,8 +587,8 @@ __global__ __launch_bounds__(256) void corr_dvol_sep_kernel(DvolArgs a, VolLayou
         if (REC) {
           const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
           uint2 h0, l0s, h1, l1s;
-          rec_split4(v, h0, l0s);
-          rec_split4(v + 4, h1, l1s);
+          rec_split4(v, h0, l0s, rec_s);
+          rec_split4(v + 4, h1, l1s, rec_s);
           char* rp = rowb + (f >> 5) * 128 + (f & 31) * 2;
           dvstore4(rp, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}), policy);
           dvstore4(rp + 64, __builtin_bit_cast(f32x4, u32x4{l0s.x, l0s.y, l1s.x, l1s.y}), policy);
@@ -800,8 +801,10 @@ __global__ __launch_bounds__(256) void corr_f2cat_kernel(const float* __restrict
 // level is the 2x2 mean of the one above it), and leaves as [32 hi | 32 lo] bf16 records -- what corr_f2cat_kernel (strided
 // 4-byte reads, 46 us for 29 MB in) followed by to_records (39 MB in and out again) produced in two.
 constexpr int F2C_MAX_PLANE = 12288;          // floats of one level-0 plane kept in LDS (48 KB; + 1/3 for the pooled levels)
-__global__ __launch_bounds__(256) void corr_f2cat_rec_kernel(const float* __restrict__ f2, char* __restrict__ f2r, VolLayout L) {
+__global__ __launch_bounds__(256) void corr_f2cat_rec_kernel(const float* __restrict__ f2, char* __restrict__ f2r, VolLayout L,
+                                                             const unsigned* __restrict__ amax) {     // word of fmap2 (bounds its means too)
   extern __shared__ float pl[];               // level 0 | level 1 | level 2 | level 3, row-major, true sizes
+  const float rec_s = fs_scale_of_amax(fs_amax_load(amax));
   const int H = L.H, W = L.W, HW = H * W;
   const float* src = f2 + (int64_t)blockIdx.x * HW;
   if ((HW & 3) == 0) {
@@ -845,8 +848,8 @@ __global__ __launch_bounds__(256) void corr_f2cat_rec_kernel(const float* __rest
       v[i] = (ty < L.th[l] && y < h && x < w) ? lv[y * w + x] : 0.f;
     }
     uint2 h0, l0, h1, l1;
-    rec_split4(v, h0, l0);
-    rec_split4(v + 4, h1, l1);
+    rec_split4(v, h0, l0, rec_s);
+    rec_split4(v + 4, h1, l1, rec_s);
     char* d = dst + (u >> 2) * 128 + (u & 3) * 16;
     gstore4(d, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}));
     gstore4(d + 64, __builtin_bit_cast(f32x4, u32x4{l0.x, l0.y, l1.x, l1.y}));
@@ -940,7 +943,8 @@ extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, co
 
 // dvol [B*H*W][P] (=, or += when accumulate) sum over the n lookups of (d out_t / d V)^T dout_t; dout[t]: [B,H,W,CH]
 // channels-last; coords[t] with per-lookup strides coords_str[3*t + {0,1,2}] = (bs, cs, ps).  n <= 16 per call.
-// records != 0: rows are written as [32 bf16 hi | 32 bf16 lo] records (operands of fsraft_gemm_rec_nt / _tn).
+// records != 0: rows are written as [32 hi | 32 lo] fp16 records of dV * scale(dvol_amax) (operands of fsraft_gemm_rec_nt / _tn);
+// dvol_amax: a word bounding |dV| -- (number of lookups of the step) x max |dout| does (fsraft_amax_scaled).
 // Queries [q0, q0 + nq) only (nq == 0: all from q0), written to dvol rows 0 .. nq-1: the memory-efficient path builds the
 // gradient volume a chunk of queries at a time.
 int g_dvol_policy = 0;
@@ -967,7 +971,8 @@ extern "C" int fsraft_set_dvol_box(int on) {
 
 extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n,
                                       float* dvol, int num_levels, int B, int H, int W, int radius, int accumulate, int records,
-                                      int add_grid, int64_t q0, int64_t nq, unsigned* qlist, const unsigned* wmask, hipStream_t stream) {
+                                      int add_grid, int64_t q0, int64_t nq, unsigned* qlist, const unsigned* wmask,
+                                      const unsigned* dvol_amax, hipStream_t stream) {
   VolLayout L;
   if (!dout || !coords || !coords_str || !dvol || n < 1 || n > DV_MAXN || B < 1 || !vol_layout_make(H, W, num_levels, L) ||
       ((uintptr_t)dvol % 16))
@@ -975,6 +980,7 @@ extern "C" int fsraft_corr_dvol_build(const float* const* dout, const float* con
   if (radius != 3 && radius != 4) return FS_ERR_ARG;
   DvolArgs a;
   a.n = n;
+  a.amax = dvol_amax;
   for (int t = 0; t < n; ++t) {
     if (!dout[t] || !coords[t]) return FS_ERR_ARG;
     a.dout[t] = dout[t];
@@ -1078,14 +1084,15 @@ extern "C" int fsraft_corr_f2cat(const float* fmap2, float* f2cat, int num_level
 
 // fmap2 [B][C][H][W] -> f2cat [B][C][P / 32] records (what fsraft_corr_f2cat + fsraft_to_records give), for planes of at most
 // 12288 pixels (FS_ERR_ARG above that: the caller takes the two-kernel route)
-extern "C" int fsraft_corr_f2cat_rec(const float* fmap2, void* f2r, int num_levels, int B, int C, int H, int W, hipStream_t stream) {
+extern "C" int fsraft_corr_f2cat_rec(const float* fmap2, void* f2r, int num_levels, int B, int C, int H, int W, const unsigned* amax2,
+                                     hipStream_t stream) {
   VolLayout L;
   if (!fmap2 || !f2r || B < 1 || C < 1 || !vol_layout_make(H, W, num_levels, L) || (int64_t)H * W > F2C_MAX_PLANE ||
       ((uintptr_t)f2r % 16) || ((uintptr_t)fmap2 % 16))
     return FS_ERR_ARG;
   int fl = 0;
   for (int l = 0; l < L.nlev; ++l) fl += L.h[l] * L.w[l];
-  hipLaunchKernelGGL(corr_f2cat_rec_kernel, dim3(B * C), dim3(256), (size_t)fl * 4, stream, fmap2, (char*)f2r, L);
+  hipLaunchKernelGGL(corr_f2cat_rec_kernel, dim3(B * C), dim3(256), (size_t)fl * 4, stream, fmap2, (char*)f2r, L, amax2);
   return fs_launch_status();
 }
 

@@ -18,6 +18,7 @@ struct GemmArgs {
   const float* Bm; int64_t ldb, sB;
   float* C; int64_t ldc, sC;
   int M, N, K; float alpha; int accumulate;
+  const unsigned* a_amax; const unsigned* b_amax;     // split kernels: amax words of A and B (NULL: scale 1)
 };
 
 template <class Cfg, bool BT>
@@ -68,7 +69,7 @@ using STN = SplitTnCfg<128, 128, 2, 2, 1>;     // TN: A [K][M], B [K][N], both k
 template <class Cfg, int NCH_>
 struct SplitRowLoader {          // chunk e: row e / 8, k = kt*32 + 4*(e % 8)
   static constexpr int NCH = NCH_, NREG = NCH_ * 4;
-  const float* base; int64_t ld; int rows_valid, K;
+  const float* base; int64_t ld; int rows_valid, K; float s;
   __device__ __forceinline__ void fetch_chunk(int kt, float (&r)[NREG], int j) const {
     const int e = threadIdx.x + 256 * j;
     const int row = e >> 3, k = kt * 32 + 4 * (e & 7);
@@ -77,7 +78,7 @@ struct SplitRowLoader {          // chunk e: row e / 8, k = kt*32 + 4*(e % 8)
     r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
   }
   __device__ __forceinline__ void stage_chunk(char* tile, const float* r4, int j) const {
-    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4);
+    stage_convert<Cfg::PITCH>(tile, threadIdx.x + 256 * j, r4, s);
   }
 };
 template <int COLS, int NCH_>
@@ -94,7 +95,8 @@ struct SplitKmajorLoader {       // chunk e: k = kt*32 + e / (COLS/4), columns 4
 };
 
 template <class Cfg>
-__device__ __forceinline__ void store_tile(const GemmArgs& g, float* C, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0) {
+__device__ __forceinline__ void store_tile(const GemmArgs& g, float* C, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0, float inv) {
+  const float alpha = g.alpha * inv;
 #pragma unroll
   for (int nt = 0; nt < Cfg::TN; ++nt) {
     const int n = n0 + acc_col<Cfg>(nt);
@@ -106,7 +108,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, float* C, f32x16 (
         const int m = m0 + acc_row<Cfg>(mt, r);
         if (m >= g.M) continue;
         float* o = C + (int64_t)m * g.ldc + n;
-        const float v = g.alpha * acc[mt][nt][r];
+        const float v = alpha * acc[mt][nt][r];
         *o = g.accumulate ? *o + v : v;
       }
   }
@@ -115,8 +117,9 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, float* C, f32x16 (
 __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) char lds[SNT::LDS_BYTES];
   const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128, b = blockIdx.z;
-  SplitRowLoader<SNT, SNT::NCH_A> la{g.A + b * g.sA + (int64_t)m0 * g.lda, g.lda, g.M - m0, g.K};
-  SplitRowLoader<SNT, SNT::NCH_B> lb{g.Bm + b * g.sB + (int64_t)n0 * g.ldb, g.ldb, g.N - n0, g.K};
+  const float sa = fs_scale_of_amax(fs_amax_load(g.a_amax)), sb = fs_scale_of_amax(fs_amax_load(g.b_amax));
+  SplitRowLoader<SNT, SNT::NCH_A> la{g.A + b * g.sA + (int64_t)m0 * g.lda, g.lda, g.M - m0, g.K, sa};
+  SplitRowLoader<SNT, SNT::NCH_B> lb{g.Bm + b * g.sB + (int64_t)n0 * g.ldb, g.ldb, g.N - n0, g.K, sb};
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -125,13 +128,14 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   split_mainloop<SNT>(lds, (g.K + 31) / 32, la, lb, acc);
-  store_tile<SNT>(g, g.C + b * g.sC, acc, m0, n0);
+  store_tile<SNT>(g, g.C + b * g.sC, acc, m0, n0, fs_inv_scale(sa) * fs_inv_scale(sb));
 }
 
 // C[b][m][n] = alpha * sum_k A[b][k][m] * B[b][k][n]
 __global__ __launch_bounds__(256) void gemm_split_tn_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) char lds[STN::LDS_BYTES];
   const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128, b = blockIdx.z;
+  const float sa = fs_scale_of_amax(fs_amax_load(g.a_amax)), sb = fs_scale_of_amax(fs_amax_load(g.b_amax));
   SplitKmajorLoader<128, STN::NCH_A> la{g.A + b * g.sA + m0, g.lda, g.M - m0, g.K};
   SplitKmajorLoader<128, STN::NCH_B> lb{g.Bm + b * g.sB + n0, g.ldb, g.N - n0, g.K};
   f32x16 acc[2][2];
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(256) void gemm_split_tn_kernel(GemmArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  split_mainloop_tn<STN>(lds, (g.K + 31) / 32, la, lb, acc);
-  store_tile<STN>(g, g.C + b * g.sC, acc, m0, n0);
+  split_mainloop_tn<STN>(lds, (g.K + 31) / 32, la, lb, acc, nullptr, sa, sb);
+  store_tile<STN>(g, g.C + b * g.sC, acc, m0, n0, fs_inv_scale(sa) * fs_inv_scale(sb));
 }
 
 int g_gemm_split = 1;
@@ -152,9 +156,9 @@ int g_gemm_split = 1;
 // trans_b != 0: Bm is [N][K] (k contiguous); else Bm is [K][N].  Strides sA/sB/sC are per-batch element counts.
 extern "C" int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB,
                                float* C, int64_t ldc, int64_t sC, int batch, int M, int N, int K, int trans_b,
-                               float alpha, int accumulate, hipStream_t stream) {
+                               float alpha, int accumulate, const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
   if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 1) return FS_ERR_ARG;
-  GemmArgs g{A, lda, sA, Bm, ldb, sB, C, ldc, sC, M, N, K, alpha, accumulate};
+  GemmArgs g{A, lda, sA, Bm, ldb, sB, C, ldc, sC, M, N, K, alpha, accumulate, a_amax, b_amax};
   dim3 grid(ceil_div(N, 128), ceil_div(M, 128), batch);
   const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (K % 4 == 0) && (sA % 4 == 0) && (sB % 4 == 0) &&
                        ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0);
@@ -168,10 +172,10 @@ extern "C" int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const fl
 // Requires lda, ldb, M, N multiples of 4 and 16-byte aligned bases.
 extern "C" int fsraft_gemm_tn_split(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB,
                                     float* C, int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha,
-                                    int accumulate, hipStream_t stream) {
+                                    int accumulate, const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
   if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 1) return FS_ERR_ARG;
   if ((lda % 4) || (ldb % 4) || (M % 4) || (N % 4) || (sA % 4) || (sB % 4) || ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16)) return FS_ERR_ARG;
-  GemmArgs g{A, lda, sA, Bm, ldb, sB, C, ldc, sC, M, N, K, alpha, accumulate};
+  GemmArgs g{A, lda, sA, Bm, ldb, sB, C, ldc, sC, M, N, K, alpha, accumulate, a_amax, b_amax};
   dim3 grid(ceil_div(N, 128), ceil_div(M, 128), batch);
   hipLaunchKernelGGL(gemm_split_tn_kernel, grid, dim3(256), 0, stream, g);
   return fs_launch_status();

@@ -1,11 +1,9 @@
-// Split-bf16 ("bf16x3") block-GEMM core for gfx950: fp32 operands are split on the fly into
-// hi = bf16(x) and lo = bf16(x - hi) and every product is evaluated as
-//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi            (fp32 accumulation in the MFMA)
-// with three v_mfma_f32_32x32x16_bf16 per 32x32x16 block.  Relative error per product is ~2^-16..2^-17
-// (the dropped a_lo*b_lo term and the rounding of lo), the exponent range is fp32's, and the
-// matrix pipe runs 16x faster per instruction than v_mfma_f32_32x32x2_f32, i.e. 5.3x faster per
-// useful FLOP.  Measured end to end on RAFT (368x496, 12 iterations, update block only in this mode):
-// EPE 4.6e-5 mean / 1.0e-4 max against the fp32 reference, 20x inside the 1e-3 gate.
+// Split ("fp16x3", split_arith.hpp) block-GEMM core for gfx950: fp32 operands are scaled by their tensor's power-of-two
+// scale and split on the fly into hi = fp16(x s) and lo = fp16(x s - hi); every product is evaluated as
+//     a*b ~= (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) / (s_a s_b)            (fp32 accumulation in the MFMA)
+// with three v_mfma_f32_32x32x16_f16 per 32x32x16 block: ~2^-22 relative per product, and the matrix pipe runs 16x
+// faster per instruction than v_mfma_f32_32x32x2_f32, i.e. 5.3x faster per useful FLOP.  (Rounds 1-5 split into bf16
+// pieces: no scales, 2^-17 per product.)
 //
 // Operand images in LDS are ROW-major here ([row][k], k contiguous), which is the natural order of
 // channels-last activations and of the packed weights, so staging is a straight 16-byte load ->
@@ -22,8 +20,6 @@
 #include "common.hpp"
 #include <type_traits>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // SWZ_ = true: rows are stored unpadded (128 B) and the eight 16-byte slots of row r are permuted by
 // slot ^ ((r >> 1) & 7) instead -- the 16 rows of a ds_read_b128 lane group then still cover all 64 banks once,
@@ -71,22 +67,7 @@ __device__ __attribute__((aligned(16))) float g_fsraft_zero16[4];
 
 // fp32 x4 -> (hi, lo) bf16 x4.  hi = RNE bf16(x); lo = RNE bf16(x - hi): 3 VALU ops per element
 // (v_cvt_pk_bf16_f32 packs two conversions; the back-conversion of hi is a shift / mask).
-__device__ __forceinline__ void split4(const float* r, uint2& hi, uint2& lo) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  unsigned h[2], l[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const f2 x = {r[2 * i], r[2 * i + 1]};
-    const bf2 hb = __builtin_convertvector(x, bf2);
-    h[i] = __builtin_bit_cast(unsigned, hb);
-    const float h0 = __builtin_bit_cast(float, h[i] << 16), h1 = __builtin_bit_cast(float, h[i] & 0xffff0000u);
-    const f2 d = {x[0] - h0, x[1] - h1};
-    l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf2));
-  }
-  hi = make_uint2(h[0], h[1]);
-  lo = make_uint2(l[0], l[1]);
-}
+__device__ __forceinline__ void split4(const float* r, uint2& hi, uint2& lo, float s = 1.0f) { fs_split4(r, s, hi, lo); }
 
 // byte offset of 16-byte slot `slot` (0..7: hi k 0-7, 8-15, 16-23, 24-31, then the same for lo) of row `row`
 template <int PITCH>
@@ -95,9 +76,9 @@ __device__ __forceinline__ int slot_offset(int row, int slot) {
 }
 // staging of one 16-byte chunk e (row = e / 8, k = 4 * (e % 8)) of fp32 data into a [row][hi 32 | lo 32] image
 template <int PITCH>
-__device__ __forceinline__ void stage_convert(char* tile, int e, const float* r) {
+__device__ __forceinline__ void stage_convert(char* tile, int e, const float* r, float s = 1.0f) {
   uint2 hi, lo;
-  split4(r, hi, lo);
+  split4(r, hi, lo, s);
   const int row = e >> 3, kq = e & 7;                 // 8 bytes of hi at slot kq / 2, half kq % 2; lo four slots further
   *reinterpret_cast<uint2*>(tile + slot_offset<PITCH>(row, kq >> 1) + (kq & 1) * 8) = hi;
   *reinterpret_cast<uint2*>(tile + slot_offset<PITCH>(row, 4 + (kq >> 1)) + (kq & 1) * 8) = lo;
@@ -177,18 +158,18 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
     const char* Bs = cur + Cfg::A_BYTES + rb * Cfg::PITCH;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN];
+      p16x8 ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN];
       const int oah = slot_offset<Cfg::PITCH>(ra, 2 * s + lh) - ra * Cfg::PITCH, oal = slot_offset<Cfg::PITCH>(ra, 4 + 2 * s + lh) - ra * Cfg::PITCH;
       const int obh = slot_offset<Cfg::PITCH>(rb, 2 * s + lh) - rb * Cfg::PITCH, obl = slot_offset<Cfg::PITCH>(rb, 4 + 2 * s + lh) - rb * Cfg::PITCH;
 #pragma unroll
       for (int mt = 0; mt < Cfg::TM; ++mt) {
-        ah[mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * Cfg::PITCH + oah);
-        al[mt] = *reinterpret_cast<const bf16x8*>(As + mt * 32 * Cfg::PITCH + oal);
+        ah[mt] = *reinterpret_cast<const p16x8*>(As + mt * 32 * Cfg::PITCH + oah);
+        al[mt] = *reinterpret_cast<const p16x8*>(As + mt * 32 * Cfg::PITCH + oal);
       }
 #pragma unroll
       for (int nt = 0; nt < Cfg::TN; ++nt) {
-        bh[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + obh);
-        bl[nt] = *reinterpret_cast<const bf16x8*>(Bs + nt * 32 * Cfg::PITCH + obl);
+        bh[nt] = *reinterpret_cast<const p16x8*>(Bs + nt * 32 * Cfg::PITCH + obh);
+        bl[nt] = *reinterpret_cast<const p16x8*>(Bs + nt * 32 * Cfg::PITCH + obl);
       }
       if (abl & 2) {      // keep the fragment reads alive without issuing MFMAs
 #pragma unroll
@@ -201,9 +182,9 @@ __device__ __forceinline__ void split_mainloop(char* __restrict__ lds, int KT, c
       for (int mt = 0; mt < Cfg::TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < Cfg::TN; ++nt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = fs_mfma_32x32x16(al[mt], bh[nt], acc[mt][nt]);
+          acc[mt][nt] = fs_mfma_32x32x16(ah[mt], bl[nt], acc[mt][nt]);
+          acc[mt][nt] = fs_mfma_32x32x16(ah[mt], bh[nt], acc[mt][nt]);
         }
     }
   };
@@ -270,21 +251,21 @@ struct SplitTnCfg {
 
 // chunk e of a [32][COLS] fp32 tile: k = e / (COLS/4), 4 consecutive columns from 4 * (e % (COLS/4))
 template <int COLS, int PITCH, int PLANE>
-__device__ __forceinline__ void stage_convert_kmajor(char* tile, int e, const float* r) {
+__device__ __forceinline__ void stage_convert_kmajor(char* tile, int e, const float* r, float s = 1.0f) {
   uint2 hi, lo;
-  split4(r, hi, lo);
+  split4(r, hi, lo, s);
   char* p = tile + (e / (COLS / 4)) * PITCH + (e % (COLS / 4)) * 8;
   *reinterpret_cast<uint2*>(p) = hi;
   *reinterpret_cast<uint2*>(p + PLANE) = lo;
 }
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
+__device__ __forceinline__ p16x8 tr_frag(const char* p, int pitch) {
   // two transposed 4x16 blocks: k .. k+3 and k+4 .. k+7 of this lane's column
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * pitch));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(p16x8, v);
 }
 
 // COLSUM: additionally accumulate, per thread, the column sums of the A operand (its 4 columns are the same
@@ -292,7 +273,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
 // gradient's own loads.
 template <class Cfg, class LA, class LB, bool COLSUM = false>
 __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT, const LA& la, const LB& lb,
-                                                  f32x16 (&acc)[Cfg::TM][Cfg::TN], float* colsum = nullptr) {
+                                                  f32x16 (&acc)[Cfg::TM][Cfg::TN], float* colsum = nullptr,
+                                                  float sa = 1.0f, float sb = 1.0f) {     // sa, sb: scales of the two operands
   static_assert(LA::NCH == Cfg::NCH_A && LB::NCH == Cfg::NCH_B, "loader tile shape must match the config");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -302,7 +284,7 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
   auto stage = [&](char* dst, bool count) {
 #pragma unroll
     for (int c = 0; c < LA::NCH; ++c) {
-      stage_convert_kmajor<Cfg::BM, Cfg::PA, Cfg::A_PLANE>(dst, threadIdx.x + Cfg::NT * c, ra + 4 * c);
+      stage_convert_kmajor<Cfg::BM, Cfg::PA, Cfg::A_PLANE>(dst, threadIdx.x + Cfg::NT * c, ra + 4 * c, sa);
       if (COLSUM && count) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) colsum[q] += ra[4 * c + q];
@@ -310,7 +292,7 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
     }
 #pragma unroll
     for (int c = 0; c < LB::NCH; ++c)
-      stage_convert_kmajor<Cfg::BN, Cfg::PB, Cfg::B_PLANE>(dst + 2 * Cfg::A_PLANE, threadIdx.x + Cfg::NT * c, rb + 4 * c);
+      stage_convert_kmajor<Cfg::BN, Cfg::PB, Cfg::B_PLANE>(dst + 2 * Cfg::A_PLANE, threadIdx.x + Cfg::NT * c, rb + 4 * c, sb);
   };
   if (KT > 0) {
     fetch_all(la, 0, ra);
@@ -329,7 +311,7 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
     const char* Bs = cur + 2 * Cfg::A_PLANE + (8 * lh + q) * Cfg::PB + (wn * (Cfg::TN * 32) + 16 * gb + 4 * p4) * 2;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN];
+      p16x8 ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN];
 #pragma unroll
       for (int mt = 0; mt < Cfg::TM; ++mt) {
         ah[mt] = tr_frag(As + s * 16 * Cfg::PA + mt * 64, Cfg::PA);
@@ -344,9 +326,9 @@ __device__ __forceinline__ void split_mainloop_tn(char* __restrict__ lds, int KT
       for (int mt = 0; mt < Cfg::TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < Cfg::TN; ++nt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = fs_mfma_32x32x16(al[mt], bh[nt], acc[mt][nt]);
+          acc[mt][nt] = fs_mfma_32x32x16(ah[mt], bl[nt], acc[mt][nt]);
+          acc[mt][nt] = fs_mfma_32x32x16(ah[mt], bh[nt], acc[mt][nt]);
         }
     }
     if (Cfg::NBUF == 1) __syncthreads();

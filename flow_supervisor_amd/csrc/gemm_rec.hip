@@ -16,7 +16,13 @@ struct RecGemmArgs {
   // sparse k (fsraft_gemm_rec_*_list): per (batch entry, tile of the sparse operand) `kcount` k-tile numbers in `klist`
   // (kl_stride ints apart); kl_by_n: the lists belong to the N tiles (B operand rows), else to the M tiles
   const int* klist; const int* kcount; int kl_stride, kl_by_n;
+  const unsigned* a_amax; const unsigned* b_amax;   // amax words the records of A / B were split with (NULL: scale 1)
 };
+
+// alpha times the factor that takes the accumulators of scaled records back (exact: powers of two)
+__device__ __forceinline__ float rec_alpha(const RecGemmArgs& g) {
+  return g.alpha * fs_inv_scale(fs_scale_of_amax(fs_amax_load(g.a_amax))) * fs_inv_scale(fs_scale_of_amax(fs_amax_load(g.b_amax)));
+}
 
 int g_rec_mfma16 = 0;      // fsraft_set_tuning-style switch (fsraft_set_rec_mfma16): the NT kernel on v_mfma_f32_16x16x32_bf16
 
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
     else rec_mainloop<G>(lds, o, pa, kt0, kt, acc);
   }
   float* C = g.C + b * g.sC;
+  const float alpha = rec_alpha(g);
 #pragma unroll
   for (int nt = 0; nt < G::TN; ++nt) {
 #pragma unroll
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_rec_nt_kernel(RecGemmArgs g) {
         const int m = m0 + (M16 ? rec16_row<G>(mt, r) : rec_row<G>(mt, r));
         if (m >= g.M || n >= g.N) continue;
         float* p = C + (int64_t)m * g.ldc + n;
-        const float v = g.alpha * acc[mt][nt][r];
+        const float v = alpha * acc[mt][nt][r];
         if (g.atomic) atomicAdd(p, v);
         else gstore1(p, v);
       }
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(512) void gemm_rec_tn_kernel(RecGemmArgs g, int K) 
     rec_mainloop<GT>(lds, o, pa, kt0, kt, acc);
   }
   float* C = g.C + b * g.sC;
+  const float alpha = rec_alpha(g);
 #pragma unroll
   for (int nt = 0; nt < GT::TN; ++nt) {
     const int n = n0 + rec_col<GT>(nt);
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_rec_tn_kernel(RecGemmArgs g, int K) 
         const int m = m0 + rec_row<GT>(mt, r);
         if (m >= g.M) continue;
         float* p = C + (int64_t)m * g.ldc + n;
-        const float v = g.alpha * acc[mt][nt][r];
+        const float v = alpha * acc[mt][nt][r];
         if (g.atomic) atomicAdd(p, v);
         else gstore1(p, v);
       }
@@ -152,8 +160,9 @@ __global__ __launch_bounds__(512) void gemm_rec_tn_kernel(RecGemmArgs g, int K) 
 
 // fp32 rows -> records: dst row = ceil(K / 32) records, the tail of the last one zero
 __global__ __launch_bounds__(256) void to_records_kernel(const float* __restrict__ src, int64_t ld, char* __restrict__ dst, int64_t dpitch,
-                                                         int64_t rows, int K, int KR) {
+                                                         int64_t rows, int K, int KR, const unsigned* __restrict__ amax) {
   const int64_t total = rows * KR * 4;                       // 8-float units
+  const float sc = fs_scale_of_amax(fs_amax_load(amax));
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int u = (int)(e % (KR * 4));
     const int64_t row = e / (KR * 4);
@@ -169,8 +178,8 @@ __global__ __launch_bounds__(256) void to_records_kernel(const float* __restrict
       for (int i = 0; i < 8; ++i) v[i] = k + i < K ? gload1(s + i) : 0.f;
     }
     uint2 h0, l0, h1, l1;
-    rec_split4(v, h0, l0);
-    rec_split4(v + 4, h1, l1);
+    rec_split4(v, h0, l0, sc);
+    rec_split4(v + 4, h1, l1, sc);
     char* d = dst + row * dpitch + (u >> 2) * 128 + (u & 3) * 16;
     gstore4(d, __builtin_bit_cast(f32x4, u32x4{h0.x, h0.y, h1.x, h1.y}));
     gstore4(d + 64, __builtin_bit_cast(f32x4, u32x4{l0.x, l0.y, l1.x, l1.y}));
@@ -205,14 +214,16 @@ int zero_matrices(float* C, int64_t ldc, int64_t sC, int batch, int M, int N, hi
 }
 }  // namespace
 
-extern "C" int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, hipStream_t stream) {
-  if (!src || !dst || rows < 1 || K < 1 || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16)) return FS_ERR_ARG;
+// amax: the word of src (fsraft_amax*, or a producer's dst_amax); the records hold fp16 pieces of x * scale(amax).  NULL: scale 1.
+extern "C" int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, const unsigned* amax,
+                                 hipStream_t stream) {
+  if (!src || !dst || rows < 1 || K < 1 || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16) || ((uintptr_t)amax & 3)) return FS_ERR_ARG;
   const int KR = (K + 31) / 32;
   if (dst_ld == 0) dst_ld = (int64_t)KR * 32;
   if (dst_ld < (int64_t)KR * 32 || dst_ld % 32) return FS_ERR_ARG;
   const int64_t total = rows * KR * 4;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(to_records_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, (char*)dst, dst_ld * 4, rows, K, KR);
+  hipLaunchKernelGGL(to_records_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, (char*)dst, dst_ld * 4, rows, K, KR, amax);
   return fs_launch_status();
 }
 
@@ -223,7 +234,7 @@ extern "C" int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_
 namespace {
 int gemm_rec_nt_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc, int64_t sC,
                      int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist, const int* kcount,
-                     int kl_stride, int kl_by_n, hipStream_t stream) {
+                     int kl_stride, int kl_by_n, const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
   if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 32 || (K % 32) || ksplit < 1 || ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16))
     return FS_ERR_ARG;
   if (lda == 0) lda = K;
@@ -237,7 +248,7 @@ int gemm_rec_nt_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int
     if (rc) return rc;
   }
   RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0,
-                klist, kcount, kl_stride, kl_by_n};
+                klist, kcount, kl_stride, kl_by_n, a_amax, b_amax};
   dim3 grid(ceil_div(N, G::BN) * ceil_div(M, G::BM), ksplit, batch);
   if (klist) hipLaunchKernelGGL((gemm_rec_nt_kernel<false, true>), grid, dim3(512), 0, stream, g);
   else if (g_rec_mfma16) hipLaunchKernelGGL((gemm_rec_nt_kernel<true, false>), grid, dim3(512), 0, stream, g);
@@ -248,8 +259,8 @@ int gemm_rec_nt_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int
 
 extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
                                   int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
-                                  hipStream_t stream) {
-  return gemm_rec_nt_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, nullptr, nullptr, 0, 0, stream);
+                                  const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
+  return gemm_rec_nt_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, nullptr, nullptr, 0, 0, a_amax, b_amax, stream);
 }
 // The same contraction over LISTED k-tiles only: klist[(b * tiles + tile) * kl_stride + i], i < kcount[b * tiles + tile], ascending
 // k-tile numbers (32 k each) for every tile of the sparse operand -- the 128-row tiles of B (kl_by_n != 0) or the 256-row tiles
@@ -257,10 +268,10 @@ extern "C" int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const 
 extern "C" int fsraft_gemm_rec_nt_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
                                        int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit,
                                        int accumulate, const int* klist, const int* kcount, int kl_stride, int kl_by_n,
-                                       hipStream_t stream) {
+                                       const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
   if (!klist || !kcount || kl_stride < 1 || K / 32 > REC_LIST_MAX) return FS_ERR_ARG;
   return gemm_rec_nt_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, klist, kcount, kl_stride,
-                          kl_by_n, stream);
+                          kl_by_n, a_amax, b_amax, stream);
 }
 
 // C[b][m][n] = alpha * sum_k A[b][k][m] B[b][k][n]: A [batch][K][lda floats] with the records along m, B [batch][K][ldb
@@ -269,7 +280,7 @@ extern "C" int fsraft_gemm_rec_nt_list(const void* A, int64_t lda, int64_t sA, c
 namespace {
 int gemm_rec_tn_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc, int64_t sC,
                      int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist, const int* kcount,
-                     int kl_stride, int kl_by_n, hipStream_t stream) {
+                     int kl_stride, int kl_by_n, const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
   if (!A || !Bm || !C || batch < 1 || M < 1 || N < 1 || K < 1 || ksplit < 1 || (lda % 32) || (ldb % 32) || lda < M || ldb < N ||
       ((uintptr_t)A % 16) || ((uintptr_t)Bm % 16))
     return FS_ERR_ARG;
@@ -281,7 +292,7 @@ int gemm_rec_tn_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int
     if (rc) return rc;
   }
   RecGemmArgs g{(const char*)A, sA, (unsigned)lda * 4u, (const char*)Bm, sB, (unsigned)ldb * 4u, C, ldc, sC, M, N, KT, ksplit, alpha, atomic ? 1 : 0,
-                klist, kcount, kl_stride, kl_by_n};
+                klist, kcount, kl_stride, kl_by_n, a_amax, b_amax};
   dim3 grid(ceil_div(N, GT::BN) * ceil_div(M, GT::BM), ksplit, batch);
   if (klist) hipLaunchKernelGGL(gemm_rec_tn_kernel<true>, grid, dim3(512), 0, stream, g, K);
   else hipLaunchKernelGGL(gemm_rec_tn_kernel<false>, grid, dim3(512), 0, stream, g, K);
@@ -291,18 +302,18 @@ int gemm_rec_tn_impl(const void* A, int64_t lda, int64_t sA, const void* Bm, int
 
 extern "C" int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
                                   int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
-                                  hipStream_t stream) {
-  return gemm_rec_tn_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, nullptr, nullptr, 0, 0, stream);
+                                  const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
+  return gemm_rec_tn_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, nullptr, nullptr, 0, 0, a_amax, b_amax, stream);
 }
 // k-major twin of fsraft_gemm_rec_nt_list: the lists belong to the 256-column tiles of A (M tiles; kl_by_n == 0) or the
 // 128-column tiles of B, a k-tile is 32 consecutive k-rows.
 extern "C" int fsraft_gemm_rec_tn_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C,
                                        int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit,
                                        int accumulate, const int* klist, const int* kcount, int kl_stride, int kl_by_n,
-                                       hipStream_t stream) {
+                                       const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream) {
   if (!klist || !kcount || kl_stride < 1 || (K + 31) / 32 > REC_LIST_MAX) return FS_ERR_ARG;
   return gemm_rec_tn_impl(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha, ksplit, accumulate, klist, kcount, kl_stride,
-                          kl_by_n, stream);
+                          kl_by_n, a_amax, b_amax, stream);
 }
 
 extern "C" int fsraft_set_rec_mfma16(int on) {

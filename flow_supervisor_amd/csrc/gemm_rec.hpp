@@ -20,7 +20,6 @@
 #include "common.hpp"
 #include <type_traits>
 
-typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // raw buffer descriptor (wave-uniform inputs only): base, 0 stride, `bytes` records of 1 byte, default data format
@@ -109,12 +108,12 @@ __device__ __forceinline__ void rec_setup_km(RecOperands<Cfg>& o, const void* A,
 
 typedef short rec_s16x4 __attribute__((ext_vector_type(4)));
 // 8 consecutive k of this lane's column out of a k-major image: two transposed 4 x 16 blocks, rows k .. k+3 and k+4 .. k+7
-__device__ __forceinline__ bf16x8r rec_tr_frag(const char* p, int pitch) {
+__device__ __forceinline__ p16x8 rec_tr_frag(const char* p, int pitch) {
   const rec_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rec_s16x4 __attribute__((address_space(3)))*)(p));
   const rec_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rec_s16x4 __attribute__((address_space(3)))*)(p + 4 * pitch));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8r, v);
+  return __builtin_bit_cast(p16x8, v);
 }
 
 // Where the A pieces of k-tile t come from.  Plain GEMM: a fixed per-lane offset and the k-tile in the scalar offset.
@@ -201,7 +200,7 @@ __device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOp
     for (int j = 0; j < NPB; ++j) issue_b(t, SL, j, k);
   };
 
-  struct Frag { bf16x8r ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN]; };
+  struct Frag { p16x8 ah[Cfg::TM], al[Cfg::TM], bh[Cfg::TN], bl[Cfg::TN]; };
   // fragment addressing.  Rows of records: this lane's row of the wave's sub-tile; slot of (k-step s, hi / lo) = 2 s + lh
   // (+ 4); rows 32 apart share (row >> 1) & 7, so the swizzled slot offsets are per-lane constants.  k-major: lane 4 q + p
   // of a 16-lane group supplies k-row q (+ 8 lh + 16 s), columns 16 gb + 4 p .. + 3 of the 32-column block; the chunk
@@ -237,13 +236,13 @@ __device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOp
     } else {
 #pragma unroll
       for (int mt = 0; mt < Cfg::TM; ++mt) {
-        f.ah[mt] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((2 * s + lh) ^ sa) << 4));
-        f.al[mt] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((4 + 2 * s + lh) ^ sa) << 4));
+        f.ah[mt] = *reinterpret_cast<const p16x8*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((2 * s + lh) ^ sa) << 4));
+        f.al[mt] = *reinterpret_cast<const p16x8*>(fa + SL * Cfg::SLOT + mt * 32 * 128 + (((4 + 2 * s + lh) ^ sa) << 4));
       }
 #pragma unroll
       for (int nt = 0; nt < Cfg::TN; ++nt) {
-        f.bh[nt] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((2 * s + lh) ^ sb) << 4));
-        f.bl[nt] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((4 + 2 * s + lh) ^ sb) << 4));
+        f.bh[nt] = *reinterpret_cast<const p16x8*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((2 * s + lh) ^ sb) << 4));
+        f.bl[nt] = *reinterpret_cast<const p16x8*>(fb + SL * Cfg::SLOT + nt * 32 * 128 + (((4 + 2 * s + lh) ^ sb) << 4));
       }
     }
   };
@@ -254,9 +253,9 @@ __device__ __forceinline__ void rec_mainloop(char* __restrict__ lds, const RecOp
     for (int mt = 0; mt < Cfg::TM; ++mt)
 #pragma unroll
       for (int nt = 0; nt < Cfg::TN; ++nt) {
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = fs_mfma_32x32x16(f.al[mt], f.bh[nt], acc[mt][nt]);
+        acc[mt][nt] = fs_mfma_32x32x16(f.ah[mt], f.bl[nt], acc[mt][nt]);
+        acc[mt][nt] = fs_mfma_32x32x16(f.ah[mt], f.bh[nt], acc[mt][nt]);
         const int i = mt * Cfg::TN + nt;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -354,20 +353,20 @@ __device__ __forceinline__ void rec_mainloop16(char* __restrict__ lds, const Rec
   const char* fb = lds + Cfg::A_BYTES + rb * 128;
   const int a_hi = (g4 ^ sa) << 4, a_lo = ((4 + g4) ^ sa) << 4, b_hi = (g4 ^ sb) << 4, b_lo = ((4 + g4) ^ sb) << 4;
 
-  struct FragA { bf16x8r h[2], l[2]; };                  // the two 16-row blocks of one mt
-  struct FragB { bf16x8r h[2 * TN], l[2 * TN]; };        // all 16-column blocks of the wave's columns
+  struct FragA { p16x8 h[2], l[2]; };                  // the two 16-row blocks of one mt
+  struct FragB { p16x8 h[2 * TN], l[2 * TN]; };        // all 16-column blocks of the wave's columns
   auto read_a = [&](int SL, int mt, FragA& f) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      f.h[mi] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + (mt * 32 + mi * 16) * 128 + a_hi);
-      f.l[mi] = *reinterpret_cast<const bf16x8r*>(fa + SL * Cfg::SLOT + (mt * 32 + mi * 16) * 128 + a_lo);
+      f.h[mi] = *reinterpret_cast<const p16x8*>(fa + SL * Cfg::SLOT + (mt * 32 + mi * 16) * 128 + a_hi);
+      f.l[mi] = *reinterpret_cast<const p16x8*>(fa + SL * Cfg::SLOT + (mt * 32 + mi * 16) * 128 + a_lo);
     }
   };
   auto read_b = [&](int SL, FragB& f) {
 #pragma unroll
     for (int nb = 0; nb < 2 * TN; ++nb) {
-      f.h[nb] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nb * 16 * 128 + b_hi);
-      f.l[nb] = *reinterpret_cast<const bf16x8r*>(fb + SL * Cfg::SLOT + nb * 16 * 128 + b_lo);
+      f.h[nb] = *reinterpret_cast<const p16x8*>(fb + SL * Cfg::SLOT + nb * 16 * 128 + b_hi);
+      f.l[nb] = *reinterpret_cast<const p16x8*>(fb + SL * Cfg::SLOT + nb * 16 * 128 + b_lo);
     }
   };
   rec_f32x4 c[TM][2][2 * TN];
@@ -386,9 +385,9 @@ __device__ __forceinline__ void rec_mainloop16(char* __restrict__ lds, const Rec
     for (int nb = 0; nb < NG; ++nb) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        c[mt][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l[mi], b.h[nb], c[mt][mi][nb], 0, 0, 0);
-        c[mt][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h[mi], b.l[nb], c[mt][mi][nb], 0, 0, 0);
-        c[mt][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h[mi], b.h[nb], c[mt][mi][nb], 0, 0, 0);
+        c[mt][mi][nb] = fs_mfma_16x16x32(a.l[mi], b.h[nb], c[mt][mi][nb]);
+        c[mt][mi][nb] = fs_mfma_16x16x32(a.h[mi], b.l[nb], c[mt][mi][nb]);
+        c[mt][mi][nb] = fs_mfma_16x16x32(a.h[mi], b.h[nb], c[mt][mi][nb]);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k)
@@ -481,18 +480,4 @@ __device__ __forceinline__ int rec_col(int nt) {
 }
 
 // fp32 x4 -> hi / lo bf16 x4 (same rounding as gemm_core_split.hpp::split4)
-__device__ __forceinline__ void rec_split4(const float* r, uint2& hi, uint2& lo) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  unsigned h[2], l[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const f2 x = {r[2 * i], r[2 * i + 1]};
-    h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf2));
-    const float h0 = __builtin_bit_cast(float, h[i] << 16), h1 = __builtin_bit_cast(float, h[i] & 0xffff0000u);
-    const f2 d = {x[0] - h0, x[1] - h1};
-    l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf2));
-  }
-  hi = make_uint2(h[0], h[1]);
-  lo = make_uint2(l[0], l[1]);
-}
+__device__ __forceinline__ void rec_split4(const float* r, uint2& hi, uint2& lo, float s = 1.0f) { fs_split4(r, s, hi, lo); }

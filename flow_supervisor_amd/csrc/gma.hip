@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 // the logits: for n % 32 == 0 a row of records is exactly as long as the fp32 row, so the map exists ONCE -- in the form every
 // later reader takes it in (attn @ v and attn^T @ dagg of all iterations, the softmax backward below) -- and the separate
 // fp32 -> records pass (read + write of the whole map) is gone.
+// Probabilities are bounded by 1: their records are split with the fixed scale 2^14 -- the scale of an amax word holding 1.0,
+// which is the word the GEMMs reading them are given.
+constexpr float GMA_P_SCALE = 16384.0f;
 __global__ __launch_bounds__(256) void softmax_rows_rec_kernel(float* __restrict__ S, int n) {
   extern __shared__ float row[];
   __shared__ float red[4];
@@ -112,8 +115,8 @@ __global__ __launch_bounds__(256) void softmax_rows_rec_kernel(float* __restrict
       asm volatile("" : "+v"(v[i]));
     }
     uint2 h0, l0, h1, l1;
-    rec_split4(v, h0, l0);
-    rec_split4(v + 4, h1, l1);
+    rec_split4(v, h0, l0, GMA_P_SCALE);
+    rec_split4(v + 4, h1, l1, GMA_P_SCALE);
     char* d = out + (u >> 2) * 128 + (u & 3) * 16;
     *reinterpret_cast<u32x4*>(d) = u32x4{h0.x, h0.y, h1.x, h1.y};
     *reinterpret_cast<u32x4*>(d + 64) = u32x4{l0.x, l0.y, l1.x, l1.y};
@@ -122,7 +125,10 @@ __global__ __launch_bounds__(256) void softmax_rows_rec_kernel(float* __restrict
 
 // Backward of the above: A as records (a = hi + lo), dA fp32 in, dS = A * (dA - sum_j dA_j A_j) out AS RECORDS over dA -- the
 // two GEMMs that consume dS read records, so neither the fp32 dS nor a conversion pass of it exists.
-__global__ __launch_bounds__(256) void softmax_rows_bwd_rec_kernel(const char* __restrict__ A, float* __restrict__ dA, int n) {
+// ds_amax: a word bounding |dS| (|dS| <= 2 max |dA|), the one the GEMMs reading dS are given
+__global__ __launch_bounds__(256) void softmax_rows_bwd_rec_kernel(const char* __restrict__ A, float* __restrict__ dA, int n,
+                                                                   const unsigned* __restrict__ ds_amax) {
+  const float ds_scale = fs_scale_of_amax(fs_amax_load(ds_amax));
   extern __shared__ float row[];          // [2][n]: A row, dA row
   __shared__ float red[4];
   const char* a = A + (int64_t)blockIdx.x * n * 4;
@@ -136,10 +142,7 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_rec_kernel(const char* _
     const f32x4 d0 = reinterpret_cast<const f32x4*>(d)[u * 2], d1 = reinterpret_cast<const f32x4*>(d)[u * 2 + 1];
     float av[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      av[2 * i] = __builtin_bit_cast(float, h[i] << 16) + __builtin_bit_cast(float, l[i] << 16);
-      av[2 * i + 1] = __builtin_bit_cast(float, h[i] & 0xffff0000u) + __builtin_bit_cast(float, l[i] & 0xffff0000u);
-    }
+    for (int i = 0; i < 4; ++i) fs_unsplit2(h[i], l[i], 1.0f / GMA_P_SCALE, av[2 * i], av[2 * i + 1]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) ra[u * 8 + i] = av[i];
     reinterpret_cast<f32x4*>(rd)[u * 2] = d0;
@@ -157,8 +160,8 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_rec_kernel(const char* _
       asm volatile("" : "+v"(v[i]));
     }
     uint2 h0, l0, h1, l1;
-    rec_split4(v, h0, l0);
-    rec_split4(v + 4, h1, l1);
+    rec_split4(v, h0, l0, ds_scale);
+    rec_split4(v + 4, h1, l1, ds_scale);
     char* o = out + (u >> 2) * 128 + (u & 3) * 16;
     *reinterpret_cast<u32x4*>(o) = u32x4{h0.x, h0.y, h1.x, h1.y};
     *reinterpret_cast<u32x4*>(o + 64) = u32x4{l0.x, l0.y, l1.x, l1.y};
@@ -252,10 +255,10 @@ extern "C" int fsraft_softmax_rows_rec(float* S, int64_t rows, int n, hipStream_
 }
 // A: records of fsraft_softmax_rows_rec; dA: fp32 gradient in, records of dS out (in place).  n % 32 == 0, n <= 8160 (two rows
 // in dynamic LDS + the static reduction words within 64 KB).
-extern "C" int fsraft_softmax_rows_bwd_rec(const void* A, float* dA, int64_t rows, int n, hipStream_t s) {
+extern "C" int fsraft_softmax_rows_bwd_rec(const void* A, float* dA, int64_t rows, int n, const unsigned* ds_amax, hipStream_t s) {
   if (!A || !dA || rows < 1 || n < 32 || (n % 32) || n > 8160 || rows > 0x7fffffff || ((uintptr_t)A % 16) || ((uintptr_t)dA % 16))
     return FS_ERR_ARG;
-  hipLaunchKernelGGL(softmax_rows_bwd_rec_kernel, dim3((unsigned)rows), dim3(256), (size_t)n * 8, s, (const char*)A, dA, n);
+  hipLaunchKernelGGL(softmax_rows_bwd_rec_kernel, dim3((unsigned)rows), dim3(256), (size_t)n * 8, s, (const char*)A, dA, n, ds_amax);
   return fs_launch_status();
 }
 extern "C" int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,

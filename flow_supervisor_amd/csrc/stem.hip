@@ -37,12 +37,15 @@ struct StemArgs {
   const float* dy;                               // weight gradient: [B][Ho][Wo][N]
   float* scratch;                                // weight gradient: [slots][64][192] partial sums
   int B, H, W, Ho, Wo, N, tx, ty, ntiles;
+  const unsigned* x_amax;                        // amax word of the images (NULL: scale 1, |x| < 2^15)
+  const unsigned* dy_amax;                       // weight gradient: amax word of dy
 };
 
-__device__ __forceinline__ void split1(float v, unsigned short& hi, unsigned short& lo) {
-  const __bf16 h = (__bf16)v;
+__device__ __forceinline__ void split1(float v, unsigned short& hi, unsigned short& lo, float s) {
+  _Float16 h, l;
+  fs_split1(v, s, h, l);
   hi = __builtin_bit_cast(unsigned short, h);
-  lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+  lo = __builtin_bit_cast(unsigned short, l);
 }
 
 // ---------------------------------------------------------------- forward
@@ -59,11 +62,24 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const StemArgs a) {
   char* wl = lds + SF_WBYTES;
   char* pbuf = lds + 2 * SF_WBYTES;          // two patch buffers of (hi plane, lo plane)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+  // scales (split_arith.hpp): the images' from their word; the weights' from their largest magnitude, which every workgroup
+  // works out for itself (it reads all N x 147 of them anyway)
+  __shared__ unsigned wred[8];
+  unsigned wm = 0u;
+  for (int e = threadIdx.x; e < a.N * 147; e += 512) wm = fs_umax(wm, fs_abs_bits(a.w[e]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wm = fs_umax(wm, (unsigned)__shfl_xor((int)wm, o, 64));
+  if (lane == 0) wred[wave] = wm;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wm = fs_umax(wm, wred[i]);
+  const float sw = fs_scale_of_amax(wm), sx = fs_scale_of_amax(fs_amax_load(a.x_amax));
+  const float inv = fs_inv_scale(sw) * fs_inv_scale(sx);
   for (int e = threadIdx.x; e < 64 * ST_K; e += 512) {
     const int n = e / ST_K, k = e - n * ST_K, c = k >> 6, ky = (k >> 3) & 7, kx = k & 7;
     const float v = (n < a.N && ky < 7 && kx < 7) ? a.w[((n * 3 + c) * 7 + ky) * 7 + kx] : 0.f;
     unsigned short h, l;
-    split1(v, h, l);
+    split1(v, h, l, sw);
     *reinterpret_cast<unsigned short*>(wh + n * SF_WPITCH + k * 2) = h;
     *reinterpret_cast<unsigned short*>(wl + n * SF_WPITCH + k * 2) = l;
   }
@@ -96,7 +112,7 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const StemArgs a) {
       const int e = threadIdx.x + 512 * j;
       if (e < 3 * SF_PR * ST_PC) {
         unsigned short h, l;
-        split1(rp[j], h, l);
+        split1(rp[j], h, l, sx);
         *reinterpret_cast<unsigned short*>(ph + e * 2) = h;
         *reinterpret_cast<unsigned short*>(ph + SF_PBYTES + e * 2) = l;
       }
@@ -133,15 +149,15 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const StemArgs a) {
         ahv[i] = *reinterpret_cast<const unsigned*>(ph + ao + 4 * i);
         alv[i] = *reinterpret_cast<const unsigned*>(pl + ao + 4 * i);
       }
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, ahv), al = __builtin_bit_cast(bf16x8, alv);
+      const p16x8 ah = __builtin_bit_cast(p16x8, ahv), al = __builtin_bit_cast(p16x8, alv);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (j < nb) {
           const int bo = (j * 32 + l31) * SF_WPITCH + (s * 16 + lh * 8) * 2;
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + bo), bl = *reinterpret_cast<const bf16x8*>(wl + bo);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+          const p16x8 bh = *reinterpret_cast<const p16x8*>(wh + bo), bl = *reinterpret_cast<const p16x8*>(wl + bo);
+          acc[j] = fs_mfma_32x32x16(al, bh, acc[j]);
+          acc[j] = fs_mfma_32x32x16(ah, bl, acc[j]);
+          acc[j] = fs_mfma_32x32x16(ah, bh, acc[j]);
         }
       }
       if (s & 1) __builtin_amdgcn_sched_barrier(0);   // (or every fragment of all twelve k-steps is loaded up front: 220 registers, one workgroup per CU)
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const StemArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dx = (r & 3) + 8 * (r >> 2);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] + bv), ro, oxl + dx < a.Wo ? vo : ST_OOB,
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_fmaf(acc[j][r], inv, bv)), ro, oxl + dx < a.Wo ? vo : ST_OOB,
                                                   (unsigned)(dx * a.N) * 4u, 0);
           }
         }
@@ -194,6 +210,8 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_kernel(const StemArgs a) {
   const int kg = wave >> 2, mi = wave & 1, ns = (wave >> 1) & 1;       // pixel row of the tile, n half, k' half
   const int lh = lane >> 5, gb = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3, l31 = lane & 31;
   const int tpi = a.tx * a.ty;
+  const float sdy = fs_scale_of_amax(fs_amax_load(a.dy_amax)), sx = fs_scale_of_amax(fs_amax_load(a.x_amax));
+  const float inv = fs_inv_scale(sdy) * fs_inv_scale(sx);
   f32x16 acc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_kernel(const StemArgs a) {
   for (; tile < a.ntiles; tile += gridDim.x) {
     // ---- registers -> LDS: dY planes (k-major: [pixel][n]) and the fp32 patch
 #pragma unroll
-    for (int c = 0; c < SW_NDY; ++c) stage_convert_kmajor<64, SW_DYPITCH, SW_DYPLANE>(dyh, threadIdx.x + 512 * c, rdy + 4 * c);
+    for (int c = 0; c < SW_NDY; ++c) stage_convert_kmajor<64, SW_DYPITCH, SW_DYPLANE>(dyh, threadIdx.x + 512 * c, rdy + 4 * c, sdy);
 #pragma unroll
     for (int j = 0; j < SW_NCHP; ++j)
       if (threadIdx.x + 512 * j < 3 * SW_PR * ST_PC) patch[threadIdx.x + 512 * j] = rp[j];
@@ -249,8 +267,8 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_kernel(const StemArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (ky < 7 && i < 7) ? src[i] : 0.f;
       uint2 h0, l0, h1, l1;
-      split4(v, h0, l0);
-      split4(v + 4, h1, l1);
+      split4(v, h0, l0, sx);
+      split4(v + 4, h1, l1, sx);
       char* dst = imh + px * SW_IMPITCH + g * 16;
       *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
       *reinterpret_cast<uint4*>(dst + SW_IMPLANE) = make_uint4(l0.x, l0.y, l1.x, l1.y);
@@ -261,20 +279,22 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_kernel(const StemArgs a) {
     for (int s = 0; s < SW_TH; ++s) {
       const int k0 = (kg * SW_TH + s) * 16;
       const char* Ap = dyh + (k0 + 8 * lh + q) * SW_DYPITCH + (mi * 32 + 16 * gb + 4 * p4) * 2;
-      const bf16x8 ah = tr_frag(Ap, SW_DYPITCH), al = tr_frag(Ap + SW_DYPLANE, SW_DYPITCH);
+      const p16x8 ah = tr_frag(Ap, SW_DYPITCH), al = tr_frag(Ap + SW_DYPLANE, SW_DYPITCH);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const char* Bp = imh + (k0 + 8 * lh + q) * SW_IMPITCH + ((3 * ns + j) * 32 + 16 * gb + 4 * p4) * 2;
-        const bf16x8 bh = tr_frag(Bp, SW_IMPITCH), bl = tr_frag(Bp + SW_IMPLANE, SW_IMPITCH);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+        const p16x8 bh = tr_frag(Bp, SW_IMPITCH), bl = tr_frag(Bp + SW_IMPLANE, SW_IMPITCH);
+        acc[j] = fs_mfma_32x32x16(al, bh, acc[j]);
+        acc[j] = fs_mfma_32x32x16(ah, bl, acc[j]);
+        acc[j] = fs_mfma_32x32x16(ah, bh, acc[j]);
       }
     }
     __syncthreads();                             // the planes are free for the next tile
   }
   // the two k halves of the workgroup meet in LDS (the planes are free), one partial matrix per workgroup leaves
   float* sum = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc[j] *= inv;
   __syncthreads();
   if (kg == 1) {
 #pragma unroll
@@ -337,11 +357,11 @@ int stem_check(const void* x, const void* w, int B, int H, int W, int N) {
 extern "C" int fsraft_stem_slots(void) { return 512; }
 
 extern "C" int fsraft_stem7x7s2_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int N,
-                                    hipStream_t stream) {
+                                    const unsigned* x_amax, hipStream_t stream) {
   const int rc = stem_check(x, w, B, H, W, N);
   if (rc || !out) return rc ? rc : FS_ERR_ARG;
   StemArgs a{};
-  a.x = x; a.w = w; a.bias = bias; a.out = out;
+  a.x = x; a.w = w; a.bias = bias; a.out = out; a.x_amax = x_amax;
   a.B = B; a.H = H; a.W = W; a.N = N;
   a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
   a.tx = ceil_div(a.Wo, ST_TW); a.ty = ceil_div(a.Ho, SF_TH);
@@ -353,11 +373,11 @@ extern "C" int fsraft_stem7x7s2_fwd(const float* x, const float* w, const float*
 
 // dw [N][3][7][7] is overwritten; scratch: fsraft_stem_slots() * 64 * 192 floats
 extern "C" int fsraft_stem7x7s2_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int N,
-                                      hipStream_t stream) {
+                                      const unsigned* x_amax, const unsigned* dy_amax, hipStream_t stream) {
   const int rc = stem_check(x, dy, B, H, W, N);
   if (rc || !dw || !scratch || ((uintptr_t)dy & 15)) return rc ? rc : FS_ERR_ARG;
   StemArgs a{};
-  a.x = x; a.dy = dy; a.scratch = scratch;
+  a.x = x; a.dy = dy; a.scratch = scratch; a.x_amax = x_amax; a.dy_amax = dy_amax;
   a.B = B; a.H = H; a.W = W; a.N = N;
   a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
   a.tx = ceil_div(a.Wo, ST_TW); a.ty = ceil_div(a.Ho, SW_TH);

@@ -141,6 +141,102 @@ def zeros(*shape, device):
     return _ZEROS.take(shape, device)
 
 
+# ------------------------------------------------------------------ amax words (split arithmetic, csrc/split_arith.hpp)
+# Every tensor the matrix pipe reads is split into fp16 pieces of x * scale, the scale a power of two derived ON THE DEVICE
+# from the tensor's "amax word": one 4-byte word holding the bit pattern of max |x| (or an upper bound).  A word is a
+# 1-element tensor of the zero pool.  Producers inside the library raise the word of their destination (Dst.amax,
+# fsraft_conv_desc.dst_amax, ...); for everything else `ensure_amax` runs fsraft_amax_jobs over the tensor right before its
+# consumer -- always correct, one more small launch.  A buffer carries its word as the attribute `_fs_amax` ONLY when every
+# kernel that writes it raises the word (views find their base's word): `tracked()` is for code that knows that.
+def new_amax(device):
+    return zeros(1, device=device)
+
+
+def tracked(t, word=None):
+    """Mark buffer t as carrying an amax word that all of its writers raise; returns t."""
+    t._fs_amax = new_amax(t.device) if word is None else word
+    return t
+
+
+def amax_of(t):
+    """The amax word a tensor (or the buffer it is a view of) carries, or None."""
+    w = getattr(t, "_fs_amax", None)
+    if w is None and t._base is not None:
+        w = getattr(t._base, "_fs_amax", None)
+    return w
+
+
+_AMAX_ONE = {}
+
+
+def amax_one(device):
+    """A word holding the bit pattern of 1.0: for tensors bounded by 1 (gates, softmax rows)."""
+    k = torch.device(device).index or 0
+    w = _AMAX_ONE.get(k)
+    if w is None:
+        w = _AMAX_ONE[k] = torch.ones(1, device=device, dtype=torch.float32)
+    return w
+
+
+def amax_jobs(jobs):
+    """jobs: (data_ptr, rows, C, ld, word tensor); word = max(word, max |x|) for each, 32 jobs per launch."""
+    n = len(jobs)
+    if not n:
+        return
+    ptrs = (ctypes.c_void_p * n)(*[j[0] for j in jobs])
+    rows = (ctypes.c_int64 * n)(*[j[1] for j in jobs])
+    cs = (ctypes.c_int64 * n)(*[j[2] for j in jobs])
+    lds = (ctypes.c_int64 * n)(*[j[3] for j in jobs])
+    words = (ctypes.c_void_p * n)(*[j[4].data_ptr() for j in jobs])
+    L.check(_lib().fsraft_amax_jobs(ctypes.cast(ptrs, L._PP), rows, cs, lds, ctypes.cast(words, L._PP), n, L.stream()), "amax_jobs")
+
+
+def amax_tensor(t):
+    """Fresh word holding max |t| of a contiguous fp32 tensor."""
+    w = new_amax(t.device)
+    amax_jobs([(t.data_ptr(), 1, t.numel(), t.numel(), w)])
+    return w
+
+
+def amax_scaled(word, factor):
+    """Fresh word = factor * word (a bound derived from another tensor's: fsraft_amax_scaled)."""
+    out = new_amax(word.device)
+    L.check(_lib().fsraft_amax_scaled(L.ptr(word), float(factor), L.ptr(out), L.stream()), "amax_scaled")
+    return out
+
+
+def amax_of_tensors(ts):
+    """One word bounding max |x| over the contiguous fp32 tensors ts: the word they share if they all are views of one tracked
+    buffer, else a fresh word computed now (one launch)."""
+    ws = [amax_of(t) for t in ts]
+    if ws[0] is not None and all(w is ws[0] for w in ws):
+        return ws[0]
+    w = new_amax(ts[0].device)
+    amax_jobs([(t.data_ptr(), 1, t.numel(), t.numel(), w) for t in ts])
+    return w
+
+
+def _wptr(t):
+    """Device address of the amax word a record tensor was split with (None in exact-fp32 mode / no word: scale 1)."""
+    w = amax_of(t) if t is not None else None
+    return L.ptr(w)
+
+
+def ensure_amax(views):
+    """Give every V of `views` an amax word: the one its buffer carries, else a fresh one computed now (one batched launch
+    for all that need it).  Returns the words' device addresses (0 in exact-fp32 mode: the kernels do not scale)."""
+    if exact_mode():
+        return [None] * len(views)
+    jobs = []
+    for v in views:
+        if v.amax is None:
+            v.amax = new_amax(v.t.device)
+            rows = v.t.numel() // v.ld
+            jobs.append((v.ptr, rows, v.C, v.ld, v.amax))
+    amax_jobs(jobs)
+    return [v.amax.data_ptr() for v in views]
+
+
 def pyramid_sizes(H, W, num_levels=4):
     out = []
     for _ in range(num_levels):
@@ -172,7 +268,8 @@ def corr_build(fmap1, fmap2, num_levels=4):
     pp, keep = L.ptr_array(levels)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(_lib().fsraft_corr_build(L.ptr(fmap1), L.ptr(fmap2), pp, num_levels, B, C, H, W, L.stream()), "corr_build")
+    a1, a2 = (None, None) if exact_mode() else (amax_tensor(fmap1), amax_tensor(fmap2))
+    L.check(_lib().fsraft_corr_build(L.ptr(fmap1), L.ptr(fmap2), pp, num_levels, B, C, H, W, L.ptr(a1), L.ptr(a2), L.stream()), "corr_build")
     if t:
         N = H * W
         t.end("corr_build", e0, 2.0 * B * N * N * C, 4.0 * B * (2 * N * C + N * sum(h * w for h, w in sizes)))
@@ -230,11 +327,12 @@ def corr_build_tiled(fmap1, fmap2, num_levels=4, recs=None):
     t = TIMER
     e0 = t.begin() if t else None
     if recs is not None:
-        L.check(_lib().fsraft_corr_build_rec(L.ptr(recs[0]), L.ptr(recs[1]), L.ptr(vol), num_levels, B, C, H, W, L.stream()),
-                "corr_build_rec")
+        L.check(_lib().fsraft_corr_build_rec(L.ptr(recs[0]), L.ptr(recs[1]), L.ptr(vol), num_levels, B, C, H, W, _wptr(recs[0]),
+                                             _wptr(recs[1]), L.stream()), "corr_build_rec")
     else:
-        L.check(_lib().fsraft_corr_build_tiled(L.ptr(fmap1), L.ptr(fmap2), L.ptr(vol), num_levels, B, C, H, W, L.stream()),
-                "corr_build_tiled")
+        a1, a2 = (None, None) if exact_mode() else (amax_tensor(fmap1), amax_tensor(fmap2))
+        L.check(_lib().fsraft_corr_build_tiled(L.ptr(fmap1), L.ptr(fmap2), L.ptr(vol), num_levels, B, C, H, W, L.ptr(a1), L.ptr(a2),
+                                               L.stream()), "corr_build_tiled")
     if t:
         N = H * W
         t.end("corr_build", e0, 2.0 * B * N * N * C, 4.0 * B * (2 * N * C + N * sum(h * w for h, w in zip(lay.h, lay.w))))
@@ -274,6 +372,12 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
         wmask = None                      # (only the bounding-box kernel honours the mask; the row kernel writes whole rows)
     # scratch for the work list of queries whose lookups spread beyond the bounding-box kernel's box (1 + rows unsigned)
     qlist = torch.empty(rows + 1, device=douts[0].device, dtype=torch.int32) if len(douts) <= 16 else None
+    word = None
+    if records:
+        # the rows leave as fp16 pieces of dV * scale: a cell collects at most one unit of bilinear weight per lookup, so
+        # |dV| <= (number of lookups) x max |dout| -- the word the two GEMMs reading the rows are given as well
+        word = amax_scaled(amax_of_tensors(douts), len(douts))
+        dvol._fs_amax = word
     t = TIMER
     e0 = t.begin() if t else None
     for g0 in range(0, len(douts), 16):
@@ -288,7 +392,7 @@ def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False,
         a_s = (ctypes.c_int64 * (3 * n))(*st)
         L.check(_lib().fsraft_corr_dvol_build(ctypes.cast(a_d, L._PP), ctypes.cast(a_c, L._PP), a_s, n, L.ptr(dvol), lay.nlev, B, H,
                                               W, radius, int(g0 > 0), int(records), int(is_flow), q0, rows, L.ptr(qlist), L.ptr(wmask),
-                                              L.stream()),
+                                              L.ptr(word), L.stream()),
                 "corr_dvol_build")
     if t:   # per lookup read dOut + read-modify-write the window taps; plus the zero fill of the dense gradient
         nl = lay.nlev
@@ -366,7 +470,8 @@ def f2cat_records(fmap2, lay):
     fmap2 = fmap2.contiguous()
     if F2CAT_REC and H * W <= F2CAT_REC_MAX_PLANE:
         f2r = torch.empty(B, C, lay.P, device=fmap2.device, dtype=torch.float32)
-        L.check(_lib().fsraft_corr_f2cat_rec(L.ptr(fmap2), L.ptr(f2r), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat_rec")
+        f2r._fs_amax = amax_tensor(fmap2)       # (bounds the pooled levels too: they are means)
+        L.check(_lib().fsraft_corr_f2cat_rec(L.ptr(fmap2), L.ptr(f2r), lay.nlev, B, C, H, W, L.ptr(f2r._fs_amax), L.stream()), "corr_f2cat_rec")
         return f2r
     f2cat = torch.empty(B, C, lay.P, device=fmap2.device, dtype=torch.float32)
     L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
@@ -403,13 +508,13 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
             a_tn = (L.ptr(dV), P, 0, ctypes.c_void_p(f1r.data_ptr() + (b * N + i0) * Cr * 4), Cr, 0,
                     ctypes.c_void_p(d2cat.data_ptr() + b * P * C * 4), C, 0, 1, P, C, n, s)
             if kt is not None:
-                L.check(lib.fsraft_gemm_rec_nt_list(*a_nt, 2, 0, L.ptr(kt.nt_list), L.ptr(kt.nt_count), kt.nt_stride, 1, L.stream()), "gemm_rec_nt_list")
-                L.check(lib.fsraft_gemm_rec_tn_list(*a_tn, 3, 1, L.ptr(kt.tn_list), L.ptr(kt.tn_count), kt.tn_stride, 0, L.stream()), "gemm_rec_tn_list")
+                L.check(lib.fsraft_gemm_rec_nt_list(*a_nt, 2, 0, L.ptr(kt.nt_list), L.ptr(kt.nt_count), kt.nt_stride, 1, _wptr(f2r), _wptr(dV), L.stream()), "gemm_rec_nt_list")
+                L.check(lib.fsraft_gemm_rec_tn_list(*a_tn, 3, 1, L.ptr(kt.tn_list), L.ptr(kt.tn_count), kt.tn_stride, 0, _wptr(dV), _wptr(f1r), L.stream()), "gemm_rec_tn_list")
             else:
                 # d1[b][:, i0:i0+n] = s * f2cat[b] [C x P] . dV [n x P]^T
-                L.check(lib.fsraft_gemm_rec_nt(*a_nt, 8, 0, L.stream()), "gemm_rec_nt")
+                L.check(lib.fsraft_gemm_rec_nt(*a_nt, 8, 0, _wptr(f2r), _wptr(dV), L.stream()), "gemm_rec_nt")
                 # d2cat[b] [P x C] += s * dV [n x P]^T . f1[b][i0:i0+n] [n x C]
-                L.check(lib.fsraft_gemm_rec_tn(*a_tn, 3, 1, L.stream()), "gemm_rec_tn")
+                L.check(lib.fsraft_gemm_rec_tn(*a_tn, 3, 1, _wptr(dV), _wptr(f1r), L.stream()), "gemm_rec_tn")
     d2 = torch.empty(B, H, W, C, device=fmap1.device, dtype=torch.float32)
     L.check(lib.fsraft_corr_dfmap2(L.ptr(d2cat), L.ptr(d2), lay.nlev, B, C, H, W, L.stream()), "corr_dfmap2")
     out = d1.view(B, C, H, W), nhwc_to_nchw(d2, C)
@@ -443,7 +548,7 @@ def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None
     if recs is not None and ALT_MFMA and SPLIT_VOLUME_BWD and C % 32 == 0 and C <= 256:
         pr, keep2 = L.ptr_array(recs[1])
         L.check(_lib().fsraft_altcorr_mfma_fwd(L.ptr(recs[0]), pr, L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out),
-                                               B, H, W, C, radius, L.stream()), "altcorr_mfma_fwd")
+                                               B, H, W, C, radius, _wptr(recs[0]), _wptr(recs[1][0]), L.stream()), "altcorr_mfma_fwd")
     else:
         L.check(_lib().fsraft_altcorr_fused_fwd(L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out), B, H, W, C,
                                                 radius, L.stream()), "altcorr_fused_fwd")
@@ -474,23 +579,23 @@ def corr_build_bwd_tiled(fmap1, fmap2, dvol, lay, records=False, f1r=None, ktile
             lib = _lib()
             e1 = tm.begin() if tm else None
             L.check(lib.fsraft_gemm_rec_nt_list(L.ptr(f2r), P, C * P * 4, L.ptr(dV), P, N * P * 4, L.ptr(d1), N, C * N, B, C, N, P, s, NT_LIST_KSPLIT, 0,
-                                                L.ptr(ktiles.nt_list), L.ptr(ktiles.nt_count), ktiles.nt_stride, 1, L.stream()),
-                    "gemm_rec_nt_list")
+                                                L.ptr(ktiles.nt_list), L.ptr(ktiles.nt_count), ktiles.nt_stride, 1, _wptr(f2r), _wptr(dvol),
+                                                L.stream()), "gemm_rec_nt_list")
             if tm:      # (algorithmic FLOPs: the dense contraction; flops_done: the listed (128-query tile, 32-cell record) pairs)
                 cnt = ktiles.nt_count
                 tm.end("gemm_f32", e1, 2.0 * B * C * N * P, 4.0 * B * (C * P + N * P + C * N),
                        flops_done=lambda cnt=cnt: 2.0 * C * 128 * 32 * float(cnt.sum().item()))
                 e1 = tm.begin()
             L.check(lib.fsraft_gemm_rec_tn_list(L.ptr(dV), P, N * P * 4, L.ptr(f1r), Cr, N * Cr * 4, L.ptr(d2cat), C, P * C, B, P, C, N, s,
-                                                TN_LIST_KSPLIT, 0, L.ptr(ktiles.tn_list), L.ptr(ktiles.tn_count), ktiles.tn_stride, 0, L.stream()),
-                    "gemm_rec_tn_list")
+                                                TN_LIST_KSPLIT, 0, L.ptr(ktiles.tn_list), L.ptr(ktiles.tn_count), ktiles.tn_stride, 0,
+                                                _wptr(dvol), _wptr(f1r), L.stream()), "gemm_rec_tn_list")
             if tm:      # (flops_done: the listed (256-cell tile, 32-query block) pairs)
                 cnt = ktiles.tn_count
                 tm.end("gemm_f32", e1, 2.0 * B * P * C * N, 4.0 * B * (N * P + N * C + P * C),
                        flops_done=lambda cnt=cnt: 2.0 * 256 * C * 32 * float(cnt.sum().item()))
         else:
-            d1 = gemm_rec_nt(f2r, dV, s)                              # [B,C,N] = s * f2cat . dV^T
-            d2cat = gemm_rec_tn(dV, f1r, P, C, s, ksplit=2)           # [B,P,C] = s * dV^T . f1^T
+            d1 = gemm_rec_nt(f2r, dV, s, b_amax=amax_of(dvol))                              # [B,C,N] = s * f2cat . dV^T
+            d2cat = gemm_rec_tn(dV, f1r, P, C, s, ksplit=2, a_amax=amax_of(dvol))           # [B,P,C] = s * dV^T . f1^T
     else:
         f2cat = torch.empty(B, C, P, device=fmap1.device, dtype=torch.float32)
         L.check(_lib().fsraft_corr_f2cat(L.ptr(fmap2.contiguous()), L.ptr(f2cat), lay.nlev, B, C, H, W, L.stream()), "corr_f2cat")
@@ -607,8 +712,10 @@ def gemm(A, Bm, trans_b, alpha=1.0, out=None, accumulate=False):
         out = torch.empty(b, M, N, device=A.device, dtype=torch.float32)
     t = TIMER
     e0 = t.begin() if t else None
+    split = trans_b and not exact_mode()       # (the kernel splits when trans_b and aligned; unused words cost two small launches)
     L.check(_lib().fsraft_gemm_f32(L.ptr(A), K, M * K, L.ptr(Bm), Bm.shape[2], Bm.shape[1] * Bm.shape[2], L.ptr(out),
-                                   N, M * N, b, M, N, K, int(trans_b), float(alpha), int(accumulate), L.stream()),
+                                   N, M * N, b, M, N, K, int(trans_b), float(alpha), int(accumulate),
+                                   L.ptr(amax_tensor(A)) if split else None, L.ptr(amax_tensor(Bm)) if split else None, L.stream()),
             "gemm_f32")
     if t:
         t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
@@ -623,20 +730,25 @@ def rec_pitch(C):
     return 32 * (r | 1)
 
 
-def to_records(x, pad=False):
+def to_records(x, pad=False, amax=None):
     """x [..., K] fp32 contiguous -> [..., ceil32(K)] "records" (same dtype container: every 32 floats of a row are replaced
-    by [32 bf16 hi | 32 bf16 lo]; the padded tail of the last record is zero).  pad=True: row pitch rec_pitch(K)."""
+    by [32 hi | 32 lo] fp16 pieces of x * scale; the padded tail of the last record is zero).  pad=True: row pitch rec_pitch(K).
+    amax: the word of x (default: the one x carries, else computed here); the result carries it as `_fs_amax`."""
     L.require_cuda_f32(x)
     x = x.contiguous()
     K = x.shape[-1]
     rows = x.numel() // K
     ldr = rec_pitch(K) if pad else (K + 31) // 32 * 32
     out = torch.empty(*x.shape[:-1], ldr, device=x.device, dtype=torch.float32)
-    L.check(_lib().fsraft_to_records(L.ptr(x), K, L.ptr(out), ldr, rows, K, L.stream()), "to_records")
+    word = amax if amax is not None else amax_of(x)
+    if word is None:
+        word = amax_tensor(x)
+    out._fs_amax = word
+    L.check(_lib().fsraft_to_records(L.ptr(x), K, L.ptr(out), ldr, rows, K, L.ptr(word), L.stream()), "to_records")
     return out
 
 
-def gemm_rec_nt(Ar, Br, alpha=1.0, ksplit=1, out=None, accumulate=False):
+def gemm_rec_nt(Ar, Br, alpha=1.0, ksplit=1, out=None, accumulate=False, a_amax=None, b_amax=None):
     """C[b] = alpha * A[b] @ B[b]^T on record operands Ar [b,M,K], Br [b,N,K] (outputs of to_records / record producers)."""
     b, M, K = Ar.shape
     N = Br.shape[1]
@@ -645,33 +757,34 @@ def gemm_rec_nt(Ar, Br, alpha=1.0, ksplit=1, out=None, accumulate=False):
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_rec_nt(L.ptr(Ar), K, M * K * 4, L.ptr(Br), K, N * K * 4, L.ptr(out), N, M * N, b, M, N, K, float(alpha),
-                                      int(ksplit), int(accumulate), L.stream()), "gemm_rec_nt")
+                                      int(ksplit), int(accumulate), L.ptr(a_amax) if a_amax is not None else _wptr(Ar),
+                                      L.ptr(b_amax) if b_amax is not None else _wptr(Br), L.stream()), "gemm_rec_nt")
     if t:
         t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
     return out
 
 
-def gemm_rec_nt_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, ksplit=1, accumulate=False):
+def gemm_rec_nt_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, ksplit=1, accumulate=False, a_amax=None, b_amax=None):
     """fsraft_gemm_rec_nt on explicit (device address, pitch in floats, batch stride in floats) triples."""
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_rec_nt(ctypes.c_void_p(A), lda, sA * 4, ctypes.c_void_p(Bm), ldb, sB * 4, ctypes.c_void_p(C), ldc, sC,
-                                      batch, M, N, K, float(alpha), int(ksplit), int(accumulate), L.stream()), "gemm_rec_nt")
+                                      batch, M, N, K, float(alpha), int(ksplit), int(accumulate), L.ptr(a_amax), L.ptr(b_amax), L.stream()), "gemm_rec_nt")
     if t:
         t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
 
 
-def gemm_rec_tn_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, ksplit=1, accumulate=False):
+def gemm_rec_tn_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, ksplit=1, accumulate=False, a_amax=None, b_amax=None):
     """fsraft_gemm_rec_tn on explicit (device address, pitch in floats, batch stride in floats) triples."""
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_rec_tn(ctypes.c_void_p(A), lda, sA * 4, ctypes.c_void_p(Bm), ldb, sB * 4, ctypes.c_void_p(C), ldc, sC,
-                                      batch, M, N, K, float(alpha), int(ksplit), int(accumulate), L.stream()), "gemm_rec_tn")
+                                      batch, M, N, K, float(alpha), int(ksplit), int(accumulate), L.ptr(a_amax), L.ptr(b_amax), L.stream()), "gemm_rec_tn")
     if t:
         t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
 
 
-def gemm_rec_tn(Ar, Br, M, N, alpha=1.0, ksplit=1, out=None, accumulate=False):
+def gemm_rec_tn(Ar, Br, M, N, alpha=1.0, ksplit=1, out=None, accumulate=False, a_amax=None, b_amax=None):
     """C[b] = alpha * A[b]^T @ B[b] on k-major record operands Ar [b,K,lda] (records along m), Br [b,K,ldb] (records along n)."""
     b, K, lda = Ar.shape
     ldb = Br.shape[2]
@@ -680,28 +793,46 @@ def gemm_rec_tn(Ar, Br, M, N, alpha=1.0, ksplit=1, out=None, accumulate=False):
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_rec_tn(L.ptr(Ar), lda, K * lda * 4, L.ptr(Br), ldb, K * ldb * 4, L.ptr(out), N, M * N, b, M, N, K,
-                                      float(alpha), int(ksplit), int(accumulate), L.stream()), "gemm_rec_tn")
+                                      float(alpha), int(ksplit), int(accumulate), L.ptr(a_amax) if a_amax is not None else _wptr(Ar),
+                                      L.ptr(b_amax) if b_amax is not None else _wptr(Br), L.stream()), "gemm_rec_tn")
     if t:
         t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
     return out
 
 
-def gemm_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, trans_b, alpha=1.0, accumulate=False):
-    """fsraft_gemm_f32 on explicit (pointer, pitch, batch stride) triples; A/Bm/C are ints (device addresses)."""
+def _amax_region(ptr, ld, stride, batch, rows, cols):
+    """Word of the [batch][rows][cols] fp32 region at device address ptr (row pitch ld, batch stride `stride`, in floats)."""
+    w = new_amax(torch.device("cuda", torch.cuda.current_device()))
+    if stride == rows * ld or batch == 1:
+        amax_jobs([(ptr, batch * rows, cols, ld, w)])
+    else:
+        amax_jobs([(ptr + 4 * b * stride, rows, cols, ld, w) for b in range(batch)])
+    return w
+
+
+def gemm_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, trans_b, alpha=1.0, accumulate=False, a_amax=None, b_amax=None):
+    """fsraft_gemm_f32 on explicit (pointer, pitch, batch stride) triples; A/Bm/C are ints (device addresses).  a_amax / b_amax:
+    the operands' words for the split kernel (trans_b); computed here when not given."""
+    if trans_b and not exact_mode():
+        a_amax = a_amax if a_amax is not None else _amax_region(A, lda, sA, batch, M, K)
+        b_amax = b_amax if b_amax is not None else _amax_region(Bm, ldb, sB, batch, N, K)
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_f32(ctypes.c_void_p(A), lda, sA, ctypes.c_void_p(Bm), ldb, sB, ctypes.c_void_p(C), ldc, sC,
-                                   batch, M, N, K, int(trans_b), float(alpha), int(accumulate), L.stream()), "gemm_f32")
+                                   batch, M, N, K, int(trans_b), float(alpha), int(accumulate), L.ptr(a_amax), L.ptr(b_amax), L.stream()), "gemm_f32")
     if t:
         t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
 
 
-def gemm_tn_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, accumulate=False):
-    """C[b][m][n] (+)= alpha * sum_k A[b][k][m] Bm[b][k][n] on the split-bf16 core (M, N, pitches % 4 == 0)."""
+def gemm_tn_raw(A, lda, sA, Bm, ldb, sB, C, ldc, sC, batch, M, N, K, alpha=1.0, accumulate=False, a_amax=None, b_amax=None):
+    """C[b][m][n] (+)= alpha * sum_k A[b][k][m] Bm[b][k][n] on the split core (M, N, pitches % 4 == 0); a_amax / b_amax: the
+    operands' words, computed here when not given."""
+    a_amax = a_amax if a_amax is not None else _amax_region(A, lda, sA, batch, K, M)
+    b_amax = b_amax if b_amax is not None else _amax_region(Bm, ldb, sB, batch, K, N)
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_tn_split(ctypes.c_void_p(A), lda, sA, ctypes.c_void_p(Bm), ldb, sB, ctypes.c_void_p(C), ldc,
-                                        sC, batch, M, N, K, float(alpha), int(accumulate), L.stream()), "gemm_tn_split")
+                                        sC, batch, M, N, K, float(alpha), int(accumulate), L.ptr(a_amax), L.ptr(b_amax), L.stream()), "gemm_tn_split")
     if t:
         t.end("gemm_f32", e0, 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
 
@@ -729,6 +860,7 @@ def softmax_rows_rec_(S):
     L.require_cuda_f32(S)
     n = S.shape[-1]
     L.check(_lib().fsraft_softmax_rows_rec(L.ptr(S), S.numel() // n, n, L.stream()), "softmax_rows_rec")
+    S._fs_amax = amax_one(S.device)         # probabilities: the records are split with the scale of a word holding 1.0
     return S
 
 
@@ -736,7 +868,9 @@ def softmax_rows_bwd_rec_(Ar, dA):
     """Ar: records of softmax_rows_rec_; dA: fp32 gradient, overwritten with the RECORDS of A * (dA - sum(dA * A, -1))."""
     L.require_cuda_f32(Ar, dA)
     n = Ar.shape[-1]
-    L.check(_lib().fsraft_softmax_rows_bwd_rec(L.ptr(Ar), L.ptr(dA), Ar.numel() // n, n, L.stream()), "softmax_rows_bwd_rec")
+    word = amax_scaled(amax_tensor(dA), 2.0)          # |A (dA - <dA, A>)| <= 2 max |dA|
+    L.check(_lib().fsraft_softmax_rows_bwd_rec(L.ptr(Ar), L.ptr(dA), Ar.numel() // n, n, L.ptr(word), L.stream()), "softmax_rows_bwd_rec")
+    dA._fs_amax = word
     return dA
 
 
@@ -767,7 +901,7 @@ def gemm_tn_split(A, Bm, alpha=1.0):
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_gemm_tn_split(L.ptr(A), M, K * M, L.ptr(Bm), N, K * N, L.ptr(out), N, M * N, b, M, N, K,
-                                        float(alpha), 0, L.stream()), "gemm_tn_split")
+                                        float(alpha), 0, L.ptr(amax_tensor(A)), L.ptr(amax_tensor(Bm)), L.stream()), "gemm_tn_split")
     if t:
         t.end("gemm_f32", e0, 2.0 * b * M * N * K, 4.0 * b * (M * K + N * K + M * N))
     return out
@@ -990,8 +1124,11 @@ def pack_weight(w, srcC, mode):
     else:
         rows, kt = Cin, conv_ktot([Cout], KH, KW)
     wpk = torch.empty(rows, kt, device=w.device, dtype=torch.float32)
+    word = amax_tensor(w) if mode >= 10 else None       # split packs hold fp16 pieces of w * scale(amax)
     L.check(_lib().fsraft_pack_conv_weight(L.ptr(w), L.ptr(wpk), Cout, Cin, KH, KW, L.int_array(srcC), len(srcC), mode,
-                                           0, L.stream()), "pack_conv_weight")
+                                           0, L.ptr(word), L.stream()), "pack_conv_weight")
+    if word is not None:
+        wpk._fs_amax = word
     return wpk
 
 
@@ -1005,6 +1142,8 @@ class PackPlan:
         self.jobs = []          # (PackJob, offset in floats, shape)
         self.total = 0
         self.keep = []
+        self.words = {}         # split packs: tuple of the pieces' data_ptrs -> amax word shared by every pack of those weights
+        self.amax_jobs = []
 
     def _job(self, ws, cin_full, kh, kw, srcC, srcOff, mode, flags=0, scale=1.0, accumulate=False):
         j = L.PackJob()
@@ -1037,6 +1176,16 @@ class PackPlan:
         if frag:
             rows = (rows + 31) // 32 * 32
         j = self._job(ws, cin_full, kh, kw, srcC, srcOff, mode, (1 if frag else 0) | (2 if s2d else 0))
+        if mode >= 10:
+            # fp16 pieces of w * scale: the scale comes from the largest magnitude of the pieces' WHOLE tensors (an upper
+            # bound for the channel ranges a job uses), one word per set of pieces, computed in run() ahead of the packs
+            key = tuple(w.data_ptr() for w in ws)
+            word = self.words.get(key)
+            if word is None:
+                word = self.words[key] = new_amax(self.device)
+                self.amax_jobs += [(w.data_ptr(), 1, w.numel(), w.numel(), word) for w in ws]
+            j.amax = word.data_ptr()
+            j._word = word
         self.jobs.append((j, self.total, (rows, kt)))
         self.total += (rows * kt + 63) // 64 * 64
         return len(self.jobs) - 1
@@ -1060,7 +1209,10 @@ class PackPlan:
             t = buf[off:off + n].view(shape)
             j.wpk = t.data_ptr()
             arr[i] = j
+            if getattr(j, "_word", None) is not None:
+                t._fs_amax = j._word
             outs.append(t)
+        amax_jobs(self.amax_jobs)
         if self.jobs:
             L.check(_lib().fsraft_pack_conv_weights(arr, len(self.jobs), L.stream()), "pack_conv_weights")
         self.keep = []
@@ -1114,7 +1266,10 @@ def fragment_order(wps):
     if nb * 32 != N:
         w = torch.cat([w, w.new_zeros(nb * 32 - N, ktot)])
     w = w.view(nb, 32, kt, 2, 2, 2, 4).permute(2, 0, 3, 4, 5, 1, 6).contiguous()      # kt, nb, hi/lo, s, k half, row, dword
-    return w.view(torch.float32).view(kt, nb, 4, 64, 4)
+    out = w.view(torch.float32).view(kt, nb, 4, 64, 4)
+    if amax_of(wps) is not None:
+        out._fs_amax = amax_of(wps)
+    return out
 
 
 def unpack_weight_grad(dwpk, shape, srcC, out=None, accumulate=False):
@@ -1123,17 +1278,18 @@ def unpack_weight_grad(dwpk, shape, srcC, out=None, accumulate=False):
         out = torch.empty(shape, device=dwpk.device, dtype=torch.float32)
         accumulate = False
     L.check(_lib().fsraft_pack_conv_weight(L.ptr(out), L.ptr(dwpk), Cout, Cin, KH, KW, L.int_array(srcC), len(srcC), 2,
-                                           int(accumulate), L.stream()), "unpack_conv_weight")
+                                           int(accumulate), None, L.stream()), "unpack_conv_weight")
     return out
 
 
 class V:
     """Channels [off, off+C) of a channels-last buffer [B,H,W,ld] (pitch = the buffer's ld)."""
-    __slots__ = ("t", "off", "C", "ld")
+    __slots__ = ("t", "off", "C", "ld", "amax")
 
-    def __init__(self, t, C=None, off=0):
+    def __init__(self, t, C=None, off=0, amax=None):
         self.t, self.off, self.ld = t, off, t.shape[-1]
         self.C = (t.shape[-1] - off) if C is None else C
+        self.amax = amax if amax is not None else amax_of(t)      # amax word (1-element tensor) or None: computed on demand
         assert off % 4 == 0 and self.ld % 4 == 0, "channel slices must stay 16-byte aligned"
 
     @property
@@ -1143,11 +1299,12 @@ class V:
 
 class Dst:
     """Output channel range starting at GEMM column n0 -> strided destination."""
-    __slots__ = ("t", "off", "bs", "ps", "cs", "n0", "acc", "mask")
+    __slots__ = ("t", "off", "bs", "ps", "cs", "n0", "acc", "mask", "amax")
 
     def __init__(self, t, off, bs, ps, cs, n0=0, acc=False):
         self.t, self.off, self.bs, self.ps, self.cs, self.n0, self.acc = t, off, bs, ps, cs, n0, acc
         self.mask = None            # optional V: ReLU-backward mask applied to this range by the epilogue
+        self.amax = amax_of(t)      # the buffer's amax word, raised by the epilogue (None: the buffer carries none)
 
     def masked(self, v):
         """Zero the written values where the forward activation v (a V over the same channels) is <= 0."""
@@ -1223,6 +1380,21 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     ws = _conv_workspace(dsts[0].t.device, B * H * W)
     if ws is not None:
         d.ws = ws.data_ptr(); d.ws_floats = ws.numel()
+    split = (wpk_split is not None or wpk_frag is not None) and not exact_mode()
+    if split:
+        # split arithmetic: scales from the amax words of the sources and of the weights
+        wsrc = wpk_split if wpk_split is not None else wpk_frag
+        ww = amax_of(wsrc)
+        if ww is None:
+            raise RuntimeError("conv_forward: the split weight pack carries no amax word (pack it with ops.pack_weight / PackPlan)")
+        d.w_amax = ww.data_ptr()
+        for i, a in enumerate(ensure_amax(srcs)):
+            d.src_amax[i] = a
+    for i, ds in enumerate(dsts):
+        if ds.amax is not None:
+            d.dst_amax[i] = ds.amax.data_ptr()
+    if epi == 2 and aux1 is not None and amax_of(aux1) is not None:       # r*h
+        d.dst_amax[1] = amax_of(aux1).data_ptr()
     t = TIMER
     e0 = t.begin() if t else None
     carried = None
@@ -1245,10 +1417,12 @@ def conv_wgrad(dy, srcs, dwpk, B, H, W, KH, KW, dbias=None):
     dy: V over the (already act'-scaled) output gradient."""
     arr = (ctypes.c_void_p * len(srcs))(*[v.ptr for v in srcs])
     pp = ctypes.cast(arr, L._PP)
+    am = ensure_amax([dy] + list(srcs))
+    a_am = (ctypes.c_void_p * len(srcs))(*am[1:])
     e0w = TIMER.begin() if TIMER else None
     L.check(_lib().fsraft_conv_wgrad(ctypes.c_void_p(dy.ptr), dy.ld, dy.C, pp, L.int_array([v.C for v in srcs]),
                                      L.int_array([v.ld for v in srcs]), len(srcs), L.ptr(dwpk), L.ptr(dbias), B, H, W,
-                                     KH, KW, L.stream()), "conv_wgrad")
+                                     KH, KW, ctypes.c_void_p(am[0]), ctypes.cast(a_am, L._PP), L.stream()), "conv_wgrad")
     if TIMER:
         cin = sum(v.C for v in srcs)
         TIMER.end("conv_wgrad", e0w, 2.0 * B * H * W * dy.C * cin * KH * KW, 4.0 * B * H * W * (cin + dy.C),
@@ -1262,10 +1436,14 @@ def conv_wgrad_multi(dys, srcs, dwpk, B, H, W, KH, KW, dbias=None):
     dy0 = dys[0]
     a_dy = (ctypes.c_void_p * n)(*[v.ptr for v in dys])
     a_src = (ctypes.c_void_p * (n * nsrc))(*[v.ptr for sl in srcs for v in sl])
+    am = ensure_amax(list(dys) + [v for sl in srcs for v in sl])
+    m_dy = (ctypes.c_void_p * n)(*am[:n])
+    m_src = (ctypes.c_void_p * (n * nsrc))(*am[n:])
     e0w = TIMER.begin() if TIMER else None
     L.check(_lib().fsraft_conv_wgrad_multi(ctypes.cast(a_dy, L._PP), n, dy0.ld, dy0.C, ctypes.cast(a_src, L._PP),
                                            L.int_array([v.C for v in srcs[0]]), L.int_array([v.ld for v in srcs[0]]), nsrc,
-                                           L.ptr(dwpk), L.ptr(dbias), B, H, W, KH, KW, L.stream()), "conv_wgrad_multi")
+                                           L.ptr(dwpk), L.ptr(dbias), B, H, W, KH, KW, ctypes.cast(m_dy, L._PP),
+                                           ctypes.cast(m_src, L._PP), L.stream()), "conv_wgrad_multi")
     if TIMER:
         cin = sum(v.C for v in srcs[0])
         TIMER.end("conv_wgrad", e0w, 2.0 * n * B * H * W * dy0.C * cin * KH * KW, 4.0 * n * B * H * W * (cin + dy0.C),
@@ -1283,7 +1461,10 @@ def stem_fwd(x, w, bias=None):
     out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, N, device=x.device, dtype=torch.float32)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(_lib().fsraft_stem7x7s2_fwd(L.ptr(x), L.ptr(w.contiguous()), L.ptr(bias), L.ptr(out), B, H, W, N, L.stream()), "stem7x7s2_fwd")
+    xa = amax_of(x)
+    if xa is None:
+        xa = x._fs_amax = amax_tensor(x)        # (kept on the image tensor: the weight gradient reads it again)
+    L.check(_lib().fsraft_stem7x7s2_fwd(L.ptr(x), L.ptr(w.contiguous()), L.ptr(bias), L.ptr(out), B, H, W, N, L.ptr(xa), L.stream()), "stem7x7s2_fwd")
     if t:
         t.end("stem", e0, 2.0 * out.numel() * 147, 4.0 * (x.numel() + out.numel()))
     return out
@@ -1301,7 +1482,9 @@ def stem_wgrad(x, dy):
     dw = torch.empty(N, 3, 7, 7, device=x.device, dtype=torch.float32)
     t = TIMER
     e0 = t.begin() if t else None
-    L.check(lib.fsraft_stem7x7s2_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(scratch), B, H, W, N, L.stream()), "stem7x7s2_wgrad")
+    xa = amax_of(x) if amax_of(x) is not None else amax_tensor(x)
+    da = amax_of(dy) if amax_of(dy) is not None else amax_tensor(dy)
+    L.check(lib.fsraft_stem7x7s2_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(scratch), B, H, W, N, L.ptr(xa), L.ptr(da), L.stream()), "stem7x7s2_wgrad")
     if t:
         t.end("stem", e0, 2.0 * dy.numel() * 147, 4.0 * (x.numel() + dy.numel()))
     return dw

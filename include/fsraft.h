@@ -34,12 +34,40 @@ typedef struct ihipStream_t* hipStream_t;
 #define FSRAFT_ERR_ARG 1
 #define FSRAFT_ERR_LAUNCH 2
 
+/* Version of this header's structs and signatures.  Round 6 (version 6) added the amax words below: trailing fields of
+ * fsraft_conv_desc / fsraft_pack_job and trailing `const unsigned*` arguments of the GEMM-shaped entry points.  A binding
+ * compiled against another version must not call in (the descriptor structs carry no size field). */
+#define FSRAFT_ABI_VERSION 6
+int fsraft_abi_version(void);
+
+/* ---- amax words: the scales of the split arithmetic ----------------------------------------------------------------------
+ * The reference multiplies in fp32 (pytorch/core/corr.py:52-60 matmul, every nn.Conv2d of update.py:6-136).  Here a GEMM-shaped
+ * kernel carries every fp32 operand x as two fp16 pieces of x * s (hi = fp16(x s), lo = fp16(x s - hi)) and evaluates a product
+ * as (a_hi b_hi + a_hi b_lo + a_lo b_hi) / (s_a s_b) on v_mfma_f32_*_f16 with fp32 accumulation: ~2^-22 per product, the fp32
+ * GEMM's accuracy class (csrc/split_arith.hpp; fsraft_set_arithmetic(0) selects exact fp32 MFMA instead).  s is a power of
+ * two per TENSOR, derived on the device from the tensor's "amax word": ONE `unsigned` in device memory holding the bit pattern
+ * of max |x| (or an upper bound).  s maps that magnitude into [2^14, 2^15): nothing overflows fp16, elements within 2^-17 of
+ * the largest keep all 22 bits, smaller ones degrade gracefully (fp16 subnormals) to a floor of 2^-39 of the largest.
+ *   - entry points that READ a tensor through the matrix pipe take its word (`..._amax`, const unsigned*); NULL = "the caller
+ *     vouches |x| < 2^15": scale 1;
+ *   - entry points that WRITE one can raise a word to the largest magnitude they stored (fsraft_conv_desc.dst_amax: one
+ *     atomicMax per workgroup), so that a chain of kernels needs no extra pass; the word must be zero (or an earlier bound)
+ *     before the producer runs;
+ *   - fsraft_amax / fsraft_amax_jobs compute words of tensors that come from elsewhere (images, parameters, gradients handed in
+ *     by autograd); fsraft_amax_scaled derives a bound from another word (dst = max(dst, factor * src)).
+ * Records (fsraft_to_records, the weight packs, the gradient volume) hold pieces of x * s: whoever reads them is given the word
+ * they were split with.  Words are written by kernels and read by later kernels on the same stream: no host synchronisation. */
+int fsraft_amax(const float* x, int64_t rows, int64_t C, int64_t ld, unsigned* word, hipStream_t stream);     /* element (r, c) at x[r * ld + c] */
+int fsraft_amax_jobs(const float* const* ptrs, const int64_t* rows, const int64_t* C, const int64_t* ld, unsigned* const* words,
+                     int n, hipStream_t stream);                        /* n tensors, 32 per launch; several may share a word */
+int fsraft_amax_scaled(const unsigned* src, float factor, unsigned* dst, hipStream_t stream);
+
 /* ---- all-pairs correlation volume + pyramid ---------------------------------------
  * Replaces CorrBlock.__init__ / CorrBlock.corr, pytorch/core/corr.py:13-27, 52-60
  * (torch.matmul + 3x avg_pool2d) and TF calc_all_field, raft/allfield.py:61-92.
  * fmap1, fmap2: [B,C,H,W].  levels[l]: [B*H*W, H>>l, W>>l] (floor), l < num_levels <= 4. */
 int fsraft_corr_build(const float* fmap1, const float* fmap2, float* const* levels, int num_levels,
-                      int B, int C, int H, int W, hipStream_t stream);
+                      int B, int C, int H, int W, const unsigned* amax1, const unsigned* amax2, hipStream_t stream);
 
 /* Backward of the pooling chain: dlevels[0] += unpool(dlevels[1..]) in place.
  * (autograd of F.avg_pool2d, pytorch/core/corr.py:25-27) */
@@ -66,11 +94,11 @@ int fsraft_corr_unpool_bwd(float* const* dlevels, int num_levels, int B, int H, 
 int fsraft_vol_layout(int H, int W, int num_levels, int* out);
 /* vol [B*H*W][P] <- all-pairs volume + pyramid (pad cells of V: unspecified, never read by the lookup) */
 int fsraft_corr_build_tiled(const float* fmap1, const float* fmap2, float* vol, int num_levels, int B, int C, int H, int W,
-                            hipStream_t stream);
+                            const unsigned* amax1, const unsigned* amax2, hipStream_t stream);
 /* the same from pre-split feature maps f1r, f2r = [B][H*W][C/32] records (fsraft_to_records of the channels-last maps,
  * C % 32 == 0): both operands staged by LDS-DMA on the record GEMM core, 256 queries x an 8x16 target patch per workgroup */
 int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vol, int num_levels, int B, int C, int H, int W,
-                          hipStream_t stream);
+                          const unsigned* amax1, const unsigned* amax2 /* the words f1r / f2r were split with */, hipStream_t stream);
 /* CorrBlock.__call__ (pytorch/core/corr.py:29-50) on that layout; out [B,H,W,L*(2r+1)^2] channels-last; one wave per query.
  * add_grid != 0: `coords` holds the FLOW and the query position is pixel grid + flow (the caller's coords0 + flow,
  * pytorch/core/raft.py:121-131, never materialised) */
@@ -80,7 +108,7 @@ int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* 
  * all iterations of a step): dvol [B*H*W][P] = (or +=, accumulate != 0) sum_t (d out_t / d V)^T dout_t, pad cells zero;
  * dout[t] is [B,H,W,CH] channels-last, coords[t] element (b, c, pix) at coords[t][b*s0 + c*s1 + pix*s2] with
  * (s0, s1, s2) = coords_str[3t .. 3t+2].  n <= 16 per call.  Each row is accumulated in LDS and written once; records != 0:
- * as [32 bf16 hi | 32 bf16 lo] records, the operand format of fsraft_gemm_rec_nt / _tn below.  Only queries [q0, q0 + nq)
+ * as [32 hi | 32 lo] fp16 records, the operand format of fsraft_gemm_rec_nt / _tn below.  Only queries [q0, q0 + nq)
  * (nq == 0: all from q0) are built, into dvol rows 0 .. nq-1 -- AlternateCorrBlock's backward walks the queries in chunks so
  * that no O(N^2) buffer exists.  qlist (nullable): caller-owned scratch of 1 + rows unsigned.  With it, one wave per query
  * builds the row from the bounding boxes of its lookups' windows (a few KB of LDS instead of the whole row) and queries whose
@@ -91,6 +119,8 @@ int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* 
 int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords, const int64_t* coords_str, int n, float* dvol,
                            int num_levels, int B, int H, int W, int radius, int accumulate, int records, int add_grid,
                            int64_t q0, int64_t nq, unsigned* qlist, const unsigned* wmask,
+                           const unsigned* dvol_amax /* records: a word bounding |dvol| -- (lookups of the step) x max |dout| does,
+                                                        a cell collects at most one unit of bilinear weight per lookup */,
                            hipStream_t stream);
 /* Backward of matmul + avg_pool2d chain (pytorch/core/corr.py:21-27, 52-60) without un-pooling the volume gradient:
  *   f2cat [B][C][P]: level-l cell = mean of fmap2 over its 2^l x 2^l pixels (0 in pad cells), so that
@@ -99,10 +129,11 @@ int fsraft_corr_dvol_build(const float* const* dout, const float* const* coords,
  *   fsraft_corr_dfmap2: d2 [B][H*W][C] = sum_l 4^-l * d2cat[b][cell_l(y>>l, x>>l)][c] over the levels whose cell exists. */
 int fsraft_corr_f2cat(const float* fmap2, float* f2cat, int num_levels, int B, int C, int H, int W, hipStream_t stream);
 int fsraft_corr_dfmap2(const float* d2cat, float* d2, int num_levels, int B, int C, int H, int W, hipStream_t stream);
-/* f2cat directly as records [B][C][P / 32] x ([32 hi | 32 lo] bf16) -- fsraft_corr_f2cat followed by fsraft_to_records in one
+/* f2cat directly as records [B][C][P / 32] x ([32 hi | 32 lo] fp16 pieces) -- fsraft_corr_f2cat followed by fsraft_to_records in one
  * pass (the plane pooled in LDS by the reference's recursion, corr.py:24-26).  Planes of at most 12288 pixels (H * W);
  * FS_ERR_ARG above that, the caller then takes the two calls. */
-int fsraft_corr_f2cat_rec(const float* fmap2, void* f2r, int num_levels, int B, int C, int H, int W, hipStream_t stream);
+int fsraft_corr_f2cat_rec(const float* fmap2, void* f2r, int num_levels, int B, int C, int H, int W,
+                          const unsigned* amax2 /* word of fmap2: bounds its pooled means too */, hipStream_t stream);
 
 /* ---- radius-r pyramid lookup --------------------------------------------------------
  * Replaces CorrBlock.__call__, pytorch/core/corr.py:29-50 (+ bilinear_sampler,
@@ -139,12 +170,14 @@ int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_level
                              int C, int radius, hipStream_t stream);
 
 /* The same lookup with the dot products of a tile of queries against a region of target rows as one small GEMM on the matrix
- * pipe (bf16x3 on pre-split operands, the arithmetic of the volume build): f1r [B][H*W][C/32 records] and f2r_levels[l]
+ * pipe (split arithmetic on pre-split operands, as the volume build): f1r [B][H*W][C/32 records] and f2r_levels[l]
  * [B][(H>>l)*(W>>l)][C/32 records] = fsraft_to_records of the channels-last maps, which are passed as well (window positions
  * outside a tile's region -- flow discontinuities -- are taken from them in fp32).  C % 32 == 0, C <= 256. */
 int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
                             int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
-                            int add_grid, float* out, int B, int H, int W, int C, int radius, hipStream_t stream);
+                            int add_grid, float* out, int B, int H, int W, int C, int radius,
+                            const unsigned* amax1, const unsigned* amax2 /* the words f1r / ALL f2r levels were split with */,
+                            hipStream_t stream);
 
 /* ---- convex 8x upsampler -------------------------------------------------------------
  * Replaces RAFT.upsample_flow, pytorch/core/raft.py:72-83 and UpsampleConvexWithMask,
@@ -190,6 +223,10 @@ typedef struct fsraft_conv_desc {
                                                                  counts (16-byte aligned, on the device the call runs on, not
                                                                  shared with a call on another stream); NULL: the buffer the
                                                                  calling thread registered with fsraft_conv_workspace, if any */
+  /* amax words (see the top of this file).  src_amax[s]: word of source s (one scale is used for all sources: the largest);
+   * w_amax: the word wpk_split / wpk_frag were packed with; dst_amax[i] (nullable): raised to the largest magnitude stored
+   * into destination i -- GRU epilogues: [0] the new hidden state (epi 3), [1] r*h (epi 2); the gates are bounded by 1 */
+  const unsigned* src_amax[3]; const unsigned* w_amax; unsigned* dst_amax[3];
 } fsraft_conv_desc;
 
 int fsraft_conv_ktot(const int* srcC, int nsrc, int KH, int KW);
@@ -204,16 +241,18 @@ int fsraft_conv_forward_stats(const fsraft_conv_desc* d, float* sum, float* sq, 
 /* dwpk[Cout][Ktot] += dY^T im2col(src);  dbias (nullable): dbias[co] += sum over pixels of dY[:, co] */
 int fsraft_conv_wgrad(const float* dy, int ldy, int Cout, const float* const* src, const int* srcC,
                       const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W, int KH, int KW,
-                      hipStream_t stream);
+                      const unsigned* dy_amax, const unsigned* const* src_amax /* [nsrc] words, or NULL */, hipStream_t stream);
 /* The same reduction over nseg (dY, X) pairs of identical shape -- the iterations of one training step -- in one launch:
  * dwpk += sum_t dY_t^T im2col(X_t).  src[t * nsrc + s] is source s of pair t. */
 int fsraft_conv_wgrad_multi(const float* const* dy, int nseg, int ldy, int Cout, const float* const* src,
                             const int* srcC, const int* srcld, int nsrc, float* dwpk, float* dbias, int B, int H, int W,
-                            int KH, int KW, hipStream_t stream);
+                            int KH, int KW, const unsigned* const* dy_amax /* [nseg] or NULL */,
+                            const unsigned* const* src_amax /* [nseg * nsrc] or NULL */, hipStream_t stream);
 /* mode 0: OIHW -> packed forward; 1: OIHW -> packed data-gradient; 2: packed -> OIHW (+=);
- * modes 10 / 11: as 0 / 1 but every 32-k run stored as [32 hi | 32 lo] bf16 (split-bf16 GEMM core) */
+ * modes 10 / 11: as 0 / 1 but every 32-k run stored as [32 hi | 32 lo] fp16 pieces of w * scale(w_amax) (split GEMM core) */
 int fsraft_pack_conv_weight(float* w_oihw, float* wpk, int Cout, int Cin, int KH, int KW, const int* srcC,
-                            int nsrc, int mode, int accumulate, hipStream_t stream);
+                            int nsrc, int mode, int accumulate, const unsigned* w_amax /* modes 10 / 11: word of w_oihw */,
+                            hipStream_t stream);
 
 /* Batched form: every packed matrix of a module (or, mode 2, every weight gradient) in one launch per 16 jobs, read in place
  * from / written in place to the parameter-shaped tensors -- no torch.cat of fused layers, no channel gather.
@@ -233,6 +272,7 @@ typedef struct {
   int srcC[3], srcOff[3], nsrc;
   int mode, flags;
   float scale; int accumulate;
+  const unsigned* amax;          /* modes 10 / 11: word bounding the job's weights (fsraft_amax_jobs over its pieces); NULL: scale 1 */
 } fsraft_pack_job;
 int fsraft_pack_conv_weights(const fsraft_pack_job* jobs, int njobs, hipStream_t stream);
 
@@ -263,7 +303,8 @@ int fsraft_conv_workspace(float* ws, int64_t floats);
 /* ---- arithmetic of the dense contractions -------------------------------------------------------------------------
  * Storage and accumulation are fp32 everywhere.  mode 1 (default): every fp32 product of the GEMM-shaped kernels (volume
  * build and its backward, the update block's / encoders' convolutions, their weight gradients, the GMA GEMMs) is evaluated
- * as three bf16 MFMA products with fp32 accumulation (hi*hi + hi*lo + lo*hi, ~2^-17 relative error per product);
+ * as three fp16 MFMA products of scaled operands with fp32 accumulation (hi*hi + hi*lo + lo*hi, ~2^-22 relative error per
+ * product: "amax words" at the top of this file; rounds 1-5 used bf16 pieces, 2^-17);
  * mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a pure fmaf chain) -- the test / reference mode.  Process-wide; not
  * to be flipped while kernels of another thread are being enqueued.  Replaces nothing in the reference (its
  * torch.backends.cuda.matmul.allow_tf32 default plays the same role on the reference's hardware). */
@@ -273,31 +314,36 @@ int fsraft_get_arithmetic(void);   /* 1 / 0 as above */
 /* ---- batched fp32 GEMM (volume backward: autograd of torch.matmul, corr.py:57) ------- */
 int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
                     int64_t ldc, int64_t sC, int batch, int M, int N, int K, int trans_b, float alpha,
-                    int accumulate, hipStream_t stream);
+                    int accumulate, const unsigned* a_amax, const unsigned* b_amax /* trans_b: the split kernel's words */,
+                    hipStream_t stream);
 
 /* C[b][m][n] = alpha * sum_k A[b][k][m] * Bm[b][k][n] (both k-major) on the split-bf16 core. */
 int fsraft_gemm_tn_split(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
                          int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int accumulate,
-                         hipStream_t stream);
+                         const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream);
 
 /* ---- GEMM on pre-split ("record") operands -------------------------------------------------------------------------
- * A record is 32 consecutive k of one row as [32 x bf16 hi | 32 x bf16 lo] (hi = bf16(x), lo = bf16(x - hi)): 128 bytes, the
- * bytes the 32 floats took.  Producers split once; the GEMM stages by LDS-DMA (no conversion, no VGPR round trip) and
- * evaluates a_hi b_hi + a_hi b_lo + a_lo b_hi on bf16 MFMA with fp32 accumulation (csrc/gemm_rec.hpp).
+ * A record is 32 consecutive k of one row as [32 x fp16 hi | 32 x fp16 lo] (hi = fp16(x s), lo = fp16(x s - hi), s the scale of
+ * the tensor's amax word): 128 bytes, the bytes the 32 floats took.  Producers split once; the GEMM stages by LDS-DMA (no
+ * conversion, no VGPR round trip), evaluates a_hi b_hi + a_hi b_lo + a_lo b_hi on fp16 MFMA with fp32 accumulation
+ * (csrc/gemm_rec.hpp) and divides s_a s_b out of the result: a_amax / b_amax are the words A / B were split with.
  * fsraft_to_records: src [rows][K] fp32 (pitch ld floats) -> dst [rows][ceil(K/32)] records (tail of the last record zero),
  * row pitch dst_ld floats (0 = dense; activation tensors use an ODD number of 128-byte lines per row so that the rows of a
  * k-tile spread over all L2 channels instead of every 4th / 8th line).
  * fsraft_gemm_rec_nt: C[b][m][n] = alpha * sum_k A[b][m][k] B[b][n][k]; A [batch][M] rows of K/32 records (row pitch lda
  * floats), B [batch][N] rows (pitch ldb; 0 = K), K % 32 == 0, sA / sB batch strides in BYTES.  ksplit > 1: K split over workgroups, partial tiles added with fp32
  * atomics (C zeroed first unless accumulate != 0). */
-int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, hipStream_t stream);
+int fsraft_to_records(const float* src, int64_t ld, void* dst, int64_t dst_ld, int64_t rows, int K, const unsigned* amax,
+                      hipStream_t stream);
 int fsraft_gemm_rec_nt(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
-                       int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream);
+                       int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
+                       const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream);
 /* C[b][m][n] = alpha * sum_k A[b][k][m] B[b][k][n]: both operands k-major, A [batch][K][lda floats] with the records along m,
  * B [batch][K][ldb floats] with the records along n (lda, ldb multiples of 32; K arbitrary).  Fragments are gathered with the
  * transposed LDS read (ds_read_b64_tr_b16). */
 int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
-                       int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, hipStream_t stream);
+                       int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate,
+                       const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream);
 
 /* The two contractions above over LISTED k-tiles only (32 k each, ascending): klist[(b * tiles + tile) * kl_stride + i],
  * i < kcount[b * tiles + tile], one list per tile of the sparse operand -- the 128-row tiles of B resp. 128-column tiles of B
@@ -306,10 +352,12 @@ int fsraft_gemm_rec_tn(const void* A, int64_t lda, int64_t sA, const void* Bm, i
  * pytorch/core/corr.py:52-60); the lists come from fsraft_corr_bwd_ktiles. */
 int fsraft_gemm_rec_nt_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
                             int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist,
-                            const int* kcount, int kl_stride, int kl_by_n, hipStream_t stream);
+                            const int* kcount, int kl_stride, int kl_by_n, const unsigned* a_amax, const unsigned* b_amax,
+                            hipStream_t stream);
 int fsraft_gemm_rec_tn_list(const void* A, int64_t lda, int64_t sA, const void* Bm, int64_t ldb, int64_t sB, float* C, int64_t ldc,
                             int64_t sC, int batch, int M, int N, int K, float alpha, int ksplit, int accumulate, const int* klist,
-                            const int* kcount, int kl_stride, int kl_by_n, hipStream_t stream);
+                            const int* kcount, int kl_stride, int kl_by_n, const unsigned* a_amax, const unsigned* b_amax,
+                            hipStream_t stream);
 /* Which k-tiles of the volume-backward GEMMs the step's lookups can reach, from their coordinates alone (arguments as
  * fsraft_corr_dvol_build; n <= 16): nt_list [B][ceil(H*W / 128)][nt_stride >= P / 32] + nt_count = records per 128-query tile
  * (dF1 = s * F2cat . dV^T with dV as the B operand, kl_by_n = 1); tn_list [B][ceil(P / 256)][tn_stride >= ceil(H*W / 32)] +
@@ -328,12 +376,14 @@ int fsraft_corr_bwd_ktiles(const float* const* coords, const int64_t* coords_str
 int fsraft_softmax_rows(float* S, int64_t rows, int n, hipStream_t stream);
 /* dA <- A * (dA - rowsum(dA * A))  (softmax backward, in place over dA) */
 int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, int n, hipStream_t stream);
-/* The same softmax (gma.py:71-74) with the probabilities written over the logits as RECORDS ([32 bf16 hi | 32 bf16 lo] per 32
+/* The same softmax (gma.py:71-74) with the probabilities written over the logits as RECORDS ([32 hi | 32 lo] fp16 per 32
  * columns: the operand form of fsraft_gemm_rec_nt / _tn): for n % 32 == 0 (n <= 16352) the record row is as long as the fp32
- * row, so the map exists once.  The backward reads those records (a = hi + lo) and turns the fp32 gradient dA into the records
- * of dS = A * (dA - rowsum(dA * A)) in place (n <= 8160). */
+ * row, so the map exists once.  Probabilities are bounded by 1: their records are split with the fixed scale 2^14, the scale
+ * of an amax word holding 1.0f -- the word to hand to the GEMMs that read them.  The backward reads those records (a = hi + lo)
+ * and turns the fp32 gradient dA into the records of dS = A * (dA - rowsum(dA * A)) in place (n <= 8160), split with the scale
+ * of ds_amax (|dS| <= 2 max |dA|). */
 int fsraft_softmax_rows_rec(float* S, int64_t rows, int n, hipStream_t stream);
-int fsraft_softmax_rows_bwd_rec(const void* A_records, float* dA, int64_t rows, int n, hipStream_t stream);
+int fsraft_softmax_rows_bwd_rec(const void* A_records, float* dA, int64_t rows, int n, const unsigned* ds_amax, hipStream_t stream);
 /* Aggregate.forward, gma.py:113: dst = x + gamma[0] * y with gamma a device scalar (the nn.Parameter). */
 int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,
                        int64_t M, int C, hipStream_t stream);
@@ -409,9 +459,10 @@ int fsraft_bn_fold_bwd(const float* part, int R, int C, const float* rs, const f
  * 192 floats of workspace (per-workgroup partial sums). */
 int fsraft_stem_slots(void);
 int fsraft_stem7x7s2_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int N,
+                         const unsigned* x_amax /* word of the images; the weights' scale is worked out in the kernel */,
                          hipStream_t stream);
 int fsraft_stem7x7s2_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int N,
-                           hipStream_t stream);
+                           const unsigned* x_amax, const unsigned* dy_amax, hipStream_t stream);
 
 /* ---- optimizer step of the train step (row e: what the DP step does after the all-reduce) ---------
  * `torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)` + `optimizer.step()` of `optim.AdamW(model.parameters(),

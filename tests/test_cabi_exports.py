@@ -131,10 +131,12 @@ def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
     nullpp = ctypes.cast(null, _lib._PP)
     strides = (ctypes.c_int64 * 3)(0, 0, 0)
     assert lib.fsraft_corr_bwd_ktiles(nullpp, strides, 1, 4, 1, 16, 16, 4, 1, 0, 0, null, null, 0, null, null, null, 0, null, None) == 1
-    assert lib.fsraft_gemm_rec_nt_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, None) == 1
-    assert lib.fsraft_gemm_rec_tn_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, None) == 1
+    assert lib.fsraft_gemm_rec_nt_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, null, null, None) == 1
+    assert lib.fsraft_gemm_rec_tn_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, null, null, None) == 1
     assert lib.fsraft_gru_bwd1(null, null, null, null, null, null, 128, null, null, null, null, 16, 128, None) == 1
     assert lib.fsraft_set_lookup_policy(3) == 1 and lib.fsraft_set_lookup_policy(-1) == 0
     assert lib.fsraft_set_ktile_exact(5) == 1 and lib.fsraft_set_ktile_exact(0) == 0
     assert lib.fsraft_conv_workspace(ctypes.c_void_p(8), 16) == 1          # misaligned scratch
     assert lib.fsraft_conv_workspace(null, 0) == 0
+    assert lib.fsraft_abi_version() == 6
+    assert lib.fsraft_amax_scaled(null, 1.0, null, None) == 1 and lib.fsraft_amax(null, 1, 1, 1, null, None) == 1
