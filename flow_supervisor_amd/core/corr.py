@@ -257,8 +257,7 @@ class AlternateCorrBlock:
             C = fmap1.shape[1]
             if C % 32 == 0 and C <= 256 and fmap1.is_cuda:
                 B = fmap1.shape[0]
-                # (one amax word for every level of the target maps: the pooled levels are means of level 0, and the lookup
-                #  kernel un-scales all of them with the same factor)
+                # (one amax word for every level of the target maps: the pooled levels are means of level 0)
                 w2 = ops.amax_tensor(self._f2[0])
                 self._recs = (ops.to_records(self._f1.view(B, -1, C)), [ops.to_records(f.view(B, -1, C), amax=w2) for f in self._f2])
 

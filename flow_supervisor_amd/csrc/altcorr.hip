@@ -383,14 +383,14 @@ struct AltRecLevels {
   const char* f2r[4];       // [B][h_l * w_l][C / 32] records of the pooled target maps
   const float* f2[4];       // the same maps in fp32 channels-last (positions outside the region)
   int h[4], w[4];
+  const unsigned* am2[4];   // the amax word each level's records were split with (NULL: scale 1)
 };
 
 template <int R>
 __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __restrict__ f1r, const float* __restrict__ f1, AltRecLevels lv,
                                                                AltCoords co, float* __restrict__ out, int nlev, int H, int W, int C,
-                                                               float scale, const unsigned* am1, const unsigned* am2) {   // words the records were split with
+                                                               float scale, const unsigned* am1) {   // am1: the word f1r was split with
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN, NRND = (NPOS + 63) / 64;
-  const float rec_inv = fs_inv_scale(fs_scale_of_amax(fs_amax_load(am1))) * fs_inv_scale(fs_scale_of_amax(fs_amax_load(am2)));
   constexpr int PARK = AM_NQ * AM_DP * 4 + AM_NQ * (NPOS + 1) * 4;      // parked products + every query's window values
   __shared__ __attribute__((aligned(1024))) char lds[AM::LDS_BYTES > PARK ? AM::LDS_BYTES : PARK];
   __shared__ int org[2];
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __res
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tiles_x = (W + AM_TW - 1) / AM_TW;
   const int b = blockIdx.z, l = blockIdx.y, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const float rec_inv = fs_inv_scale(fs_scale_of_amax(fs_amax_load(am1))) * fs_inv_scale(fs_scale_of_amax(fs_amax_load(lv.am2[l])));
   const int H2 = lv.h[l], W2 = lv.w[l], N = H * W;
   const unsigned pitch = (unsigned)C * 4u;
   const int RW = l == 0 ? AM_TW + 2 * R + 3 : l == 1 ? 14 : l == 2 ? 13 : 12;       // region width / height per level
@@ -584,7 +585,7 @@ extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* 
 extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
                                        int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
                                        int add_grid, float* out, int B, int H, int W, int C, int radius, const unsigned* amax1,
-                                       const unsigned* amax2, hipStream_t stream) {      // amax1 / amax2: the words f1r / every f2r level were split with
+                                       const unsigned* const* amax2_levels, hipStream_t stream) {   // the words f1r / each f2r level were split with
   if (!f1r || !f2r_levels || !fmap1 || !fmap2_levels || !coords || !out || num_levels < 1 || num_levels > 4 || B < 1 || H < 1 || W < 1 ||
       C < 32 || C % 32 || C > 256 || ((uintptr_t)f1r % 16) || ((uintptr_t)fmap1 % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff)
     return FS_ERR_ARG;
@@ -593,6 +594,7 @@ extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_l
   for (int l = 0; l < 4; ++l) {
     lv.f2r[l] = l < num_levels ? (const char*)f2r_levels[l] : nullptr;
     lv.f2[l] = l < num_levels ? fmap2_levels[l] : nullptr;
+    lv.am2[l] = (l < num_levels && amax2_levels) ? amax2_levels[l] : nullptr;
     lv.h[l] = h; lv.w[l] = w;
     if (l < num_levels && (!f2r_levels[l] || !fmap2_levels[l] || h < 1 || w < 1 || ((uintptr_t)f2r_levels[l] % 16) || ((uintptr_t)fmap2_levels[l] % 16)))
       return FS_ERR_ARG;
@@ -601,8 +603,8 @@ extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_l
   AltCoords co{coords, coords_bs, coords_cs, coords_ps, add_grid ? W : 0};
   dim3 grid((unsigned)(((W + AM_TW - 1) / AM_TW) * ((H + AM_TH - 1) / AM_TH)), (unsigned)num_levels, (unsigned)B);
   const float scale = 1.0f / sqrtf((float)C);
-  if (radius == 4) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<4>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1, amax2);
-  else if (radius == 3) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<3>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1, amax2);
+  if (radius == 4) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<4>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<3>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1);
   else return FS_ERR_ARG;
   return fs_launch_status();
 }

@@ -547,8 +547,9 @@ def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None
     e0 = t.begin() if t else None
     if recs is not None and ALT_MFMA and SPLIT_VOLUME_BWD and C % 32 == 0 and C <= 256:
         pr, keep2 = L.ptr_array(recs[1])
+        pw, keep3 = L.ptr_array([amax_of(r) for r in recs[1]])
         L.check(_lib().fsraft_altcorr_mfma_fwd(L.ptr(recs[0]), pr, L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out),
-                                               B, H, W, C, radius, _wptr(recs[0]), _wptr(recs[1][0]), L.stream()), "altcorr_mfma_fwd")
+                                               B, H, W, C, radius, _wptr(recs[0]), pw, L.stream()), "altcorr_mfma_fwd")
     else:
         L.check(_lib().fsraft_altcorr_fused_fwd(L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out), B, H, W, C,
                                                 radius, L.stream()), "altcorr_fused_fwd")

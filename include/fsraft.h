@@ -176,7 +176,7 @@ int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_level
 int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
                             int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
                             int add_grid, float* out, int B, int H, int W, int C, int radius,
-                            const unsigned* amax1, const unsigned* amax2 /* the words f1r / ALL f2r levels were split with */,
+                            const unsigned* amax1, const unsigned* const* amax2_levels /* the words f1r / each f2r level were split with */,
                             hipStream_t stream);
 
 /* ---- convex 8x upsampler -------------------------------------------------------------

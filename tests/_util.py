@@ -36,6 +36,21 @@ def close(a, b, atol, rtol=2e-5, what=""):
     return err
 
 
+def word_scale(word):
+    """The power-of-two scale the kernels derive from an amax word (csrc/split_arith.hpp fs_scale_of_amax), restated."""
+    import math
+    a = float(word.item()) if isinstance(word, torch.Tensor) else float(word)
+    if a == 0.0:
+        return 1.0
+    return 2.0 ** min(14 - math.floor(math.log2(a)), 62)
+
+
+def decode_records(r, word):
+    """Rows of [32 hi | 32 lo] fp16 records of x * scale(word) -> fp32 rows of x (hi + lo, un-scaled; exact in fp64)."""
+    w = r.contiguous().view(torch.float16).view(r.shape[0], -1, 2, 32).double()
+    return ((w[:, :, 0] + w[:, :, 1]) / word_scale(word)).reshape(r.shape[0], -1).float()
+
+
 def _log_margin(what, err, lim, detail):
     log = os.environ.get("FSRAFT_PARITY_LOG")
     if log:
