@@ -64,7 +64,7 @@ SIGNATURES = {
     "fsraft_altcorr_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_altcorr_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_upsample_fwd": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, _S],
-    "fsraft_upsample_bwd": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _S],
+    "fsraft_upsample_bwd": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_upflow8_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_upflow8_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_ktot": [_IP, c_int, c_int, c_int],
@@ -77,7 +77,7 @@ SIGNATURES = {
     "fsraft_abi_version": [],
     "fsraft_conv_small_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_conv_small_wgrad": [_PP, _PP, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_conv_small_dgrad": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_conv_small_dgrad": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_pack_conv_weights": [POINTER(PackJob), c_int, _S],
     "fsraft_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _IP, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_set_rec_mfma16": [c_int],
@@ -104,13 +104,13 @@ SIGNATURES = {
     "fsraft_gemm_f32": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, _S],
     "fsraft_nchw_to_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_im2col7": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_im2col7": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_col2im7": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, _S],
-    "fsraft_flow_to_nhwc": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, _S],
+    "fsraft_flow_to_nhwc": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_nhwc_to_flow": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, _S],
     "fsraft_relu_bwd": [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, _S],
-    "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, _S],
-    "fsraft_gru_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, _S],
+    "fsraft_gru_bwd1": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, _S],
+    "fsraft_gru_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, _S],
     "fsraft_col_sum": [c_void_p, c_int, c_int64, c_int, c_void_p, c_float, _S],
     "fsraft_softmax_rows": [c_void_p, c_int64, c_int, _S],
     "fsraft_softmax_rows_bwd": [c_void_p, c_void_p, c_int64, c_int, _S],
@@ -130,12 +130,12 @@ SIGNATURES = {
     "fsraft_get_tuning": [c_int],
     "fsraft_space_to_depth2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_forward_interpolate": [c_void_p, c_void_p, c_int, c_int, _S],
-    "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_int, _S],
+    "fsraft_inorm_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_inorm_relu_cl_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                 c_int, c_int, _S],
-    "fsraft_affine_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, _S],
+                                 c_int, c_int, c_void_p, _S],
+    "fsraft_affine_relu_cl_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_affine_relu_cl_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                  c_int, c_int, c_int, _S],
+                                  c_int, c_int, c_int, c_void_p, _S],
     "fsraft_axpby": [c_void_p, c_void_p, c_float, c_float, c_int64, _S],
     "fsraft_sum_n": [_PP, c_int, c_void_p, c_int64, c_int, _S],
     "fsraft_bn_fold": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, _S],
@@ -143,7 +143,7 @@ SIGNATURES = {
     "fsraft_vol_layout": [c_int, c_int, c_int, _IP],
     "fsraft_corr_build_tiled": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _S],
     "fsraft_corr_build_rec": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _S],
-    "fsraft_corr_lookup_tiled_fwd": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
+    "fsraft_corr_lookup_tiled_fwd": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, _S],
     "fsraft_corr_dvol_build": [_PP, _PP, POINTER(c_int64), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
                                c_int64, c_void_p, c_void_p, c_void_p, _S],
     "fsraft_amax_scaled": [c_void_p, c_float, c_void_p, _S],

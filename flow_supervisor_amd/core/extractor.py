@@ -164,8 +164,9 @@ class _InstNormReluCL(torch.autograd.Function):
         have = sums is not None and sums.acc is not None and tuple(sums.acc.shape) == (2, N * 8, C)
         acc = sums.acc if have else ops.zeros(2, N * 8, C, device=x.device)
         stats = torch.empty(N, C, 2, device=x.device, dtype=torch.float32)
+        ops.tracked(y)          # (the kernel raises y's amax word: the convolution behind the norm finds its scale there)
         L.check(L.load().fsraft_inorm_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(y), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(stats), N, H * W,
-                                                  C, float(eps), int(relu), int(have), ctx.s2w, L.stream()), "inorm_relu_cl_fwd")
+                                                  C, float(eps), int(relu), int(have), ctx.s2w, L.ptr(ops.amax_of(y)), L.stream()), "inorm_relu_cl_fwd")
         ctx.fused = res is not None
         ctx.save_for_backward(x, stats, y if ctx.fused else None)
         ctx.relu = relu
@@ -177,11 +178,12 @@ class _InstNormReluCL(torch.autograd.Function):
         x, stats, out = ctx.saved_tensors
         N, C, H, W = x.shape
         g = _as_cl(g)
-        dx = torch.empty_like(x)
+        dx = ops.tracked(torch.empty_like(x))              # (its word is raised by the kernel: the producing convolution's backward reads dx)
         dres = torch.empty_like(x) if ctx.fused else None
         acc = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (norm_cl.hip)
         L.check(L.load().fsraft_inorm_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(stats), L.ptr(out), L.ptr(acc[0]), L.ptr(acc[1]), L.ptr(dx),
-                                                  L.ptr(dres), N, H * W, C, int(ctx.relu), ctx.s2w, L.stream()), "inorm_relu_cl_bwd")
+                                                  L.ptr(dres), N, H * W, C, int(ctx.relu), ctx.s2w, L.ptr(ops.amax_of(dx)), L.stream()),
+                "inorm_relu_cl_bwd")
         if ctx.link is not None and ctx.link.armed:
             ctx.link.dres, dres = dres, None      # the shortcut's gradient travels through the link: conv1's backward returns the sum
         return dx if ctx.in_cl else _as_nchw(dx), None, None, dres, None, None, None     # an NCHW producer (MIOpen) gets an NCHW gradient
@@ -207,8 +209,9 @@ class _FrozenBNReluCL(torch.autograd.Function):
                                         L.ptr(cbias.detach().float().contiguous()) if cbias is not None else None, float(eps), C,
                                         L.ptr(scale), L.ptr(shift), L.ptr(rs), L.ptr(rmc), L.stream()), "bn_fold")
         y = torch.empty(N, H // 2, W // 2, 4 * C, device=x.device, dtype=torch.float32).permute(0, 3, 1, 2) if s2d else torch.empty_like(x)
+        ops.tracked(y)
         L.check(L.load().fsraft_affine_relu_cl_fwd(L.ptr(x), L.ptr(res), L.ptr(scale), L.ptr(shift), L.ptr(y), N * H * W, C, int(relu),
-                                                   H * W, ctx.s2w, L.stream()), "affine_relu_cl_fwd")
+                                                   H * W, ctx.s2w, L.ptr(ops.amax_of(y)), L.stream()), "affine_relu_cl_fwd")
         ctx.fused = res is not None
         ctx.save_for_backward(x, scale, shift, rs, rmc, y if ctx.fused else None)
         ctx.relu = relu
@@ -221,12 +224,12 @@ class _FrozenBNReluCL(torch.autograd.Function):
         x, scale, shift, rs, rm, out = ctx.saved_tensors
         N, C, H, W = x.shape
         g = _as_cl(g)
-        dx = torch.empty_like(x)
+        dx = ops.tracked(torch.empty_like(x))
         dres = torch.empty_like(x) if ctx.fused else None
         part = ops.zeros(2, N * 8, C, device=x.device)      # partial rows (see norm_cl.hip)
         L.check(L.load().fsraft_affine_relu_cl_bwd(L.ptr(g), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), L.ptr(dx), L.ptr(dres),
-                                                   L.ptr(part[0]), L.ptr(part[1]), N, H * W, C, int(ctx.relu), ctx.s2w, L.stream()),
-                "affine_relu_cl_bwd")
+                                                   L.ptr(part[0]), L.ptr(part[1]), N, H * W, C, int(ctx.relu), ctx.s2w,
+                                                   L.ptr(ops.amax_of(dx)), L.stream()), "affine_relu_cl_bwd")
         dpar = torch.empty(3, C, device=x.device, dtype=torch.float32)       # dweight, dbias, dcbias: one launch
         L.check(L.load().fsraft_bn_fold_bwd(L.ptr(part), N * 8, C, L.ptr(rs), L.ptr(rm), L.ptr(scale), L.ptr(dpar[0]), L.ptr(dpar[1]),
                                             L.ptr(dpar[2]) if ctx.has_cbias else None, L.stream()), "bn_fold_bwd")

@@ -354,11 +354,12 @@ class _Engine:
         dev = net.device
         P = self._packed(params)
 
-        def buf(c, zero=False):
+        def buf(c, zero=False, track=True):
+            # track: the buffer carries an amax word (ops.tracked) that every kernel writing it below raises -- the convolution
+            # epilogues, im2col7, flow_to_nhwc -- so that the convolutions reading it find their scale without a pass of their own
             ld = _pad4(c)
-            if zero or ld != c:
-                return ops.zeros(B, H, W, ld, device=dev)
-            return torch.empty(B, H, W, ld, device=dev, dtype=torch.float32)
+            t = ops.zeros(B, H, W, ld, device=dev) if (zero or ld != c) else torch.empty(B, H, W, ld, device=dev, dtype=torch.float32)
+            return ops.tracked(t) if track else t
 
         def conv(k, srcs, dsts, relu=False, alpha=1.0, **kw):
             l = self.layers[k]
@@ -373,15 +374,17 @@ class _Engine:
             mb, t = mslot
             if corr.data_ptr() != mb.corr[t].data_ptr():
                 mb.corr[t].copy_(corr)
+                if ops.amax_of(mb.corr) is not None:          # (a copy does not raise the slot buffer's word: do it here)
+                    ops.amax_jobs([(mb.corr[t].data_ptr(), 1, mb.corr[t].numel(), mb.corr[t].numel(), ops.amax_of(mb.corr))])
             corr = mb.corr[t]
             cor1 = mb.cor1[t] if self.c2 else None
             corflo, cols, flo1, motion = mb.corflo[t], mb.cols[t], mb.flo1[t], mb.motion[t]
         else:
             cor1 = buf(self.c1) if self.c2 else None
             corflo = buf(self.cf_c)
-            cols = torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32)      # (im2col7 writes the two pad columns itself)
+            cols = ops.tracked(torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32))      # (im2col7 writes the two pad columns itself)
             flo1 = buf(self.f1)
-            motion = buf(self.x_c)           # GMA: channels [mot_c, 2 mot_c) hold motion_global
+            motion = buf(self.x_c, track=not self.gma)    # GMA: channels [mot_c, 2 mot_c) hold motion_global (gma_mix_fwd raises no word)
         cor_out = self.c2 if self.c2 else self.c1
 
         def flow_branch():
@@ -415,7 +418,7 @@ class _Engine:
                 raise RuntimeError("GMA update block needs the attention map [B,1,H*W,H*W] (single head)")
             L.require_cuda_f32(attn)
             attn = attn.contiguous()
-            v, agg = buf(mc), buf(mc)
+            v, agg = buf(mc), buf(mc, track=False)
             conv("av", [V(motion, mc, 0)], [Dst.nhwc(v)])
             if attn_t is not None:
                 # attn @ v on the record GEMM core: the attention map was split to records once per pair (attn_t), v is
@@ -481,11 +484,12 @@ class _Engine:
         M = B * H * W
         hid = self.hid
 
-        def buf(c, zero=False):
+        def buf(c, zero=False, track=True, word=None):
+            # (track: as in forward -- here the writers are the data-gradient epilogues, gru_bwd1 / gru_bwd2 and conv_small_dgrad;
+            #  word: share another buffer's amax word)
             ld = _pad4(c)
-            if zero or ld != c:
-                return ops.zeros(B, H, W, ld, device=dev)
-            return torch.empty(B, H, W, ld, device=dev, dtype=torch.float32)
+            t = ops.zeros(B, H, W, ld, device=dev) if (zero or ld != c) else torch.empty(B, H, W, ld, device=dev, dtype=torch.float32)
+            return ops.tracked(t, word) if track else t
 
         dW, dB = self._grad_arena(st, P, dev)
         if st.keep is None:
@@ -573,7 +577,7 @@ class _Engine:
                 # (no separate ReLU-backward pass: the two data-gradient epilogues above wrote dhead already masked by head > 0)
                 hlast = S["hlast"]
                 wgrad("hd", V(dhead), [V(hlast, hid)])
-                dh = S["dh_out"] if heads_only else buf(hid)
+                dh = S["dh_out"] if heads_only else buf(hid, track=False)       # (filled by a copy below; read by gru_bwd1 only)
                 if dnet_out is not None:
                     dh.copy_(dnet_out)
                     dgrad("hd", V(dhead), [Dst.nhwc(dh, 0, 0, True)])
@@ -586,7 +590,7 @@ class _Engine:
             motion = S["motion"]
             # every GRU data gradient adds its motion part; the first one (the q convolution of the last pass covers all x_c
             # channels) overwrites instead, so the buffer needs no zero fill -- only its padding channels, if any, do
-            dmotion = mbs[0].dmotion[mbs[1]][:B] if mbs is not None else buf(self.x_c)
+            dmotion = mbs[0].dmotion[mbs[1]][:B] if mbs is not None else buf(self.x_c, track=not self.gma)
             dm_first = [True]
 
             def dm_acc():
@@ -608,12 +612,12 @@ class _Engine:
             first_pass = self.passes[0][0]
             for (sfx, _, _), (h, z, r, rh, q) in reversed(list(zip(self.passes, S["gates"]))):
                 dzr = buf(2 * hid)
-                dq = buf(hid)
+                dq = buf(hid, word=ops.amax_of(dzr))       # (one word for the two gate gradients: gru_bwd1 then raises it once)
                 if B != Bf and sfx == first_pass:          # the buffer that goes back to autograd as dnet: full size, zeros behind sample B
                     dh_full = ops.zeros(Bf, H, W, _pad4(hid), device=dev)
                     dhp = dh_full[:B]
                 else:
-                    dhp = buf(hid)
+                    dhp = buf(hid, track=False)            # (never read by a convolution)
                 zsum, qsum = ctx_sum("zi" + sfx, dzr), ctx_sum("qi" + sfx, dq)
                 ops.gru_bwd1(dh, z, q, h, dzr, dq, dhp, hid, zsum, qsum, dhn2=dh_more)
                 dh_more = None
@@ -635,7 +639,7 @@ class _Engine:
             if self.gma:
                 N, mc = H * W, self.mot_c
                 attn, v, agg = S["attn"], S["v"], S["agg"]
-                dagg, dv = buf(mc), buf(mc)
+                dagg, dv = buf(mc, track=False), buf(mc, track=False)
                 ops.gma_mix_bwd(V(dmotion, mc, mc), V(agg), P["aggregator.gamma"], V(dmotion, mc, 0), V(dagg),
                                 dB["aggregator.gamma"])
                 attn_r = S.get("attn_r")
@@ -885,8 +889,8 @@ class HeadBatch:
     def __init__(self, eng, params, st, anchor, T, B, H, W, device):
         self.eng, self.params, self.st, self.anchor = eng, params, st, anchor
         self.T, self.B, self.H, self.W = T, B, H, W
-        self.head = torch.empty(T, B, H, W, 2 * eng.head_c, device=device, dtype=torch.float32)
-        self.hlast = torch.empty(T, B, H, W, _pad4(eng.hid), device=device, dtype=torch.float32) if _pad4(eng.hid) == eng.hid else None
+        self.head = ops.tracked(torch.empty(T, B, H, W, 2 * eng.head_c, device=device, dtype=torch.float32))
+        self.hlast = ops.tracked(torch.empty(T, B, H, W, _pad4(eng.hid), device=device, dtype=torch.float32)) if _pad4(eng.hid) == eng.hid else None
         self.dhead = None
         self.dh_heads = self.dflow = None
         self.heads_done = False
@@ -925,16 +929,20 @@ class MotionBatch:
     chip at one pair per GPU (per layer -10..-35 % at four pairs, -50..-75 % at one or two: round 3, docs/history)."""
 
     def __init__(self, eng, T, B, H, W, device, zero=False):
-        def e(c):
-            return torch.empty(T, B, H, W, _pad4(c), device=device, dtype=torch.float32)
+        def e(c, track=True):
+            # (one amax word per slot buffer, raised by every kernel that writes a slot: the step's largest magnitude)
+            t = torch.empty(T, B, H, W, _pad4(c), device=device, dtype=torch.float32)
+            return ops.tracked(t) if track else t
         self.T, self.B, self.H, self.W, self.n = T, B, H, W, 0
         self.corr = e(eng.corr_c)
         self.cor1 = e(eng.c1) if eng.c2 else None
-        self.corflo, self.cols, self.flo1, self.motion = e(eng.cf_c), e(98), e(eng.f1), e(eng.x_c)
+        self.corflo, self.cols, self.flo1, self.motion = e(eng.cf_c), e(98), e(eng.f1), e(eng.x_c, not eng.gma)
         # zero: the iterations run their backward on the first k samples only (grad_samples) and park dmotion for those; the
         # batch then multiplies zeros for the others
-        self.dmotion = torch.zeros(T, B, H, W, _pad4(eng.x_c), device=device, dtype=torch.float32) if zero else e(eng.x_c)
-        self.dcorr = e(eng.corr_c)
+        self.dmotion = torch.zeros(T, B, H, W, _pad4(eng.x_c), device=device, dtype=torch.float32) if zero else e(eng.x_c, False)
+        if not eng.gma:
+            ops.tracked(self.dmotion)       # (written by the GRU data gradients only; GMA's gma_mix_bwd adds to it without raising)
+        self.dcorr = e(eng.corr_c)          # (tracked: the gradient volume takes its bound from this word)
         self.parked = set()             # slots whose iteration has handed in its dmotion
 
     @staticmethod
@@ -1018,7 +1026,7 @@ class _MaskUpFn(torch.autograd.Function):
         dflow, dmask = ops.upsample_bwd(fl, mask, dup)
         ctx.hb = None
         head = hb.head[:T].view(T * B, H, W, 2 * eng.head_c)
-        hb.dhead = torch.empty_like(hb.head)
+        hb.dhead = ops.tracked(torch.empty_like(hb.head))      # (writers: the mask head's data gradient, conv_small_dgrad)
         dhead = hb.dhead[:T].view(T * B, H, W, 2 * eng.head_c)
         hc = eng.head_c
         st = hb.st

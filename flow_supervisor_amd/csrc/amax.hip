@@ -1,4 +1,4 @@
-// amax words (split_arith.hpp): the largest magnitude of a tensor as one unsigned word in device memory, from which every
+// amax words (split_arith.hpp): a tensor's largest magnitude -- to within [1/2, 4] of it -- as one unsigned word in device memory, from which every
 // kernel that feeds the tensor to the matrix pipe derives its power-of-two scale.  Kernels that PRODUCE a tensor raise the
 // word in their epilogue (fsraft_conv_desc.dst_amax, the gradient-stage kernels, the lookups); these entry points compute it
 // for tensors that come from outside the library (images, feature maps of a PyTorch encoder, parameters, gradients handed in
@@ -23,10 +23,17 @@ __global__ __launch_bounds__(256) void amax_jobs_kernel(const AmaxJobs tab) {
   const bool v4 = (j.C & 3) == 0 && (j.ld & 3) == 0 && ((uintptr_t)j.p & 15) == 0;
   if (v4) {
     const int64_t c4 = j.C >> 2, total = j.rows * c4;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    // two loads in flight per trip; the first trip of the first workgroups publishes an early sample (split_arith.hpp)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += 2 * stride) {
       const int64_t r = e / c4, c = (e - r * c4) << 2;
-      const f32x4 v = gload4(j.p + r * j.ld + c);
-      m = fs_umax(fs_umax(m, fs_umax(fs_abs_bits(v[0]), fs_abs_bits(v[1]))), fs_umax(fs_abs_bits(v[2]), fs_abs_bits(v[3])));
+      const int64_t e2 = e + stride < total ? e + stride : e, r2 = e2 / c4, c2 = (e2 - r2 * c4) << 2;
+      const f32x4 v = gload4(j.p + r * j.ld + c), w = gload4(j.p + r2 * j.ld + c2);
+      m = fs_umax(m, fs_umax(fs_abs_bits4(v), fs_abs_bits4(w)));
+      if (e < stride && blockIdx.x < 8u && threadIdx.x < 64u) {
+        const unsigned s = fs_wave_umax(m);
+        if (threadIdx.x == 0) fs_amax_raise(j.word, s, 2u);
+      }
     }
   } else {
     const int64_t total = j.rows * j.C;
@@ -72,9 +79,9 @@ extern "C" int fsraft_amax_jobs(const float* const* ptrs, const int64_t* rows, c
       const int64_t tot = rows[i0 + i] * C[i0 + i];
       most = tot > most ? tot : most;
     }
-    // ~16 float4 per thread; at most 2048 workgroups per job
+    // ~16 float4 per thread; at most 512 workgroups per job (each may cost one atomic on the job's word)
     int64_t blocks = (most / 4 + 256 * 16 - 1) / (256 * 16);
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
     hipLaunchKernelGGL(amax_jobs_kernel, dim3((unsigned)blocks, k), dim3(256), 0, stream, tab);
     const int rc = fs_launch_status();
     if (rc) return rc;

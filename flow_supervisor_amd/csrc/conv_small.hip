@@ -243,8 +243,9 @@ constexpr int SMALL_RUN_DG = 16;
 template <int N>
 __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ w_oihw,
                                                                float* __restrict__ dx, int lddx, const float* __restrict__ relu_src,
-                                                               int ldm, int C, int B, int H, int W) {
+                                                               int ldm, int C, int B, int H, int W, unsigned* __restrict__ dx_amax) {
   static_assert(N == 2, "two output channels");
+  unsigned amx = 0u;
   const int lane = threadIdx.x & 63;
   const int c0 = lane * 4;
   const bool on = c0 < C;
@@ -300,13 +301,16 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(const float* __re
           for (int k = 0; k < 4; ++k) acc[k] = m[k] > 0.f ? acc[k] : 0.f;
         }
         gstore4(dx + pix * lddx + c0, acc);
+        amx = fs_umax(amx, fs_abs_bits4(acc));
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int o = 0; o < N; ++o) { g[0][j][o] = g[1][j][o]; g[1][j][o] = g[2][j][o]; }
     }
+    if (dx_amax && run < nwave) fs_amax_early(dx_amax, amx);   // (first run of the wave)
   }
+  if (dx_amax) fs_amax_commit_wave(dx_amax, amx);            // (nullable) word of dx, raised
 }
 
 }  // namespace
@@ -348,7 +352,8 @@ extern "C" int fsraft_conv_small_wgrad(const float* const* dy, const float* cons
 // gradient of fsraft_conv_small_fwd.  dy: channels-last with pitch ldy >= 2 (the two gradients of a pixel side by side);
 // relu_src (nullable, pitch ldm): dx is zero where relu_src <= 0 (the ReLU in front of the convolution).  C % 4 == 0, C <= 256.
 extern "C" int fsraft_conv_small_dgrad(const float* dy, int ldy, const float* w_oihw, float* dx, int lddx, const float* relu_src, int ldm,
-                                       int C, int N, int B, int H, int W, int KH, int KW, hipStream_t s) {
+                                       int C, int N, int B, int H, int W, int KH, int KW, unsigned* dx_amax, hipStream_t s) {
+  if (((uintptr_t)dx_amax & 3)) return FS_ERR_ARG;
   if (!dy || !w_oihw || !dx || N != 2 || C < 4 || C > 256 || C % 4 || lddx % 4 || ldy < 2 || KH != 3 || KW != 3 || B < 1 ||
       ((uintptr_t)dx % 16) || (relu_src && (ldm % 4 || ((uintptr_t)relu_src % 16))))
     return FS_ERR_ARG;
@@ -356,6 +361,6 @@ extern "C" int fsraft_conv_small_dgrad(const float* dy, int ldy, const float* w_
   if (nrun >= ((int64_t)1 << 31)) return FS_ERR_ARG;
   int blocks = (int)((nrun + 3) / 4);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL((conv_small_dgrad_kernel<2>), dim3(blocks), dim3(256), 0, s, dy, ldy, w_oihw, dx, lddx, relu_src, ldm, C, B, H, W);
+  hipLaunchKernelGGL((conv_small_dgrad_kernel<2>), dim3(blocks), dim3(256), 0, s, dy, ldy, w_oihw, dx, lddx, relu_src, ldm, C, B, H, W, dx_amax);
   return fs_launch_status();
 }

@@ -112,9 +112,11 @@ __device__ __forceinline__ void lookup_issue(LookupLoad<R>& ld, const float* __r
 // nothing done with them -- no LDS staging, no blends, no output: what the memory system delivers for this access pattern.
 template <int R, int QW, int AUX = 0, bool GATHER = false>
 __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __restrict__ vol, VolLayout L, Coords co,
-                                                               float* __restrict__ out, int64_t nq, int HW, int grid_w) {
+                                                               float* __restrict__ out, int64_t nq, int HW, int grid_w,
+                                                               unsigned* __restrict__ out_amax) {     // (nullable) word of `out`, raised
   using S = TL<R>;
   __shared__ __attribute__((aligned(16))) float region[4][4][S::REGION];
+  unsigned amx = 0u;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nlev = L.nlev, CH = nlev * S::N2;
   LevelGeo g[4];
@@ -179,12 +181,15 @@ __global__ __launch_bounds__(256) void lookup_tiled_fwd_kernel(const float* __re
         const float* p = base + choff[k];
         const float top = p[0] + fx * (p[1] - p[0]);
         const float bot = p[S::RP] + fx * (p[S::RP + 1] - p[S::RP]);
-        if (lane + 64 * k < S::N2) gstore1(o + l * S::N2 + lane + 64 * k, top + fy * (bot - top));
+        const float res = top + fy * (bot - top);
+        if (lane + 64 * k < S::N2) { gstore1(o + l * S::N2 + lane + 64 * k, res); amx = fs_umax(amx, fs_abs_bits(res)); }
       }
     }
     wave_lds_sync();
     if (qq + 1 < QW) cur = nxt;
+    if (out_amax && qq == 0) fs_amax_early(out_amax, amx);        // (a sample from the first queries, long before the crowd)
   }
+  if (out_amax) fs_amax_commit_wave(out_amax, amx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -910,18 +915,19 @@ __global__ __launch_bounds__(256) void corr_dfmap2_v4_kernel(const float* __rest
 }
 
 template <int R>
-int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float* out, int64_t nq, int HW, int grid_w, hipStream_t s) {
+int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float* out, int64_t nq, int HW, int grid_w, unsigned* out_amax,
+                  hipStream_t s) {
   constexpr int QW = 4;
   const dim3 grid((unsigned)((nq + 4 * QW - 1) / (4 * QW)));
   // Non-temporal window loads once the volume is larger than the 256 MB Infinity Cache (every lookup then streams ~110 MB of a
   // 1 GB volume that will not be there next time anyway): 12 lookups 0.39 -> 0.367 ms in the step (same-box A/B,
   // scripts/lookup_policy_ab.sh; sc1 alone: no change).
   const int pol = g_lookup_policy >= 0 ? g_lookup_policy : ((int64_t)nq * L.P * 4 > ((int64_t)300 << 20) ? 2 : 0);
-  if (g_lookup_policy == 100) { hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 2, true>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w); return fs_launch_status(); }
-  if (pol == 2) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 2>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
-  else if (pol == 16) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 16>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
-  else if (pol == 18) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 18>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
-  else hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 0>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w);
+  if (g_lookup_policy == 100) { hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 2, true>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w, out_amax); return fs_launch_status(); }
+  if (pol == 2) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 2>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w, out_amax);
+  else if (pol == 16) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 16>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w, out_amax);
+  else if (pol == 18) hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 18>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w, out_amax);
+  else hipLaunchKernelGGL((lookup_tiled_fwd_kernel<R, QW, 0>), grid, dim3(256), 0, s, vol, L, co, out, nq, HW, grid_w, out_amax);
   return fs_launch_status();
 }
 
@@ -930,14 +936,14 @@ int launch_lookup(const float* vol, const VolLayout& L, const Coords& co, float*
 // out: [B, H, W, L*(2r+1)^2] channels-last.  coords element (b, c, pix) at coords[b*bs + c*cs + pix*ps].
 extern "C" int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* coords, int64_t coords_bs,
                                             int64_t coords_cs, int64_t coords_ps, float* out, int B, int H, int W, int radius,
-                                            int add_grid, hipStream_t stream) {
+                                            int add_grid, unsigned* out_amax, hipStream_t stream) {
   VolLayout L;
-  if (!vol || !coords || !out || B < 1 || !vol_layout_make(H, W, num_levels, L) || ((uintptr_t)vol % 16)) return FS_ERR_ARG;
+  if (!vol || !coords || !out || B < 1 || !vol_layout_make(H, W, num_levels, L) || ((uintptr_t)vol % 16) || ((uintptr_t)out_amax & 3)) return FS_ERR_ARG;
   Coords co{coords, coords_bs, coords_cs, coords_ps};
   const int64_t nq = (int64_t)B * H * W;
   if (nq >= (int64_t)1 << 31 || (int64_t)L.P * 4 >= (int64_t)1 << 31) return FS_ERR_ARG;
-  if (radius == 4) return launch_lookup<4>(vol, L, co, out, nq, H * W, add_grid ? W : 0, stream);
-  if (radius == 3) return launch_lookup<3>(vol, L, co, out, nq, H * W, add_grid ? W : 0, stream);
+  if (radius == 4) return launch_lookup<4>(vol, L, co, out, nq, H * W, add_grid ? W : 0, out_amax, stream);
+  if (radius == 3) return launch_lookup<3>(vol, L, co, out, nq, H * W, add_grid ? W : 0, out_amax, stream);
   return FS_ERR_ARG;
 }
 

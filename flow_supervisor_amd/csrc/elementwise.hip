@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ src,
 // (loads are unconditional with a clamped index and a select: `ok ? p[i] : 0` compiles to a branch around the load, one
 //  round trip per tap -- col2im7 was bound by exactly that, 22 us per launch for 14 MB)
 __global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ flow, int64_t bs, int64_t cs, int64_t ps,
-                                                      float* __restrict__ cols, int ld, int B, int H, int W) {
+                                                      float* __restrict__ cols, int ld, int B, int H, int W,
+                                                      unsigned* __restrict__ amax) {
   const int64_t total = (int64_t)B * H * W * ld;
+  unsigned mx = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int k = (int)(e % ld);
     const int64_t m = e / ld;
@@ -96,15 +98,19 @@ __global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ 
       if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = flow[b * bs + ci * cs + ((int64_t)yy * W + xx) * ps];
     }
     cols[e] = v;
+    mx = fs_umax(mx, fs_abs_bits(v));
   }
+  if (amax) fs_amax_commit_wave(amax, mx);
 }
 
 // the same, four columns per thread and one 16-byte store (ld % 4 == 0: always; the scalar kernel above wrote 4 bytes per thread:
 // 13.8 us per launch for 11 MB at 4 x 55x128, on the forward chain of every iteration)
 __global__ __launch_bounds__(256) void im2col7_v4_kernel(const float* __restrict__ flow, int64_t bs, int64_t cs, int64_t ps,
-                                                         float* __restrict__ cols, int ld, int B, int H, int W) {
+                                                         float* __restrict__ cols, int ld, int B, int H, int W,
+                                                         unsigned* __restrict__ amax) {      // amax (nullable): word of cols, raised
   const int l4 = ld >> 2;
   const int64_t total = (int64_t)B * H * W * l4;
+  unsigned mx = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int k0 = (int)(e % l4) * 4;
     const int64_t m = e / l4;
@@ -123,7 +129,11 @@ __global__ __launch_bounds__(256) void im2col7_v4_kernel(const float* __restrict
       v[i] = in ? f : 0.f;
     }
     gstore4(cols + m * ld + k0, v);
+    mx = fs_umax(mx, fs_abs_bits4(v));
+    if (amax && e < (int64_t)gridDim.x * 256) fs_amax_early(amax, mx);      // (first trip)
   }
+  __shared__ unsigned red[4];
+  if (amax) fs_amax_commit(amax, mx, red);
 }
 
 // adjoint: dflow[b, ci, y, x] (+)= sum_t dcols[(b, y-(ky-3), x-(kx-3))][ci*49 + t]   (dflow contiguous [B,2,H,W])
@@ -155,12 +165,17 @@ __global__ __launch_bounds__(256) void col2im7_kernel(const float* __restrict__ 
 // 2-channel strided tensor -> channels [coff, coff+2) of a channels-last buffer, and the reverse (accumulating)
 __global__ __launch_bounds__(256) void flow_to_nhwc_kernel(const float* __restrict__ flow, int64_t bs, int64_t cs,
                                                            int64_t ps, float* __restrict__ dst, int ld, int coff,
-                                                           int64_t M, int HW) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= 2 * M) return;
-  const int64_t m = e >> 1; const int c = (int)(e & 1);
-  const int64_t b = m / HW, p = m % HW;
-  dst[m * ld + coff + c] = flow[b * bs + c * cs + p * ps];
+                                                           int64_t M, int HW, unsigned* __restrict__ amax) {
+  unsigned mx = 0u;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 2 * M; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e >> 1; const int c = (int)(e & 1);
+    const int64_t b = m / HW, p = m % HW;
+    const float v = flow[b * bs + c * cs + p * ps];
+    dst[m * ld + coff + c] = v;
+    mx = fs_umax(mx, fs_abs_bits(v));
+  }
+  __shared__ unsigned red[4];
+  if (amax) fs_amax_commit(amax, mx, red);      // (nullable) word of dst, raised
 }
 __global__ __launch_bounds__(256) void nhwc_to_flow_kernel(const float* __restrict__ src, int ld, int coff,
                                                            float* __restrict__ dflow, int64_t M, int HW, int accumulate) {
@@ -196,18 +211,24 @@ __global__ __launch_bounds__(256) void gru_bwd1_kernel(const float* __restrict__
                                                        const float* __restrict__ q, const float* __restrict__ h,
                                                        float* __restrict__ dzr, int ldzr, float* __restrict__ dq,
                                                        float* __restrict__ dh, float* __restrict__ dzr_sum,
-                                                       float* __restrict__ dq_sum, int64_t M, int hid) {
+                                                       float* __restrict__ dq_sum, int64_t M, int hid,
+                                                       unsigned* am_dzr, unsigned* am_dq, unsigned* am_dh) {   // (nullable) words of dzr / dq / dh, raised
   const int64_t total = M * hid;
+  unsigned m0 = 0u, m1 = 0u, m2 = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / hid; const int c = (int)(e % hid);
     const float g = dhn[e], zz = z[e], qq = q[e], hh = h[e];
-    const float dz = g * (qq - hh) * zz * (1.f - zz), dqv = g * zz * (1.f - qq * qq);
+    const float dz = g * (qq - hh) * zz * (1.f - zz), dqv = g * zz * (1.f - qq * qq), dhv = g * (1.f - zz);
     dzr[m * ldzr + c] = dz;
     dq[e] = dqv;
-    dh[e] = g * (1.f - zz);
+    dh[e] = dhv;
+    m0 = fs_umax(m0, fs_abs_bits(dz)); m1 = fs_umax(m1, fs_abs_bits(dqv)); m2 = fs_umax(m2, fs_abs_bits(dhv));
     if (dzr_sum) dzr_sum[m * ldzr + c] += dz;       // running sums over the iterations of a step (context part's backward)
     if (dq_sum) dq_sum[e] += dqv;
   }
+  if (am_dzr) fs_amax_commit_wave(am_dzr, m0);
+  if (am_dq) fs_amax_commit_wave(am_dq, m1);
+  if (am_dh) fs_amax_commit_wave(am_dh, m2);
 }
 
 // the same on four channels per thread (hid, ldzr multiples of 4, 16-byte aligned pointers); dhn2 (nullable): a second summand of
@@ -216,9 +237,11 @@ __global__ __launch_bounds__(256) void gru_bwd1_v4_kernel(const float* __restric
                                                           const float* __restrict__ z, const float* __restrict__ q,
                                                           const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
                                                           float* __restrict__ dq, float* __restrict__ dh, float* __restrict__ dzr_sum,
-                                                          float* __restrict__ dq_sum, int64_t M, int hid) {
+                                                          float* __restrict__ dq_sum, int64_t M, int hid,
+                                                          unsigned* am_dzr, unsigned* am_dq, unsigned* am_dh) {
   const int h4 = hid >> 2;
   const int64_t total = M * h4;
+  unsigned m0 = 0u, m1 = 0u, m2 = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / h4; const int c = (int)(e % h4) * 4;
     const int64_t o = m * hid + c, oz = m * ldzr + c;
@@ -235,16 +258,29 @@ __global__ __launch_bounds__(256) void gru_bwd1_v4_kernel(const float* __restric
     gstore4(dzr + oz, dz);
     gstore4(dq + o, dqv);
     gstore4(dh + o, dhv);
+    m0 = fs_umax(m0, fs_abs_bits4(dz)); m1 = fs_umax(m1, fs_abs_bits4(dqv)); m2 = fs_umax(m2, fs_abs_bits4(dhv));
     if (dzr_sum) gstore4(dzr_sum + oz, gload4(dzr_sum + oz) + dz);
     if (dq_sum) gstore4(dq_sum + o, gload4(dq_sum + o) + dqv);
+    if (e < (int64_t)gridDim.x * 256) {          // (first trip: early samples)
+      if (am_dzr) fs_amax_early(am_dzr, am_dzr == am_dq ? fs_umax(m0, m1) : m0);
+      if (am_dq && am_dq != am_dzr) fs_amax_early(am_dq, m1);
+      if (am_dh) fs_amax_early(am_dh, m2);
+    }
   }
+  // (dzr and dq may share one word -- they feed convolutions of one layer group -- and then cost one commit)
+  __shared__ unsigned red[4];
+  if (am_dzr) fs_amax_commit(am_dzr, am_dzr == am_dq ? fs_umax(m0, m1) : m0, red);
+  if (am_dq && am_dq != am_dzr) fs_amax_commit(am_dq, m1, red);
+  if (am_dh) fs_amax_commit(am_dh, m2, red);
 }
 
 __global__ __launch_bounds__(256) void gru_bwd2_v4_kernel(const float* __restrict__ drh, const float* __restrict__ r,
                                                           const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
-                                                          float* __restrict__ dh, float* __restrict__ dzr_sum, int64_t M, int hid) {
+                                                          float* __restrict__ dh, float* __restrict__ dzr_sum, int64_t M, int hid,
+                                                          unsigned* am_dzr, unsigned* am_dh) {      // (nullable) words of dzr / dh, raised
   const int h4 = hid >> 2;
   const int64_t total = M * h4;
+  unsigned m0 = 0u, m2 = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / h4; const int c = (int)(e % h4) * 4;
     const int64_t o = m * hid + c, oz = m * ldzr + hid + c;
@@ -257,23 +293,36 @@ __global__ __launch_bounds__(256) void gru_bwd2_v4_kernel(const float* __restric
     }
     gstore4(dzr + oz, dr);
     gstore4(dh + o, dhv);
+    m0 = fs_umax(m0, fs_abs_bits4(dr)); m2 = fs_umax(m2, fs_abs_bits4(dhv));
     if (dzr_sum) gstore4(dzr_sum + oz, gload4(dzr_sum + oz) + dr);
+    if (e < (int64_t)gridDim.x * 256) {
+      if (am_dzr) fs_amax_early(am_dzr, m0);
+      if (am_dh) fs_amax_early(am_dh, m2);
+    }
   }
+  __shared__ unsigned red[4];
+  if (am_dzr) fs_amax_commit(am_dzr, m0, red);
+  if (am_dh) fs_amax_commit(am_dh, m2, red);
 }
 
 // stage 2 (input of the q conv was r*h):  dzr[:, hid:2hid] = d(rh) * h * r (1-r);   dh += d(rh) * r
 __global__ __launch_bounds__(256) void gru_bwd2_kernel(const float* __restrict__ drh, const float* __restrict__ r,
                                                        const float* __restrict__ h, float* __restrict__ dzr, int ldzr,
-                                                       float* __restrict__ dh, float* __restrict__ dzr_sum, int64_t M, int hid) {
+                                                       float* __restrict__ dh, float* __restrict__ dzr_sum, int64_t M, int hid,
+                                                       unsigned* am_dzr, unsigned* am_dh) {
   const int64_t total = M * hid;
+  unsigned m0 = 0u, m2 = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / hid; const int c = (int)(e % hid);
     const float g = drh[e], rr = r[e];
-    const float dr = g * h[e] * rr * (1.f - rr);
+    const float dr = g * h[e] * rr * (1.f - rr), dhv = dh[e] + g * rr;
     dzr[m * ldzr + hid + c] = dr;
-    dh[e] += g * rr;
+    dh[e] = dhv;
+    m0 = fs_umax(m0, fs_abs_bits(dr)); m2 = fs_umax(m2, fs_abs_bits(dhv));
     if (dzr_sum) dzr_sum[m * ldzr + hid + c] += dr;
   }
+  if (am_dzr) fs_amax_commit_wave(am_dzr, m0);
+  if (am_dh) fs_amax_commit_wave(am_dh, m2);
 }
 
 // out[c] += scale * sum_m x[m][c]      (bias gradients).  grid.x covers channels in 64s, grid.y splits rows.
@@ -346,12 +395,15 @@ extern "C" int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, i
   return fs_launch_status();
 }
 extern "C" int fsraft_im2col7(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* cols, int ld, int B, int H,
-                              int W, hipStream_t s) {
-  if (!flow || !cols || ld < 100 || ld % 4) return FS_ERR_ARG;
-  if (((uintptr_t)cols & 15) == 0)
-    hipLaunchKernelGGL(im2col7_v4_kernel, dim3(grid_for((int64_t)B * H * W * (ld / 4))), dim3(256), 0, s, flow, bs, cs, ps, cols, ld, B, H, W);
+                              int W, unsigned* cols_amax, hipStream_t s) {
+  if (!flow || !cols || ld < 100 || ld % 4 || ((uintptr_t)cols_amax & 3)) return FS_ERR_ARG;
+  if (((uintptr_t)cols & 15) == 0) {
+    int g = grid_for((int64_t)B * H * W * (ld / 4));
+    if (cols_amax && g > 512) g = 512;           // (a word to raise: fewer, longer workgroups -- each may cost one atomic)
+    hipLaunchKernelGGL(im2col7_v4_kernel, dim3(g), dim3(256), 0, s, flow, bs, cs, ps, cols, ld, B, H, W, cols_amax);
+  }
   else
-    hipLaunchKernelGGL(im2col7_kernel, dim3(grid_for((int64_t)B * H * W * ld)), dim3(256), 0, s, flow, bs, cs, ps, cols, ld, B, H, W);
+    hipLaunchKernelGGL(im2col7_kernel, dim3(grid_for((int64_t)B * H * W * ld)), dim3(256), 0, s, flow, bs, cs, ps, cols, ld, B, H, W, cols_amax);
   return fs_launch_status();
 }
 extern "C" int fsraft_col2im7(const float* dcols, int ld, float* dflow, int B, int H, int W, int accumulate, hipStream_t s) {
@@ -361,10 +413,12 @@ extern "C" int fsraft_col2im7(const float* dcols, int ld, float* dflow, int B, i
   return fs_launch_status();
 }
 extern "C" int fsraft_flow_to_nhwc(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* dst, int ld, int coff,
-                                   int B, int HW, hipStream_t s) {
-  if (!flow || !dst) return FS_ERR_ARG;
+                                   int B, int HW, unsigned* dst_amax, hipStream_t s) {
+  if (!flow || !dst || ((uintptr_t)dst_amax & 3)) return FS_ERR_ARG;
   const int64_t M = (int64_t)B * HW;
-  hipLaunchKernelGGL(flow_to_nhwc_kernel, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, s, flow, bs, cs, ps, dst, ld, coff, M, HW);
+  // (with a word to raise: few workgroups -- the kernel is tiny, and every workgroup may cost one atomic on the word)
+  const int64_t wg = (2 * M + 255) / 256;
+  hipLaunchKernelGGL(flow_to_nhwc_kernel, dim3((unsigned)(dst_amax && wg > 64 ? 64 : wg)), dim3(256), 0, s, flow, bs, cs, ps, dst, ld, coff, M, HW, dst_amax);
   return fs_launch_status();
 }
 extern "C" int fsraft_nhwc_to_flow(const float* src, int ld, int coff, float* dflow, int B, int HW, int accumulate, hipStream_t s) {
@@ -382,22 +436,29 @@ namespace {
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }
 extern "C" int fsraft_gru_bwd1(const float* dhn, const float* dhn2, const float* z, const float* q, const float* h, float* dzr, int ldzr,
-                               float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid, hipStream_t s) {
-  if (!dhn || !z || !q || !h || !dzr || !dq || !dh) return FS_ERR_ARG;
+                               float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid, unsigned* dzr_amax, unsigned* dq_amax,
+                               unsigned* dh_amax, hipStream_t s) {
+  if (!dhn || !z || !q || !h || !dzr || !dq || !dh || (((uintptr_t)dzr_amax | (uintptr_t)dq_amax | (uintptr_t)dh_amax) & 3)) return FS_ERR_ARG;
   const bool v4 = hid % 4 == 0 && ldzr % 4 == 0 && al16(dhn) && al16(dhn2) && al16(z) && al16(q) && al16(h) && al16(dzr) && al16(dq) &&
                   al16(dh) && al16(dzr_sum) && al16(dq_sum);
   if (!v4 && dhn2) return FS_ERR_ARG;            // (the second summand exists for the vectorised kernel only)
-  if (v4) hipLaunchKernelGGL(gru_bwd1_v4_kernel, dim3(grid_for(M * (hid / 4))), dim3(256), 0, s, dhn, dhn2, z, q, h, dzr, ldzr, dq, dh,
-                             dzr_sum, dq_sum, M, hid);
-  else hipLaunchKernelGGL(gru_bwd1_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, dhn, z, q, h, dzr, ldzr, dq, dh, dzr_sum, dq_sum, M, hid);
+  const bool words = dzr_amax || dq_amax || dh_amax;
+  int g4 = grid_for(M * (hid / 4));
+  if (words && g4 > 1024) g4 = 1024;
+  if (v4) hipLaunchKernelGGL(gru_bwd1_v4_kernel, dim3(g4), dim3(256), 0, s, dhn, dhn2, z, q, h, dzr, ldzr, dq, dh,
+                             dzr_sum, dq_sum, M, hid, dzr_amax, dq_amax, dh_amax);
+  else hipLaunchKernelGGL(gru_bwd1_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, dhn, z, q, h, dzr, ldzr, dq, dh, dzr_sum, dq_sum, M, hid,
+                          dzr_amax, dq_amax, dh_amax);
   return fs_launch_status();
 }
 extern "C" int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh,
-                               float* dzr_sum, int64_t M, int hid, hipStream_t s) {
-  if (!drh || !r || !h || !dzr || !dh) return FS_ERR_ARG;
+                               float* dzr_sum, int64_t M, int hid, unsigned* dzr_amax, unsigned* dh_amax, hipStream_t s) {
+  if (!drh || !r || !h || !dzr || !dh || (((uintptr_t)dzr_amax | (uintptr_t)dh_amax) & 3)) return FS_ERR_ARG;
+  int g4 = grid_for(M * (hid / 4));
+  if ((dzr_amax || dh_amax) && g4 > 1024) g4 = 1024;
   if (hid % 4 == 0 && ldzr % 4 == 0 && al16(drh) && al16(r) && al16(h) && al16(dzr) && al16(dh) && al16(dzr_sum))
-    hipLaunchKernelGGL(gru_bwd2_v4_kernel, dim3(grid_for(M * (hid / 4))), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid);
-  else hipLaunchKernelGGL(gru_bwd2_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid);
+    hipLaunchKernelGGL(gru_bwd2_v4_kernel, dim3(g4), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid, dzr_amax, dh_amax);
+  else hipLaunchKernelGGL(gru_bwd2_kernel, dim3(grid_for(M * hid)), dim3(256), 0, s, drh, r, h, dzr, ldzr, dh, dzr_sum, M, hid, dzr_amax, dh_amax);
   return fs_launch_status();
 }
 extern "C" int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s) {

@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 // the logits: for n % 32 == 0 a row of records is exactly as long as the fp32 row, so the map exists ONCE -- in the form every
 // later reader takes it in (attn @ v and attn^T @ dagg of all iterations, the softmax backward below) -- and the separate
 // fp32 -> records pass (read + write of the whole map) is gone.
-// Probabilities are bounded by 1: their records are split with the fixed scale 2^14 -- the scale of an amax word holding 1.0,
+// Probabilities are bounded by 1: their records are split with the fixed scale 2^13 -- the scale of an amax word holding 1.0,
 // which is the word the GEMMs reading them are given.
-constexpr float GMA_P_SCALE = 16384.0f;
+constexpr float GMA_P_SCALE = 8192.0f;
 __global__ __launch_bounds__(256) void softmax_rows_rec_kernel(float* __restrict__ S, int n) {
   extern __shared__ float row[];
   __shared__ float red[4];

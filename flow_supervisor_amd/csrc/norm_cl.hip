@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void cl_stats_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ sums,
                                                              const float* __restrict__ sumsq, float* __restrict__ y,
                                                              float* __restrict__ stats, int HW, int C, float eps, int relu, int PIX_PER_WG,
-                                                             const float* __restrict__ res, int s2w) {
+                                                             const float* __restrict__ res, int s2w, unsigned* __restrict__ y_amax) {
+  unsigned amx = 0u;                    // (y_amax, nullable: the amax word of y, raised -- the convolution behind the norm reads it)
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int b = blockIdx.y;
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(256) void cl_inorm_apply_kernel(const float* __rest
         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + rv[i], 0.f);
       }
       *reinterpret_cast<f32x4*>(y + (s2w ? cl_pix_off(b, p, HW, C, s2w) + cl * 4 : o)) = v;
+      amx = fs_umax(amx, fs_abs_bits4(v));
     }
+  __shared__ unsigned ared[4];
+  if (y_amax) fs_amax_commit(y_amax, amx, ared);
 }
 
 // MODE 0 (instance norm): xhat = (x - mean) * rstd, g' = g * (xhat > 0 | !relu); s1[b][c] += sum g', s2[b][c] += sum g' xhat
@@ -102,8 +106,10 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
                                                           const float* __restrict__ pa, const float* __restrict__ pb,
                                                           float* __restrict__ s1, float* __restrict__ s2,
                                                           float* __restrict__ dx, int HW, int C, int relu, int PIX_PER_WG,
-                                                          const float* __restrict__ out, float* __restrict__ dres, int s2w) {
+                                                          const float* __restrict__ out, float* __restrict__ dres, int s2w,
+                                                          unsigned* __restrict__ dx_amax) {        // (MODE 1: word of dx, raised)
   __shared__ f32x4 red[2][256];
+  unsigned amx = 0u;
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int b = blockIdx.y;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
         a2[i] += gg * (MODE == 0 ? t : xv[i]);
         dv[i] = gg * A[i];
       }
-      if (MODE == 1) *reinterpret_cast<f32x4*>(dx + o) = dv;
+      if (MODE == 1) { *reinterpret_cast<f32x4*>(dx + o) = dv; amx = fs_umax(amx, fs_abs_bits4(dv)); }
     }
   red[0][threadIdx.x] = a1; red[1][threadIdx.x] = a2;
   __syncthreads();
@@ -151,13 +157,16 @@ __global__ __launch_bounds__(256) void cl_bwd_sums_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) { atomicAdd(s1 + base + i, t1[i]); atomicAdd(s2 + base + i, t2[i]); }
   }
+  if (MODE == 1 && dx_amax) fs_amax_commit(dx_amax, amx, reinterpret_cast<unsigned*>(&red[0][0]));
 }
 
 // dx = rstd * (g' - mean(g') - xhat * mean(g' xhat))
 __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                  const float* __restrict__ stats, const float* __restrict__ s1,
                                                                  const float* __restrict__ s2, float* __restrict__ dx, int HW,
-                                                                 int C, int relu, int PIX_PER_WG, const float* __restrict__ out, int s2w) {
+                                                                 int C, int relu, int PIX_PER_WG, const float* __restrict__ out, int s2w,
+                                                                 unsigned* __restrict__ dx_amax) {
+  unsigned amx = 0u;
   const int c4n = C >> 2, lanes_p = 256 / c4n;
   const int cl = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int b = blockIdx.y;
@@ -192,15 +201,20 @@ __global__ __launch_bounds__(256) void cl_inorm_bwd_apply_kernel(const float* __
         dv[i] = rstd[i] * (gg - m1[i] - xh * m2[i]);
       }
       *reinterpret_cast<f32x4*>(dx + o) = dv;
+      amx = fs_umax(amx, fs_abs_bits4(dv));
     }
+  __shared__ unsigned ared[4];
+  if (dx_amax) fs_amax_commit(dx_amax, amx, ared);
 }
 
 // y = relu?(x * scale[c] + shift[c])
 __global__ __launch_bounds__(256) void cl_affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ y,
-                                                            int64_t M, int C, int relu, const float* __restrict__ res, int HW, int s2w) {
+                                                            int64_t M, int C, int relu, const float* __restrict__ res, int HW, int s2w,
+                                                            unsigned* __restrict__ y_amax) {
   const int c4n = C >> 2;
   const int64_t total = M * c4n;
+  unsigned amx = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int c = (int)(e % c4n) * 4;
     f32x4 v = reinterpret_cast<const f32x4*>(x)[e];
@@ -217,7 +231,11 @@ __global__ __launch_bounds__(256) void cl_affine_fwd_kernel(const float* __restr
     } else {
       reinterpret_cast<f32x4*>(y)[e] = v;
     }
+    amx = fs_umax(amx, fs_abs_bits4(v));
+    if (y_amax && e < (int64_t)gridDim.x * 256) fs_amax_early(y_amax, amx);
   }
+  __shared__ unsigned ared[4];
+  if (y_amax) fs_amax_commit(y_amax, amx, ared);
 }
 
 inline bool cl_ok(int C) { return C >= 4 && C <= 256 && C % 4 == 0; }      // (threads beyond (256 / (C/4)) * (C/4) idle)
@@ -234,48 +252,51 @@ extern "C" int fsraft_set_norm_blocks(int target_workgroups) {     // tuning hoo
 // x, y: [B][HW][C].  sums / sumsq: [B * 8][C] partial-row scratch that must be ZERO on entry; stats: [B][C][2] = (mean, rstd) out.
 // res (nullable, [B][HW][C]): fused residual unit, y = relu(res + relu?(norm(x))).
 extern "C" int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B,
-                                        int HW, int C, float eps, int relu, int have_sums, int s2d_w, hipStream_t s) {
-  if (!x || !y || !sums || !sumsq || !stats || B < 1 || HW < 1 || !cl_ok(C) || !s2d_ok(HW, s2d_w)) return FS_ERR_ARG;
+                                        int HW, int C, float eps, int relu, int have_sums, int s2d_w, unsigned* y_amax, hipStream_t s) {
+  if (!x || !y || !sums || !sumsq || !stats || B < 1 || HW < 1 || !cl_ok(C) || !s2d_ok(HW, s2d_w) || ((uintptr_t)y_amax & 3)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
   // have_sums: the producing convolution already accumulated the partial rows (fsraft_conv_forward_stats): no pass of our own
   if (!have_sums) hipLaunchKernelGGL(cl_stats_kernel, grid, dim3(256), 0, s, x, sums, sumsq, HW, C, ppw);
-  hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw, res, s2d_w);
+  hipLaunchKernelGGL(cl_inorm_apply_kernel, grid, dim3(256), 0, s, x, sums, sumsq, y, stats, HW, C, eps, relu, ppw, res, s2d_w, y_amax);
   return fs_launch_status();
 }
 // s1, s2: [B * 8][C] partial-row scratch, ZERO on entry.  Fused residual unit: out = the forward result y, dres receives the shortcut's
 // gradient g * (out > 0), and the norm branch continues from that; both NULL otherwise.
 extern "C" int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2,
-                                        float* dx, float* dres, int B, int HW, int C, int relu, int s2d_w, hipStream_t s) {
-  if (!g || !x || !stats || !s1 || !s2 || !dx || B < 1 || HW < 1 || !cl_ok(C) || (out != nullptr) != (dres != nullptr) || !s2d_ok(HW, s2d_w))
+                                        float* dx, float* dres, int B, int HW, int C, int relu, int s2d_w, unsigned* dx_amax, hipStream_t s) {
+  if (!g || !x || !stats || !s1 || !s2 || !dx || B < 1 || HW < 1 || !cl_ok(C) || (out != nullptr) != (dres != nullptr) || !s2d_ok(HW, s2d_w) ||
+      ((uintptr_t)dx_amax & 3))
     return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
-  hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw, out, dres, s2d_w);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<0>), grid, dim3(256), 0, s, g, x, stats, nullptr, s1, s2, nullptr, HW, C, relu, ppw, out, dres, s2d_w, nullptr);
   // fused residual unit: the first kernel just wrote dres = g * (out > 0) -- exactly what the second would rebuild from g and out,
   // so it reads that one tensor instead of the two (and in the plain layout, whatever layout g arrived in)
-  if (dres) hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, dres, x, stats, s1, s2, dx, HW, C, relu, ppw, nullptr, 0);
-  else hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw, out, s2d_w);
+  if (dres) hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, dres, x, stats, s1, s2, dx, HW, C, relu, ppw, nullptr, 0, dx_amax);
+  else hipLaunchKernelGGL(cl_inorm_bwd_apply_kernel, grid, dim3(256), 0, s, g, x, stats, s1, s2, dx, HW, C, relu, ppw, out, s2d_w, dx_amax);
   return fs_launch_status();
 }
 extern "C" int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M,
-                                         int C, int relu, int HW, int s2d_w, hipStream_t s) {
-  if (!x || !scale || !shift || !y || M < 1 || C < 4 || C % 4 || (s2d_w && (HW < 4 || M % HW || !s2d_ok(HW, s2d_w)))) return FS_ERR_ARG;
+                                         int C, int relu, int HW, int s2d_w, unsigned* y_amax, hipStream_t s) {
+  if (!x || !scale || !shift || !y || M < 1 || C < 4 || C % 4 || (s2d_w && (HW < 4 || M % HW || !s2d_ok(HW, s2d_w))) || ((uintptr_t)y_amax & 3))
+    return FS_ERR_ARG;
   int64_t blocks = (M * (C / 4) + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(cl_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, y, M, C, relu, res, HW > 0 ? HW : 1, s2d_w);
+  if (blocks > (y_amax ? 2048 : 8192)) blocks = y_amax ? 2048 : 8192;
+  hipLaunchKernelGGL(cl_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, y, M, C, relu, res, HW > 0 ? HW : 1, s2d_w, y_amax);
   return fs_launch_status();
 }
 // dx = g' * scale[c]; partial sums of g' and g' * x over pixels, spread over B * 8 rows to keep the atomics apart:
 // dsum_g, dsum_gx: [B * 8][C], ZERO on entry; the caller adds the rows up.  out / dres as in fsraft_inorm_relu_cl_bwd.
 extern "C" int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* out,
                                          float* dx, float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu,
-                                         int s2d_w, hipStream_t s) {
+                                         int s2d_w, unsigned* dx_amax, hipStream_t s) {
+  if ((uintptr_t)dx_amax & 3) return FS_ERR_ARG;
   if (!g || !x || !scale || !shift || !dx || !dsum_g || !dsum_gx || B < 1 || HW < 1 || !cl_ok(C) ||
       (out != nullptr) != (dres != nullptr) || !s2d_ok(HW, s2d_w)) return FS_ERR_ARG;
   const int ppw = pix_per_wg(B, HW);
   dim3 grid(ceil_div(HW, ppw), B);
-  hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw, out, dres, s2d_w);
+  hipLaunchKernelGGL((cl_bwd_sums_kernel<1>), grid, dim3(256), 0, s, g, x, scale, shift, dsum_g, dsum_gx, dx, HW, C, relu, ppw, out, dres, s2d_w, dx_amax);
   return fs_launch_status();
 }
 

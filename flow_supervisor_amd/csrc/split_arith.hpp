@@ -6,10 +6,10 @@
 // accumulation: three matrix instructions per product block -- the cost of the bf16x3 split of rounds 1-5 (fp16 and bf16
 // MFMA issue at the same rate) -- but 22 significant bits per operand instead of 16: the dropped a_lo*b_lo term is 2^-22
 // relative, products of fp16 pieces are exact in fp32 (11 x 11 bits), so what is left is fp32 accumulation, as in the
-// reference's fp32 GEMMs.  fp16 has 5 exponent bits where bf16 had fp32's 8, hence the scale: s maps the tensor's largest
-// magnitude into [2^14, 2^15) (fs_scale_of_amax), i.e. no element overflows, every element within 2^-17 of the largest keeps
-// all 22 bits, and smaller ones degrade gracefully through fp16's subnormals to an absolute floor of 2^-39 of the largest
-// magnitude (scripts/probes/mfma_f16_denorm.hip: the matrix pipe keeps subnormal inputs).  Scales are exact powers of two and
+// reference's fp32 GEMMs.  fp16 has 5 exponent bits where bf16 had fp32's 8, hence the scale: s maps the tensor's amax word
+// into [2^13, 2^14) (fs_scale_of_amax) -- the word may sit up to a factor 2 below the true maximum (fs_amax_commit), so every
+// element lands below 2^15 and nothing overflows; every element within 2^-16 of the largest keeps all 22 bits, and smaller ones
+// degrade gracefully through fp16's subnormals to an absolute floor of 2^-38 of the largest magnitude (scripts/probes/mfma_f16_denorm.hip: the matrix pipe keeps subnormal inputs).  Scales are exact powers of two and
 // are divided out of the fp32 accumulators in the epilogue: no rounding is added by them.
 #pragma once
 
@@ -66,24 +66,25 @@ __device__ __forceinline__ void fs_split1(float x, float s, _Float16& hi, _Float
 }
 
 // ---- amax words and scales -------------------------------------------------------------------------------------------
-// An "amax word" is one unsigned in device memory holding the bit pattern of max |x| over a tensor (or an upper bound of it):
-// producers raise it with atomicMax (bit patterns of non-negative floats order like the floats; NaN sorts above infinity,
-// so a NaN anywhere makes the scale NaN and the result NaN, as fp32 arithmetic would), consumers derive the tensor's scale
-// from it.  A NULL word means "the caller vouches |x| < 2^15": scale 1.
-#define FS_AMAX_UNIT 0x46800000u        // bit pattern of 2^14: the amax that maps to scale 1
+// An "amax word" is one unsigned in device memory holding the bit pattern of a magnitude w with max |x| < 2 w over a tensor:
+// the exact maximum (fsraft_amax), an upper bound, or what producers raised it to with atomicMax (bit patterns of
+// non-negative floats order like the floats; NaN sorts above infinity, so a NaN anywhere makes the scale NaN and the result
+// NaN, as fp32 arithmetic would).  Consumers derive the tensor's scale from it.  A NULL word means "the caller vouches
+// |x| < 2^15": scale 1.
+#define FS_AMAX_UNIT 0x46000000u        // bit pattern of 2^13: the amax that maps to scale 1
 
 __device__ __forceinline__ unsigned fs_abs_bits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned fs_amax_load(const unsigned* w) {      // wave-uniform pointer -> scalar load (the word was
   return w ? *w : FS_AMAX_UNIT;                                            // written by an earlier kernel: caches are clean)
 }
-// scale of a tensor whose largest magnitude has the bit pattern `amax_bits`: the power of two that maps it into [2^14, 2^15);
-// 1 for an all-zero tensor; never above 2^62 (tensors whose largest magnitude is below 2^-48 keep fewer bits), so that the
-// product of two scales and its reciprocal stay finite normal numbers
+// scale of a tensor whose word has the bit pattern `amax_bits`: the power of two that maps the word into [2^13, 2^14) and
+// hence every element below 2^15; 1 for an all-zero tensor; never above 2^62 (tensors whose largest magnitude is below 2^-49
+// keep fewer bits), so that the product of two scales and its reciprocal stay finite normal numbers
 __device__ __forceinline__ float fs_scale_of_amax(unsigned amax_bits) {
   if (amax_bits == 0) return 1.0f;
   const int e = (int)(amax_bits >> 23);                 // biased exponent (0: an fp32 subnormal)
   if (e == 255) return __builtin_bit_cast(float, 0x7fc00000u);
-  int se = 127 + 14 - (e - 127);                        // biased exponent of the scale
+  int se = 127 + 13 - (e - 127);                        // biased exponent of the scale
   se = se > 127 + 62 ? 127 + 62 : se;
   return __builtin_bit_cast(float, (unsigned)se << 23);
 }
@@ -94,12 +95,34 @@ __device__ __forceinline__ float fs_inv_scale(float s) {
   if ((b & 0x7f800000u) == 0x7f800000u) return s;       // NaN stays NaN
   return __builtin_bit_cast(float, (254u << 23) - b);
 }
-// raise an amax word to the largest of the workgroup's per-thread maxima `m` (bit patterns).  `red`: LDS scratch of at least
-// (threads / 64) words, free to use; every thread of the workgroup must call.  One atomic per workgroup, and none when the
-// word already holds at least the value (the word only grows inside a launch, so a stale read can only cause a spare atomic).
-__device__ __forceinline__ void fs_amax_commit(unsigned* word, unsigned m, unsigned* red) {
+// ---- raising a word from a producer ----
+// Atomics on ONE address serialise at the memory side (~11 ns each: 3520 of them took 40 us of the GMA gamma-gradient kernel, and a
+// first version of this file that let every wave of gru_bwd1 issue three turned 19 us into 212).  So: (1) a word is only
+// touched when the value's EXPONENT exceeds the word's -- a scale needs the word to within a factor 2, which this keeps (same
+// exponent => value < 2 x word); (2) what is written is the value ONE binade up (early samples: two), so that the thousands of
+// workgroups behind the first few find a word they do not exceed and skip -- the word may then sit up to 4x above the true
+// maximum, which costs two of the ~10 binades of slack the fp16 pieces have; (3) streaming kernels let a handful of waves
+// publish a sample after their first loop trip (fs_amax_early), long before the crowd arrives.  The word only grows inside a
+// launch, so a stale read can only cause a spare atomic.
+__device__ __forceinline__ bool fs_amax_worth(unsigned m, unsigned cur) { return (m >> 23) > (cur >> 23) || (cur == 0u && m != 0u); }
+__device__ __forceinline__ unsigned fs_amax_up(unsigned m, unsigned binades) {      // m x 2^binades, never beyond the largest finite exponent
+  const unsigned e = m >> 23;
+  return (m == 0u || e >= 255u) ? m : (e + binades > 254u ? (254u << 23) | (m & 0x7fffffu) : m + (binades << 23));
+}
+__device__ __forceinline__ unsigned fs_wave_umax(unsigned m) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fs_umax(m, (unsigned)__shfl_xor((int)m, o, 64));
+  return m;
+}
+__device__ __forceinline__ void fs_amax_raise(unsigned* word, unsigned m, unsigned up) {     // one lane
+  // (device-scope relaxed load: served by L2, where the atomics land -- not by this CU's L1, which would keep showing the
+  //  value it saw first)
+  if (fs_amax_worth(m, __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMax(word, fs_amax_up(m, up));
+}
+// the workgroup's per-thread maxima `m` (bit patterns) -> the word.  `red`: LDS scratch of at least (threads / 64) words, free
+// to use; every thread of the workgroup must call.  At most one atomic per workgroup.
+__device__ __forceinline__ void fs_amax_commit(unsigned* word, unsigned m, unsigned* red) {
+  m = fs_wave_umax(m);
   const int nw = (int)(blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
   const int tid = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
   __syncthreads();
@@ -107,6 +130,22 @@ __device__ __forceinline__ void fs_amax_commit(unsigned* word, unsigned m, unsig
   __syncthreads();
   if (tid == 0) {
     for (int i = 1; i < nw; ++i) m = fs_umax(m, red[i]);
-    if (m > __builtin_nontemporal_load(word)) atomicMax(word, m);
+    fs_amax_raise(word, m, 1u);
   }
+}
+// the same without barriers, at most one atomic per WAVE: for kernels whose waves leave early
+__device__ __forceinline__ void fs_amax_commit_wave(unsigned* word, unsigned m) {
+  m = fs_wave_umax(m);
+  if ((threadIdx.x & 63) == 0) fs_amax_raise(word, m, 1u);
+}
+// an early sample, two binades up, from wave 0 of the first eight workgroups (call once, after the first loop trip; wave-uniform
+// control flow around the call)
+__device__ __forceinline__ void fs_amax_early(unsigned* word, unsigned m) {
+  if (blockIdx.x < 8u && threadIdx.x < 64u && blockIdx.y == 0u && blockIdx.z == 0u) {
+    m = fs_wave_umax(m);
+    if (threadIdx.x == 0) fs_amax_raise(word, m, 2u);
+  }
+}
+__device__ __forceinline__ unsigned fs_abs_bits4(fs_f32x4 v) {
+  return fs_umax(fs_umax(fs_abs_bits(v[0]), fs_abs_bits(v[1])), fs_umax(fs_abs_bits(v[2]), fs_abs_bits(v[3])));
 }

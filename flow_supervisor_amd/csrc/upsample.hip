@@ -82,8 +82,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // dmask (channels-last, same layout as mask) and T[n,c,k,y,x] = sum_s p_k[s] * dup[c][s]  (planar: upsample_dflow_kernel gathers along x)
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const float* __restrict__ mask,
                                                            const float* __restrict__ dup, float* __restrict__ dmask,
-                                                           float* __restrict__ T, int H, int W) {
+                                                           float* __restrict__ T, int H, int W, unsigned* __restrict__ dmask_amax) {
   __shared__ float tile[2][8][64];
+  unsigned amx = 0u;
   const int xb = blockIdx.x * 8, y = blockIdx.y, n = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sy = lane >> 3, sx = lane & 7;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const flo
     }
     float* dm = dmask + pix * 576 + lane;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dm[k * 64] = p[k] * (dp[k] - dot);
+    for (int k = 0; k < 9; ++k) { const float dv = p[k] * (dp[k] - dot); dm[k * 64] = dv; amx = fs_umax(amx, fs_abs_bits(dv)); }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const float t0 = wave_sum(p[k] * g0);
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Flow2 flow, const flo
       }
     }
   }
+  if (dmask_amax) fs_amax_commit_wave(dmask_amax, amx);      // (nullable) word of dmask, raised
 }
 
 // ---- the same two kernels on 16-byte accesses (mask, up, dup, dmask 16-byte aligned).  A workgroup owns 16 neighbouring coarse
@@ -197,7 +199,9 @@ __global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(Flow2 flow, const 
 }
 
 __global__ __launch_bounds__(256) void upsample_bwd_v4_kernel(Flow2 flow, const float* __restrict__ mask, const float* __restrict__ dup,
-                                                              float* __restrict__ dmask, float* __restrict__ T, int H, int W) {
+                                                              float* __restrict__ dmask, float* __restrict__ T, int H, int W,
+                                                              unsigned* __restrict__ dmask_amax) {
+  unsigned amx = 0u;
   const int y = blockIdx.y, n = blockIdx.z;
   const int xl = threadIdx.x >> 4, sub = threadIdx.x & 15, sy = sub >> 1, sx = (sub & 1) * 4;
   const int x0 = blockIdx.x * 16 + xl;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_v4_kernel(Flow2 flow, const 
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const f32x4 dp = g0 * f0[k] + g1 * f1[k];
-    if (ok) gstore4(dm + k * 64, m[k] * (dp - dot));
+    if (ok) { const f32x4 dv = m[k] * (dp - dot); gstore4(dm + k * 64, dv); amx = fs_umax(amx, fs_abs_bits4(dv)); }
     const f32x4 a = m[k] * g0, b = m[k] * g1;
     float t0 = (a[0] + a[1]) + (a[2] + a[3]), t1 = (b[0] + b[1]) + (b[2] + b[3]);
 #pragma unroll
@@ -232,6 +236,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_v4_kernel(Flow2 flow, const 
       T[((int64_t)n * 18 + 9 + k) * HWp + pl] = t1;
     }
   }
+  __shared__ unsigned red[4];
+  if (dmask_amax) fs_amax_commit(dmask_amax, amx, red);      // (one look at the word per workgroup: 21 K of them at the bench shape)
 }
 
 // dflow[n,c,y,x] = 8 * sum_k T[n, c, k, y-(ky-1), x-(kx-1)]   (deterministic gather, no atomics)
@@ -336,14 +342,14 @@ extern "C" int fsraft_upsample_fwd(const float* flow, int64_t flow_bs, int64_t f
 // dmask_nhwc [N,H,W,576], dflow [N,2,H,W] contiguous; scratch holds N*H*W*18 floats.
 extern "C" int fsraft_upsample_bwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int64_t flow_ps,
                                    const float* mask_nhwc, const float* dup, float* dmask_nhwc, float* dflow,
-                                   float* scratch, int N, int H, int W, hipStream_t stream) {
-  if (!flow || !mask_nhwc || !dup || !dmask_nhwc || !dflow || !scratch || N < 1 || H < 1 || W < 1) return FS_ERR_ARG;
+                                   float* scratch, int N, int H, int W, unsigned* dmask_amax, hipStream_t stream) {
+  if (!flow || !mask_nhwc || !dup || !dmask_nhwc || !dflow || !scratch || N < 1 || H < 1 || W < 1 || ((uintptr_t)dmask_amax & 3)) return FS_ERR_ARG;
   Flow2 f{flow, flow_bs, flow_cs, flow_ps};
   if (g_upsample_v4 && (((uintptr_t)mask_nhwc | (uintptr_t)dup | (uintptr_t)dmask_nhwc) & 15) == 0)
-    hipLaunchKernelGGL(upsample_bwd_v4_kernel, dim3(ceil_div(W, 16), H, N), dim3(256), 0, stream, f, mask_nhwc, dup, dmask_nhwc, scratch, H, W);
+    hipLaunchKernelGGL(upsample_bwd_v4_kernel, dim3(ceil_div(W, 16), H, N), dim3(256), 0, stream, f, mask_nhwc, dup, dmask_nhwc, scratch, H, W, dmask_amax);
   else
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ceil_div(W, 8), H, N), dim3(256), 0, stream, f, mask_nhwc, dup,
-                       dmask_nhwc, scratch, H, W);
+                       dmask_nhwc, scratch, H, W, dmask_amax);
   const int64_t total = (int64_t)N * 2 * H * W;
   hipLaunchKernelGGL(upsample_dflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, scratch, dflow,
                      N, H, W);

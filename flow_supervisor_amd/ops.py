@@ -153,8 +153,12 @@ def new_amax(device):
 
 
 def tracked(t, word=None):
-    """Mark buffer t as carrying an amax word that all of its writers raise; returns t."""
-    t._fs_amax = new_amax(t.device) if word is None else word
+    """Mark buffer t as carrying an amax word that all of its writers raise; returns t.  (The word is noted on t and on the
+    tensor t is a view of: views made from t later find it through their `_base`, which is that root.)"""
+    w = new_amax(t.device) if word is None else word
+    t._fs_amax = w
+    if t._base is not None and t._base.numel() == t.numel():      # (a re-shaped whole -- never a slice of a shared pool chunk)
+        t._base._fs_amax = w
     return t
 
 
@@ -178,11 +182,24 @@ def amax_one(device):
     return w
 
 
+_AMAX_TRACE = None
+
+
 def amax_jobs(jobs):
     """jobs: (data_ptr, rows, C, ld, word tensor); word = max(word, max |x|) for each, 32 jobs per launch."""
     n = len(jobs)
     if not n:
         return
+    if os.environ.get("FSRAFT_AMAX_TRACE"):           # debugging aid: who still needs a pass of its own (printed at exit)
+        global _AMAX_TRACE
+        import atexit
+        import collections
+        import traceback
+        if _AMAX_TRACE is None:
+            _AMAX_TRACE = collections.Counter()
+            atexit.register(lambda: [print(f"amax pass x{c}: {k}", flush=True) for k, c in _AMAX_TRACE.most_common(40)])
+        fr = traceback.extract_stack(limit=6)[:-1]
+        _AMAX_TRACE[" < ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(fr))] += 1
     ptrs = (ctypes.c_void_p * n)(*[j[0] for j in jobs])
     rows = (ctypes.c_int64 * n)(*[j[1] for j in jobs])
     cs = (ctypes.c_int64 * n)(*[j[2] for j in jobs])
@@ -347,13 +364,13 @@ def corr_lookup_tiled_fwd(vol, lay, coords, radius, is_flow=False, out=None):
     bs, cs, ps = _planar2_strides(coords)
     ch = lay.nlev * (2 * radius + 1) ** 2
     if out is None:
-        out = torch.empty(B, H, W, ch, device=coords.device, dtype=torch.float32)
+        out = tracked(torch.empty(B, H, W, ch, device=coords.device, dtype=torch.float32))     # (the lookup raises the word)
     elif tuple(out.shape) != (B, H, W, ch) or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError(f"lookup out= must be a contiguous fp32 [{B},{H},{W},{ch}] tensor")
     t = TIMER
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_corr_lookup_tiled_fwd(L.ptr(vol), lay.nlev, L.ptr(coords), bs, cs, ps, L.ptr(out), B, H, W, radius,
-                                                int(is_flow), L.stream()), "corr_lookup_tiled_fwd")
+                                                int(is_flow), _wptr(out), L.stream()), "corr_lookup_tiled_fwd")
     if t:
         t.end("corr_lookup_fwd", e0, 0.0, 4.0 * B * H * W * (lay.nlev * (2 * radius + 2) ** 2 + 2 + ch))
     return out
@@ -989,11 +1006,11 @@ def upsample_bwd(flow, mask_nhwc, dup):
     N, _, H, W = flow.shape
     bs, cs, ps = _planar2_strides(flow)
     dup = dup.contiguous()
-    dmask = torch.empty_like(mask_nhwc)
+    dmask = tracked(torch.empty_like(mask_nhwc))          # (its only writer, below, raises the word: the mask head's backward reads it)
     dflow = torch.empty(N, 2, H, W, device=flow.device, dtype=torch.float32)
     scratch = torch.empty(N * H * W * 18, device=flow.device, dtype=torch.float32)
     L.check(_lib().fsraft_upsample_bwd(L.ptr(flow), bs, cs, ps, L.ptr(mask_nhwc), L.ptr(dup), L.ptr(dmask),
-                                       L.ptr(dflow), L.ptr(scratch), N, H, W, L.stream()), "upsample_bwd")
+                                       L.ptr(dflow), L.ptr(scratch), N, H, W, _wptr(dmask), L.stream()), "upsample_bwd")
     return dflow, dmask
 
 
@@ -1044,7 +1061,7 @@ def nhwc_to_nchw(src, C=None, coff=0, dst=None, accumulate=False):
 def im2col7(flow, cols):
     B, _, H, W = flow.shape
     bs, cs, ps = _planar2_strides(flow)
-    L.check(_lib().fsraft_im2col7(L.ptr(flow), bs, cs, ps, L.ptr(cols), cols.shape[-1], B, H, W, L.stream()), "im2col7")
+    L.check(_lib().fsraft_im2col7(L.ptr(flow), bs, cs, ps, L.ptr(cols), cols.shape[-1], B, H, W, _wptr(cols), L.stream()), "im2col7")
     return cols
 
 
@@ -1057,7 +1074,7 @@ def col2im7(dcols, dflow, accumulate):
 def flow_to_nhwc(flow, dst, coff):
     B, _, H, W = flow.shape
     bs, cs, ps = _planar2_strides(flow)
-    L.check(_lib().fsraft_flow_to_nhwc(L.ptr(flow), bs, cs, ps, L.ptr(dst), dst.shape[-1], coff, B, H * W, L.stream()),
+    L.check(_lib().fsraft_flow_to_nhwc(L.ptr(flow), bs, cs, ps, L.ptr(dst), dst.shape[-1], coff, B, H * W, _wptr(dst), L.stream()),
             "flow_to_nhwc")
 
 
@@ -1076,13 +1093,13 @@ def gru_bwd1(dhn, z, q, h, dzr, dq, dh, hid, dzr_sum=None, dq_sum=None, dhn2=Non
     """dhn2: optional second summand of the incoming hidden-state gradient (same shape as dhn)."""
     M = dhn.numel() // hid
     L.check(_lib().fsraft_gru_bwd1(L.ptr(dhn), L.ptr(dhn2), L.ptr(z), L.ptr(q), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dq),
-                                   L.ptr(dh), L.ptr(dzr_sum), L.ptr(dq_sum), M, hid, L.stream()), "gru_bwd1")
+                                   L.ptr(dh), L.ptr(dzr_sum), L.ptr(dq_sum), M, hid, _wptr(dzr), _wptr(dq), _wptr(dh), L.stream()), "gru_bwd1")
 
 
 def gru_bwd2(drh, r, h, dzr, dh, hid, dzr_sum=None):
     M = drh.numel() // hid
     L.check(_lib().fsraft_gru_bwd2(L.ptr(drh), L.ptr(r), L.ptr(h), L.ptr(dzr), dzr.shape[-1], L.ptr(dh), L.ptr(dzr_sum), M, hid,
-                                   L.stream()), "gru_bwd2")
+                                   _wptr(dzr), _wptr(dh), L.stream()), "gru_bwd2")
 
 
 def col_sum_(x, C, out, scale=1.0):
@@ -1519,7 +1536,7 @@ def conv_small_dgrad(dy, w_oihw, dst, mask, B, H, W):
     e0 = t.begin() if t else None
     L.check(_lib().fsraft_conv_small_dgrad(ctypes.c_void_p(dy.ptr), dy.ld, L.ptr(w_oihw), ctypes.c_void_p(dst.ptr), dst.ld,
                                            ctypes.c_void_p(mask.ptr) if mask is not None else None, mask.ld if mask is not None else 0,
-                                           C, 2, B, H, W, 3, 3, L.stream()), "conv_small_dgrad")
+                                           C, 2, B, H, W, 3, 3, L.ptr(dst.amax), L.stream()), "conv_small_dgrad")
     if t:
         t.end("conv_small", e0, 2.0 * B * H * W * 2 * C * 9, 4.0 * B * H * W * (C * (2 if mask is not None else 1) + 2))
 

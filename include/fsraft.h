@@ -46,13 +46,14 @@ int fsraft_abi_version(void);
  * as (a_hi b_hi + a_hi b_lo + a_lo b_hi) / (s_a s_b) on v_mfma_f32_*_f16 with fp32 accumulation: ~2^-22 per product, the fp32
  * GEMM's accuracy class (csrc/split_arith.hpp; fsraft_set_arithmetic(0) selects exact fp32 MFMA instead).  s is a power of
  * two per TENSOR, derived on the device from the tensor's "amax word": ONE `unsigned` in device memory holding the bit pattern
- * of max |x| (or an upper bound).  s maps that magnitude into [2^14, 2^15): nothing overflows fp16, elements within 2^-17 of
- * the largest keep all 22 bits, smaller ones degrade gracefully (fp16 subnormals) to a floor of 2^-39 of the largest.
+ * of a magnitude w with max |x| < 2 w (an upper bound, or what producers raised it to: within [1/2, 4] of the maximum).  s maps
+ * w into [2^13, 2^14): every element lands below 2^15, nothing overflows fp16, elements within 2^-14 of the largest keep all 22
+ * bits, smaller ones degrade gracefully (fp16 subnormals) to a floor of 2^-36 of the largest.
  *   - entry points that READ a tensor through the matrix pipe take its word (`..._amax`, const unsigned*); NULL = "the caller
  *     vouches |x| < 2^15": scale 1;
- *   - entry points that WRITE one can raise a word to the largest magnitude they stored (fsraft_conv_desc.dst_amax: one
- *     atomicMax per workgroup), so that a chain of kernels needs no extra pass; the word must be zero (or an earlier bound)
- *     before the producer runs;
+ *   - entry points that WRITE one can raise a word (fsraft_conv_desc.dst_amax, `..._amax` outputs: an atomicMax, one binade
+ *     up, whenever a workgroup stored a magnitude whose exponent exceeds the word's -- hence the factors), so that a chain of
+ *     kernels needs no extra pass; the word must be zero (or an earlier bound) before the producer runs;
  *   - fsraft_amax / fsraft_amax_jobs compute words of tensors that come from elsewhere (images, parameters, gradients handed in
  *     by autograd); fsraft_amax_scaled derives a bound from another word (dst = max(dst, factor * src)).
  * Records (fsraft_to_records, the weight packs, the gradient volume) hold pieces of x * s: whoever reads them is given the word
@@ -103,7 +104,8 @@ int fsraft_corr_build_rec(const void* f1r, const void* f2r, float* vol, int num_
  * add_grid != 0: `coords` holds the FLOW and the query position is pixel grid + flow (the caller's coords0 + flow,
  * pytorch/core/raft.py:121-131, never materialised) */
 int fsraft_corr_lookup_tiled_fwd(const float* vol, int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs,
-                                 int64_t coords_ps, float* out, int B, int H, int W, int radius, int add_grid, hipStream_t stream);
+                                 int64_t coords_ps, float* out, int B, int H, int W, int radius, int add_grid,
+                                 unsigned* out_amax /* nullable: word of `out`, raised */, hipStream_t stream);
 /* Gradient volume of n lookups at once (grid_sampler_2d_backward w.r.t. the volume, pytorch/core/utils/utils.py:57-71, for
  * all iterations of a step): dvol [B*H*W][P] = (or +=, accumulate != 0) sum_t (d out_t / d V)^T dout_t, pad cells zero;
  * dout[t] is [B,H,W,CH] channels-last, coords[t] element (b, c, pix) at coords[t][b*s0 + c*s1 + pix*s2] with
@@ -188,7 +190,7 @@ int fsraft_upsample_fwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int
 /* dmask_nhwc [N,H,W,576], dflow [N,2,H,W]; scratch: N*H*W*18 floats. */
 int fsraft_upsample_bwd(const float* flow, int64_t flow_bs, int64_t flow_cs, int64_t flow_ps,
                         const float* mask_nhwc, const float* dup, float* dmask_nhwc, float* dflow, float* scratch,
-                        int N, int H, int W, hipStream_t stream);
+                        int N, int H, int W, unsigned* dmask_amax /* nullable: word of dmask_nhwc, raised */, hipStream_t stream);
 /* upflow8, pytorch/core/utils/utils.py:80-82 (raft-small). flow [N,C,H,W] -> up [N,C,8H,8W]. */
 int fsraft_upflow8_fwd(const float* flow, float* up, int N, int C, int H, int W, hipStream_t stream);
 int fsraft_upflow8_bwd(const float* dup, float* dflow, int N, int C, int H, int W, hipStream_t stream);
@@ -290,7 +292,8 @@ int fsraft_conv_small_wgrad(const float* const* dy, const float* const* x, int n
  * relu_src <= 0 (nullable: the ReLU in front of the convolution, pitch ldm).  dy channels-last with pitch ldy >= 2; dx
  * channels-last with pitch lddx, 16-byte aligned.  C % 4 == 0, C <= 256, N == 2, 3x3. */
 int fsraft_conv_small_dgrad(const float* dy, int ldy, const float* w_oihw, float* dx, int lddx, const float* relu_src, int ldm,
-                            int C, int N, int B, int H, int W, int KH, int KW, hipStream_t stream);
+                            int C, int N, int B, int H, int W, int KH, int KW, unsigned* dx_amax /* nullable: word of dx, raised */,
+                            hipStream_t stream);
 
 /* Scratch buffer for the split-K route of the convolutions at small pixel counts (one or two pairs per GPU: the layer's
  * k-tiles are dealt to several workgroups per tile, which park partial tiles here; a second kernel adds them and applies the
@@ -378,7 +381,7 @@ int fsraft_softmax_rows(float* S, int64_t rows, int n, hipStream_t stream);
 int fsraft_softmax_rows_bwd(const float* A, float* dA, int64_t rows, int n, hipStream_t stream);
 /* The same softmax (gma.py:71-74) with the probabilities written over the logits as RECORDS ([32 hi | 32 lo] fp16 per 32
  * columns: the operand form of fsraft_gemm_rec_nt / _tn): for n % 32 == 0 (n <= 16352) the record row is as long as the fp32
- * row, so the map exists once.  Probabilities are bounded by 1: their records are split with the fixed scale 2^14, the scale
+ * row, so the map exists once.  Probabilities are bounded by 1: their records are split with the fixed scale 2^13, the scale
  * of an amax word holding 1.0f -- the word to hand to the GEMMs that read them.  The backward reads those records (a = hi + lo)
  * and turns the fp32 gradient dA into the records of dS = A * (dA - rowsum(dA * A)) in place (n <= 8160), split with the scale
  * of ds_amax (|dS| <= 2 max |dA|). */
@@ -434,13 +437,16 @@ int fsraft_forward_interpolate(const float* flow, float* out, int H, int W, hipS
  * stride 2) -- and the backward reads the gradient g and the saved result `out` from that layout; x, res, dx, dres stay
  * [B][HW][C].  0: everything [B][HW][C].  (fsraft_affine_relu_cl_fwd takes HW for this; ignored when s2d_w == 0.) */
 int fsraft_inorm_relu_cl_fwd(const float* x, const float* res, float* y, float* sums, float* sumsq, float* stats, int B, int HW,
-                             int C, float eps, int relu, int have_sums, int s2d_w, hipStream_t stream);
+                             int C, float eps, int relu, int have_sums, int s2d_w, unsigned* y_amax /* nullable: word of y, raised */,
+                             hipStream_t stream);
 int fsraft_inorm_relu_cl_bwd(const float* g, const float* x, const float* stats, const float* out, float* s1, float* s2, float* dx,
-                             float* dres, int B, int HW, int C, int relu, int s2d_w, hipStream_t stream);
+                             float* dres, int B, int HW, int C, int relu, int s2d_w, unsigned* dx_amax /* nullable: word of dx, raised */,
+                             hipStream_t stream);
 int fsraft_affine_relu_cl_fwd(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t M, int C,
-                              int relu, int HW, int s2d_w, hipStream_t stream);
+                              int relu, int HW, int s2d_w, unsigned* y_amax, hipStream_t stream);
 int fsraft_affine_relu_cl_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* out, float* dx,
-                              float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, int s2d_w, hipStream_t stream);
+                              float* dres, float* dsum_g, float* dsum_gx, int B, int HW, int C, int relu, int s2d_w, unsigned* dx_amax,
+                              hipStream_t stream);
 
 /* Frozen-BatchNorm parameter folding in one launch per direction (instead of ~11 framework launches on [C] tensors per layer
  * and step): scale = weight * rsqrt(var + eps), shift = bias - (mean - cbias) * scale, rs = rsqrt(var + eps), rmc = mean - cbias
@@ -485,15 +491,19 @@ int fsraft_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, int 
  * stride-2 ResidualBlock) is a stride-1 2x2 / 1x1 convolution of fsraft_conv_forward over dst viewed as [B][H/2][W/2][4C]. */
 int fsraft_space_to_depth2(const float* src, float* dst, int B, int H, int W, int C, int inverse, hipStream_t s);
 int fsraft_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, int ld, int coff, int accumulate, hipStream_t s);
-int fsraft_im2col7(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* cols, int ld, int B, int H, int W, hipStream_t s);
+int fsraft_im2col7(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* cols, int ld, int B, int H, int W,
+                   unsigned* cols_amax /* nullable: raised */, hipStream_t s);
 int fsraft_col2im7(const float* dcols, int ld, float* dflow, int B, int H, int W, int accumulate, hipStream_t s);
-int fsraft_flow_to_nhwc(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* dst, int ld, int coff, int B, int HW, hipStream_t s);
+int fsraft_flow_to_nhwc(const float* flow, int64_t bs, int64_t cs, int64_t ps, float* dst, int ld, int coff, int B, int HW,
+                        unsigned* dst_amax /* nullable: raised */, hipStream_t s);
 int fsraft_nhwc_to_flow(const float* src, int ld, int coff, float* dflow, int B, int HW, int accumulate, hipStream_t s);
 int fsraft_relu_bwd(float* g, int ldg, const float* y, int ldy, int64_t M, int C, hipStream_t s);
 /* dzr_sum / dq_sum (nullable, same layouts as dzr / dq): running sums over the iterations of a step; dhn2 (nullable): a second
  * summand of the incoming gradient (dh' = dhn + dhn2: the heads' part and the part arriving from the next iteration) */
-int fsraft_gru_bwd1(const float* dhn, const float* dhn2, const float* z, const float* q, const float* h, float* dzr, int ldzr, float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid, hipStream_t s);
-int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh, float* dzr_sum, int64_t M, int hid, hipStream_t s);
+int fsraft_gru_bwd1(const float* dhn, const float* dhn2, const float* z, const float* q, const float* h, float* dzr, int ldzr, float* dq, float* dh, float* dzr_sum, float* dq_sum, int64_t M, int hid,
+                    unsigned* dzr_amax, unsigned* dq_amax, unsigned* dh_amax /* nullable: words of the three outputs, raised */, hipStream_t s);
+int fsraft_gru_bwd2(const float* drh, const float* r, const float* h, float* dzr, int ldzr, float* dh, float* dzr_sum, int64_t M, int hid,
+                    unsigned* dzr_amax, unsigned* dh_amax, hipStream_t s);
 int fsraft_col_sum(const float* x, int ld, int64_t M, int C, float* out, float scale, hipStream_t s);
 int fsraft_axpby(const float* x, float* y, float a, float b, int64_t n, hipStream_t s);
 /* out[0..count) = (accumulate ? out : 0) + src[0] + ... + src[n - 1], added in list order (count % 4 == 0, 16-byte aligned): the sum

@@ -42,7 +42,7 @@ def word_scale(word):
     a = float(word.item()) if isinstance(word, torch.Tensor) else float(word)
     if a == 0.0:
         return 1.0
-    return 2.0 ** min(14 - math.floor(math.log2(a)), 62)
+    return 2.0 ** min(13 - math.floor(math.log2(a)), 62)
 
 
 def decode_records(r, word):

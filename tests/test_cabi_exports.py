@@ -133,7 +133,7 @@ def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert lib.fsraft_corr_bwd_ktiles(nullpp, strides, 1, 4, 1, 16, 16, 4, 1, 0, 0, null, null, 0, null, null, null, 0, null, None) == 1
     assert lib.fsraft_gemm_rec_nt_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, null, null, None) == 1
     assert lib.fsraft_gemm_rec_tn_list(null, 0, 0, null, 0, 0, null, 0, 0, 1, 32, 32, 32, 1.0, 1, 0, null, null, 0, 0, null, null, None) == 1
-    assert lib.fsraft_gru_bwd1(null, null, null, null, null, null, 128, null, null, null, null, 16, 128, None) == 1
+    assert lib.fsraft_gru_bwd1(null, null, null, null, null, null, 128, null, null, null, null, 16, 128, null, null, null, None) == 1
     assert lib.fsraft_set_lookup_policy(3) == 1 and lib.fsraft_set_lookup_policy(-1) == 0
     assert lib.fsraft_set_ktile_exact(5) == 1 and lib.fsraft_set_ktile_exact(0) == 0
     assert lib.fsraft_conv_workspace(ctypes.c_void_p(8), 16) == 1          # misaligned scratch
