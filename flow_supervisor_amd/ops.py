@@ -245,6 +245,16 @@ def ensure_amax(views):
     if exact_mode():
         return [None] * len(views)
     jobs = []
+    if AMAX_AUDIT and not torch.cuda.is_current_stream_capturing():
+        # every word a buffer CARRIES is checked against the truth (synchronises): a writer that forgot to raise it shows up
+        # here, not as an overflow three layers later.  tests/ run the whole GPU suite once in this mode.
+        for v in views:
+            if v.amax is not None:
+                true = float(v.t[..., v.off:v.off + v.C].abs().max())
+                word = float(v.amax.item())
+                if not (true == 0.0 or 2.0 * word > true) or word != word:
+                    raise RuntimeError(f"amax audit: word {word:g} does not bound max |x| = {true:g} (shape {tuple(v.t.shape)}, "
+                                       f"channels [{v.off}, {v.off + v.C}))")
     for v in views:
         if v.amax is None:
             v.amax = new_amax(v.t.device)
@@ -252,6 +262,9 @@ def ensure_amax(views):
             jobs.append((v.ptr, rows, v.C, v.ld, v.amax))
     amax_jobs(jobs)
     return [v.amax.data_ptr() for v in views]
+
+
+AMAX_AUDIT = bool(os.environ.get("FSRAFT_AMAX_AUDIT"))     # (module attribute: tests set it)
 
 
 def pyramid_sizes(H, W, num_levels=4):
@@ -570,6 +583,8 @@ def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None
     else:
         L.check(_lib().fsraft_altcorr_fused_fwd(L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out), B, H, W, C,
                                                 radius, L.stream()), "altcorr_fused_fwd")
+    if amax_of(out) is not None:          # (a tracked destination -- a MotionBatch slot: these kernels raise no word themselves)
+        amax_jobs([(out.data_ptr(), 1, out.numel(), out.numel(), amax_of(out))])
     if t:   # compulsory bytes of the alt path per iteration = fmap1 + the pooled fmap2 pyramid + coords + out
         t.end("altcorr_fwd", e0, 2.0 * B * H * W * nl * (2 * radius + 2) ** 2 * C,
               4.0 * B * (H * W * C + sum(f.shape[1] * f.shape[2] for f in f2_levels) * C + H * W * (2 + out.shape[-1])))
@@ -761,6 +776,10 @@ def to_records(x, pad=False, amax=None):
     word = amax if amax is not None else amax_of(x)
     if word is None:
         word = amax_tensor(x)
+    elif AMAX_AUDIT and not torch.cuda.is_current_stream_capturing():
+        true = float(x.abs().max())
+        if not (true == 0.0 or 2.0 * float(word.item()) > true):
+            raise RuntimeError(f"amax audit (to_records): word {float(word.item()):g} does not bound max |x| = {true:g}")
     out._fs_amax = word
     L.check(_lib().fsraft_to_records(L.ptr(x), K, L.ptr(out), ldr, rows, K, L.ptr(word), L.stream()), "to_records")
     return out

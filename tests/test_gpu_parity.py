@@ -2783,3 +2783,54 @@ def test_tf_twins_train_through_volume_pyramid_and_lookup():
     g1 = torch.randn(1, 22, 24, 32, device=DEV, requires_grad=True)
     with pytest.raises(RuntimeError, match="forward-only"):
         raft_tf.calc_all_field(g1, g1, num_pool=3)
+
+
+@pytest.mark.parametrize("kind", ["basic", "small", "alt", "gma", "l2l"])
+def test_amax_words_bound_their_tensors(kind):
+    """Round 6: every GEMM-shaped kernel scales its operands from amax words, and a buffer CARRIES a word only if every kernel
+    writing it raises the word (ops.tracked).  A writer that forgot would leave the word too low and the fp16 pieces would
+    overflow some day; this runs a train step of every model family in audit mode (ops.AMAX_AUDIT: each carried word is
+    compared with the tensor's true maximum before the kernel that reads it) and on weights / images scaled far from 1, where
+    a missing scale cannot hide."""
+    from flow_supervisor_amd import ops
+    from flow_supervisor_amd.core.l2l import L2L
+    from flow_supervisor_amd.core.raft import RAFT
+    old = ops.AMAX_AUDIT
+    ops.AMAX_AUDIT = True
+    try:
+        ops.set_arithmetic(True)
+        seed = 3
+        if kind == "gma":
+            m = _gma_model(seed).train()
+        elif kind == "l2l":
+            m = L2L(ns(False))
+            m.load_state_dict(procedural_state_dict(shapes("l2l_basic"), seed))
+            m = m.to(DEV).train()
+        else:
+            a = ns(kind == "small")
+            a.alternate_corr = kind == "alt"
+            m = RAFT(a)
+            m.load_state_dict(procedural_state_dict(shapes("raft_small" if kind == "small" else "raft_basic"), seed))
+            m = m.to(DEV).train()
+        m.freeze_bn()
+        B, H, W = 2, 128, 192
+        im1, im2 = (t.to(DEV) for t in synthetic_pair(B, H, W, seed + 1))
+        for scale in (1.0, 3e3):          # the second pass: update-block weights x 3e3 -> activations and gradients far outside fp16's own range
+            if scale != 1.0:
+                with torch.no_grad():
+                    for n_, p in m.named_parameters():
+                        if "update_block" in n_ and n_.endswith("weight") and ("convc1" in n_ or "convf1" in n_ or "flow_head.conv2" in n_):
+                            p.mul_(scale)
+            if kind == "l2l":
+                preds = m(im1[:, :, 8:104, 16:144].contiguous(), im2[:, :, 8:104, 16:144].contiguous(), im1, im2,
+                          torch.tensor([16] * B), torch.tensor([8] * B), iters=4)
+            else:
+                preds = m(im1, im2, iters=3)
+            loss = O.sequence_loss_zero_gt(preds)
+            loss.backward()
+            assert torch.isfinite(loss), (kind, scale)
+            assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None), (kind, scale)
+            m.zero_grad(set_to_none=True)
+    finally:
+        ops.AMAX_AUDIT = old
+        ops.set_arithmetic(True)
