@@ -520,6 +520,19 @@ def gen_chairs_b8(iters=3):
     save(name, small=False, H=H, W=W, iters=iters, seed=seed, B=B, **_train_digest(model, preds, stride=4 if iters == 3 else 8))
 
 
+def gen_bench_batch():
+    """BASELINE.json config 3 at the per-GPU batch bench.py times: RAFT, FOUR pairs of 440x1024, 12
+    iterations, fwd + bwd -- loss, strided predictions and the parameter-gradient digests of the benchmarked step itself."""
+    seed, H, W, B = 631, 440, 1024, 4
+    model = RAFT(args_ns(False))
+    model.load_state_dict(procedural_state_dict(shapes_of(model), seed))
+    model.train()
+    model.freeze_bn()
+    im1, im2 = synthetic_pair(B, H, W, seed + 1)
+    preds = model(im1, im2, iters=12)
+    save("train_step_basic_440x1024_b4", small=False, H=H, W=W, iters=12, seed=seed, B=B, **_train_digest(model, preds, stride=8))
+
+
 def gen_warm_start():
     """forward_interpolate of the reference (core/utils/utils.py:26-54) on seeded flows: smooth + noise, a case where
     many vectors leave the image, and a constant shift (whole columns of the grid inherit their nearest landed neighbour)."""
@@ -571,3 +584,5 @@ if __name__ == "__main__":
         gen_chairs_b8()
     if "chairs_b8" in which or "chairs_b8_it12" in which:
         gen_chairs_b8(iters=12)
+    if "bench_b4" in which:
+        gen_bench_batch()
