@@ -451,6 +451,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
       return m0 + row < M ? (int64_t)m0 + row : -1;
     }
   };
+  // (the look at the destination words is taken here, long before they are needed: split_arith.hpp fs_amax_peek)
+  const unsigned peek0 = fs_amax_peek(a.damax[0]), peek1 = fs_amax_peek(a.damax[1]), peek2 = fs_amax_peek(a.damax[2]);
   __syncthreads();                                   // the k-loop's last LDS reads are done
 #pragma unroll
   for (int nt = 0; nt < Cfg::TN; ++nt) {
@@ -599,7 +601,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
   if (track) {                                       // the parked tile is no longer needed: its memory takes the reduction
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      if (a.damax[i]) fs_amax_commit(a.damax[i], mydi == i ? mx : 0u, reinterpret_cast<unsigned*>(tile));
+      if (a.damax[i]) fs_amax_commit_peeked(a.damax[i], mydi == i ? mx : 0u, reinterpret_cast<unsigned*>(tile), i == 0 ? peek0 : i == 1 ? peek1 : peek2);
   }
 }
 

@@ -133,6 +133,25 @@ __device__ __forceinline__ void fs_amax_commit(unsigned* word, unsigned m, unsig
     fs_amax_raise(word, m, 1u);
   }
 }
+// the same with the look at the word taken EARLIER (fs_amax_peek before the epilogue's stores): the L2 round trip of the look
+// -- ~1 us, measured as +1.8 % on the convolution launches when it sat at the very end of the kernel -- then hides behind the
+// stores; a look that is a few microseconds old can only cause a spare atomic.
+__device__ __forceinline__ unsigned fs_amax_peek(const unsigned* word) {
+  const int tid = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+  return (word && tid == 0) ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+__device__ __forceinline__ void fs_amax_commit_peeked(unsigned* word, unsigned m, unsigned* red, unsigned cur) {
+  m = fs_wave_umax(m);
+  const int nw = (int)(blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+  const int tid = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < nw; ++i) m = fs_umax(m, red[i]);
+    if (fs_amax_worth(m, cur)) atomicMax(word, fs_amax_up(m, 1u));
+  }
+}
 // the same without barriers, at most one atomic per WAVE: for kernels whose waves leave early
 __device__ __forceinline__ void fs_amax_commit_wave(unsigned* word, unsigned m) {
   m = fs_wave_umax(m);

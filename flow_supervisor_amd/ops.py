@@ -265,6 +265,7 @@ def ensure_amax(views):
 
 
 AMAX_AUDIT = bool(os.environ.get("FSRAFT_AMAX_AUDIT"))     # (module attribute: tests set it)
+_NO_WORDS = int(os.environ.get("FSRAFT_NO_WORDS", "0"))   # measurement only: bit 0 = convolutions read no words (scale 1), bit 1 = raise none
 
 
 def pyramid_sizes(H, W, num_levels=4):
@@ -1418,6 +1419,8 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
     if ws is not None:
         d.ws = ws.data_ptr(); d.ws_floats = ws.numel()
     split = (wpk_split is not None or wpk_frag is not None) and not exact_mode()
+    if _NO_WORDS & 1:        # (measurement only, scripts/conv_micro.py: the kernels then run with scale 1 / raise nothing)
+        split = False
     if split:
         # split arithmetic: scales from the amax words of the sources and of the weights
         wsrc = wpk_split if wpk_split is not None else wpk_frag
@@ -1428,7 +1431,7 @@ def conv_forward(srcs, wpk, bias, B, H, W, KH, KW, N, dsts, relu=False, alpha=1.
         for i, a in enumerate(ensure_amax(srcs)):
             d.src_amax[i] = a
     for i, ds in enumerate(dsts):
-        if ds.amax is not None:
+        if ds.amax is not None and not (_NO_WORDS & 2):
             d.dst_amax[i] = ds.amax.data_ptr()
     if epi == 2 and aux1 is not None and amax_of(aux1) is not None:       # r*h
         d.dst_amax[1] = amax_of(aux1).data_ptr()

@@ -74,10 +74,20 @@ for name, kh, kw, cs, cout in LAYERS:
     wps = ops.pack_weight(w, cs, 10)
     wpf = ops.fragment_order(wps)
     out = torch.zeros(B, H, W, (cout + 3) // 4 * 4, device=dev)
+    if os.environ.get("CONV_MICRO_TRACK", "1") == "1":
+        ops.tracked(out)                 # (as in the step: the epilogue raises the destination's amax word)
     dy = torch.randn(B, H, W, (cout + 3) // 4 * 4, device=dev)
     dys = [V(torch.randn_like(dy), cout) for _ in range(NSEG)]
     xss = [[V(torch.randn_like(v.t), v.C) for v in srcs] for _ in range(NSEG)]
     dwpk = torch.zeros_like(wpk)
+    if os.environ.get("CONV_MICRO_SHAREWORD") == "1":      # one amax word for all segments' dY and one per source (as a step-wide word would be)
+        wdy = ops.amax_of_tensors([v.t for v in dys])
+        for v in dys:
+            v.amax = wdy
+        for si in range(len(cs)):
+            wsrc = ops.amax_of_tensors([xs[si].t for xs in xss])
+            for xs in xss:
+                xs[si].amax = wsrc
     for kind in ("fwd", "wgrad"):
         def run():
             if kind == "fwd":

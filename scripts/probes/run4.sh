@@ -1,0 +1,6 @@
+mkdir -p gpurun_out/r06
+for i in 1 2; do
+CONV_MICRO_GRAPH=1 python scripts/conv_micro.py 20 > gpurun_out/r06/micro4_full_$i.txt 2>&1
+FSRAFT_NO_WORDS=2 CONV_MICRO_GRAPH=1 python scripts/conv_micro.py 20 > gpurun_out/r06/micro4_noraise_$i.txt 2>&1
+FSRAFT_NO_WORDS=3 CONV_MICRO_GRAPH=1 python scripts/conv_micro.py 20 > gpurun_out/r06/micro4_nowords_$i.txt 2>&1
+done
