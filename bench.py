@@ -190,7 +190,7 @@ def step_check(dev, batch, height=440, width=1024, iters=12):
     of 440x1024, 12 iterations), forward AND backward, on the procedural weights / inputs of tests/golden/
     train_step_basic_440x1024_b4.npz -- which holds the reference's loss and per-parameter gradient digests for that very step
     (tests/golden/make_golden.py::gen_bench_batch).  Compared: the loss, every parameter-gradient norm, the first 32 elements of
-    six gradients spread over the model.  Limits = the parity suite's one tolerance table (tests/test_gpu_parity.py)."""
+    six gradients spread over the model.  Limits = the parity suite's one tolerance table (tests/_gpu_common.py)."""
     import numpy as np
     from oracle.weights import procedural_state_dict, synthetic_pair
     from flow_supervisor_amd.core.raft import RAFT
@@ -360,9 +360,21 @@ def main():
         if seen != world:            # a collective that did not see every rank would make every later number meaningless: fail the run
             print(f"bench: rank {rank}: the all-reduce of ones returned {seen}, expected {world} ranks", file=sys.stderr, flush=True)
             sys.exit(4)
+        #  the short limit above is for the rendezvous and this first collective; the steady-state collectives -- behind
+        # code-object loads, a hipGraph capture, MIOpen's first calls, all of which may skew the ranks by minutes on a first
+        # 8-GPU run -- get a long one, so that the watchdog does not abort a healthy run
+        coll_timeout = float(os.environ.get("FSRAFT_COLLECTIVE_TIMEOUT_S", "1800"))
+        try:
+            import datetime
+            from torch.distributed import distributed_c10d as c10d
+            c10d._set_pg_timeout(datetime.timedelta(seconds=coll_timeout), dist.group.WORLD)
+        except Exception as e:       # noqa: BLE001  (private API: keep the short limit and say so)
+            coll_timeout = init_timeout
+            print(f"bench: could not raise the collective timeout ({type(e).__name__}: {e})", file=sys.stderr)
         rccl = {"backend": dist.get_backend() + (" (= RCCL)" if dist.get_backend() == "nccl" else " staged through host memory: ranks share a device"),
                 "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": seen,
-                "first_all_reduce_ms": 1e3 * (time.perf_counter() - t_first), "init_timeout_s": init_timeout}
+                "first_all_reduce_ms": 1e3 * (time.perf_counter() - t_first), "init_timeout_s": init_timeout,
+                "collective_timeout_s": coll_timeout}
     # MIOpen exhaustive find (cudnn.benchmark) costs ~7 minutes of start-up for the encoder shapes and
     # is off: the encoders are framework callers of the path, not what this benchmark is about.
     torch.backends.cudnn.benchmark = False

@@ -8,7 +8,7 @@ and nothing else: per iteration `corr_fn(coords1)` returns NCHW `[B, 324, H/8, W
 and returns NCHW tensors (`net`, `up_mask [B, 576, H/8, W/8]`, `delta_flow`), `upsample_flow(coords1 - coords0, up_mask)` runs
 every iteration, `coords1` is carried and detached exactly as in pytorch/core/raft.py:99-144.  The loop below restates those
 lines; `bench.py --variant dropin` measures it so that the drop-in route has a throughput number next to the headline's
-(VERDICT r4 next #6); `tests/test_gpu_parity.py::test_reference_shaped_shell_matches_the_package_shell` holds its outputs and
+(VERDICT r4 next #6); `tests/test_gpu_end_to_end.py::test_reference_shaped_shell_matches_the_package_shell` holds its outputs and
 gradients to the package shell's.
 """
 import torch

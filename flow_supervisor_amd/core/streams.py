@@ -25,21 +25,32 @@ Rules the callers keep: weights packed for the kernels (extractor._prepare_packs
 fork when both streams will read them; tensors produced on the side stream are handed to `join`, which makes the caller's stream
 wait and tells the caching allocator about their second stream.
 """
+import threading
+
 import torch
 
 OVERLAP = True          # False: every branch on the caller's stream, one after the other
-_SIDE = {}
+_SIDE = {}              # (device index, which, host thread) -> stream
+_LOCK = threading.Lock()
 
 
 def side_stream(device, which=0):
+    """The calling THREAD's side stream `which` of `device` (one stream per (device, which) for the whole process made
+    two host threads driving the same device share a stream -- and with it the split-K scratch and the zero-pool chunk that
+    ops keys on (device, stream): thread B's partial-tile kernel could land between thread A's partial and finish kernels)."""
     device = torch.device(device)
-    s = _SIDE.get((device.index, which))
+    key = (device.index, which, threading.get_ident())
+    s = _SIDE.get(key)
     if s is None:
-        s = _SIDE[(device.index, which)] = torch.cuda.Stream(device=device)
+        with _LOCK:
+            s = _SIDE.get(key)
+            if s is None:
+                s = _SIDE[key] = torch.cuda.Stream(device=device)
     return s
 
 
 _QUIET_DEPTH = [0]
+_QUIET_PREV = [True]
 
 
 class accumulate_grad_warning_off:
@@ -48,20 +59,29 @@ class accumulate_grad_warning_off:
     A parameter used on both streams (the encoders of the flow-supervisor forward) gets gradients from nodes on two streams; its
     AccumulateGrad node belongs to one of them and the engine synchronises the other -- here that is the design."""
 
+    # (ADVICE r5: covers the TrainStep / SemiTrainStep backward calls only -- a bare loss.backward() on the package's two-stream
+    #  forward still gets torch's warning; the depth counter is guarded, and a user who had switched the warning off keeps it off)
     def __enter__(self):
         setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if setter is not None:
-            if _QUIET_DEPTH[0] == 0:
-                setter(False)
-            _QUIET_DEPTH[0] += 1
+            with _LOCK:
+                if _QUIET_DEPTH[0] == 0:
+                    getter = getattr(torch._C, "_warn_on_accumulate_grad_stream_mismatch", None)      # (private: present on torch 2.10)
+                    try:
+                        _QUIET_PREV[0] = bool(getter()) if callable(getter) else True
+                    except Exception:       # noqa: BLE001
+                        _QUIET_PREV[0] = True
+                    setter(False)
+                _QUIET_DEPTH[0] += 1
         return self
 
     def __exit__(self, *exc):
         setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if setter is not None:
-            _QUIET_DEPTH[0] -= 1
-            if _QUIET_DEPTH[0] == 0:
-                setter(True)
+            with _LOCK:
+                _QUIET_DEPTH[0] -= 1
+                if _QUIET_DEPTH[0] == 0:
+                    setter(_QUIET_PREV[0])
         return False
 
 
@@ -108,7 +128,9 @@ def order_current_behind_all(device, *more):
     device = torch.device(device)
     cur = torch.cuda.current_stream(device)
     capturing = torch.cuda.is_current_stream_capturing()
-    for (idx, _), s in list(_SIDE.items()):
+    # (every thread's side streams of the device: this runs in the autograd engine's worker thread, the forks were made by
+    #  the thread that ran the forward; another model's idle / un-captured streams fall out below)
+    for (idx, _, _tid), s in list(_SIDE.items()):
         if idx != device.index or s == cur:
             continue
         if capturing:

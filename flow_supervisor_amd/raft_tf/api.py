@@ -153,6 +153,12 @@ class CorrBlock:
         self.corr_pyramid = []
 
     def __call__(self, corr_pyramid, coords, is_coord=True):
+        #  the reference always hands in stop_gradient(coords) (raft/semi.py:59, 99): the lookup has no gradient
+        # w.r.t. them.  A caller that passes coords with a live gradient would get it cut silently -- say so once.
+        if coords.requires_grad and torch.is_grad_enabled():
+            import warnings
+            warnings.warn("raft_tf CorrBlock: the lookup does not differentiate through `coords` (the reference passes "
+                          "tf.stop_gradient(coords)); their gradient is cut here", RuntimeWarning, stacklevel=2)
         B, H, W, _ = coords.shape
         levels = [lv.reshape(B * H * W, 1, lv.shape[-2], lv.shape[-1]) for lv in corr_pyramid]
         h2, w2 = corr_pyramid[0].shape[-2:]

@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_parity.py::test_two_process_train_step_matches_single_process: one data-parallel rank
+"""Child process of tests/test_gpu_runtime.py::test_two_process_train_step_matches_single_process: one data-parallel rank
 running the REAL TrainStep (HIP path) on its shard.  Ranks share cuda:0, so the exchange goes over gloo staged through
 host memory (RCCL refuses two ranks on one device); everything else is the code path bench.py runs at N > 1.
 usage: _dp_worker.py rank world port global_batch out.pt [H W iters]"""

@@ -1,6 +1,7 @@
-"""Debug helper (not collected by pytest): the per-step batches (update.HeadBatch / MotionBatch / batched heads backward) against the
-per-iteration path on odd shapes and iteration counts -- RAFT, RAFT with alt-corr, L2L.  Prints the worst relative difference of
-the parameter gradients per case.  usage (GPU box): python tests/debug_batches.py"""
+"""Helper of tests/test_gpu_end_to_end.py::test_per_step_batches_against_the_per_iteration_path_on_odd_shapes (not collected by
+pytest): the per-step batches (update.HeadBatch / MotionBatch / batched heads backward) against the per-iteration path on odd
+shapes and iteration counts -- RAFT, RAFT with alt-corr, L2L.  Run directly it prints the worst relative difference of the
+parameter gradients per case: python tests/_per_iteration_compare.py (GPU box)."""
 import argparse
 import os
 import sys

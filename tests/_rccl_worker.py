@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_parity.py::test_rccl_exchange_at_world_size_one: a fresh process that initialises the
+"""Child process of tests/test_gpu_runtime.py::test_rccl_exchange_at_world_size_one: a fresh process that initialises the
 `nccl` (= RCCL) backend with ONE rank and forces FlatGradients to issue its asynchronous bucket all-reduces from the backward
 hooks anyway (FSRAFT_DP_FORCE_COLLECTIVE=1; parallel.py skips them at world size 1).  This runs, on the one GPU a test box
 has, the part of the N > 1 step no other test reaches: RCCL's own stream against the compute stream around the hook-time
