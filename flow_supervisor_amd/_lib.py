@@ -116,8 +116,8 @@ SIGNATURES = {
     "fsraft_softmax_rows_bwd": [c_void_p, c_void_p, c_int64, c_int, _S],
     "fsraft_softmax_rows_rec": [c_void_p, c_int64, c_int, _S],
     "fsraft_softmax_rows_bwd_rec": [c_void_p, c_void_p, c_int64, c_int, c_void_p, _S],
-    "fsraft_gma_mix_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, _S],
-    "fsraft_gma_mix_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, _S],
+    "fsraft_gma_mix_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, _S],
+    "fsraft_gma_mix_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, _S],
     "fsraft_inorm_relu_fwd": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, _S],
     "fsraft_inorm_relu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, _S],
     "fsraft_affine_relu_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, _S],

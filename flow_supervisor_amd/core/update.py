@@ -305,10 +305,11 @@ class _Engine:
         B, H, W, _ = inp.shape
         P = self._packed(params)
         out = {}
+        vinp = V(inp, self.inp_c)           # (one view for the four convolutions: its amax word is worked out once)
         for k in self.ctx_keys:
             l = self.layers[k]
             buf = torch.empty(B, H, W, P[k][3], device=inp.device, dtype=torch.float32)
-            ops.conv_forward([V(inp, self.inp_c)], P[k][0], P[k][2], B, H, W, l.kh, l.kw, P[k][3], [Dst.nhwc(buf)],
+            ops.conv_forward([vinp], P[k][0], P[k][2], B, H, W, l.kh, l.kw, P[k][3], [Dst.nhwc(buf)],
                              wpk_split=P[k][5])
             out[k] = buf
         return out
@@ -323,6 +324,7 @@ class _Engine:
         dinp = (ops.zeros if pad else (lambda *sh, device: torch.empty(*sh, device=device, dtype=torch.float32)))(
             B, H, W, _pad4(self.inp_c), device=inp.device)
         acc = pad
+        vinp = V(inp, self.inp_c)
         for k in self.ctx_keys:
             g = cst.dsum.get(k)
             parts = cst.parts.get(k)
@@ -334,8 +336,9 @@ class _Engine:
                 continue
             l = self.layers[k]
             n = P[k][3]
-            ops.conv_wgrad(V(g, n), [V(inp, self.inp_c)], dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
-            ops.conv_forward([V(g, n)], P[k][1], None, B, H, W, l.kh, l.kw, self.inp_c, [Dst.nhwc(dinp, 0, 0, acc)],
+            vg = V(g, n)
+            ops.conv_wgrad(vg, [vinp], dW[k], B, H, W, l.kh, l.kw, dbias=dB[k])
+            ops.conv_forward([vg], P[k][1], None, B, H, W, l.kh, l.kw, self.inp_c, [Dst.nhwc(dinp, 0, 0, acc)],
                              wpk_split=P[k][6])
             acc = True
         if not acc:
@@ -384,7 +387,7 @@ class _Engine:
             corflo = buf(self.cf_c)
             cols = ops.tracked(torch.empty(B, H, W, _pad4(98), device=dev, dtype=torch.float32))      # (im2col7 writes the two pad columns itself)
             flo1 = buf(self.f1)
-            motion = buf(self.x_c, track=not self.gma)    # GMA: channels [mot_c, 2 mot_c) hold motion_global (gma_mix_fwd raises no word)
+            motion = buf(self.x_c)           # GMA: channels [mot_c, 2 mot_c) hold motion_global
         cor_out = self.c2 if self.c2 else self.c1
 
         def flow_branch():
@@ -424,7 +427,7 @@ class _Engine:
                 # attn @ v on the record GEMM core: the attention map was split to records once per pair (attn_t), v is
                 # transposed ([mc][N], 3.6 MB) so that both operands are rows of records along the contraction index
                 Nr = attn_t.shape[-1]
-                vt = ops.to_records(ops.transpose_batched(v.view(B, N, mc)))          # [B, mc, Nr]
+                vt = ops.to_records(ops.transpose_batched(v.view(B, N, mc)), amax=ops.amax_of(v))          # [B, mc, Nr]
                 ops.gemm_rec_nt_raw(attn_t.data_ptr(), Nr, N * Nr, vt.data_ptr(), Nr, mc * Nr, agg.data_ptr(), mc, N * mc, B, N, mc, Nr,
                                     ksplit=2, a_amax=ops.amax_of(attn_t), b_amax=ops.amax_of(vt))
             else:
@@ -590,7 +593,7 @@ class _Engine:
             motion = S["motion"]
             # every GRU data gradient adds its motion part; the first one (the q convolution of the last pass covers all x_c
             # channels) overwrites instead, so the buffer needs no zero fill -- only its padding channels, if any, do
-            dmotion = mbs[0].dmotion[mbs[1]][:B] if mbs is not None else buf(self.x_c, track=not self.gma)
+            dmotion = mbs[0].dmotion[mbs[1]][:B] if mbs is not None else buf(self.x_c)
             dm_first = [True]
 
             def dm_acc():
@@ -639,13 +642,13 @@ class _Engine:
             if self.gma:
                 N, mc = H * W, self.mot_c
                 attn, v, agg = S["attn"], S["v"], S["agg"]
-                dagg, dv = buf(mc, track=False), buf(mc, track=False)
+                dagg, dv = buf(mc), buf(mc, track=False)        # (dagg: raised by gma_mix_bwd; dv comes out of a GEMM that raises nothing)
                 ops.gma_mix_bwd(V(dmotion, mc, mc), V(agg), P["aggregator.gamma"], V(dmotion, mc, 0), V(dagg),
                                 dB["aggregator.gamma"])
                 attn_r = S.get("attn_r")
                 if attn_r is not None:   # dv = attn^T dagg: both operands k-major records -> transposed-read record GEMM
                     Nr = attn_r.shape[-1]
-                    dr = ops.to_records(dagg.view(B, N, mc))
+                    dr = ops.to_records(dagg.view(B, N, mc), amax=ops.amax_of(dagg))
                     ops.gemm_rec_tn_raw(attn_r.data_ptr(), Nr, N * Nr, dr.data_ptr(), dr.shape[-1], N * dr.shape[-1], dv.data_ptr(), mc,
                                         N * mc, B, N, mc, N, ksplit=2, a_amax=ops.amax_of(attn_r), b_amax=ops.amax_of(dr))
                 elif N % 4 == 0:     # (exact-fp32 test mode) both operands k-major -> transposed-read split GEMM
@@ -936,12 +939,10 @@ class MotionBatch:
         self.T, self.B, self.H, self.W, self.n = T, B, H, W, 0
         self.corr = e(eng.corr_c)
         self.cor1 = e(eng.c1) if eng.c2 else None
-        self.corflo, self.cols, self.flo1, self.motion = e(eng.cf_c), e(98), e(eng.f1), e(eng.x_c, not eng.gma)
+        self.corflo, self.cols, self.flo1, self.motion = e(eng.cf_c), e(98), e(eng.f1), e(eng.x_c)
         # zero: the iterations run their backward on the first k samples only (grad_samples) and park dmotion for those; the
         # batch then multiplies zeros for the others
-        self.dmotion = torch.zeros(T, B, H, W, _pad4(eng.x_c), device=device, dtype=torch.float32) if zero else e(eng.x_c, False)
-        if not eng.gma:
-            ops.tracked(self.dmotion)       # (written by the GRU data gradients only; GMA's gma_mix_bwd adds to it without raising)
+        self.dmotion = ops.tracked(torch.zeros(T, B, H, W, _pad4(eng.x_c), device=device, dtype=torch.float32)) if zero else e(eng.x_c)
         self.dcorr = e(eng.corr_c)          # (tracked: the gradient volume takes its bound from this word)
         self.parked = set()             # slots whose iteration has handed in its dmotion
 

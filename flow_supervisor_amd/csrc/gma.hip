@@ -194,39 +194,52 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_big_kernel(const float* 
 // dst[m][c] = x[m][c] + gamma * y[m][c]   (C % 4 == 0, 16-byte aligned rows)
 __global__ __launch_bounds__(256) void gma_mix_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y,
                                                           int ldy, const float* __restrict__ gamma, float* __restrict__ dst,
-                                                          int ldd, int64_t M, int C) {
+                                                          int ldd, int64_t M, int C, unsigned* __restrict__ dst_amax) {
   const float g = gamma[0];
   const int c4n = C >> 2;
   const int64_t total = M * c4n;
+  unsigned amx = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / c4n; const int c = (int)(e % c4n) * 4;
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * ldx + c);
     const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ldy + c);
-    *reinterpret_cast<f32x4*>(dst + m * ldd + c) = xv + g * yv;
+    const f32x4 r = xv + g * yv;
+    *reinterpret_cast<f32x4*>(dst + m * ldd + c) = r;
+    amx = fs_umax(amx, fs_abs_bits4(r));
+    if (dst_amax && e < (int64_t)gridDim.x * 256) fs_amax_early(dst_amax, amx);
   }
+  __shared__ unsigned ared[4];
+  if (dst_amax) fs_amax_commit(dst_amax, amx, ared);      // (nullable) word of dst, raised
 }
 
 // d = dL/d dst:  dx[m][c] += d;  dy[m][c] = gamma * d;  dgamma += sum d * y
 __global__ __launch_bounds__(256) void gma_mix_bwd_kernel(const float* __restrict__ d, int ldd, const float* __restrict__ y,
                                                           int ldy, const float* __restrict__ gamma, float* __restrict__ dx,
                                                           int ldx, float* __restrict__ dy, int lddy,
-                                                          float* __restrict__ dgamma, int64_t M, int C) {
+                                                          float* __restrict__ dgamma, int64_t M, int C,
+                                                          unsigned* __restrict__ dx_amax, unsigned* __restrict__ dy_amax) {   // (nullable) words of dx / dy, raised
   __shared__ float red[4];
   const float g = gamma[0];
   const int c4n = C >> 2;
   const int64_t total = M * c4n;
   float acc = 0.f;
+  unsigned ax = 0u, ay = 0u;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t m = e / c4n; const int c = (int)(e % c4n) * 4;
     const f32x4 dv = *reinterpret_cast<const f32x4*>(d + m * ldd + c);
     const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ldy + c);
     f32x4* px = reinterpret_cast<f32x4*>(dx + m * ldx + c);
-    *px = *px + dv;
-    *reinterpret_cast<f32x4*>(dy + m * lddy + c) = g * dv;
+    const f32x4 nx = *px + dv, ny = g * dv;
+    *px = nx;
+    *reinterpret_cast<f32x4*>(dy + m * lddy + c) = ny;
+    ax = fs_umax(ax, fs_abs_bits4(nx)); ay = fs_umax(ay, fs_abs_bits4(ny));
     acc += dv[0] * yv[0] + dv[1] * yv[1] + dv[2] * yv[2] + dv[3] * yv[3];
   }
   acc = block_reduce<false>(acc, red);
   if (threadIdx.x == 0) atomicAdd(dgamma, acc);
+  __shared__ unsigned ared[4];
+  if (dx_amax) fs_amax_commit(dx_amax, ax, ared);
+  if (dy_amax) fs_amax_commit(dy_amax, ay, ared);
 }
 
 inline int grid_for(int64_t work) { int64_t g = (work + 255) / 256; return (int)(g < 1 ? 1 : g > 4096 ? 4096 : g); }
@@ -262,18 +275,21 @@ extern "C" int fsraft_softmax_rows_bwd_rec(const void* A, float* dA, int64_t row
   return fs_launch_status();
 }
 extern "C" int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,
-                                  int64_t M, int C, hipStream_t s) {
-  if (!x || !y || !gamma || !dst || C % 4 || ldx % 4 || ldy % 4 || ldd % 4) return FS_ERR_ARG;
-  hipLaunchKernelGGL(gma_mix_fwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, x, ldx, y, ldy, gamma, dst, ldd, M, C);
+                                  int64_t M, int C, unsigned* dst_amax, hipStream_t s) {
+  if (!x || !y || !gamma || !dst || C % 4 || ldx % 4 || ldy % 4 || ldd % 4 || ((uintptr_t)dst_amax & 3)) return FS_ERR_ARG;
+  int gf = grid_for(M * (C / 4));
+  if (dst_amax && gf > 1024) gf = 1024;
+  hipLaunchKernelGGL(gma_mix_fwd_kernel, dim3(gf), dim3(256), 0, s, x, ldx, y, ldy, gamma, dst, ldd, M, C, dst_amax);
   return fs_launch_status();
 }
 extern "C" int fsraft_gma_mix_bwd(const float* d, int ldd, const float* y, int ldy, const float* gamma, float* dx, int ldx,
-                                  float* dy, int lddy, float* dgamma, int64_t M, int C, hipStream_t s) {
-  if (!d || !y || !gamma || !dx || !dy || !dgamma || C % 4 || ldd % 4 || ldy % 4 || ldx % 4 || lddy % 4) return FS_ERR_ARG;
+                                  float* dy, int lddy, float* dgamma, int64_t M, int C, unsigned* dx_amax, unsigned* dy_amax, hipStream_t s) {
+  if (!d || !y || !gamma || !dx || !dy || !dgamma || C % 4 || ldd % 4 || ldy % 4 || ldx % 4 || lddy % 4 ||
+      (((uintptr_t)dx_amax | (uintptr_t)dy_amax) & 3)) return FS_ERR_ARG;
   // one atomic per workgroup on the ONE dgamma address: 3520 of them took ~40 of the kernel's 51 us (they serialise at the
   // memory side); 512 grid-striding workgroups leave 512
   const int grid = grid_for(M * (C / 4));
   hipLaunchKernelGGL(gma_mix_bwd_kernel, dim3(grid > 512 ? 512 : grid), dim3(256), 0, s, d, ldd, y, ldy, gamma, dx, ldx, dy,
-                     lddy, dgamma, M, C);
+                     lddy, dgamma, M, C, dx_amax, dy_amax);
   return fs_launch_status();
 }

@@ -916,7 +916,7 @@ def gma_mix_fwd(x, y, gamma, dst):
     """dst = x + gamma * y over V channel slices (gma.py:113); gamma: 1-element device tensor."""
     M = x.t.numel() // x.ld
     L.check(_lib().fsraft_gma_mix_fwd(ctypes.c_void_p(x.ptr), x.ld, ctypes.c_void_p(y.ptr), y.ld, L.ptr(gamma),
-                                      ctypes.c_void_p(dst.ptr), dst.ld, M, x.C, L.stream()), "gma_mix_fwd")
+                                      ctypes.c_void_p(dst.ptr), dst.ld, M, x.C, L.ptr(dst.amax), L.stream()), "gma_mix_fwd")
 
 
 def gma_mix_bwd(d, y, gamma, dx, dy, dgamma):
@@ -924,7 +924,7 @@ def gma_mix_bwd(d, y, gamma, dx, dy, dgamma):
     M = d.t.numel() // d.ld
     L.check(_lib().fsraft_gma_mix_bwd(ctypes.c_void_p(d.ptr), d.ld, ctypes.c_void_p(y.ptr), y.ld, L.ptr(gamma),
                                       ctypes.c_void_p(dx.ptr), dx.ld, ctypes.c_void_p(dy.ptr), dy.ld, L.ptr(dgamma), M, d.C,
-                                      L.stream()), "gma_mix_bwd")
+                                      L.ptr(dx.amax), L.ptr(dy.amax), L.stream()), "gma_mix_bwd")
 
 
 SPLIT_VOLUME_BWD = True     # dF2 through the k-major split-bf16 GEMM (needs H*W % 4 == 0)

@@ -389,10 +389,11 @@ int fsraft_softmax_rows_rec(float* S, int64_t rows, int n, hipStream_t stream);
 int fsraft_softmax_rows_bwd_rec(const void* A_records, float* dA, int64_t rows, int n, const unsigned* ds_amax, hipStream_t stream);
 /* Aggregate.forward, gma.py:113: dst = x + gamma[0] * y with gamma a device scalar (the nn.Parameter). */
 int fsraft_gma_mix_fwd(const float* x, int ldx, const float* y, int ldy, const float* gamma, float* dst, int ldd,
-                       int64_t M, int C, hipStream_t stream);
+                       int64_t M, int C, unsigned* dst_amax /* nullable: raised */, hipStream_t stream);
 /* d = dL/d dst:  dx += d;  dy = gamma * d;  dgamma[0] += sum(d * y) */
 int fsraft_gma_mix_bwd(const float* d, int ldd, const float* y, int ldy, const float* gamma, float* dx, int ldx,
-                       float* dy, int lddy, float* dgamma, int64_t M, int C, hipStream_t stream);
+                       float* dy, int lddy, float* dgamma, int64_t M, int C, unsigned* dx_amax, unsigned* dy_amax /* nullable: raised */,
+                       hipStream_t stream);
 
 /* ---- normalisation + ReLU around the encoder convolutions (callers of the path) ------------------------------
  * pytorch/core/extractor.py:6-57: relu(norm(conv(x))) with norm = InstanceNorm2d (feature net) or a frozen
