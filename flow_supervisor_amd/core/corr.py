@@ -161,9 +161,20 @@ class CorrBlock:
         if self._tracks_grad and torch.is_grad_enabled():
             if not self._state.stash:
                 self._state.is_flow = is_flow
-            return _LookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow, out)
+            if channels_last:
+                return _LookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, out)
+            # the reference-shaped call: the lookup itself stays channels-last (an autograd node of its own), the NCHW tensor the
+            # caller receives is a copy that remembers it -- BasicUpdateBlock.forward continues from the original (update.to_channels_last)
+            from .update import from_channels_last
+            return from_channels_last(_LookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, None))
         res = ops.corr_lookup_tiled_fwd(self._vol, self._lay, coords, self.radius, is_flow, out=out)
-        return res if channels_last else ops.nhwc_to_nchw(res)
+        if channels_last:
+            return res
+        y = ops.nhwc_to_nchw(res)
+        from . import update as _u
+        if _u.TWINS:
+            y._fs_cl = (res, y._version)
+        return y
 
     @staticmethod
     @on_tensor_device
@@ -269,6 +280,15 @@ class AlternateCorrBlock:
         if self._tracks_grad and torch.is_grad_enabled():
             if not self._state.stash:
                 self._state.is_flow = is_flow
-            return _AltLookupFn.apply(self._anchor, coords.detach(), self, channels_last, is_flow, out)
+            if channels_last:
+                return _AltLookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, out)
+            from .update import from_channels_last          # (as CorrBlock.__call__: the NCHW copy remembers the channels-last lookup)
+            return from_channels_last(_AltLookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, None))
         res = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs, out=out)
-        return res if channels_last else ops.nhwc_to_nchw(res)
+        if channels_last:
+            return res
+        y = ops.nhwc_to_nchw(res)
+        from . import update as _u
+        if _u.TWINS:
+            y._fs_cl = (res, y._version)
+        return y

@@ -1078,17 +1078,33 @@ class _FromCL(torch.autograd.Function):
         return ops.nchw_to_nhwc(g)
 
 
+TWINS = True      # False: every NCHW tensor crossing the reference-shaped API is converted again by its consumer (rounds 1-5)
+
+
 def to_channels_last(x):
-    """[B,C,H,W] -> [B,H,W,C] (C must be a multiple of 4 for the GEMM kernels)."""
+    """[B,C,H,W] -> [B,H,W,C] (C must be a multiple of 4 for the GEMM kernels).
+    An NCHW tensor that one of this package's reference-shaped entry points returned (CorrBlock.__call__, BasicUpdateBlock.forward)
+    carries its channels-last original as `_fs_cl` (from_channels_last): the reference's loop hands `corr`, `net` and `up_mask`
+    straight from one swapped block to the next (pytorch/core/raft.py:125-137), and the consumer then continues from the twin --
+    same autograd graph, one node earlier -- instead of transposing the copy back.  The twin is dropped
+    as soon as the NCHW tensor was written in place (`_version`)."""
     if x.shape[1] % 4 != 0:
         raise RuntimeError("channel count must be a multiple of 4")
     if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
         return x.permute(0, 2, 3, 1)          # already [B][H][W][C] in memory (the channels_last context encoder's output): a view
+    tw = getattr(x, "_fs_cl", None) if TWINS else None
+    if tw is not None and tw[1] == x._version and tw[0].shape[0] == x.shape[0] and tw[0].shape[-1] >= x.shape[1] \
+            and tuple(tw[0].shape[1:3]) == tuple(x.shape[2:]) and tw[0].requires_grad == x.requires_grad:
+        return tw[0]
     return _ToCL.apply(x)
 
 
 def from_channels_last(x):
-    return _FromCL.apply(x)
+    """[B,H,W,C] -> NCHW contiguous (what the reference's callers receive); the result remembers x (see to_channels_last)."""
+    y = _FromCL.apply(x)
+    if TWINS:
+        y._fs_cl = (x, y._version)
+    return y
 
 
 class _UpdateBlockBase(nn.Module):

@@ -323,3 +323,38 @@ def test_reference_shaped_shell_matches_the_package_shell():
     with torch.no_grad():
         lo, up = b.eval()(im1, im2, iters=3, test_mode=True)
     assert lo.shape == (2, 2, 16, 24) and up.shape == (2, 2, 128, 192)
+
+
+def test_reference_shaped_calls_hand_channels_last_twins_from_block_to_block():
+    """the NCHW tensors the reference-shaped entry points return (CorrBlock.__call__, BasicUpdateBlock.forward)
+    remember their channels-last originals, and the next swapped block continues from those instead of transposing the copy back.
+    Same numbers and gradients with the twins on and off; a tensor written in place by the caller loses its twin."""
+    from flow_supervisor_amd.core import update as U
+    from flow_supervisor_amd.core.raft_dropin import ReferenceShapedRAFT
+    seed = 5
+    im1, im2 = (t.to(DEV) for t in synthetic_pair(2, 128, 192, seed + 1))
+    res = {}
+    old = U.TWINS
+    try:
+        for flag in (True, False):
+            U.TWINS = flag
+            m = ReferenceShapedRAFT(ns(False))
+            m.load_state_dict(procedural_state_dict(shapes("raft_basic"), seed))
+            m = m.to(DEV).train()
+            m.freeze_bn()
+            preds = m(im1, im2, iters=3)
+            O.sequence_loss_zero_gt(preds).backward()
+            res[flag] = (preds[-1].detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        U.TWINS = old
+    close(res[True][0], res[False][0], 1e-5, what="last prediction, twins on / off")
+    for k in res[False][1]:
+        e = _rel_l2(res[True][1][k], res[False][1][k])
+        assert e < 2e-3 or res[False][1][k].norm().item() < 1e-4, (k, e)
+    # the twin follows the tensor's version
+    x_cl = torch.randn(1, 6, 8, 16, device=DEV)
+    y = U.from_channels_last(x_cl)
+    assert U.to_channels_last(y) is x_cl
+    y.mul_(2.0)
+    back = U.to_channels_last(y)
+    assert back is not x_cl and torch.equal(back, 2.0 * x_cl)
