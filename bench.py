@@ -56,6 +56,10 @@ def parse():
                          "two backward passes, one AdamW step (use --batch-per-gpu 1, the recipe's batch size)")
     ap.add_argument("--crop-height", type=int, default=368)
     ap.add_argument("--crop-width", type=int, default=768)
+    ap.add_argument("--flow-regime", choices=["smooth", "rough"], default="smooth",
+                    help="rough: every lookup is centred on flow_init ~ N(0, 8 px at 1/8 resolution) + the iterations' updates, i.e. "
+                         "neighbouring queries read unrelated windows (the data-dependent kernels -- lookup, gradient volume, the listed "
+                         "volume-backward GEMMs, the alt-corr lookup -- at their other operating point; VERDICT r5 next #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--one-stream", action="store_true", help="every branch of the forward pass on the caller's stream (core/streams.py "
@@ -454,7 +458,22 @@ def main():
             ls, lu = sstep(sup, unsup)
             return ls + lu
     else:
-        step = TrainStep(model, lr=1.6e-5, iters=a.iters, capturable=use_graph)
+        tstep0 = TrainStep(model, lr=1.6e-5, iters=a.iters, capturable=use_graph)
+        step = tstep0
+        if a.flow_regime == "rough":
+            # a fixed rough warm start: N(0, 8) cells at 1/8 resolution (64 px), independent per query
+            finit = 8.0 * torch.randn(B, 2, a.height // 8, a.width // 8, device=dev, generator=g)
+
+            class _Rough:          # (same call surface as TrainStep for the code below)
+                def __call__(self, i1, i2):
+                    return tstep0(i1, i2, flow_init=finit)
+
+                def forward_backward(self, i1, i2):
+                    return tstep0.forward_backward(i1, i2, flow_init=finit)
+
+                exchange = staticmethod(tstep0.exchange)
+                update = staticmethod(tstep0.update)
+            step = _Rough()
 
     eager_step = step
     if split_graph:
@@ -704,6 +723,7 @@ def main():
         "metric": f"image-pairs/s fwd+bwd, {a.iters} GRU iters, " + ("436x1024" if (a.height, a.width) == (440, 1024) else f"{a.height}x{a.width}")
                   + (f" (flow-supervisor step: {a.iters}+{a.iters} iters, crop {a.crop_height}x{a.crop_width})" if semi else ""),
         "variant": a.variant,
+        "flow_regime": a.flow_regime,
         "value": pairs / dt, "unit": "image-pairs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

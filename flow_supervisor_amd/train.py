@@ -221,12 +221,13 @@ class TrainStep:
         """clip_grad_norm_ + AdamW on the (exchanged) flat gradient buffer."""
         self._update()
 
-    def _forward_backward(self, image1, image2, flow_gt=None, global_batch=None, exchange=True):
+    def _forward_backward(self, image1, image2, flow_gt=None, global_batch=None, exchange=True, flow_init=None):
         if global_batch is None:
             self.grads.begin(exchange=exchange)
         else:
             self.grads.begin(image1.shape[0], global_batch, exchange=exchange)
-        preds = self.model(image1, image2, iters=self.iters)
+        # flow_init: RAFT.forward's warm start (pytorch/core/raft.py:118-119), [B,2,H/8,W/8]
+        preds = self.model(image1, image2, iters=self.iters, **({} if flow_init is None else {"flow_init": flow_init}))
         loss = raft_sequence_loss(preds, flow_gt)
         with streams.accumulate_grad_warning_off():
             loss.backward()                       # bucket hooks start each all-reduce as its gradients complete

@@ -197,7 +197,8 @@ def test_step_replayed_as_two_hipgraphs_with_the_exchange_between_them():
         assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
 
 
-def test_bench_starts_its_own_ranks(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_starts_its_own_ranks(tmp_path, world):
     """`python3 bench.py --gpus 2 ...` typed as is, no torchrun and no WORLD_SIZE around it, must start its
     two ranks itself (children, before the parent touches the GPU), run the data-parallel step on both and print ONE JSON line
     with n_gpus = 2.  On a one-GPU box the ranks share cuda:0 and exchange over gloo through host memory; on a box with two
@@ -208,23 +209,25 @@ def test_bench_starts_its_own_ranks(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--height", "128",
+    # world = 8: the driver's `--gpus 8` command line, here with eight ranks sharing the box's device(s) --
+    # control flow, consensus and the per-rank report of the line at the world size the scaling bench runs at
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--height", "128",
                         "--width", "192", "--iters", "3", "--batch-per-gpu", "1", "--no-cpu-baseline", "--no-extra"],
-                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    print("bench --gpus 2:", {k: out[k] for k in ("value", "n_gpus", "ms_per_step", "rccl")})
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2
-    assert out["rccl"]["world_size"] == 2 and out["rccl"]["ranks_seen_by_all_reduce"] == 2
+    print(f"bench --gpus {world}:", {k: out[k] for k in ("value", "n_gpus", "ms_per_step", "rccl")})
+    assert out["n_gpus"] == world and out["config"]["global_batch"] == world
+    assert out["rccl"]["world_size"] == world and out["rccl"]["ranks_seen_by_all_reduce"] == world
     assert out["rccl"]["graph"] == "captured", out["rccl"]
     assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"]     # finite loss on the replayed steps
     # the self-diagnosing part of the line: one entry per rank for the wall time and for each of the three parts
     # of the two-graph route, and they add up to the step
     for k in ("per_rank_ms_per_step", "per_rank_graph_fb_ms", "per_rank_exchange_ms", "per_rank_graph_up_ms"):
-        assert len(out["rccl"][k]) == 2 and all(v > 0 for v in out["rccl"][k]), (k, out["rccl"])
-    parts = [sum(out["rccl"][k][r] for k in ("per_rank_graph_fb_ms", "per_rank_exchange_ms", "per_rank_graph_up_ms")) for r in range(2)]
+        assert len(out["rccl"][k]) == world and all(v > 0 for v in out["rccl"][k]), (k, out["rccl"])
+    parts = [sum(out["rccl"][k][r] for k in ("per_rank_graph_fb_ms", "per_rank_exchange_ms", "per_rank_graph_up_ms")) for r in range(world)]
     assert all(p <= 1.15 * max(out["rccl"]["per_rank_ms_per_step"]) for p in parts), (parts, out["rccl"])
 
 
