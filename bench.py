@@ -415,7 +415,7 @@ def main():
                                         alternate_corr=a.variant == "alt")).to(dev).train()
     model.freeze_bn()                                 # pytorch/train.py:203-204
     broadcast_parameters(model)
-    # The whole step is captured in a hipGraph and replayed (866 launches per step; the gaps between dependent kernels of one
+    # The whole step is captured in a hipGraph and replayed (724 kernel launches per step in the rocprofv3 summary of this command, profiles/r06_kernel_stats.csv; the gaps between dependent kernels of one
     # stream are what the graph removes, and with eight ranks on one host also eight Python threads competing for cores:
     # profiles/r03_host_time.txt).  Several ranks: the step is replayed as TWO graphs -- forward + loss + backward with
     # the gradients gathered into the flat buffer, then clip + AdamW + weight re-packing -- with the ONE all-reduce of the flat

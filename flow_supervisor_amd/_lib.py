@@ -148,8 +148,9 @@ SIGNATURES = {
                                c_int64, c_void_p, c_void_p, c_void_p, _S],
     "fsraft_amax_scaled": [c_void_p, c_float, c_void_p, _S],
     "fsraft_set_alt_tile": [c_int],
+    "fsraft_set_alt_rough_pct": [c_int],
     "fsraft_altcorr_fused_fwd": [c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
-    "fsraft_altcorr_mfma_fwd": [c_void_p, _PP, c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, _PP, _S],
+    "fsraft_altcorr_mfma_fwd": [c_void_p, _PP, c_void_p, _PP, c_int, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, _PP, c_void_p, _S],
     "fsraft_corr_f2cat": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_dfmap2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _S],
     "fsraft_corr_f2cat_rec": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, _S],

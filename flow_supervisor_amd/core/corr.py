@@ -215,7 +215,7 @@ class _AltBuildFn(torch.autograd.Function):
 class _AltLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, coords, block, channels_last, is_flow, out_buf=None):
-        out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow, recs=block._recs, out=out_buf)
+        out = ops.altcorr_fused_fwd(block._f1, block._f2, coords, block.radius, is_flow, recs=block._recs, out=out_buf, regime=block._regime)
         ctx.state, ctx.cl, ctx.is_flow = block._state, channels_last, is_flow
         ctx.save_for_backward(coords)
         return out if channels_last else ops.nhwc_to_nchw(out)
@@ -263,14 +263,17 @@ class AlternateCorrBlock:
             # channels-last copies once per pair instead of once per level per iteration (corr.py:82-83)
             self._f1 = ops.nchw_to_nhwc(fmap1.detach())
             self._f2 = [ops.nchw_to_nhwc(self.pyramid[i][1].detach()) for i in range(self.num_levels)]
-            # ... and the same maps pre-split to records for the tile GEMM of the lookup (bf16x3, as the volume build)
+            # ... and the same maps pre-split to records for the tile GEMM of the lookup (split arithmetic, as the volume build)
             self._recs = None
+            self._regime = None
             C = fmap1.shape[1]
             if C % 32 == 0 and C <= 256 and fmap1.is_cuda:
                 B = fmap1.shape[0]
                 # (one amax word for every level of the target maps: the pooled levels are means of level 0)
                 w2 = ops.amax_tensor(self._f2[0])
                 self._recs = (ops.to_records(self._f1.view(B, -1, C)), [ops.to_records(f.view(B, -1, C), amax=w2) for f in self._f2])
+                # every lookup picks its kernel by the spread of the flow it is handed (fsraft_altcorr_mfma_fwd's `regime`)
+                self._regime = torch.zeros(8, dtype=torch.int32, device=fmap1.device) if ops.ALT_DISPATCH else None
 
     @on_tensor_device
     def __call__(self, coords, channels_last=False, is_flow=False, out=None):
@@ -284,7 +287,7 @@ class AlternateCorrBlock:
                 return _AltLookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, out)
             from .update import from_channels_last          # (as CorrBlock.__call__: the NCHW copy remembers the channels-last lookup)
             return from_channels_last(_AltLookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, None))
-        res = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs, out=out)
+        res = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs, out=out, regime=self._regime)
         if channels_last:
             return res
         y = ops.nhwc_to_nchw(res)

@@ -197,9 +197,11 @@ struct AltCoords {
 
 template <int R>
 __global__ __launch_bounds__(256) void altcorr_fused_fwd_kernel(const float* __restrict__ f1, AltLevels lv, AltCoords co,
-                                                                float* __restrict__ out, int nlev, int B, int HW, int C, float scale) {
+                                                                float* __restrict__ out, int nlev, int B, int HW, int C, float scale,
+                                                                const int* __restrict__ regime) {
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN;
   __shared__ float dots[4][NPOS + 4];
+  if (regime && regime[0] == 0) return;                 // (dispatched launch: the matrix-pipe kernel takes the smooth regime)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t q = (int64_t)blockIdx.x * 4 + wave;
   const int64_t nq = (int64_t)B * HW;
@@ -268,8 +270,10 @@ constexpr int AT_TQ = 4, AT_RS = 16, AT_CS = 64, AT_PITCH = AT_CS + 1;   // odd 
 
 template <int R>
 __global__ __launch_bounds__(1024) void altcorr_tile_fwd_kernel(const float* __restrict__ f1, AltLevels lv, AltCoords co,
-                                                                float* __restrict__ out, int nlev, int H, int W, int C, float scale) {
+                                                                float* __restrict__ out, int nlev, int H, int W, int C, float scale,
+                                                                const int* __restrict__ regime) {
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN, NRND = (NPOS + 63) / 64;
+  if (regime && regime[0] == 0) return;                   // (dispatched launch: the matrix-pipe kernel takes the smooth regime)
   __shared__ float region[AT_RS * AT_RS * AT_PITCH];      // 65 KB
   __shared__ __attribute__((aligned(16))) float f1s[16][256];
   __shared__ float dots[16][NPOS + 4];
@@ -389,8 +393,10 @@ struct AltRecLevels {
 template <int R>
 __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __restrict__ f1r, const float* __restrict__ f1, AltRecLevels lv,
                                                                AltCoords co, float* __restrict__ out, int nlev, int H, int W, int C,
-                                                               float scale, const unsigned* am1) {   // am1: the word f1r was split with
+                                                               float scale, const unsigned* am1,      // am1: the word f1r was split with
+                                                               const int* __restrict__ regime) {
   constexpr int RD = 2 * R + 1, WIN = RD + 1, NPOS = WIN * WIN, NRND = (NPOS + 63) / 64;
+  if (regime && regime[0] != 0) return;                    // (dispatched launch: rough flow goes to the fp32 tile kernel)
   constexpr int PARK = AM_NQ * AM_DP * 4 + AM_NQ * (NPOS + 1) * 4;      // parked products + every query's window values
   __shared__ __attribute__((aligned(1024))) char lds[AM::LDS_BYTES > PARK ? AM::LDS_BYTES : PARK];
   __shared__ int org[2];
@@ -516,7 +522,64 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Which of the two lookups a launch should use.  The matrix-pipe kernel multiplies a tile's 24 queries with
+// ONE region of target rows per level (17 x 15 cells at level 0: the windows of a smooth flow + two cells); a window position
+// outside the region costs a C-long fp32 dot product from L2 in one thread.  On a flow whose neighbouring queries look at
+// unrelated places most positions go that way and the kernel is 1.4x SLOWER than the fp32 tile kernel, which it beats 3x on
+// smooth flow (profiles/r06_altcorr_regimes.txt).  The statistic: over all 6 x 4 tiles, the fraction u of queries whose level-0
+// window leaves their tile's region, counted among the queries whose window meets the image at all (a window outside the
+// image costs neither kernel anything).  regime[0] = (100 u > g_alt_rough_pct); regime[1..3]: uncovered / counted queries and
+// the ticket of the last-workgroup-decides reduction, zero between launches.
+template <int R>
+__global__ __launch_bounds__(256) void altcorr_regime_kernel(AltCoords co, int B, int H, int W, int rough_pct, int* __restrict__ regime) {
+  constexpr int WIN = 2 * R + 2, RW = AM_TW + 2 * R + 3, RH = AM_TH + 2 * R + 3;
+  __shared__ int red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tiles_x = (W + AM_TW - 1) / AM_TW, tiles_y = (H + AM_TH - 1) / AM_TH, ntile = B * tiles_x * tiles_y;
+  int unc = 0, cnt = 0;
+  // a tile per half wave (24 of its 32 lanes), two tiles per wave and trip
+  for (int t = (blockIdx.x * 4 + wave) * 2 + half; t < ntile; t += gridDim.x * 8) {
+    const int b = t / (tiles_x * tiles_y), tt = t - b * tiles_x * tiles_y, ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int n = l31 < AM_NQ ? l31 : 0;
+    const int qx = tx * AM_TW + n % AM_TW, qy = ty * AM_TH + n / AM_TW;
+    const bool act = l31 < AM_NQ && qx < W && qy < H;
+    float cx = 0.f, cy = 0.f;
+    if (act) {
+      const int pix = qy * W + qx;
+      cx = co.p[b * co.bs + pix * co.ps]; cy = co.p[b * co.bs + co.cs + pix * co.ps];
+      if (co.grid_w > 0) { cx += (float)qx; cy += (float)qy; }
+      cx = (cx > -30000.f && cx < 30000.f) ? cx : -30000.f;
+      cy = (cy > -30000.f && cy < 30000.f) ? cy : -30000.f;
+    }
+    const int ox = (int)floorf(cx) - R, oy = (int)floorf(cy) - R;
+    int mx = act ? ox : 0x7fffffff, my = act ? oy : 0x7fffffff;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) { mx = min(mx, __shfl_xor(mx, d, 64)); my = min(my, __shfl_xor(my, d, 64)); }   // (stays inside the half)
+    const bool meets = act && ox + WIN > 0 && ox < W && oy + WIN > 0 && oy < H;
+    const bool out = meets && (ox - mx + WIN > RW || oy - my + WIN > RH);
+    unc += out ? 1 : 0; cnt += meets ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { unc += __shfl_xor(unc, d, 64); cnt += __shfl_xor(cnt, d, 64); }
+  if (lane == 0) { red[0][wave] = unc; red[1][wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unc = red[0][0] + red[0][1] + red[0][2] + red[0][3]; cnt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (unc) atomicAdd(&regime[1], unc);
+    if (cnt) atomicAdd(&regime[2], cnt);
+    __threadfence();
+    if (atomicAdd(&regime[3], 1) == (int)gridDim.x - 1) {          // the last workgroup decides and clears the sums for the next launch
+      const int u = atomicExch(&regime[1], 0), c = atomicExch(&regime[2], 0);
+      atomicExch(&regime[3], 0);
+      regime[0] = (rough_pct >= 0 && (int64_t)u * 100 > (int64_t)c * rough_pct) ? 1 : 0;
+      regime[4] = u; regime[5] = c;                                // (kept for reports: what the decision was taken on)
+    }
+  }
+}
+
 int g_alt_tile = 1;       // 1: tile kernel where it applies (C a multiple of 64), 0: wave-per-query kernel
+int g_alt_rough_pct = 35; // dispatched launches: fp32 tile kernel when more than this per cent of the queries leave their tile's region (-1: never)
 
 }  // namespace
 
@@ -548,9 +611,9 @@ extern "C" int fsraft_altcorr_bwd(const float* fmap1, const float* fmap2, const 
 // f1 [B,H,W,C] channels-last, f2[l] [B, H >> l, W >> l, C] channels-last (l < num_levels <= 4), coords element (b, c, pix) at
 // coords[b*bs + c*cs + pix*ps] (add_grid != 0: the tensor holds the flow); out [B,H,W,num_levels*(2r+1)^2] = the lookup of
 // CorrBlock on the same maps (scaled by 1/sqrt(C)), without the volume.
-extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_levels, int num_levels, const float* coords,
-                                        int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B,
-                                        int H, int W, int C, int radius, hipStream_t stream) {
+static int altcorr_fp32_fwd(const float* fmap1, const float* const* fmap2_levels, int num_levels, const float* coords,
+                            int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B,
+                            int H, int W, int C, int radius, const int* regime, hipStream_t stream) {   // regime: run only if regime[0] != 0
   if (!fmap1 || !fmap2_levels || !coords || !out || num_levels < 1 || num_levels > 4 || B < 1 || H < 1 || W < 1 || C < 1 ||
       C > 64 * MAXK)
     return FS_ERR_ARG;
@@ -568,15 +631,21 @@ extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* 
   const float scale = 1.0f / sqrtf((float)C);
   if (g_alt_tile && C % 64 == 0 && C <= 256 && ((uintptr_t)fmap1 % 16) == 0) {
     dim3 tg((unsigned)(((W + AT_TQ - 1) / AT_TQ) * ((H + AT_TQ - 1) / AT_TQ)), (unsigned)B);
-    if (radius == 4) hipLaunchKernelGGL(altcorr_tile_fwd_kernel<4>, tg, dim3(1024), 0, stream, fmap1, lv, co, out, num_levels, H, W, C, scale);
-    else if (radius == 3) hipLaunchKernelGGL(altcorr_tile_fwd_kernel<3>, tg, dim3(1024), 0, stream, fmap1, lv, co, out, num_levels, H, W, C, scale);
+    if (radius == 4) hipLaunchKernelGGL(altcorr_tile_fwd_kernel<4>, tg, dim3(1024), 0, stream, fmap1, lv, co, out, num_levels, H, W, C, scale, regime);
+    else if (radius == 3) hipLaunchKernelGGL(altcorr_tile_fwd_kernel<3>, tg, dim3(1024), 0, stream, fmap1, lv, co, out, num_levels, H, W, C, scale, regime);
     else return FS_ERR_ARG;
     return fs_launch_status();
   }
-  if (radius == 4) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
-  else if (radius == 3) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale);
+  if (radius == 4) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<4>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale, regime);
+  else if (radius == 3) hipLaunchKernelGGL(altcorr_fused_fwd_kernel<3>, grid, dim3(256), 0, stream, fmap1, lv, co, out, num_levels, B, H * W, C, scale, regime);
   else return FS_ERR_ARG;
   return fs_launch_status();
+}
+
+extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_levels, int num_levels, const float* coords,
+                                        int64_t coords_bs, int64_t coords_cs, int64_t coords_ps, int add_grid, float* out, int B,
+                                        int H, int W, int C, int radius, hipStream_t stream) {
+  return altcorr_fp32_fwd(fmap1, fmap2_levels, num_levels, coords, coords_bs, coords_cs, coords_ps, add_grid, out, B, H, W, C, radius, nullptr, stream);
 }
 
 // The same lookup with the region products on the matrix pipe: f1r [B][H*W][C/32] and f2r_levels[l] [B][(H>>l)*(W>>l)][C/32]
@@ -585,7 +654,8 @@ extern "C" int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* 
 extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
                                        int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
                                        int add_grid, float* out, int B, int H, int W, int C, int radius, const unsigned* amax1,
-                                       const unsigned* const* amax2_levels, hipStream_t stream) {   // the words f1r / each f2r level were split with
+                                       const unsigned* const* amax2_levels,      // the words f1r / each f2r level were split with
+                                       int* regime, hipStream_t stream) {        // 8 zeroed ints: dispatch by flow regime; NULL: always this kernel
   if (!f1r || !f2r_levels || !fmap1 || !fmap2_levels || !coords || !out || num_levels < 1 || num_levels > 4 || B < 1 || H < 1 || W < 1 ||
       C < 32 || C % 32 || C > 256 || ((uintptr_t)f1r % 16) || ((uintptr_t)fmap1 % 16) || (int64_t)H * W * C * 4 >= 0x7fffffff)
     return FS_ERR_ARG;
@@ -603,13 +673,27 @@ extern "C" int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_l
   AltCoords co{coords, coords_bs, coords_cs, coords_ps, add_grid ? W : 0};
   dim3 grid((unsigned)(((W + AM_TW - 1) / AM_TW) * ((H + AM_TH - 1) / AM_TH)), (unsigned)num_levels, (unsigned)B);
   const float scale = 1.0f / sqrtf((float)C);
-  if (radius == 4) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<4>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1);
-  else if (radius == 3) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<3>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1);
-  else return FS_ERR_ARG;
-  return fs_launch_status();
+  if (radius != 3 && radius != 4) return FS_ERR_ARG;
+  if (regime) {
+    if ((uintptr_t)regime & 3) return FS_ERR_ARG;
+    const int ntile = (int)(grid.x * (unsigned)B);
+    const dim3 rg((unsigned)((ntile + 7) / 8 < 64 ? (ntile + 7) / 8 : 64));
+    if (radius == 4) hipLaunchKernelGGL(altcorr_regime_kernel<4>, rg, dim3(256), 0, stream, co, B, H, W, g_alt_rough_pct, regime);
+    else hipLaunchKernelGGL(altcorr_regime_kernel<3>, rg, dim3(256), 0, stream, co, B, H, W, g_alt_rough_pct, regime);
+  }
+  if (radius == 4) hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<4>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1, regime);
+  else hipLaunchKernelGGL(altcorr_mfma_fwd_kernel<3>, grid, dim3(256), 0, stream, (const char*)f1r, fmap1, lv, co, out, num_levels, H, W, C, scale, amax1, regime);
+  int rc = fs_launch_status();
+  if (rc || !regime) return rc;
+  return altcorr_fp32_fwd(fmap1, fmap2_levels, num_levels, coords, coords_bs, coords_cs, coords_ps, add_grid, out, B, H, W, C, radius, regime, stream);
 }
 
 extern "C" int fsraft_set_alt_tile(int on) {
   g_alt_tile = on;
+  return FS_OK;
+}
+
+extern "C" int fsraft_set_alt_rough_pct(int pct) {
+  g_alt_rough_pct = pct;
   return FS_OK;
 }

@@ -558,12 +558,14 @@ def corr_bwd_chunked(fmap1, fmap2, douts, coords, lay, radius, is_flow=False, ch
 
 
 ALT_MFMA = True      # AlternateCorrBlock lookups on the matrix pipe (fsraft_altcorr_mfma_fwd) when the records are supplied
+ALT_DISPATCH = os.environ.get("FSRAFT_ALT_DISPATCH", "1") != "0"   # alt-corr lookups pick their kernel per launch by flow regime (0: always the matrix-pipe kernel)
 
 
-def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None, out=None):
+def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None, out=None, regime=None):
     """f1_cl [B,H,W,C], f2_levels[l] [B,H>>l,W>>l,C] channels-last -> [B,H,W,L*(2r+1)^2] (scaled by 1/sqrt(C)).
-    recs = (f1r, [f2r per level]): the same maps as records -> the tile GEMM kernel (bf16x3); without them, or with the
-    exact-fp32 arithmetic selected, the fp32 dot-product kernels."""
+    recs = (f1r, [f2r per level]): the same maps as records -> the tile GEMM kernel (split arithmetic); without them, or with
+    the exact-fp32 arithmetic selected, the fp32 dot-product kernels.  regime: 8 zeroed int32 on the device -> the launch
+    picks between the two by the spread of the flow (fsraft.h, fsraft_altcorr_mfma_fwd)."""
     L.require_cuda_f32(f1_cl, coords, *f2_levels)
     B, H, W, C = f1_cl.shape
     bs, cs, ps = _planar2_strides(coords)
@@ -580,7 +582,8 @@ def altcorr_fused_fwd(f1_cl, f2_levels, coords, radius, is_flow=False, recs=None
         pr, keep2 = L.ptr_array(recs[1])
         pw, keep3 = L.ptr_array([amax_of(r) for r in recs[1]])
         L.check(_lib().fsraft_altcorr_mfma_fwd(L.ptr(recs[0]), pr, L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out),
-                                               B, H, W, C, radius, _wptr(recs[0]), pw, L.stream()), "altcorr_mfma_fwd")
+                                               B, H, W, C, radius, _wptr(recs[0]), pw, L.ptr(regime) if regime is not None else None,
+                                               L.stream()), "altcorr_mfma_fwd")
     else:
         L.check(_lib().fsraft_altcorr_fused_fwd(L.ptr(f1_cl), pp, nl, L.ptr(coords), bs, cs, ps, int(is_flow), L.ptr(out), B, H, W, C,
                                                 radius, L.stream()), "altcorr_fused_fwd")

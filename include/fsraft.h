@@ -174,12 +174,16 @@ int fsraft_altcorr_fused_fwd(const float* fmap1, const float* const* fmap2_level
 /* The same lookup with the dot products of a tile of queries against a region of target rows as one small GEMM on the matrix
  * pipe (split arithmetic on pre-split operands, as the volume build): f1r [B][H*W][C/32 records] and f2r_levels[l]
  * [B][(H>>l)*(W>>l)][C/32 records] = fsraft_to_records of the channels-last maps, which are passed as well (window positions
- * outside a tile's region -- flow discontinuities -- are taken from them in fp32).  C % 32 == 0, C <= 256. */
+ * outside a tile's region -- flow discontinuities -- are taken from them in fp32).  C % 32 == 0, C <= 256.
+ * regime: NULL, or 8 ints of device memory, zero before the first call and private to the caller's stream.  With it the call
+ * dispatches by flow regime: a statistic kernel counts the queries whose level-0 window leaves their tile's region, and of the
+ * two lookup kernels enqueued behind it (this one and fsraft_altcorr_fused_fwd's) the one the decision names does the work, the
+ * other returns at once.  After the call regime[0] = 1 if the fp32 kernel ran, regime[4] / regime[5] = uncovered / counted queries. */
 int fsraft_altcorr_mfma_fwd(const void* f1r, const void* const* f2r_levels, const float* fmap1, const float* const* fmap2_levels,
                             int num_levels, const float* coords, int64_t coords_bs, int64_t coords_cs, int64_t coords_ps,
                             int add_grid, float* out, int B, int H, int W, int C, int radius,
                             const unsigned* amax1, const unsigned* const* amax2_levels /* the words f1r / each f2r level were split with */,
-                            hipStream_t stream);
+                            int* regime, hipStream_t stream);
 
 /* ---- convex 8x upsampler -------------------------------------------------------------
  * Replaces RAFT.upsample_flow, pytorch/core/raft.py:72-83 and UpsampleConvexWithMask,

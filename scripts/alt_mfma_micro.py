@@ -76,3 +76,20 @@ for name, flow in flows(B, H, W):
         res[0].append(timeit(lambda: ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True)))
         res[1].append(timeit(lambda: ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True, recs=recs)))
     print(f"47x156  {name:38s} fp32 tile kernel {sorted(res[0])[1]:7.1f} us   matrix pipe {sorted(res[1])[1]:7.1f} us")
+
+# the per-launch dispatch (fsraft_altcorr_mfma_fwd's regime buffer): uncovered fraction u, the kernel chosen, the time of the dispatched
+# call (statistic kernel + the chosen lookup + the other one's empty launch) beside both kernels alone, over a sweep of flow roughness
+print("sigma of the flow noise [1/8-resolution cells] | uncovered queries u | chosen | fp32 tile / matrix pipe / dispatched  [us]")
+reg = torch.zeros(8, dtype=torch.int32, device=dev)
+for sigma in (0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 4.0, 6.0, 8.0, 16.0, 200.0):
+    flow = torch.tensor([3.3, -1.7], device=dev).view(1, 2, 1, 1) + sigma * torch.randn(B, 2, H, W, device=dev)
+    t0 = sorted(timeit(lambda: ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True)) for _ in range(3))[1]
+    t1 = sorted(timeit(lambda: ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True, recs=recs)) for _ in range(3))[1]
+    t2 = sorted(timeit(lambda: ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True, recs=recs, regime=reg)) for _ in range(3))[1]
+    r = reg.tolist()
+    a = ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True)
+    d = ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True, recs=recs, regime=reg)
+    e = (a - d).abs().max().item() / a.abs().max().item()
+    assert e < 3e-5 and r[1] == 0 and r[2] == 0 and r[3] == 0, (e, r)
+    worse = t2 / min(t0, t1)
+    print(f"  {sigma:6.1f}   u = {r[4] / max(r[5], 1):5.3f} ({r[4]} of {r[5]})   {'fp32 tile' if r[0] else 'matrix pipe'}   {t0:7.1f} / {t1:7.1f} / {t2:7.1f}   dispatched / best = {worse:.2f}")

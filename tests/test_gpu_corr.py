@@ -111,6 +111,18 @@ def test_alt_lookup_on_the_matrix_pipe(B, C, H, W, nlev):
         close(got.permute(0, 3, 1, 2), ref, 1e-4, what=f"matrix-pipe alt lookup vs oracle, {name}")
         fp32 = ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True)
         close(got, fp32, 1e-4, what=f"matrix-pipe alt lookup vs fp32 tile kernel, {name}")
+        # the per-launch dispatch: whichever kernel the flow statistic names, the result is that kernel's, bit for
+        # bit; the sums and the ticket are back at zero for the next launch; smooth flow stays on the matrix pipe, rough flow leaves it
+        reg = torch.zeros(8, dtype=torch.int32, device=DEV)
+        for _ in range(2):
+            auto = ops.altcorr_fused_fwd(f1c, lv, flow, 4, is_flow=True, recs=recs, regime=reg)
+            r = reg.tolist()
+            assert r[1:4] == [0, 0, 0] and r[0] in (0, 1) and 0 <= r[4] <= r[5] <= B * H * W, r
+            assert torch.equal(auto, fp32 if r[0] else got), f"dispatched alt lookup is not the {'fp32' if r[0] else 'matrix-pipe'} kernel's, {name}"
+        if name == "smooth":
+            assert r[0] == 0 and r[4] == 0, r
+        if name == "rough" and H * W >= 96:
+            assert r[0] == 1, r
 
 
 @pytest.mark.parametrize("B,H,W,n,spread", [(2, 40, 48, 5, 2.0), (1, 37, 53, 12, 1.0), (1, 55, 128, 12, 3.0), (2, 24, 40, 3, 40.0)])
