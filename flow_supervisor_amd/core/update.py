@@ -1096,7 +1096,10 @@ def to_channels_last(x):
     if tw is not None and tw[1] == x._version and tw[0].shape[0] == x.shape[0] and tw[0].shape[-1] >= x.shape[1] \
             and tuple(tw[0].shape[1:3]) == tuple(x.shape[2:]) and tw[0].requires_grad == x.requires_grad:
         return tw[0]
-    return _ToCL.apply(x)
+    y = _ToCL.apply(x)
+    if TWINS:       # ... and a tensor the caller passes again and again (`inp`, once per iteration: raft.py:129) is converted once: the
+        x._fs_cl = (y, x._version)      # per-step context convolutions are shared by IDENTITY of their channels-last input (_ctx_state)
+    return y
 
 
 def from_channels_last(x):

@@ -527,10 +527,11 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd_kernel(const char* __res
 // ONE region of target rows per level (17 x 15 cells at level 0: the windows of a smooth flow + two cells); a window position
 // outside the region costs a C-long fp32 dot product from L2 in one thread.  On a flow whose neighbouring queries look at
 // unrelated places most positions go that way and the kernel is 1.4x SLOWER than the fp32 tile kernel, which it beats 3x on
-// smooth flow (profiles/r06_altcorr_regimes.txt).  The statistic: over all 6 x 4 tiles, the fraction u of queries whose level-0
+// smooth flow (profiles/r06_altcorr_regimes.txt).  The statistic: over all 6 x 4 tiles, the number of queries whose level-0
 // window leaves their tile's region, counted among the queries whose window meets the image at all (a window outside the
-// image costs neither kernel anything).  regime[0] = (100 u > g_alt_rough_pct); regime[1..3]: uncovered / counted queries and
-// the ticket of the last-workgroup-decides reduction, zero between launches.
+// image costs neither kernel anything), as a fraction u of ALL queries.  regime[0] = (100 u > g_alt_rough_pct) -- the two
+// kernels cross at u ~ 0.7; regime[1..3]: uncovered / in-image queries and the ticket of the last-workgroup-decides
+// reduction, zero between launches.
 template <int R>
 __global__ __launch_bounds__(256) void altcorr_regime_kernel(AltCoords co, int B, int H, int W, int rough_pct, int* __restrict__ regime) {
   constexpr int WIN = 2 * R + 2, RW = AM_TW + 2 * R + 3, RH = AM_TH + 2 * R + 3;
@@ -572,14 +573,14 @@ __global__ __launch_bounds__(256) void altcorr_regime_kernel(AltCoords co, int B
     if (atomicAdd(&regime[3], 1) == (int)gridDim.x - 1) {          // the last workgroup decides and clears the sums for the next launch
       const int u = atomicExch(&regime[1], 0), c = atomicExch(&regime[2], 0);
       atomicExch(&regime[3], 0);
-      regime[0] = (rough_pct >= 0 && (int64_t)u * 100 > (int64_t)c * rough_pct) ? 1 : 0;
+      regime[0] = (rough_pct >= 0 && (int64_t)u * 100 > (int64_t)B * H * W * rough_pct) ? 1 : 0;
       regime[4] = u; regime[5] = c;                                // (kept for reports: what the decision was taken on)
     }
   }
 }
 
 int g_alt_tile = 1;       // 1: tile kernel where it applies (C a multiple of 64), 0: wave-per-query kernel
-int g_alt_rough_pct = 35; // dispatched launches: fp32 tile kernel when more than this per cent of the queries leave their tile's region (-1: never)
+int g_alt_rough_pct = 65; // dispatched launches: fp32 tile kernel when more than this per cent of the queries leave their tile's region (-1: never)
 
 }  // namespace
 

@@ -45,7 +45,7 @@ int fsraft_set_lookup_qb(int qb);     /* queries per workgroup of the row-major 
 int fsraft_set_norm_blocks(int target_workgroups);   /* workgroups per launch of the channels-last norm kernels (default 4096) */
 int fsraft_set_rec_mfma16(int on);    /* record GEMM (NT): 1 = v_mfma_f32_16x16x32_bf16, 0 = 32x32x16 */
 int fsraft_set_alt_tile(int on);      /* alt-corr forward: 1 (default) 4x4-query tile kernel, 0 wave per query */
-int fsraft_set_alt_rough_pct(int pct); /* fsraft_altcorr_mfma_fwd with a regime buffer: the fp32 kernel takes the launch when more than pct per cent of the queries leave their tile's region (default 35; -1 never, i.e. always the matrix-pipe kernel) */
+int fsraft_set_alt_rough_pct(int pct); /* fsraft_altcorr_mfma_fwd with a regime buffer: the fp32 kernel takes the launch when more than pct per cent of the queries leave their tile's region (default 65; -1 never, i.e. always the matrix-pipe kernel) */
 
 #ifdef __cplusplus
 }
