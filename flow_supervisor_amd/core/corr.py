@@ -163,15 +163,17 @@ class CorrBlock:
                 self._state.is_flow = is_flow
             if channels_last:
                 return _LookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, out)
-            # the reference-shaped call: the lookup itself stays channels-last (an autograd node of its own), the NCHW tensor the
-            # caller receives is a copy that remembers it -- BasicUpdateBlock.forward continues from the original (update.to_channels_last)
-            from .update import from_channels_last
-            return from_channels_last(_LookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, None))
+            # the reference-shaped call: the lookup itself stays channels-last (an autograd node of its own); the NCHW-shaped tensor the
+            # caller receives is a view of it (update.as_nchw) -- BasicUpdateBlock.forward continues from the original (update.to_channels_last)
+            from .update import as_nchw
+            return as_nchw(_LookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, None))
         res = ops.corr_lookup_tiled_fwd(self._vol, self._lay, coords, self.radius, is_flow, out=out)
         if channels_last:
             return res
-        y = ops.nhwc_to_nchw(res)
         from . import update as _u
+        if _u.NCHW_VIEWS and _u.TWINS:
+            return res.permute(0, 3, 1, 2)
+        y = ops.nhwc_to_nchw(res)
         if _u.TWINS:
             y._fs_cl = (res, y._version)
         return y
@@ -285,13 +287,15 @@ class AlternateCorrBlock:
                 self._state.is_flow = is_flow
             if channels_last:
                 return _AltLookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, out)
-            from .update import from_channels_last          # (as CorrBlock.__call__: the NCHW copy remembers the channels-last lookup)
-            return from_channels_last(_AltLookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, None))
+            from .update import as_nchw          # (as CorrBlock.__call__)
+            return as_nchw(_AltLookupFn.apply(self._anchor, coords.detach(), self, True, is_flow, None))
         res = ops.altcorr_fused_fwd(self._f1, self._f2, coords, self.radius, is_flow, recs=self._recs, out=out, regime=self._regime)
         if channels_last:
             return res
-        y = ops.nhwc_to_nchw(res)
         from . import update as _u
+        if _u.NCHW_VIEWS and _u.TWINS:
+            return res.permute(0, 3, 1, 2)
+        y = ops.nhwc_to_nchw(res)
         if _u.TWINS:
             y._fs_cl = (res, y._version)
         return y

@@ -720,10 +720,11 @@ class _Engine:
 
 class _CtxState:
     """Per-step state of the context convolution: its outputs (forward) and the summed gate gradients (backward)."""
-    __slots__ = ("key", "inp", "bufs", "dsum", "parts", "anchor", "consumed", "zero")
+    __slots__ = ("key", "inp", "bufs", "dsum", "parts", "anchor", "consumed", "zero", "keep")
 
     def __init__(self, key, inp, bufs):
         self.key, self.inp, self.bufs, self.dsum, self.anchor, self.consumed, self.zero = key, inp, bufs, {}, None, False, None
+        self.keep = None        # the tracked input tensor itself, for as long as the anchor stands for it (_forward_nchw reuses it by identity)
         self.parts = {}         # CTX_SUM_DEFERRED: per key the iterations' gate-gradient buffers, summed once in context_backward
 
 
@@ -745,7 +746,7 @@ class _CtxFn(torch.autograd.Function):
         cst.bufs = None
         # (state -> anchor -> grad_fn -> ctx -> state is a reference cycle: cut it here, or the context features and whatever else
         #  the state holds wait for the cyclic collector -- tens of MB per step that only show up as a creeping peak)
-        cst.anchor = None
+        cst.anchor = cst.keep = None
         ctx.cst = ctx.st = ctx.P = ctx.engine = None
         return None, None, None, None, None, dinp
 
@@ -1079,6 +1080,7 @@ class _FromCL(torch.autograd.Function):
 
 
 TWINS = True      # False: every NCHW tensor crossing the reference-shaped API is converted again by its consumer (rounds 1-5)
+NCHW_VIEWS = True # `net` and `corr` leave the reference-shaped entry points as NCHW-SHAPED VIEWS of the channels-last tensors (as_nchw)
 
 
 def to_channels_last(x):
@@ -1096,10 +1098,17 @@ def to_channels_last(x):
     if tw is not None and tw[1] == x._version and tw[0].shape[0] == x.shape[0] and tw[0].shape[-1] >= x.shape[1] \
             and tuple(tw[0].shape[1:3]) == tuple(x.shape[2:]) and tw[0].requires_grad == x.requires_grad:
         return tw[0]
-    y = _ToCL.apply(x)
-    if TWINS:       # ... and a tensor the caller passes again and again (`inp`, once per iteration: raft.py:129) is converted once: the
-        x._fs_cl = (y, x._version)      # per-step context convolutions are shared by IDENTITY of their channels-last input (_ctx_state)
-    return y
+    return _ToCL.apply(x)
+
+
+def as_nchw(x):
+    """[B,H,W,C] -> [B,C,H,W] for the tensors the reference's loop only hands from one swapped block to the next (`corr`:
+    raft.py:125-127, `net`: raft.py:129): a permuted VIEW -- shape and values of the reference's tensor, torch.channels_last
+    memory format, no copy; `to_channels_last` of it is the original again, and autograd's permutes cost nothing.  (`up_mask`
+    stays a contiguous copy: the reference's own upsample_flow does `mask.view(N, 1, 9, 8, 8, H, W)`, raft.py:75.)"""
+    if NCHW_VIEWS and TWINS:
+        return x.permute(0, 3, 1, 2)
+    return from_channels_last(x)
 
 
 def from_channels_last(x):
@@ -1166,6 +1175,7 @@ class _UpdateBlockBase(nn.Module):
             cst = _CtxState((weakref.ref(inp), inp._version, pkey, st), inp.detach(), bufs)
             if track:
                 cst.anchor = _CtxFn.apply(eng, st, cst, params, anchor, inp)
+                cst.keep = inp
             self.__dict__["_cst"] = cst
         return cst
 
@@ -1235,15 +1245,20 @@ class _UpdateBlockBase(nn.Module):
         # The channels-last copy of `inp` is reused while the caller passes the SAME tensor object at the same version
         # (identity through a weak reference: a freed tensor's address is handed out again by the caching allocator, so
         # an address-keyed cache would serve the previous pair's context features to the next pair).
+        # When `inp` carries a gradient, the cache holds the channels-last tensor WEAKLY: the step's autograd graph keeps it alive
+        # (_CtxFn's input) for exactly as long as it can be reused, and the module does not pin the previous step's graph.  Round 5
+        # converted such an `inp` anew on every call, and with a new object per call the once-per-step context convolutions
+        # (_ctx_state: shared by identity of their input) ran, forward and backward, once per ITERATION in the reference-shaped loop.
         cache = self.__dict__.get("_inp_cache")
-        if (cache is None or cache[0]() is not inp or cache[1] != inp._version
-                or (inp.requires_grad and torch.is_grad_enabled())):
+        tracked = inp.requires_grad and torch.is_grad_enabled()
+        inp_cl = None
+        if cache is not None and cache[0]() is inp and cache[1] == inp._version and cache[3] == tracked:
+            inp_cl = cache[2]() if tracked else cache[2]
+        if inp_cl is None:
             inp_cl = to_channels_last(inp)
-            self.__dict__["_inp_cache"] = None if inp.requires_grad else (weakref.ref(inp), inp._version, inp_cl)
-        else:
-            inp_cl = cache[2]
+            self.__dict__["_inp_cache"] = (weakref.ref(inp), inp._version, weakref.ref(inp_cl) if tracked else inp_cl, tracked)
         h, mask, delta = self.forward_cl(to_channels_last(net), inp_cl, to_channels_last(corr), flow, attention)
-        return from_channels_last(h), (from_channels_last(mask) if mask is not None else None), delta
+        return as_nchw(h), (from_channels_last(mask) if mask is not None else None), delta
 
 
 class SmallUpdateBlock(_UpdateBlockBase):

@@ -1,7 +1,7 @@
 # refresh of the judged evidence: bench line via the driver's launch line, kernel stats, PMC traffic, variants, round-4 micro evidence
 # usage (on the GPU box, repo root): FSRAFT_COMMIT=<short sha> bash scripts/refresh_evidence.sh <tag>   -> gpurun_out/*_<tag>*,
 # copied to profiles/ by hand (gpurun_out/ is scratch)
-tag=${1:-r05}
+tag=${1:-r06}
 export MIOPEN_FIND_MODE=2
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench_${tag}_1gpu.json
 cut -c1-300 gpurun_out/bench_${tag}_1gpu.json
@@ -20,6 +20,15 @@ python bench.py --variant dropin --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/b
 python bench.py --height 368 --width 496 --batch-per-gpu 8 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_chairs.json; cut -c1-200 gpurun_out/bench_${tag}_chairs.json
 python bench.py --variant l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_l2l.json
 python bench.py --variant gma_l2l --batch-per-gpu 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_gma_l2l.json; cut -c1-300 gpurun_out/bench_${tag}_gma_l2l.json
+# round 6: flow regimes: the headline and the alt variant from a rough warm start, the alt lookup's dispatch sweep
+python bench.py --flow-regime rough --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_rough.json; cut -c1-200 gpurun_out/bench_${tag}_rough.json
+python bench.py --variant alt --height 376 --width 1248 --batch-per-gpu 1 --no-cpu-baseline --flow-regime rough 2>&1 | tail -1 > gpurun_out/bench_${tag}_alt_rough.json; cut -c1-200 gpurun_out/bench_${tag}_alt_rough.json
+FSRAFT_ALT_DISPATCH=0 python bench.py --variant alt --height 376 --width 1248 --batch-per-gpu 1 --no-cpu-baseline --flow-regime rough 2>&1 | tail -1 > gpurun_out/bench_${tag}_alt_rough_nodispatch.json; cut -c1-200 gpurun_out/bench_${tag}_alt_rough_nodispatch.json
+python scripts/alt_mfma_micro.py 2>&1 | tail -19 > gpurun_out/altcorr_regimes_${tag}.txt
+# round 6: the split arithmetic against fp64 per layer shape; stall counters of the convolution kernels
+python scripts/conv_accuracy.py > gpurun_out/conv_accuracy_${tag}.txt 2>&1
+python3 scripts/stall_pmc.py ${tag} c2 hd zrc > /dev/null 2>&1
+bash scripts/prof.sh ${tag}_dropin --variant dropin
 # gradient-volume kernels under PMC, the lookup's gather floor, per-layer convolution times
 bash scripts/dvol_pmc.sh ${tag} > /dev/null 2>&1
 python scripts/dvol_micro.py 2>&1 | tail -9 > gpurun_out/dvol_micro_${tag}.txt

@@ -306,10 +306,19 @@ def test_reference_shaped_shell_matches_the_package_shell():
     a.freeze_bn(); b.freeze_bn()
     im1, im2 = (t.to(DEV) for t in synthetic_pair(2, 128, 192, 33))
     outs = []
-    for m in (a, b):
-        preds = m(im1, im2, iters=4)
-        raft_sequence_loss(preds).backward()
-        outs.append((preds, {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    from flow_supervisor_amd.core import update as U
+    calls = []
+    real = U._Engine.context
+    U._Engine.context = lambda self, inp, params: (calls.append(1), real(self, inp, params))[1]
+    try:
+        for m in (a, b):
+            preds = m(im1, im2, iters=4)
+            raft_sequence_loss(preds).backward()
+            outs.append((preds, {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        U._Engine.context = real
+    # (round 6: the reference's loop passes the same `inp` every iteration; its context convolutions run once per step in both shells)
+    assert len(calls) == 2, f"context convolutions ran {len(calls)} times for two steps"
     (pa, ga), (pb, gb) = outs
     assert len(pa) == len(pb) == 4 and pb[0].shape == (2, 2, 128, 192)
     for i in range(4):
