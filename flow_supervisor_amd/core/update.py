@@ -1080,7 +1080,7 @@ class _FromCL(torch.autograd.Function):
 
 
 TWINS = True      # False: every NCHW tensor crossing the reference-shaped API is converted again by its consumer (rounds 1-5)
-NCHW_VIEWS = True # `net` and `corr` leave the reference-shaped entry points as NCHW-SHAPED VIEWS of the channels-last tensors (as_nchw)
+NCHW_VIEWS = True # `net`, `up_mask` and `corr` leave the reference-shaped entry points as NCHW-SHAPED VIEWS of the channels-last tensors (as_nchw)
 
 
 def to_channels_last(x):
@@ -1102,10 +1102,12 @@ def to_channels_last(x):
 
 
 def as_nchw(x):
-    """[B,H,W,C] -> [B,C,H,W] for the tensors the reference's loop only hands from one swapped block to the next (`corr`:
-    raft.py:125-127, `net`: raft.py:129): a permuted VIEW -- shape and values of the reference's tensor, torch.channels_last
-    memory format, no copy; `to_channels_last` of it is the original again, and autograd's permutes cost nothing.  (`up_mask`
-    stays a contiguous copy: the reference's own upsample_flow does `mask.view(N, 1, 9, 8, 8, H, W)`, raft.py:75.)"""
+    """[B,H,W,C] -> [B,C,H,W] for the tensors the reference's loop hands from one swapped block to the next (`corr`:
+    raft.py:125-127, `net`: raft.py:129, `up_mask`: raft.py:137): a permuted VIEW -- shape and values of the reference's tensor,
+    torch.channels_last memory format, no copy; `to_channels_last` of it is the original again, and autograd's permutes cost
+    nothing.  The one thing the reference's own code does to such a tensor besides passing it on -- `mask.view(N, 1, 9, 8, 8, H, W)`
+    in upsample_flow, raft.py:75 -- splits the channel dimension only, which a channels-last view allows
+    (test_reference_upsample_flow_takes_the_mask_view)."""
     if NCHW_VIEWS and TWINS:
         return x.permute(0, 3, 1, 2)
     return from_channels_last(x)
@@ -1258,7 +1260,7 @@ class _UpdateBlockBase(nn.Module):
             inp_cl = to_channels_last(inp)
             self.__dict__["_inp_cache"] = (weakref.ref(inp), inp._version, weakref.ref(inp_cl) if tracked else inp_cl, tracked)
         h, mask, delta = self.forward_cl(to_channels_last(net), inp_cl, to_channels_last(corr), flow, attention)
-        return as_nchw(h), (from_channels_last(mask) if mask is not None else None), delta
+        return as_nchw(h), (as_nchw(mask) if mask is not None else None), delta
 
 
 class SmallUpdateBlock(_UpdateBlockBase):

@@ -334,6 +334,39 @@ def test_reference_shaped_shell_matches_the_package_shell():
     assert lo.shape == (2, 2, 16, 24) and up.shape == (2, 2, 128, 192)
 
 
+def test_reference_upsample_flow_takes_the_mask_view():
+    """`up_mask` leaves BasicUpdateBlock.forward as an NCHW-shaped view of the channels-last mask (update.as_nchw).  A maintainer who
+    keeps the reference's OWN upsample_flow (pytorch/core/raft.py:72-83: `mask.view(N, 1, 9, 8, 8, H, W)`, softmax over the nine taps,
+    unfold, sum, permute, reshape -- the oracle's restatement of those lines) must get the same flow from the view as from a contiguous
+    copy, and as from this package's kernel."""
+    from flow_supervisor_amd.core import update as U
+    from flow_supervisor_amd.core.raft import convex_upsample
+    ns_ = argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False, corr_levels=4, corr_radius=4)
+    blk = U.BasicUpdateBlock(ns_).to(DEV)
+    B, H, W = 2, 12, 20
+    net = torch.tanh(rand_tensor((B, 128, H, W), 3)).to(DEV)
+    inp = torch.relu(rand_tensor((B, 128, H, W), 4)).to(DEV)
+    corr = rand_tensor((B, 324, H, W), 5).to(DEV)
+    flow = rand_tensor((B, 2, H, W), 6).to(DEV)
+    with torch.no_grad():
+        n2, mask, delta = blk(net, inp, corr, flow)
+    assert mask.shape == (B, 576, H, W) and n2.shape == (B, 128, H, W)
+    assert not mask.is_contiguous() and mask.is_contiguous(memory_format=torch.channels_last)
+    import torch.nn.functional as F
+
+    def with_view(flow, mask):       # the tensor calls of raft.py:72-83, `.view` included
+        N, _, H, W = flow.shape
+        w = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+        nb = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
+        return (w * nb).sum(2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2, 8 * H, 8 * W)
+
+    up_view = with_view(flow, mask)
+    up_copy = with_view(flow, mask.contiguous())
+    assert torch.equal(up_view, up_copy)
+    close(up_view, O.upsample_flow(flow.cpu(), mask.cpu()), 1e-5, what="view-style upsampling vs the oracle")
+    close(convex_upsample(flow, mask), up_copy, 1e-5, what="convex upsampler on the mask view")
+
+
 def test_reference_shaped_calls_hand_channels_last_twins_from_block_to_block():
     """the NCHW tensors the reference-shaped entry points return (CorrBlock.__call__, BasicUpdateBlock.forward)
     remember their channels-last originals, and the next swapped block continues from those instead of transposing the copy back.
