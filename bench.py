@@ -35,7 +35,7 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_MFMA_TF = 157.3    # v_mfma_f32_32x32x2_f32 (exact fp32) dense peak, same guide
-PEAK_BF16_MFMA_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guide (not the 2:1-sparse figure)
+PEAK_BF16_MFMA_TF = 2500.0  # v_mfma_f32_32x32x16_f16 / _bf16 dense peak, same guide (not the 2:1-sparse figure)
 
 
 def parse():
@@ -793,7 +793,7 @@ def main():
                 basis = ("algorithmic fp32 FLOPs vs the fp32 vector / MFMA peak (157.3 TFLOP/s); the kernel is a vector-ALU dot-product "
                          "kernel fed from L2" if fam == "altcorr_fwd" else
                          "FLOPs of alt_cuda_corr.backward's window products vs the fp32 peak; computed here as chunks of the gradient "
-                         "volume + bf16x3 GEMMs" if fam == "altcorr_bwd" else "algorithmic fp32 FLOPs vs dense fp32 MFMA peak")
+                         "volume + fp16x3 GEMMs" if fam == "altcorr_bwd" else "algorithmic fp32 FLOPs vs dense fp32 MFMA peak")
             else:
                 ach, peak, unit = s["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
             kern[fam] = {"bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": unit,

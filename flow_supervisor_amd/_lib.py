@@ -183,7 +183,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_int
     _lib = lib
-    # Arithmetic per GEMM family: FSRAFT_ARITHMETIC=0 exact-fp32 MFMA everywhere, 1 (default) bf16x3 products;
+    # Arithmetic per GEMM family: FSRAFT_ARITHMETIC=0 exact-fp32 MFMA everywhere, 1 (default) fp16x3 products of scaled operands;
     # FSRAFT_CONV_SPLIT / FSRAFT_WGRAD_SPLIT / FSRAFT_BUILD_SPLIT switch one family (the parity suite runs both modes of each).
     arith = os.environ.get("FSRAFT_ARITHMETIC")
     if arith is not None:

@@ -313,7 +313,7 @@ def _prepare_packs(root):
 
 
 def _weight_packs(conv):
-    """Packed forward / data-gradient matrices of a convolution for the split-bf16 implicit GEMM, cached on the module and
+    """Packed forward / data-gradient matrices of a convolution for the split (fp16x3) implicit GEMM, cached on the module and
     rebuilt whenever the weight tensor changes (optimizer step, load_state_dict).  The encoders build all of theirs at once
     (_prepare_packs at the top of forward); a convolution used on its own gets here with a stale cache and packs itself."""
     c = conv.__dict__.get("_fs_packs")

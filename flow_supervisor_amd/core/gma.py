@@ -1,7 +1,7 @@
 """GMA attention and aggregation (pytorch/core/gma.py) on libfsraft kernels.
 
 ``Attention`` runs once per image pair: q,k = to_qk(context) (1x1 implicit-GEMM conv), sim = scale * q k^T
-(split-bf16 NT GEMM), row softmax in place over the [B,1,N,N] map.  ``Aggregate`` runs every iteration inside
+(split (fp16x3) NT GEMM), row softmax in place over the [B,1,N,N] map.  ``Aggregate`` runs every iteration inside
 ``GMAUpdateBlock`` (core/update.py) as v = to_v(motion), attn @ v, motion + gamma * out; the stand-alone
 ``Aggregate.forward`` here uses the same kernels for callers outside the update block.
 
@@ -147,7 +147,7 @@ class _AttentionFn(torch.autograd.Function):
             dx = _conv1x1(dqk, w, C, 2 * D, B, H, W, 1) if ctx.needs_input_grad[0] else None
             return dx, dw, None, None
         dSt = ops.transpose_batched(dS.view(B, N, N))        # tiled transpose: 4-6 TB/s, the strided copy reaches 1.5-2
-        if N % 4 == 0 and D % 4 == 0:      # k-major operands on the transposed-read split-bf16 GEMM
+        if N % 4 == 0 and D % 4 == 0:      # k-major operands on the transposed-read split (fp16x3) GEMM
             ops.gemm_tn_raw(dSt.data_ptr(), N, N * N, qk.data_ptr() + 4 * D, 2 * D, N * 2 * D, dqk.data_ptr(), 2 * D,
                             N * 2 * D, B, N, D, N, scale)
             ops.gemm_tn_raw(dS.data_ptr(), N, N * N, qk.data_ptr(), 2 * D, N * 2 * D, dqk.data_ptr() + 4 * D, 2 * D,

@@ -91,11 +91,11 @@ def warn_mixed_precision(args):
     """`args.mixed_precision` (pytorch/core/raft.py:99-127, train.py:232: autocast around the encoders and the update block) is
     accepted for signature compatibility and has NO effect here: the models do not enter autocast -- under it the encoders would
     leave the fsraft kernels for the framework's half-precision convolutions, which are SLOWER on this stack than the fp32 path
-    (bench.py's value_north_star_encoders) -- and every kernel of the path stores and accumulates in fp32 (GEMM products bf16x3 or
-    exact fp32, fsraft_set_arithmetic): at least the precision the flag would give, at full speed.  Said once, loudly."""
+    (bench.py's value_north_star_encoders) -- and every kernel of the path stores and accumulates in fp32 (GEMM products as three fp16 products of
+    scaled operands, <= 2^-22 each, or exact fp32: fsraft_set_arithmetic): at least the precision the flag would give, at full speed.  Said once, loudly."""
     if getattr(args, "mixed_precision", False) and not _MIXED_WARNED[0]:
         import warnings
         _MIXED_WARNED[0] = True
         warnings.warn("flow_supervisor_amd: args.mixed_precision=True has no effect -- the models do not enter autocast and the "
-                      "fsraft kernels compute in fp32 (bf16x3 or exact-fp32 products); results are those of mixed_precision=False",
+                      "fsraft kernels compute in fp32 (fp16x3 products of scaled operands, <= 2^-22 each, or exact-fp32 products); results are those of mixed_precision=False",
                       stacklevel=3)

@@ -334,7 +334,7 @@ class VolLayout:
         return t.reshape(rows, 1, self.th[l] * 4, self.tw[l] * 4)[:, :, :self.h[l], :self.w[l]].contiguous()
 
 
-BUILD_REC = True       # volume build on the record GEMM core when the arithmetic mode is split-bf16 and C % 32 == 0
+BUILD_REC = True       # volume build on the record GEMM core when the arithmetic mode is split (fp16x3) and C % 32 == 0
 
 
 def fmap_records(fmap):
@@ -392,7 +392,7 @@ def corr_lookup_tiled_fwd(vol, lay, coords, radius, is_flow=False, out=None):
 
 def corr_dvol_build(douts, coords, lay, B, radius, records=False, is_flow=False, q0=0, nq=0, wmask=None, out=None):
     """Gradient volume [B*H*W, P] of all stashed lookups (douts[t]: [B,H,W,CH] channels-last, coords[t]: [B,2,H,W]);
-    records=True: rows of [32 hi | 32 lo] bf16 records (the operand format of gemm_rec_nt / gemm_rec_tn).
+    records=True: rows of [32 hi | 32 lo] fp16 records (the operand format of gemm_rec_nt / gemm_rec_tn).
     q0 / nq: build only queries [q0, q0 + nq) (into rows 0 .. nq-1).  wmask (KTileLists.wmask): write only the records the two
     list GEMMs of corr_build_bwd_tiled(ktiles=...) read -- the rest of the returned tensor is then UNINITIALISED.
     out: optional preallocated [rows, P] tensor."""
@@ -930,11 +930,11 @@ def gma_mix_bwd(d, y, gamma, dx, dy, dgamma):
                                       L.ptr(dx.amax), L.ptr(dy.amax), L.stream()), "gma_mix_bwd")
 
 
-SPLIT_VOLUME_BWD = True     # dF2 through the k-major split-bf16 GEMM (needs H*W % 4 == 0)
+SPLIT_VOLUME_BWD = True     # dF2 through the k-major split (fp16x3) GEMM (needs H*W % 4 == 0)
 
 
 def gemm_tn_split(A, Bm, alpha=1.0):
-    """C[b] = alpha * A[b]^T @ Bm[b] with A [b,K,M], Bm [b,K,N] (both k-major), split-bf16 core."""
+    """C[b] = alpha * A[b]^T @ Bm[b] with A [b,K,M], Bm [b,K,N] (both k-major), split (fp16x3) core."""
     L.require_cuda_f32(A, Bm)
     b, K, M = A.shape
     N = Bm.shape[2]
@@ -1156,7 +1156,7 @@ def conv_ktot(srcC, KH, KW):
 
 def pack_weight(w, srcC, mode):
     """w: [Cout,Cin,KH,KW] contiguous.  mode 0 -> [Cout,Ktot]; mode 1 -> [Cin,Ktot'] (data gradient);
-    modes 10 / 11: same matrices with every 32-k run stored as [32 hi | 32 lo] bf16 (split-bf16 core)."""
+    modes 10 / 11: same matrices with every 32-k run stored as [32 hi | 32 lo] fp16 (split (fp16x3) core)."""
     L.require_cuda_f32(w)
     w = w.contiguous()
     Cout, Cin, KH, KW = w.shape
@@ -1276,13 +1276,13 @@ def unpack_weight_grads(items, device):
 
 
 def exact_mode():
-    """True while the exact-fp32 convolution kernels are selected (fsraft_set_arithmetic(0)); in split-bf16 mode only
+    """True while the exact-fp32 convolution kernels are selected (fsraft_set_arithmetic(0)); in split (fp16x3) mode only
     layers with <= 32 outputs still read the fp32 packs."""
     return _lib().fsraft_get_tuning(3) == 0
 
 
 def set_arithmetic(split):
-    """fsraft_set_arithmetic: True / 1 = every GEMM-shaped kernel on bf16x3 products (the default), False / 0 = exact fp32
+    """fsraft_set_arithmetic: True / 1 = every GEMM-shaped kernel on fp16x3 products of scaled operands (the default), False / 0 = exact fp32
     MFMA.  Also picks the matching host-side routes (record operands for the volume backward and the GMA GEMMs)."""
     global SPLIT_VOLUME_BWD
     L.check(_lib().fsraft_set_arithmetic(1 if split else 0), "set_arithmetic")

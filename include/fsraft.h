@@ -206,7 +206,7 @@ int fsraft_upflow8_bwd(const float* dup, float* dflow, int N, int C, int H, int 
 typedef struct fsraft_conv_desc {
   const float* src[3]; int srcC[3]; int srcld[3]; int nsrc;   /* concatenated inputs            */
   const float* wpk; const float* bias;                        /* packed weights, bias[N] or NULL */
-  const float* wpk_split;                                     /* same, packed split-bf16 (modes 10/11), or NULL */
+  const float* wpk_split;                                     /* same, packed as [hi | lo] fp16 records (modes 10/11), or NULL */
   int B, H, W, KH, KW, N;                                     /* N = output channels             */
   float* dst[3]; int64_t dst_bs[3]; int64_t dst_ps[3]; int64_t dst_cs[3];
   int dst_n0[3]; int dst_acc[3]; int ndst;                    /* output channel ranges           */
@@ -324,7 +324,7 @@ int fsraft_gemm_f32(const float* A, int64_t lda, int64_t sA, const float* Bm, in
                     int accumulate, const unsigned* a_amax, const unsigned* b_amax /* trans_b: the split kernel's words */,
                     hipStream_t stream);
 
-/* C[b][m][n] = alpha * sum_k A[b][k][m] * Bm[b][k][n] (both k-major) on the split-bf16 core. */
+/* C[b][m][n] = alpha * sum_k A[b][k][m] * Bm[b][k][n] (both k-major) on the split (fp16x3) core. */
 int fsraft_gemm_tn_split(const float* A, int64_t lda, int64_t sA, const float* Bm, int64_t ldb, int64_t sB, float* C,
                          int64_t ldc, int64_t sC, int batch, int M, int N, int K, float alpha, int accumulate,
                          const unsigned* a_amax, const unsigned* b_amax, hipStream_t stream);

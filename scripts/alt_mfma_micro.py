@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""AlternateCorrBlock lookup: the tile GEMM kernel on the matrix pipe (csrc/altcorr.hip altcorr_mfma_fwd_kernel, bf16x3 on
+"""AlternateCorrBlock lookup: the tile GEMM kernel on the matrix pipe (csrc/altcorr.hip altcorr_mfma_fwd_kernel, split arithmetic on
 records) against the fp32 tile kernel (altcorr_tile_fwd_kernel) and against CorrBlock's volume lookup, for smooth flow,
 flow with discontinuities (window positions outside a tile's region), rough flow, flow that leaves the image; several
 shapes incl. ragged tiles; then timing at the KITTI shape."""

@@ -114,7 +114,7 @@ def test_alt_cuda_corr_module_contract():
 @pytest.mark.parametrize("B,C,H,W,nlev", [(1, 256, 47, 156, 4), (2, 128, 17, 19, 4), (1, 64, 8, 12, 3), (1, 96, 5, 7, 2)])
 def test_alt_lookup_on_the_matrix_pipe(B, C, H, W, nlev):
     """altcorr_mfma_fwd_kernel (tiles of 6 x 4 queries, the products with a region of target rows as a
-    bf16x3 GEMM on records) against the oracle's lookup of the dense volume (what AlternateCorrBlock must equal,
+    split-arithmetic GEMM on records) against the oracle's lookup of the dense volume (what AlternateCorrBlock must equal,
     SURVEY.md 8c) and against the fp32 tile kernel: smooth flow, motion boundaries inside tiles (window positions outside a
     tile's region take the fp32 route), rough flow, flow that leaves the image; ragged tiles and 2..4 levels."""
     import torch.nn.functional as F
