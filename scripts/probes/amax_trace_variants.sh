@@ -1,3 +1,4 @@
+# usage (GPU box, repo root): bash scripts/probes/amax_trace_variants.sh  -- FSRAFT_AMAX_TRACE per bench variant: call sites that still run a standalone amax pass
 for v in gma alt l2l; do
   extra=""
   [ $v = alt ] && extra="--height 376 --width 1248 --batch-per-gpu 1"

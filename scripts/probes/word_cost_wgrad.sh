@@ -1,3 +1,4 @@
+# usage (GPU box, repo root): bash scripts/probes/word_cost_wgrad.sh  -- 12-segment weight gradients with distinct / shared / no amax words
 mkdir -p gpurun_out/r06
 for i in 1 2; do
 for l in "c2 " "zr " "q  " "hd " "m2 " "c1 " "cv "; do
