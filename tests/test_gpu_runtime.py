@@ -8,6 +8,55 @@ from _gpu_common import *      # noqa: F401,F403  (helpers, fixtures, tolerance 
 pytestmark = pytest.mark.gpu
 
 
+def test_amax_words_of_external_tensors():
+    """fsraft_amax_jobs / fsraft_amax_scaled (include/fsraft.h "amax words", csrc/amax.hip) on tensors no kernel of the library produced:
+    the word w must satisfy max|x| / 2 <= w <= 4 max|x| (what a power-of-two scale needs, csrc/split_arith.hpp), 0 for an all-zero
+    tensor, NaN for a tensor holding one; rows with a pitch (ld > C), channel counts that are not multiples of four (the scalar path),
+    a pointer that is not 16-byte aligned, more than 32 jobs in one call (two launches), several jobs raising ONE word."""
+    from flow_supervisor_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+
+    def word_of(jobs_of, n=1):
+        ws = [ops.new_amax(DEV) for _ in range(n)]
+        ops.amax_jobs(jobs_of(ws))
+        torch.cuda.synchronize()
+        return [float(w.item()) for w in ws]
+
+    def check(w, t, what):
+        m = float(t.abs().max().item())
+        assert (m == 0.0 and w == 0.0) or (m / 2 <= w <= 4 * m), (what, w, m)
+
+    for n, scale in ((1, 1.0), (7, 1e-6), (4096, 3e4), (1 << 20, 1.0), ((1 << 22) + 3, 1e-3)):
+        t = (torch.randn(n, generator=g) * scale).to(DEV)
+        check(word_of(lambda ws: [(t.data_ptr(), 1, n, n, ws[0])])[0], t, f"contiguous n={n}")
+    z = torch.zeros(1000, device=DEV)
+    assert word_of(lambda ws: [(z.data_ptr(), 1, 1000, 1000, ws[0])])[0] == 0.0
+    bad = torch.randn(5000, generator=g).to(DEV)
+    bad[1234] = float("nan")
+    assert math.isnan(word_of(lambda ws: [(bad.data_ptr(), 1, 5000, 5000, ws[0])])[0])
+    # rows with a pitch: only the first C columns of every row count (the pad columns hold something larger)
+    for rows, C, ld in ((300, 98, 100), (64, 324, 324), (1000, 2, 4), (17, 126, 128)):
+        t = torch.randn(rows, ld, generator=g).to(DEV)
+        t[:, C:] = 1e6
+        check(word_of(lambda ws: [(t.data_ptr(), rows, C, ld, ws[0])])[0], t[:, :C], f"rows={rows} C={C} ld={ld}")
+    # a pointer that is only 4-byte aligned
+    base = torch.randn(4099, generator=g).to(DEV)
+    t = base[3:]
+    check(word_of(lambda ws: [(t.data_ptr(), 1, t.numel(), t.numel(), ws[0])])[0], t, "unaligned")
+    # 40 jobs in one call, each with its own word; then all of them into one word
+    ts = [(torch.randn(100 + 37 * i, generator=g) * (2.0 ** (i - 20))).to(DEV) for i in range(40)]
+    ws = word_of(lambda ws: [(t.data_ptr(), 1, t.numel(), t.numel(), w) for t, w in zip(ts, ws)], n=40)
+    for i, (w, t) in enumerate(zip(ws, ts)):
+        check(w, t, f"job {i} of 40")
+    w1 = word_of(lambda ws: [(t.data_ptr(), 1, t.numel(), t.numel(), ws[0]) for t in ts])[0]
+    check(w1, torch.cat(ts), "40 jobs, one word")
+    # a bound derived from another word: dst = max(dst, factor * src)
+    src = ops.amax_tensor(ts[30])
+    out = ops.amax_scaled(src, 12.0)
+    torch.cuda.synchronize()
+    assert float(out.item()) == 12.0 * float(src.item())
+
+
 def test_flat_adamw_matches_torch_adamw_with_clipping():
     """parallel.FlatAdamW (csrc/optim.hip: clip_grad_norm_ + AdamW as one kernel over flat buffers, pytorch/train.py:137, 280-282)
     against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over six steps: parameters, clipped gradients, returned norm.
