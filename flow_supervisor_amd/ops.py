@@ -7,6 +7,7 @@ see core/corr.py, core/update.py and core/raft.py for the autograd.Function wrap
 import ctypes
 import math
 import os
+import threading
 
 import torch
 import torch.optim.optimizer as _optimizer_module
@@ -112,7 +113,8 @@ class _ZeroPool:
         small = nb <= 256
         size = self.SMALL if small else self.CHUNK
         tag = (self.epoch, self._capture_id(device))
-        key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream, small)
+        # (per host thread as well: the carve below is a read-modify-write of the entry -- ADVICE r5)
+        key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream, small, threading.get_ident())
         ent = self.cur.get(key)
         if ent is None or ent[1] + nb > size or ent[2] != tag:
             ent = [torch.zeros(size // 4, device=device, dtype=torch.float32), 0, tag]
@@ -1363,7 +1365,7 @@ class Dst:
         return Dst(buf, 0, C * H * W, 1, H * W, n0, acc)
 
 
-_CONV_WS = {}                 # (device index, stream) -> scratch tensor
+_CONV_WS = {}                 # (device index, stream, host thread) -> scratch tensor
 CONV_WS_FLOATS = 24 << 20     # 96 MB: three slices of the largest small-M layer (8832 pixels x 512 outputs)
 CONV_WS_MAX_PIXELS = 16384    # the split-K route only exists for grids that leave CUs idle
 
@@ -1372,10 +1374,12 @@ def _conv_workspace(device, pixels):
     """The split-K scratch buffer of a small convolution enqueued on `device`'s current stream, or None (the C ABI allocates
     nothing; the buffer travels in the call's descriptor, fsraft_conv_desc.ws).  One buffer per (device, stream): convolutions
     issued on two streams (core/l2l.py runs the supervisor's encoders beside the student's iterations) or by two host threads
-    (one per device, the reference's nn.DataParallel caller) never share slabs, and nothing is registered process-wide."""
+    (one per device, the reference's nn.DataParallel caller) never share slabs, and nothing is registered process-wide.
+    ADVICE r5: the host thread is part of the key as well -- two threads enqueueing on ONE stream of one device (legal, if unusual)
+    would otherwise interleave their partial-tile and finish launches over one buffer."""
     if pixels > CONV_WS_MAX_PIXELS:
         return None
-    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     ws = _CONV_WS.get(key)
     if ws is None:
         ws = _CONV_WS.setdefault(key, torch.empty(CONV_WS_FLOATS, device=device, dtype=torch.float32))
